@@ -1,0 +1,174 @@
+/* nestfit_amd.h -- C ABI of the MI355X-native NH3 log-likelihood engine.
+ *
+ * Drop-in boundary for the hot path of autocorr/nestfit v0.2: everything that
+ * runs inside `AmmoniaRunner.c_loglikelihood` (prior transform -> model spectra
+ * -> chi^2), batched over live points and map pixels on one gfx950 device.
+ * Plain pointers and sizes only; no torch / numpy types.  All functions return
+ * 0 on success and a non-zero code on failure (text via nfa_last_error());
+ * the one exception is nfa_loglike_callback, which has MultiNest's `LogLike`
+ * signature and therefore no error channel (it writes NaN into *lnew).
+ *
+ * Each entry point names the reference interface it replaces (file:line in
+ * /root/reference).  INTEGRATION.md shows the ctypes / Cython stubs a
+ * maintainer of the reference would add to bind them.
+ */
+#ifndef NESTFIT_AMD_H
+#define NESTFIT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFA_OK            0
+#define NFA_ERR_ARG       1   /* invalid argument (reference: assert / ValueError) */
+#define NFA_ERR_DEVICE    2   /* HIP runtime error, or no gfx950 device            */
+#define NFA_ERR_STATE     3   /* call order / missing table                        */
+
+typedef struct nfa_specset nfa_specset;  /* device-resident spectra of 1..n_pix pixels */
+typedef struct nfa_priors  nfa_priors;   /* device-resident prior program              */
+typedef struct nfa_runner  nfa_runner;   /* (specset, priors, ncomp, cold, lte) bundle */
+
+/* ---- process / device ---------------------------------------------------- */
+const char *nfa_last_error(void);
+int nfa_version(void);
+int nfa_device_count(int *count);
+int nfa_set_device(int device);              /* one process per GPU: call first */
+int nfa_device_synchronize(void);
+int nfa_device_name(char *buf, int buflen);
+
+/* Numerical mode of the FastExp replacement (per process):
+ *   0 = "table": the reference's three-table product held in LDS
+ *       (nestfit/core/fastexp.c:234-283), bit-identical table indices;
+ *   1 = "poly" : exp(-(double)(float)x) by fp64 range reduction + polynomial,
+ *       same branch structure (negative / zero / Taylor / >=32), <=4e-16 rel
+ *       from the table product. */
+int nfa_set_exp_mode(int mode);
+int nfa_get_exp_mode(void);
+
+/* 1/(e^x-1) interpolation table.  The reference builds T0_X, T0_Y with numpy at
+ * import (nestfit/models/hyperfine.pyx:12-20); the host passes the same
+ * arrays so device and reference index identical numbers.  n must be 1000. */
+int nfa_set_iemtex_table(const double *t0_x, const double *t0_y, int64_t n);
+
+/* ---- spectra --------------------------------------------------------------
+ * Replaces AmmoniaSpectrum.__init__ / Spectrum.__init__
+ * (nestfit/models/ammonia.pyx:244-277, nestfit/core/core.pyx:486-520) for all
+ * spectra of one pixel or of a whole cube.  Inputs are copied to the device;
+ * the caller keeps ownership of its arrays.
+ *   sizes[n_spec], trans_ids[n_spec] (1..9), xarr[s] -> sizes[s] doubles
+ *   (ascending Hz, shared by all pixels), data[n_pix][sum(sizes)] channel-
+ *   contiguous per pixel with spectra concatenated in order, noise[n_pix][n_spec].
+ */
+int nfa_specset_create(nfa_specset **out, int n_spec, const int64_t *sizes,
+                       const int32_t *trans_ids, const double *const *xarr,
+                       int64_t n_pix, const double *data, const double *noise);
+int nfa_specset_destroy(nfa_specset *ss);
+int nfa_specset_set_data(nfa_specset *ss, int64_t pix, const double *data);
+/* null_lnZ[n_pix][n_spec] = -sum(data^2)/(2 noise^2)   (core.pyx:517-520) */
+int nfa_specset_null_lnz(const nfa_specset *ss, double *out);
+/* tbg[sum(sizes)] = 1/expm1(h nu / (k TCMB))           (ammonia.pyx:273-277) */
+int nfa_specset_tbg(const nfa_specset *ss, double *out);
+int64_t nfa_specset_chan_tot(const nfa_specset *ss);
+
+/* ---- priors ---------------------------------------------------------------
+ * Replaces PriorTransformer + the Prior family (nestfit/core/core.pyx:169-476).
+ * A prior program is the ordered list of priors (executed in order, in place,
+ * like c_transform, core.pyx:459-476) plus the Distribution tables
+ * (core.pyx:23-45: xax, pdf, cdf, ppf of `size` doubles each).
+ */
+enum {
+    NFA_PRIOR_SIMPLE = 0,             /* Prior                  core.pyx:169-197 */
+    NFA_PRIOR_DUPLICATE = 1,          /* DuplicatePrior         core.pyx:200-221 */
+    NFA_PRIOR_CONSTANT = 2,           /* ConstantPrior          core.pyx:224-238 */
+    NFA_PRIOR_ORDERED = 3,            /* OrderedPrior           core.pyx:241-258 */
+    NFA_PRIOR_SPACED = 4,             /* SpacedPrior            core.pyx:261-292 */
+    NFA_PRIOR_CENSEP = 5,             /* CenSepPrior            core.pyx:295-318 */
+    NFA_PRIOR_RESOLVED_CENSEP = 6,    /* ResolvedCenSepPrior    core.pyx:321-366 */
+    NFA_PRIOR_RESOLVED_PLACEMENT = 7  /* ResolvedPlacementPrior core.pyx:369-435 */
+};
+
+typedef struct {
+    int64_t size;
+    double  du, dx, xmin, xmax;
+    const double *xax, *pdf, *cdf, *ppf;
+} nfa_dist_desc;
+
+typedef struct {
+    int32_t kind;
+    int32_t p_ix;      /* parameter slot (vcen slot for the composite kinds) */
+    int32_t p_ix2;     /* duplicate slot / sigm slot                         */
+    int32_t dist0;     /* main / vcen / independent distribution             */
+    int32_t dist1;     /* vsep / dependent distribution                      */
+    int32_t dist2;     /* sigm distribution                                  */
+    int32_t sub_kind;  /* kind of the sigm sub-prior (SIMPLE/CONSTANT/ORDERED) */
+    int32_t pad_;
+    double  value;     /* constant value                                     */
+    double  sep_scale; /* FWHM * scale                                       */
+} nfa_prior_desc;
+
+int nfa_priors_create(nfa_priors **out, const nfa_prior_desc *priors, int n_prior,
+                      const nfa_dist_desc *dists, int n_dist, int n_param);
+int nfa_priors_destroy(nfa_priors *p);
+/* PriorTransformer.transform (core.pyx:478-483) over B rows of U[B][n_param*ncomp],
+ * host memory, in place.  NFA_ERR_ARG when ndim != n_param*ncomp. */
+int nfa_priors_transform_batch(const nfa_priors *p, double *U, int64_t B,
+                               int ncomp, int ndim);
+
+/* ---- runner ---------------------------------------------------------------
+ * Replaces AmmoniaRunner (nestfit/models/ammonia.pyx:369-447).  `priors` may be
+ * NULL for predict-only use (amm_predict, ammonia.pyx:364-366).
+ */
+int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors,
+                      int ncomp, int cold, int lte);
+int nfa_runner_destroy(nfa_runner *r);
+int nfa_runner_ndim(const nfa_runner *r);
+
+/* AmmoniaRunner.c_loglikelihood (ammonia.pyx:423-432) for B unit-cube rows of
+ * pixel `pix[b]` (pix == NULL: pixel 0).  U[B][ndim] host memory, overwritten
+ * in place with the physical parameters exactly like the reference mutates
+ * `utheta`; lnL[B] out. */
+int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U,
+                             double *lnL, int64_t B);
+
+/* AmmoniaRunner.predict / amm_predict (ammonia.pyx:437-447, 364-366) for B
+ * parameter rows theta[B][ndim] (no priors).  spectra_out[B][chan_tot] and/or
+ * lnL_out[B] may be NULL. */
+int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *theta,
+                             int64_t B, double *spectra_out, double *lnL_out);
+
+/* Same as nfa_runner_loglike_batch with every buffer already resident in device
+ * memory (from nfa_malloc); enqueued on the runner's stream, returns without
+ * synchronising.  d_pix may be NULL. */
+int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_U,
+                                 double *d_lnL, int64_t B);
+int nfa_runner_synchronize(nfa_runner *r);
+
+/* MultiNest `LogLike` (nestfit/core/cmultinest.pxd:27-28; the reference's
+ * trampoline is mn_loglikelihood, nestfit/core/core.pyx:622-624).  Pass the
+ * nfa_runner* as MultiNest's `context`. */
+void nfa_loglike_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx);
+
+/* ---- device memory + events (for harnesses that keep inputs in HBM) ------- */
+int nfa_malloc(void **dptr, int64_t bytes);
+int nfa_free(void *dptr);
+int nfa_memcpy_h2d(void *dst, const void *src, int64_t bytes);
+int nfa_memcpy_d2h(void *dst, const void *src, int64_t bytes);
+int nfa_event_create(void **ev);
+int nfa_event_destroy(void *ev);
+int nfa_event_record(void *ev, nfa_runner *r);       /* on the runner's stream */
+int nfa_event_synchronize(void *ev);
+int nfa_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* ---- unit-test hooks (device evaluation of the scalar building blocks) ---- */
+int nfa_test_fastexp(const double *x, double *out, int64_t n, int mode);    /* fastexp.c:234-283 via math.pxd:17 */
+int nfa_test_iemtex(const double *x, double *out, int64_t n);               /* hyperfine.pyx:23-45 */
+int nfa_test_partition(const double *trot, double *qpara, double *qorth, int64_t n); /* ammonia.pyx:304-315 */
+int nfa_test_windows(nfa_runner *r, int spec, double voff, double sigm,
+                     int32_t *lo, int32_t *hi);                             /* hyperfine.pyx:70-93 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NESTFIT_AMD_H */

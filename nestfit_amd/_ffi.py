@@ -1,0 +1,152 @@
+"""ctypes binding of include/nestfit_amd.h (the engine's C ABI).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no
+gfx950 device is visible, every compute entry point raises `EngineError`.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / 'lib' / 'libnestfit_amd.so'
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+class EngineError(RuntimeError):
+    """The HIP engine reported an error (or is unavailable)."""
+
+
+class DistDesc(C.Structure):
+    _fields_ = [('size', C.c_int64), ('du', C.c_double), ('dx', C.c_double),
+                ('xmin', C.c_double), ('xmax', C.c_double),
+                ('xax', _dp), ('pdf', _dp), ('cdf', _dp), ('ppf', _dp)]
+
+
+class PriorDesc(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('p_ix', C.c_int32), ('p_ix2', C.c_int32),
+                ('dist0', C.c_int32), ('dist1', C.c_int32), ('dist2', C.c_int32),
+                ('sub_kind', C.c_int32), ('pad_', C.c_int32),
+                ('value', C.c_double), ('sep_scale', C.c_double)]
+
+
+# name -> (restype, argtypes); exactly the symbols declared in the header
+SIGNATURES = {
+    'nfa_last_error': (C.c_char_p, []),
+    'nfa_version': (C.c_int, []),
+    'nfa_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'nfa_set_device': (C.c_int, [C.c_int]),
+    'nfa_device_synchronize': (C.c_int, []),
+    'nfa_device_name': (C.c_int, [C.c_char_p, C.c_int]),
+    'nfa_set_exp_mode': (C.c_int, [C.c_int]),
+    'nfa_get_exp_mode': (C.c_int, []),
+    'nfa_set_iemtex_table': (C.c_int, [_dp, _dp, C.c_int64]),
+    'nfa_specset_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _lp, _ip,
+                                     C.POINTER(_dp), C.c_int64, _dp, _dp]),
+    'nfa_specset_destroy': (C.c_int, [C.c_void_p]),
+    'nfa_specset_set_data': (C.c_int, [C.c_void_p, C.c_int64, _dp]),
+    'nfa_specset_null_lnz': (C.c_int, [C.c_void_p, _dp]),
+    'nfa_specset_tbg': (C.c_int, [C.c_void_p, _dp]),
+    'nfa_specset_chan_tot': (C.c_int64, [C.c_void_p]),
+    'nfa_priors_create': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(PriorDesc), C.c_int,
+                                    C.POINTER(DistDesc), C.c_int, C.c_int]),
+    'nfa_priors_destroy': (C.c_int, [C.c_void_p]),
+    'nfa_priors_transform_batch': (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int, C.c_int]),
+    'nfa_runner_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int]),
+    'nfa_runner_destroy': (C.c_int, [C.c_void_p]),
+    'nfa_runner_ndim': (C.c_int, [C.c_void_p]),
+    'nfa_runner_loglike_batch': (C.c_int, [C.c_void_p, _ip, _dp, _dp, C.c_int64]),
+    'nfa_runner_predict_batch': (C.c_int, [C.c_void_p, _ip, _dp, C.c_int64, _dp, _dp]),
+    'nfa_runner_loglike_batch_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int64]),
+    'nfa_runner_synchronize': (C.c_int, [C.c_void_p]),
+    'nfa_loglike_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
+    'nfa_malloc': (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
+    'nfa_free': (C.c_int, [C.c_void_p]),
+    'nfa_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'nfa_memcpy_d2h': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'nfa_event_create': (C.c_int, [C.POINTER(C.c_void_p)]),
+    'nfa_event_destroy': (C.c_int, [C.c_void_p]),
+    'nfa_event_record': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'nfa_event_synchronize': (C.c_int, [C.c_void_p]),
+    'nfa_event_elapsed_ms': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    'nfa_test_fastexp': (C.c_int, [_dp, _dp, C.c_int64, C.c_int]),
+    'nfa_test_iemtex': (C.c_int, [_dp, _dp, C.c_int64]),
+    'nfa_test_partition': (C.c_int, [_dp, _dp, _dp, C.c_int64]),
+    'nfa_test_windows': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _ip, _ip]),
+}
+
+_lib = None
+_tables_installed = False
+
+
+def load():
+    """dlopen the engine and bind every symbol of the header (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise EngineError(
+            f'{LIB_PATH} is missing: build it with `python -m nestfit_amd.build` '
+            '(the engine has no CPU fallback)')
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EngineError(load().nfa_last_error().decode() or f'engine error {rc}')
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iemtex_tables():
+    """T0_X, T0_Y as the reference builds them (nestfit/models/hyperfine.pyx:12-20)."""
+    H, KB = 6.62607015e-27, 1.380649e-16
+    t0_xmin = (H * 23.0e9 / KB) / 8.0
+    t0_xmax = (H * 28.0e9 / KB) / 2.7
+    t0_x = np.linspace(t0_xmin, t0_xmax, 1000)
+    t0_y = 1.0 / (np.exp(t0_x) - 1.0)
+    return np.ascontiguousarray(t0_x), np.ascontiguousarray(t0_y)
+
+
+def engine():
+    """Loaded library with the device tables installed (requires a GPU)."""
+    global _tables_installed
+    lib = load()
+    if not _tables_installed:
+        t0_x, t0_y = iemtex_tables()
+        check(lib.nfa_set_iemtex_table(dptr(t0_x), dptr(t0_y), t0_x.size))
+        _tables_installed = True
+    return lib
+
+
+def set_device(index):
+    check(load().nfa_set_device(int(index)))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().nfa_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def set_exp_mode(mode):
+    """0/'table': LDS product tables (reference FastExp); 1/'poly': fp64 polynomial."""
+    mode = {'table': 0, 'poly': 1}.get(mode, mode)
+    check(load().nfa_set_exp_mode(int(mode)))
+
+
+def get_exp_mode():
+    return load().nfa_get_exp_mode()

@@ -1,0 +1,44 @@
+"""The C-ABI library loads without a GPU and exports exactly what the header declares."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared():
+    text = (ROOT / 'include' / 'nestfit_amd.h').read_text()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(nfa_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nestfit_amd import _ffi
+    lib = _ffi.load()
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/nestfit_amd.h but not exported'
+    assert sorted(_ffi.SIGNATURES) == names
+    assert lib.nfa_version() >= 100
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: on a host without a device every compute call raises."""
+    import nestfit_amd as na
+    if na.device_count() > 0:
+        pytest.skip('a GPU is visible; covered by the gpu suite')
+    x = np.linspace(23.69e9, 23.70e9, 64)
+    with pytest.raises(na.EngineError):
+        na.AmmoniaSpectrum(x, np.zeros(64), 0.1, 1)
+    ut = na.get_irdc_priors(size=50)
+    with pytest.raises(na.EngineError):
+        ut.transform(np.full(6, 0.5), 1)
+
+
+def test_product_never_imports_the_oracle():
+    for f in list((ROOT / 'nestfit_amd').rglob('*.py')) + list((ROOT / 'nestfit_amd').rglob('*.hip')):
+        assert 'oracle' not in f.read_text().replace('test oracle', '').replace('CPU oracle', ''), f
