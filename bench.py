@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: log-likelihood evaluations per second at the
+metric shape of BASELINE.json (config C2: B = 4096 live-point draws per pixel,
+NH3 (1,1)+(2,2), 1024 channels each, 2 velocity components, get_irdc_priors).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (prior transform -> model spectra -> chi^2)
+over one batch of B unit-cube rows for this rank's pixel.  Every input of the
+timed region (unit-cube rows for all steps, spectra, prior tables) is resident
+in HBM before the clock starts.  For N > 1 the driver launches one rank per GPU
+(torch.distributed.run); pixels are striped over ranks like the reference's
+get_multiproc_indices (nestfit/main.py:565-571), per-GPU work is fixed (weak
+scaling) and there is no data-path collective: the only communication is the
+barrier / max-time reduction around the timed region and the end-of-run gather
+of per-pixel summaries.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import ctypes as C
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+WORKLOADS = {
+    # name: (trans ids, channels, vhalf, ncomp, truth key, B)
+    'C2': ((1, 2), 1024, 30.0, 2, 'TRUTH_2COMP', 4096),
+    'C4': ((1, 2, 3), 2048, 40.0, 3, 'TRUTH_3COMP', 4096),
+    'C1': ((1,), 256, 30.0, 1, 'TRUTH_1COMP', 4096),
+}
+
+
+def algorithmic_bytes(trans, n_chan, ncomp):
+    """sum_s N_s*8 (data) + ndim*8 (u in) + ndim*8 (theta out) + 8 (lnL)."""
+    ndim = 6 * ncomp
+    return len(trans) * n_chan * 8 + 2 * ndim * 8 + 8
+
+
+def make_pixel(na, trans, n_chan, vhalf, truth, noise, seed):
+    """Synthetic pixel: engine model spectrum of `truth` + default_rng(seed) normal noise."""
+    from nestfit_amd.synth import freq_axis
+    rng = np.random.default_rng(seed)
+    axes = [freq_axis(t, n_chan, vhalf) for t in trans]
+    spec_data = []
+    for t, x in zip(trans, axes):
+        s = na.AmmoniaSpectrum(x, np.zeros(n_chan), noise, t)
+        na.amm_predict(s, truth)
+        spec_data.append([x, s.get_spec() + rng.normal(0, noise, n_chan), noise, t])
+    return spec_data
+
+
+def _cpu_worker(args):
+    """cpu_baseline worker: the oracle (reference-flag build) on one core."""
+    spec_data, program, ncomp, U, reps = args
+    from oracle import nfo
+    spectra = [nfo.AmmoniaSpectrum(x, d, n, t, native=True) for x, d, n, t in spec_data]
+    run = nfo.AmmoniaRunner(spectra, nfo.PriorSet(program), ncomp=ncomp, native=True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        Uc = U.copy()
+        run.loglikelihood_batch(Uc)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(spec_data, program, ncomp, U, budget_s=12.0):
+    """Times the CPU oracle (same algorithm, reference compile flags) on a bounded
+    sample of the same workload: 1 core, then all cores (one process per core,
+    like the reference's fit_cube(nproc))."""
+    from oracle import nfo
+    nfo.build(native=True)
+    sample = U[:1024].copy()
+    t = _cpu_worker((spec_data, program, ncomp, sample, 1))
+    per_eval = t / sample.shape[0]
+    one_core = 1.0 / per_eval
+    cores = min(len(os.sched_getaffinity(0)), 16)     # the GPU box gives 16 cores per GPU
+    reps = max(1, int(budget_s / (per_eval * sample.shape[0])))
+    with mp.get_context('spawn').Pool(cores) as pool:   # fresh interpreters: never touch the GPU
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker, [(spec_data, program, ncomp, sample, reps)] * cores)
+        wall = time.perf_counter() - t0
+    all_cores = cores * reps * sample.shape[0] / wall
+    return {
+        'value': all_cores, 'unit': 'evals/s', 'cores': cores, 'kind': 'port',
+        'sample': f'{reps} x 1024 rows of the same U per core, {cores} processes '
+                  f'(oracle/nf_oracle.c, -O3 -march=native -ffast-math)',
+        'one_core': one_core,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=0, help='rows per step (default: workload B)')
+    ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'table'),
+                    choices=['table', 'poly'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile-events', action='store_true',
+                    help='do not record per-kernel HIP events inside the timed region')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+
+    import nestfit_amd as na
+    from nestfit_amd import _ffi, synth
+    na.set_device(local_rank)                 # one process per GPU, before any other call
+    na.set_exp_mode(args.exp_mode)
+    lib = _ffi.engine()
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    trans, n_chan, vhalf, ncomp, truth_key, B = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    truth = getattr(synth, truth_key)
+    ndim = 6 * ncomp
+    noise = 0.2
+    # pixel striping: rank r owns pixels i_lon with i_lon % world == r (main.py:565-571);
+    # here one pixel per rank, seeded by its global index
+    spec_data = make_pixel(na, trans, n_chan, vhalf, truth, noise, seed=5 + rank)
+    ut = na.get_irdc_priors(size=500, vsys=0.0)
+    runner = na.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp)
+    rh = runner._run.handle
+
+    # inputs of all steps resident in HBM before the clock starts
+    n_total = args.warmup + args.steps
+    U_host = np.random.default_rng(7 + rank).uniform(size=(B, ndim))
+    d_U = C.c_void_p()
+    d_lnL = C.c_void_p()
+    _ffi.check(lib.nfa_malloc(C.byref(d_U), n_total * B * ndim * 8))
+    _ffi.check(lib.nfa_malloc(C.byref(d_lnL), B * 8))
+    for k in range(n_total):
+        _ffi.check(lib.nfa_memcpy_h2d(C.c_void_p(d_U.value + k * B * ndim * 8),
+                                      U_host.ctypes.data_as(C.c_void_p), B * ndim * 8))
+
+    def step(k):
+        _ffi.check(lib.nfa_runner_loglike_batch_dev(rh, None, C.c_void_p(d_U.value + k * B * ndim * 8),
+                                                    d_lnL, B))
+
+    def sync():
+        _ffi.check(lib.nfa_runner_synchronize(rh))
+        _ffi.check(lib.nfa_device_synchronize())
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    profile = not args.no_profile_events
+    if profile:
+        _ffi.check(lib.nfa_runner_set_profiling(rh, 1))
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, n_total):
+        step(k)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    prior_ms = C.c_double(0)
+    lnl_ms = C.c_double(0)
+    calls = C.c_int64(0)
+    if profile:
+        _ffi.check(lib.nfa_runner_get_profile(rh, C.byref(prior_ms), C.byref(lnl_ms), C.byref(calls)))
+        _ffi.check(lib.nfa_runner_set_profiling(rh, 0))
+
+    # results of the last step, for the end-of-run gather and a sanity check
+    lnL = np.empty(B)
+    _ffi.check(lib.nfa_memcpy_d2h(lnL.ctypes.data_as(C.c_void_p), d_lnL, B * 8))
+    if not np.isfinite(lnL).all():
+        raise SystemExit('non-finite log-likelihood in the benchmark batch')
+
+    t_max = elapsed
+    summary = [(rank, float(lnL.max()), int(args.steps * B))]
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_max = float(t.item())
+        # end-of-run gather of fixed-size per-pixel records
+        rec = torch.tensor([float(rank), float(lnL.max()), float(args.steps * B)],
+                           dtype=torch.float64, device='cuda')
+        out = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(out, rec)
+        summary = [(int(o[0].item()), float(o[1].item()), int(o[2].item())) for o in out]
+
+    if rank == 0:
+        total_evals = sum(s[2] for s in summary)
+        value = total_evals / t_max
+        bytes_eval = algorithmic_bytes(trans, n_chan, ncomp)
+        roof = None
+        if profile and calls.value > 0:
+            avg_s = lnl_ms.value / calls.value / 1e3
+            achieved = bytes_eval * B / avg_s / 1e9
+            roof = {
+                'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'kernel': 'lnl_kernel', 'avg_launch_us': avg_s * 1e6,
+                'algorithmic_bytes_per_eval': bytes_eval, 'evals_per_launch': B,
+                'prior_kernel_avg_us': prior_ms.value / calls.value * 1e3,
+                'note': 'algorithmic bytes (SURVEY 8d) / lnl_kernel time; the kernel is fp64-VALU '
+                        'bound, the pixel data stay in L2 (see DESIGN.md)',
+            }
+            tfile = ROOT / 'profiles' / 'pmc_traffic.json'
+            if tfile.exists():
+                try:
+                    roof['traffic'] = json.loads(tfile.read_text()).get(args.workload, {}).get(
+                        args.exp_mode)
+                except Exception:
+                    pass
+        cpu = None
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(spec_data, ut.lower(), ncomp, U_host)
+        name = C.create_string_buffer(128)
+        lib.nfa_device_name(name, 128)
+        line = {
+            'metric': 'loglikelihood evals/sec, 1024-ch 2-comp NH3(1,1)+(2,2); HBM GB/s vs peak',
+            'value': value, 'unit': 'evals/s', 'n_gpus': args.gpus, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': t_max / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'{args.workload}: B={B} live-point draws per step per GPU, '
+                            f'NH3 {"+".join(f"({t},{t})" for t in trans)}, {n_chan} ch, '
+                            f'{ncomp} comp, get_irdc_priors(size=500)',
+                'exp_mode': args.exp_mode, 'pixels_per_gpu': 1, 'sharding': 'pixel stripes, no collective',
+                'device': name.value.decode(),
+            },
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        if cpu:
+            line['speedup_vs_cpu_all_cores'] = value / cpu['value']
+        print(json.dumps(line), flush=True)
+
+    lib.nfa_free(d_U)
+    lib.nfa_free(d_lnL)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -144,6 +144,11 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
 int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_U,
                                  double *d_lnL, int64_t B);
 int nfa_runner_synchronize(nfa_runner *r);
+/* Per-kernel timing of nfa_runner_loglike_batch_dev with HIP events recorded on
+ * the runner's stream: summed milliseconds of the prior-transform kernel and of
+ * the likelihood kernel over the calls made since profiling was switched on. */
+int nfa_runner_set_profiling(nfa_runner *r, int on);
+int nfa_runner_get_profile(nfa_runner *r, double *prior_ms, double *lnl_ms, int64_t *calls);
 
 /* MultiNest `LogLike` (nestfit/core/cmultinest.pxd:27-28; the reference's
  * trampoline is mn_loglikelihood, nestfit/core/core.pyx:622-624).  Pass the

@@ -764,6 +764,10 @@ struct nfa_runner {
     double *d_U = nullptr, *d_lnL = nullptr, *d_spec = nullptr;
     int    *d_pix = nullptr;
     int64_t cap_B = 0, cap_spec = 0;
+    // optional per-kernel timing (HIP events on the runner's stream)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;      // triples: before priors, before lnl, after lnl
+    size_t ev_used = 0;
 };
 
 extern "C" {
@@ -1001,6 +1005,7 @@ int nfa_runner_destroy(nfa_runner *r) {
     if (!r) return NFA_OK;
     (void)hipStreamSynchronize(r->stream);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
+    for (hipEvent_t x : r->ev) (void)hipEventDestroy(x);
     (void)hipStreamDestroy(r->stream);
     delete r;
     return NFA_OK;
@@ -1081,9 +1086,44 @@ int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_
     if (!r || !d_U || !d_lnL) return fail(NFA_ERR_ARG, "null argument");
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     if (B <= 0) return NFA_OK;
+    hipEvent_t *e = nullptr;
+    if (r->profiling) {
+        if (r->ev_used + 3 > r->ev.size()) {
+            for (int k = 0; k < 3; ++k) { hipEvent_t x; HIP_TRY(hipEventCreate(&x)); r->ev.push_back(x); }
+        }
+        e = &r->ev[r->ev_used];
+        r->ev_used += 3;
+        HIP_TRY(hipEventRecord(e[0], r->stream));
+    }
     int rc = launch_priors(r->pr, d_U, B, r->ncomp, r->stream);
     if (rc) return rc;
-    return launch_lnl(r, d_pix, d_U, d_lnL, nullptr, B);
+    if (e) HIP_TRY(hipEventRecord(e[1], r->stream));
+    rc = launch_lnl(r, d_pix, d_U, d_lnL, nullptr, B);
+    if (rc) return rc;
+    if (e) HIP_TRY(hipEventRecord(e[2], r->stream));
+    return NFA_OK;
+}
+
+int nfa_runner_set_profiling(nfa_runner *r, int on) {
+    if (!r) return fail(NFA_ERR_ARG, "null runner");
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    r->profiling = on != 0;
+    r->ev_used = 0;
+    return NFA_OK;
+}
+
+int nfa_runner_get_profile(nfa_runner *r, double *prior_ms, double *lnl_ms, int64_t *calls) {
+    if (!r || !prior_ms || !lnl_ms || !calls) return fail(NFA_ERR_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    double a = 0, b = 0;
+    for (size_t k = 0; k + 2 < r->ev_used + 0 && k + 2 < r->ev.size() + 0; k += 3) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, r->ev[k], r->ev[k + 1])); a += t;
+        HIP_TRY(hipEventElapsedTime(&t, r->ev[k + 1], r->ev[k + 2])); b += t;
+    }
+    *prior_ms = a; *lnl_ms = b; *calls = (int64_t)(r->ev_used / 3);
+    r->ev_used = 0;
+    return NFA_OK;
 }
 
 int nfa_runner_synchronize(nfa_runner *r) {
