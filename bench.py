@@ -106,7 +106,8 @@ def main():
     ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='rows per step (default: workload B)')
     ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'table'),
-                    choices=['table', 'poly'])
+                    choices=['table', 'poly', 'fast'])
+    ap.add_argument('--nparts', type=int, default=0, help='engine A/B knob: waves per spectrum (0 = auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile-events', action='store_true',
                     help='do not record per-kernel HIP events inside the timed region')
@@ -122,6 +123,8 @@ def main():
     from nestfit_amd import _ffi, synth
     na.set_device(local_rank)                 # one process per GPU, before any other call
     na.set_exp_mode(args.exp_mode)
+    if args.nparts:
+        _ffi.set_option('nparts', args.nparts)
     lib = _ffi.engine()
 
     dist = None

@@ -43,9 +43,15 @@ int nfa_device_name(char *buf, int buflen);
  *       (nestfit/core/fastexp.c:234-283), bit-identical table indices;
  *   1 = "poly" : exp(-(double)(float)x) by fp64 range reduction + polynomial,
  *       same branch structure (negative / zero / Taylor / >=32), <=4e-16 rel
- *       from the table product. */
+ *       from the table product;
+ *   2 = "fast" : window / table indices and the float-narrowed FastExp argument
+ *       in fp64 exactly as above, exponentials in fp32 with split exponents;
+ *       <= 1e-6 relative on brightness temperature (the metric's tolerance). */
 int nfa_set_exp_mode(int mode);
 int nfa_get_exp_mode(void);
+/* Engine tuning knobs for A/B measurements: "nparts" = waves per spectrum of
+ * one item in the likelihood kernel (0 = automatic). */
+int nfa_set_option(const char *key, int value);
 
 /* 1/(e^x-1) interpolation table.  The reference builds T0_X, T0_Y with numpy at
  * import (nestfit/models/hyperfine.pyx:12-20); the host passes the same
@@ -167,7 +173,7 @@ int nfa_event_synchronize(void *ev);
 int nfa_event_elapsed_ms(void *start, void *stop, float *ms);
 
 /* ---- unit-test hooks (device evaluation of the scalar building blocks) ---- */
-int nfa_test_fastexp(const double *x, double *out, int64_t n, int mode);    /* fastexp.c:234-283 via math.pxd:17 */
+int nfa_test_fastexp(const double *x, double *out, int64_t n, int mode);    /* fastexp.c:234-283 via math.pxd:17; mode 3: 1 - FastExp(x) of the fast mode */
 int nfa_test_iemtex(const double *x, double *out, int64_t n);               /* hyperfine.pyx:23-45 */
 int nfa_test_partition(const double *trot, double *qpara, double *qorth, int64_t n); /* ammonia.pyx:304-315 */
 int nfa_test_windows(nfa_runner *r, int spec, double voff, double sigm,

@@ -43,6 +43,7 @@ SIGNATURES = {
     'nfa_device_name': (C.c_int, [C.c_char_p, C.c_int]),
     'nfa_set_exp_mode': (C.c_int, [C.c_int]),
     'nfa_get_exp_mode': (C.c_int, []),
+    'nfa_set_option': (C.c_int, [C.c_char_p, C.c_int]),
     'nfa_set_iemtex_table': (C.c_int, [_dp, _dp, C.c_int64]),
     'nfa_specset_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _lp, _ip,
                                      C.POINTER(_dp), C.c_int64, _dp, _dp]),
@@ -145,9 +146,14 @@ def device_count():
 
 
 def set_exp_mode(mode):
-    """0/'table': LDS product tables (reference FastExp); 1/'poly': fp64 polynomial."""
-    mode = {'table': 0, 'poly': 1}.get(mode, mode)
+    """0/'table': LDS product tables (reference FastExp); 1/'poly': fp64 polynomial;
+    2/'fast': fp32 exponentials on the fp64 float-narrowed arguments."""
+    mode = {'table': 0, 'poly': 1, 'fast': 2}.get(mode, mode)
     check(load().nfa_set_exp_mode(int(mode)))
+
+
+def set_option(key, value):
+    check(load().nfa_set_option(key.encode(), int(value)))
 
 
 def get_exp_mode():

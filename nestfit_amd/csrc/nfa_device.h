@@ -1,0 +1,974 @@
+// nfa_device.h -- device code of the MI355X (gfx950) NH3 log-likelihood engine.
+//
+// Hot path of autocorr/nestfit v0.2 (AmmoniaRunner.c_loglikelihood,
+// nestfit/models/ammonia.pyx:423-432) as two kernels per batch:
+//
+//   setup_kernel    unit cube -> theta            core/core.pyx:459-476
+//                   theta -> channel-independent  models/ammonia.pyx:337-361
+//                   scalars (Trot/Tex, partition sums, main-line tau)
+//   lnl_kernel      model spectrum + chi^2        models/hyperfine.pyx:52-118,
+//                                                 core/core.pyx:522-530
+//
+// lnl_kernel execution model (wave = 64 lanes):
+//   * a work item is one (theta, pixel); it is cut into WPI = n_spec x n_parts
+//     wavefronts, one per (spectrum, interleaved row part), so that a batch of a
+//     few thousand live points still puts >= 8 waves on every SIMD;
+//   * inside a wave lanes are frequency channels: a row is 64 consecutive
+//     channels (coalesced 512-B loads of x, data, T0, tbg); the optical depth of
+//     the row lives in one register per lane;
+//   * the (component, hyperfine line) constants of the wave's spectrum are formed
+//     with lanes = lines, kept in the wave's LDS slice and broadcast-read in the
+//     row loop; a ballot over the line windows selects the lines that touch a row;
+//   * chi^2 is reduced with wave shuffles, the WPI partial sums of an item meet in
+//     LDS at one workgroup barrier (fixed summation order: bitwise reproducible).
+// No MFMA: the path is elementwise fp64/fp32 plus reductions.
+//
+// Numerical modes (template MODE): 0 "table" and 1 "poly" evaluate FastExp like
+// the reference (float-narrowed argument, Taylor below 2^-5, zero from 32, same
+// table indices) in fp64; 2 "fast" keeps every index computation in fp64 but
+// evaluates the exponentials in fp32 with split exponents (<= 3e-7 relative on
+// Tb, tolerance of the metric: 1e-6).
+//
+// Compile with -ffp-contract=off: FMA only where written, so window and table
+// indices round like the reference's plain double arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MAXSPEC   16
+#define MAXCOMP   10          // ResolvedPlacementPrior's own limit (core.pyx:399)
+#define T0_SIZE   1000
+// table layout inside g_tabs (doubles); the LDS copy starts at SM_EXP2
+#define SM_T0X    0
+#define SM_T0Y    1000
+#define SM_EXP2   2000        // 2^(i/32), i = 0..31          (poly)
+#define SM_FEA    2032        // exp(-(128+j) 2^(l-12)) [10][128] (table)
+#define SM_FEB    (SM_FEA + 1280)   // exp(-j 2^(l-20)) [10][256]
+#define SM_FEC    (SM_FEB + 2560)   // exp(-j 2^(l-28)) [10][256]
+#define SM_END_POLY   2032
+#define SM_END_TABLE  (SM_FEC + 2560)   // 8432 doubles
+
+__constant__ int    c_nhf[NFA_N_LEVELS];
+__constant__ double c_nu[NFA_N_LEVELS];
+__constant__ double c_ea[NFA_N_LEVELS];
+__constant__ double c_voff[NFA_N_LEVELS][NFA_MAX_HF_N];
+__constant__ double c_tauw[NFA_N_LEVELS][NFA_MAX_HF_N];
+
+struct SpecDev {
+    int     n_spec, ncomp, cold, lte;
+    int     size[MAXSPEC], trans[MAXSPEC], off[MAXSPEC];
+    double  nu_min[MAXSPEC], nu_chan[MAXSPEC];
+    int64_t chan_tot;
+    const double *xarr, *t0, *tbg, *data, *noise;
+    double  t0_xmin, t0_xmax, t0_inv_dx;
+};
+
+// derived-parameter record of one item (doubles), written by setup_kernel:
+//   [c*4 + 0] tex  [c*4 + 1] sigm/CKMS  [c*4 + 2] voff/CKMS  [c*4 + 3] 1/tex
+//   [4*ncomp + (c*nspec + s)*DREC_CS + 0] main-line optical depth of (component, spectrum)
+//                                    + 1 kind, + 2.. the y(T0) = 1/(e^(T0/tex)-1) model:
+// x = T0/tex is monotonic in the channel, so the table cells of the first and last channel
+// of the spectrum bound the cells of all its channels.  The fast mode evaluates
+//      up = !(T0 < split);  dT = T0 - m;  y = (up ? A1 : A0) + ((up ? B1 : B0) + q dT) dT
+//   kind 1  one table cell:      A0 + B0 T0                         (split = inf, m = q = 0)
+//   kind 2  two adjacent cells:  second cell from T0 >= split       (m = q = 0)
+//   kind 3  outside the table:   Taylor of 1/expm1 about the band centre m (split = inf)
+//   kind 0  anything else:       per-channel evaluation of hyperfine.pyx:23-45
+#define DREC_CS 10
+#define DK_TMAIN 0
+#define DK_KIND  1
+#define DK_A0 2
+#define DK_B0 3
+#define DK_A1 4
+#define DK_B1 5
+#define DK_SPLIT 6
+#define DK_M 7
+#define DK_Q 8
+__host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncomp + ncomp * nspec * DREC_CS; }
+
+struct LnlGeom {
+    int nhf_max;       // lines per component slot in the LDS line table
+    int wave_doubles;  // LDS doubles per wave
+    int nparts;        // interleaved row parts per spectrum
+    int wpi;           // waves per item = n_spec * nparts
+    int ipb;           // items per workgroup
+};
+
+// ---------------------------------------------------------------------------
+//  wave-level helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in order; this only stops the
+    // compiler from moving LDS accesses across the hand-off point.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_excl_scan(double v, int lane, double *total) {
+    double inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    *total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+
+// Rarely taken libm paths kept out of line so they do not inflate the register
+// budget of the hot loops.
+__device__ __attribute__((noinline)) double slow_inv_expm1(double x) { return 1.0 / expm1(x); }
+__device__ __attribute__((noinline)) double slow_exp(double x) { return exp(x); }
+__device__ __attribute__((noinline)) double slow_pow(double x, double y) { return pow(x, y); }
+__device__ __attribute__((noinline)) double slow_log10(double x) { return log10(x); }
+__device__ __attribute__((noinline)) double slow_log(double x) { return log(x); }
+
+// ---------------------------------------------------------------------------
+//  FastExp replacement (reference: nestfit/core/fastexp.c:234-283, entered with
+//  a double narrowed to float, nestfit/core/math.pxd:17)
+// ---------------------------------------------------------------------------
+// exp(-t) for t = (double)float in [2^-5, 32): n = rint(-t*32/ln2),
+// exp(-t) = 2^(n>>5) * 2^((n&31)/32) * exp(r), |r| <= ln2/64.
+__device__ __forceinline__ double exp_neg_poly(double t, const double *sm) {
+    const double C32 = 46.16624130844682903551758979206054;   // 32/ln2
+    const double L_HI = 6.93147180369123816490e-01 / 32.0;    // fdlibm ln2 split
+    const double L_LO = 1.90821492927058770002e-10 / 32.0;
+    const double n = __builtin_rint(-t * C32);
+    double r = __builtin_fma(-n, L_HI, -t);
+    r = __builtin_fma(-n, L_LO, r);
+    const int ni = (int)n;
+    const int m = ni & 31, q = ni >> 5;
+    double p = 1.0 / 720.0;
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double v = sm[SM_EXP2 + m] * p;
+    // multiply by 2^q (result stays normal: q >= -47 for t < 32)
+    return __longlong_as_double(__double_as_longlong(v) + ((long long)q << 52));
+}
+
+// MODE 0: the reference's three-table product; MODE 1: polynomial.  The
+// branches of fastexp.c (negative, zero, Taylor, >= 32) are rare per wave and
+// handled under one wave-uniform test.
+template <int MODE>
+__device__ __forceinline__ double nf_fastexp(double xd, const double *sm) {
+    const float x = (float)xd;                               // math.pxd:17 narrowing
+    const uint32_t bits = __float_as_uint(x);
+    const int l = (int)((bits & 0x7f800000u) >> 23) - 122;    // fastexp.c:262
+    double r;
+    if (MODE == 0) {
+        const int lc = min(max(l, 0), 9);
+        const int j0 = (bits & 0x007f0000u) >> 16;            // fastexp.c:276-278
+        const int j1 = (bits & 0x0000ff00u) >> 8;
+        const int j2 = (bits & 0x000000ffu);
+        r = sm[SM_FEA + lc * 128 + j0] * sm[SM_FEB + lc * 256 + j1] * sm[SM_FEC + lc * 256 + j2];
+    } else {
+        r = exp_neg_poly((double)x, sm);                      // out-of-range lanes are replaced below
+    }
+    const bool special = (l < 0) || (l >= 10) || (x < 0.0f);
+    if (__ballot(special) != 0ull) {
+        const double t = (double)x;                           // fastexp.c:264-270; x == 0 gives exactly 1
+        double ty = 1.0 - t * (1.0 / 3.0);
+        ty = 1.0 - (t * ty) * 0.5;
+        ty = 1.0 - (t * ty);
+        r = (l < 0) ? ty : r;
+        r = (l >= 10) ? 0.0 : r;                              // fastexp.c:272-273 (also NaN, inf)
+        if (x < 0.0f) r = slow_exp(-(double)x);               // fastexp.c:259
+    }
+    return r;
+}
+
+// exp(-x) in fp32 with the exponent split in two floats (MODE 2).  Like FastExp:
+// exactly 0 from x = 32 (and for NaN), exp(|x|) for negative x.
+__device__ __forceinline__ float exp_neg_f32(float x) {
+    const float NEG_L2E_HI = -1.44269502162933349609375f;         // -(float)log2(e)
+    const float NEG_L2E_LO = -1.925963033500011e-08f;             // -(log2(e) - hi)
+    const float LN2F = 0.693147180559945f;
+    const float yh = x * NEG_L2E_HI;
+    float yl = __builtin_fmaf(x, NEG_L2E_HI, -yh);
+    yl = __builtin_fmaf(x, NEG_L2E_LO, yl);
+    float e = __builtin_amdgcn_exp2f(yh);
+    e = __builtin_fmaf(e * LN2F, yl, e);
+    return (x < 32.0f) ? e : 0.0f;
+}
+
+// 1/(e^x-1) (nestfit/models/hyperfine.pyx:23-45), tables in global memory:
+// the index is nearly uniform over a row, the reads stay in L1.
+__device__ __forceinline__ double nf_iemtex(double x, const double *__restrict__ t0x,
+                                            const double *__restrict__ t0y, double xmin,
+                                            double xmax, double inv_dx) {
+    const bool in_tab = (xmin < x) && (x < xmax);
+    long i_lo = in_tab ? (long)((x - xmin) * inv_dx) : 0;
+    i_lo = i_lo > T0_SIZE - 2 ? T0_SIZE - 2 : i_lo;           // never taken inside the table
+    const double x_lo = t0x[i_lo];
+    const double y_lo = t0y[i_lo];
+    const double y_hi = t0y[i_lo + 1];
+    const double slope = (y_hi - y_lo) * inv_dx;
+    double res = slope * (x - x_lo) + y_lo;
+    if (!in_tab) res = slow_inv_expm1(x);
+    return res;
+}
+
+__device__ __forceinline__ double nf_swift(double tkin) {    // ammonia.pyx:280-286
+    return tkin / (1.0 + (tkin / 41.18) * slow_log(1.0 + 0.6 * slow_exp(-15.7 / tkin)));
+}
+
+template <int MODE>
+__device__ __forceinline__ double nf_partition_level(int j, double trot, const double *sm) {
+    // ammonia.pyx:289-295
+    const double dj = (double)j;
+    const double arg = NFA_H * (NFA_BROT * dj * (double)(j + 1) + (NFA_CROT - NFA_BROT) * dj * dj)
+                       / (NFA_KB * trot);
+    return (double)(2 * j + 1) * nf_fastexp<MODE>(arg, sm);
+}
+
+// Line centre, width and channel window of hyperfine line i of transition t
+// (reference: nestfit/models/hyperfine.pyx:70-91).  Plain double arithmetic,
+// no contraction: the floor() arguments must round like the reference's.
+struct LineConst { double nucen, idenom; int lo, hi; };
+__device__ __forceinline__ LineConst nf_line(int t, int i, double v_over_c, double s_over_c, double nu0,
+                                             double nu_min, double nu_chan, int N) {
+    LineConst r;
+    const double hf_freq   = (1.0 - c_voff[t][i] / NFA_CKMS) * nu0;
+    const double hf_width  = s_over_c * hf_freq;             // (sigm / CKMS) * hf_freq
+    const double hf_offset = v_over_c * hf_freq;             // (voff / CKMS) * hf_freq
+    const double hf_nucen  = hf_freq - hf_offset;
+    const double hf_idenom = 0.5 / (hf_width * hf_width);
+    const double nu_cutoff = sqrt(12.5 / hf_idenom);
+    const double nu_lo = (hf_nucen - nu_min - nu_cutoff);
+    const double nu_hi = (hf_nucen - nu_min + nu_cutoff);
+    long lo = (long)floor(nu_lo / nu_chan);
+    long hi = (long)floor(nu_hi / nu_chan);
+    if (hi < 0 || lo > N - 1) { lo = 0; hi = 0; }             // `continue`: empty window
+    else {
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > N - 1 ? N - 1 : hi;
+    }
+    r.nucen = hf_nucen; r.idenom = hf_idenom; r.lo = (int)lo; r.hi = (int)hi;
+    return r;
+}
+
+// The LDS copy of the exponential tables starts at smem[0]; helper functions
+// index with the absolute g_tabs offsets, hence the shifted base pointer.
+template <int MODE>
+__device__ __forceinline__ const double *stage_exp_tables(double *smem, const double *g_tabs, int *n_shared) {
+    const int n = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : 32;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) smem[i] = g_tabs[SM_EXP2 + i];
+    __syncthreads();
+    *n_shared = n;
+    return smem - SM_EXP2;
+}
+
+// ---------------------------------------------------------------------------
+//  derive_item: everything of c_amm_predict that does not depend on the channel
+//  (ammonia.pyx:337-361), one wave per item.  The heavy libm calls live here
+//  (setup_kernel) so that lnl_kernel stays lean.
+// ---------------------------------------------------------------------------
+#define COMP_STRIDE 8        // LDS per component: trot, tex, qpara, qorth, 10**ntot, spare x3
+
+// One item: theta (LDS, w_theta[ndim]) -> record Db.  w_comp[ncomp*COMP_STRIDE] and
+// w_zlev[ncomp*9] are LDS scratch of the wave.
+template <int MODE>
+__device__ __forceinline__ void derive_item(const SpecDev &S, const double *w_theta, double *w_comp,
+                                            double *w_zlev, double *__restrict__ Db, const double *sm,
+                                            const double *__restrict__ g_tabs, int lane) {
+    const int ncomp = S.ncomp, nspec = S.n_spec;
+    if (lane < ncomp) {                                      // ammonia.pyx:337-346, 351
+        double trot = w_theta[ncomp + lane];
+        double tex  = w_theta[2 * ncomp + lane];
+        if (S.cold) trot = nf_swift(trot);
+        if (S.lte) tex = trot;
+        double *cc = w_comp + lane * COMP_STRIDE;
+        cc[0] = trot;
+        cc[1] = tex;
+        cc[4] = slow_pow(10.0, w_theta[3 * ncomp + lane]);
+        double *d = Db + lane * 4;
+        d[0] = tex;
+        d[1] = w_theta[4 * ncomp + lane] / NFA_CKMS;         // hyperfine.pyx:72
+        d[2] = w_theta[lane] / NFA_CKMS;                     // hyperfine.pyx:73
+        d[3] = 1.0 / tex;
+    }
+    wave_lds_sync();
+    for (int c = 0; c < ncomp; ++c) {                        // ammonia.pyx:304-315, 347-348
+        const double trot = w_comp[c * COMP_STRIDE];
+        const int j = lane;
+        double lev = 0.0;
+        if (j < NFA_NPART) lev = nf_partition_level<MODE>(j, trot, sm);
+        const bool is_orth = (j % 3) == 0;
+        const double qp = wave_sum((j < NFA_NPART && !is_orth) ? lev : 0.0);
+        const double qo = wave_sum((j < NFA_NPART && is_orth) ? 2 * lev : 0.0);
+        if (lane == 0) { w_comp[c * COMP_STRIDE + 2] = qp; w_comp[c * COMP_STRIDE + 3] = qo; }
+        if (j >= 1 && j <= NFA_N_LEVELS) w_zlev[c * NFA_N_LEVELS + (j - 1)] = lev;
+    }
+    wave_lds_sync();
+    for (int k = lane; k < ncomp * nspec; k += 64) {         // ammonia.pyx:349-361
+        const int c = k / nspec, s = k - c * nspec;
+        const int t = S.trans[s] - 1;
+        const double nu0 = c_nu[t];
+        const bool para = ((t + 1) % 3) != 0;
+        const double *cc = w_comp + c * COMP_STRIDE;
+        const double tex = cc[1];
+        const double sigm = w_theta[4 * ncomp + c];
+        const double orth = w_theta[5 * ncomp + c];
+        const double zlev = w_zlev[c * NFA_N_LEVELS + t];
+        const double qtot = para ? cc[2] : cc[3];
+        const double species_frac = para ? 1.0 - orth : orth;
+        const double pop_rotstate = cc[4] * species_frac * zlev / qtot;
+        const double ex = slow_exp(-NFA_H * nu0 / (NFA_KB * tex));
+        const double expterm = (1.0 - ex) / (1.0 + ex);
+        const double fracterm = (NFA_CCMS * NFA_CCMS) * c_ea[t] / (8 * M_PI * (nu0 * nu0));
+        const double widthterm = NFA_CKMS / (sigm * nu0 * sqrt(2 * M_PI));
+        const double tau_main = pop_rotstate * fracterm * expterm * widthterm;
+        double *dk = Db + 4 * ncomp + k * DREC_CS;
+        dk[DK_TMAIN] = slow_pow(10.0, slow_log10(tau_main));         // ammonia.pyx:361, hyperfine.pyx:63
+        // y(T0) model over the spectrum's band (used by the fast mode only)
+        const double T0a = S.t0[S.off[s]], T0b = S.t0[S.off[s] + S.size[s] - 1];
+        const double inv_tex = 1.0 / tex;
+        const double xa = T0a * inv_tex, xb = T0b * inv_tex;
+        const bool ina = S.t0_xmin < xa && xa < S.t0_xmax, inb = S.t0_xmin < xb && xb < S.t0_xmax;
+        double kind = 0.0, A0 = 0.0, B0 = 0.0, A1 = 0.0, B1 = 0.0, split = INFINITY, m = 0.0, q = 0.0;
+        const double *t0x = g_tabs + SM_T0X, *t0y = g_tabs + SM_T0Y;
+        if (ina && inb) {
+            const long ia = (long)((xa - S.t0_xmin) * S.t0_inv_dx);
+            const long ib = (long)((xb - S.t0_xmin) * S.t0_inv_dx);
+            if (ia >= 0 && ib <= T0_SIZE - 2 && ib - ia <= 1) {
+                const double sl0 = (t0y[ia + 1] - t0y[ia]) * S.t0_inv_dx;
+                A0 = t0y[ia] - sl0 * t0x[ia];
+                B0 = sl0 * inv_tex;
+                A1 = A0; B1 = B0;
+                kind = 1.0;
+                if (ib != ia) {
+                    const double sl1 = (t0y[ib + 1] - t0y[ib]) * S.t0_inv_dx;
+                    A1 = t0y[ib] - sl1 * t0x[ib];
+                    B1 = sl1 * inv_tex;
+                    split = t0x[ib] * tex;
+                    kind = 2.0;
+                }
+            }
+        } else if (!ina && !inb && ((xa <= S.t0_xmin && xb <= S.t0_xmin) || (xa >= S.t0_xmax && xb >= S.t0_xmax))) {
+            m = 0.5 * (T0a + T0b);
+            const double y = slow_inv_expm1(m * inv_tex);
+            A0 = y;
+            B0 = -y * (1.0 + y) * inv_tex;
+            q = 0.5 * (1.0 + 2.0 * y) * y * (1.0 + y) * inv_tex * inv_tex;
+            A1 = A0; B1 = B0;
+            kind = 3.0;
+        }
+        dk[DK_KIND] = kind; dk[DK_A0] = A0; dk[DK_B0] = B0; dk[DK_A1] = A1; dk[DK_B1] = B1;
+        dk[DK_SPLIT] = split; dk[DK_M] = m; dk[DK_Q] = q; dk[9] = 0.0;
+    }
+    wave_lds_sync();
+}
+
+// ---------------------------------------------------------------------------
+//  lnl_kernel
+// ---------------------------------------------------------------------------
+struct __attribute__((aligned(16))) LineRec {
+    double nucen, idenom;                        // first 16-B read
+    union { double htau; float htau_f; };        // second 16-B read: weight and window
+    int lo, len;                                 // window [lo, lo+len)
+};
+
+// 1 - FastExp(tau) of the reference for fp32 tau (MODE 2): the reference's cubic
+// below 2^-5 (fastexp.c:264-270) including its 1 - (1 - q) rounding, which decides
+// where a faint channel comes out exactly 0; tau*P8(tau) below 0.5; 1 - exp(-tau)
+// above (exactly 1 from 32 and for NaN).
+__device__ __forceinline__ double one_minus_fastexp_f32(float t) {
+    const float r3 = __builtin_fmaf(t, -1.0f / 3.0f, 1.0f);
+    const float r2 = __builtin_fmaf(t * r3, -0.5f, 1.0f);
+    const double r1 = 1.0 - (double)(t * r2);
+    const double w_small = 1.0 - r1;
+    float p = 1.0f / 362880.0f;                               // (1 - e^-t)/t = sum (-t)^k/(k+1)!
+    p = __builtin_fmaf(p, t, -1.0f / 40320.0f);
+    p = __builtin_fmaf(p, t, 1.0f / 5040.0f);
+    p = __builtin_fmaf(p, t, -1.0f / 720.0f);
+    p = __builtin_fmaf(p, t, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, t, -1.0f / 24.0f);
+    p = __builtin_fmaf(p, t, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, t, -0.5f);
+    p = __builtin_fmaf(p, t, 1.0f);
+    const float w_big = 1.0f - exp_neg_f32(t);
+    const float wf = (t < 0.5f) ? t * p : w_big;
+    return (t < 0.03125f) ? w_small : (double)wf;
+}
+
+template <int MODE, bool WRITE_SPEC>
+__global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restrict__ pix,
+                                                   const double *__restrict__ D,
+                                                   double *__restrict__ lnL,
+                                                   double *__restrict__ spec_out, long B, LnlGeom G,
+                                                   const double *__restrict__ g_tabs) {
+    typedef typename std::conditional<MODE == 2, float, double>::type tau_t;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int n_shared;
+    const double *sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);
+    const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
+
+    // everything derived from the wave index is wave-uniform: keep it in SGPRs so that the
+    // SpecDev fields it selects come through scalar loads and the loops stay uniform
+    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ncomp = S.ncomp, nspec = S.n_spec;
+    const int drec = drec_size(ncomp, nspec);
+    const int il = wave / G.wpi, part = wave - il * G.wpi;   // item slot in the block, part of the item
+    const int s = part / G.nparts, rp = part - s * G.nparts;
+    // LDS: [tables][red: waves][per item slot: D record, then per spectrum the line table]
+    double *red = smem + n_shared;                            // [waves] partial chi^2
+    double *slot = red + ((waves + 1) & ~1) + (size_t)il * G.wave_doubles;   // wave_doubles = per item slot
+    double *w_d = slot;
+    const int P = ncomp * G.nhf_max;
+    LineRec *w_line = (LineRec *)(slot + ((drec + 1) & ~1)) + (size_t)s * P;
+    int2 *w_win = (int2 *)((LineRec *)(slot + ((drec + 1) & ~1)) + (size_t)nspec * P) + (size_t)s * P;
+
+    const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
+    const int nhf = c_nhf[t];
+    const double nu0 = c_nu[t];
+    const double *xs = S.xarr + off, *t0s = S.t0 + off, *tbgs = S.tbg + off;
+
+    for (long b0 = (long)blockIdx.x * G.ipb; b0 < B; b0 += (long)gridDim.x * G.ipb) {
+        const long b = b0 + il;
+        const bool item = b < B;
+        double acc = 0.0;
+        long p_ix = 0;
+        if (item) {
+            p_ix = pix ? (long)pix[b] : 0;
+            // the item's record: loaded by its first wave
+            if (part == 0) for (int k = lane; k < drec; k += 64) w_d[k] = D[b * drec + k];
+        }
+        __syncthreads();
+        if (item) {
+            // --- line constants + windows of spectrum s, lanes = (component, line) pairs,
+            //     shared by the nparts waves of the spectrum (hyperfine.pyx:68-91)
+            for (int p = rp * 64 + lane; p < ncomp * nhf; p += 64 * G.nparts) {
+                const int c = p / nhf, i = p - c * nhf;
+                const LineConst lc = nf_line(t, i, w_d[c * 4 + 2], w_d[c * 4 + 1], nu0, S.nu_min[s],
+                                             S.nu_chan[s], N);
+                int lo = lc.lo;
+                const int hi = lc.hi;
+                // Only the first channel of a window can lie beyond the point where
+                // FastExp returns exactly 0 (float argument >= 32, fastexp.c:272-273; also
+                // NaN): it then adds nothing, so the hot loop starts one channel later and
+                // needs no cut-off test.
+                if (hi > lo) {
+                    const double nu = xs[lo] - lc.nucen;
+                    const float a = (float)(nu * nu * lc.idenom);
+                    if (!(a < 32.0f)) lo += 1;
+                }
+                LineRec rec;
+                rec.nucen = lc.nucen;
+                rec.idenom = lc.idenom;
+                const double htau = w_d[4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
+                if (MODE == 2) { rec.htau = 0.0; rec.htau_f = (float)htau; } else rec.htau = htau;
+                rec.lo = lo;
+                rec.len = hi > lo ? hi - lo : 0;
+                w_line[c * G.nhf_max + i] = rec;
+                w_win[c * G.nhf_max + i] = make_int2(lo, hi > lo ? hi : lo);
+            }
+        }
+        __syncthreads();
+        if (item) {
+            // --- rows of 64 channels: tau profile, Tb, chi^2
+            //     (hyperfine.pyx:93-113, core.pyx:522-530); this wave owns rows rp, rp+nparts, ...
+            const double *ds = S.data + p_ix * S.chan_tot + off;
+            for (int r0 = rp * 64; r0 < N; r0 += 64 * G.nparts) {
+                const int j = r0 + lane;
+                const bool valid = j < N;
+                const int jj = valid ? j : N - 1;
+                const double xj = xs[jj];
+                const double dj = ds[jj];
+                const double T0 = t0s[jj];
+                const double tbg = tbgs[jj];
+                double pred = 0.0;
+                for (int c = 0; c < ncomp; ++c) {
+                    const LineRec *lines = w_line + c * G.nhf_max;
+                    int2 win = make_int2(0, 0);
+                    if (lane < nhf) win = w_win[c * G.nhf_max + lane];
+                    unsigned long long mask = __ballot(win.y > win.x && win.x < r0 + 64 && win.y > r0);
+                    if (mask == 0ull) continue;
+                    tau_t tau = 0;
+                    // software-pipelined walk over the lines that touch this row: the
+                    // record of the next line is in flight while the current one is used
+                    int i = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    LineRec rec = lines[i];
+                    while (true) {
+                        const bool more = mask != 0ull;
+                        LineRec nxt = rec;
+                        if (more) {
+                            i = __builtin_ctzll(mask);
+                            mask &= mask - 1;
+                            nxt = lines[i];
+                        }
+                        const double nu = xj - rec.nucen;
+                        const double tau_exp = nu * nu * rec.idenom;
+                        const bool inwin = (unsigned)(j - rec.lo) < (unsigned)rec.len;
+                        if (MODE == 2) {
+                            const float x = (float)tau_exp;               // math.pxd:17 narrowing
+                            const float NEG_L2E_HI = -1.44269502162933349609375f;
+                            const float NEG_L2E_LO = -1.925963033500011e-08f;
+                            const float yh = x * NEG_L2E_HI;
+                            float yl = __builtin_fmaf(x, NEG_L2E_HI, -yh);
+                            yl = __builtin_fmaf(x, NEG_L2E_LO, yl);
+                            float e = __builtin_amdgcn_exp2f(yh);
+                            e = __builtin_fmaf(e * 0.693147180559945f, yl, e);
+                            tau = inwin ? __builtin_fmaf(rec.htau_f, e, (float)tau) : tau;
+                        } else {
+                            const double e = nf_fastexp<MODE>(tau_exp, sm);
+                            tau = inwin ? __builtin_fma(rec.htau, e, (double)tau) : tau;
+                        }
+                        if (!more) break;
+                        rec = nxt;
+                    }
+                    const bool live = valid && !(tau == 0);           // hyperfine.pyx:104-105
+                    if (__ballot(live) == 0ull) continue;
+                    double tb;
+                    const double *dk = w_d + 4 * ncomp + (c * nspec + s) * DREC_CS;
+                    if (MODE == 2 && dk[DK_KIND] != 0.0) {
+                        const bool up = !(T0 < dk[DK_SPLIT]);
+                        const double dT = T0 - dk[DK_M];
+                        const double ya = up ? dk[DK_A1] : dk[DK_A0];
+                        const double yb = up ? dk[DK_B1] : dk[DK_B0];
+                        const double y = __builtin_fma(__builtin_fma(dk[DK_Q], dT, yb), dT, ya);
+                        tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
+                    } else {
+                        const double y = nf_iemtex(T0 / w_d[c * 4], g_t0x, g_t0y, S.t0_xmin, S.t0_xmax,
+                                                   S.t0_inv_dx);
+                        if (MODE == 2) tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
+                        else tb = (T0 * (y - tbg)) * (1.0 - nf_fastexp<MODE>((double)tau, sm));
+                    }
+                    if (live) pred += tb;
+                }
+                if (WRITE_SPEC) { if (valid) spec_out[b * S.chan_tot + off + j] = pred; }
+                const double dev = dj - pred;
+                if (valid) acc = __builtin_fma(dev, dev, acc);
+            }
+            acc = wave_sum(acc);
+        }
+        // --- the item's partial sums meet in LDS; fixed order (core.pyx:530, ammonia.pyx:429-432)
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (item && part == 0 && lane == 0 && lnL) {
+            double tot = 0.0;
+            for (int ss = 0; ss < nspec; ++ss) {
+                double a = 0.0;
+                for (int q = 0; q < G.nparts; ++q) a += red[il * G.wpi + ss * G.nparts + q];
+                const double noise = S.noise[p_ix * nspec + ss];
+                tot += -a / (2 * (noise * noise));
+            }
+            lnL[b] = tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+//  prior_kernel: PriorTransformer.c_transform (core.pyx:459-476), one wave per
+//  unit-cube row, in place.
+// ---------------------------------------------------------------------------
+struct DistDev {
+    int     size, pad;
+    double  du, dx, xmin, xmax;
+    const double *xax, *pdf, *cdf, *ppf;
+};
+#define MAXPRIOR 16
+#define MAXDIST  16
+struct PriorProg {
+    int n_prior, n_dist, n_param, max_size;
+    nfa_prior_desc pr[MAXPRIOR];
+    DistDev        ds[MAXDIST];
+};
+
+__device__ __forceinline__ double d_ppf_interp(const DistDev &d, double u) {   // core.pyx:47-63
+    long i_lo = (long)((double)(d.size - 1) * u);
+    long i_hi = i_lo + 1;
+    i_lo = i_lo < 0 ? 0 : (i_lo > d.size - 1 ? d.size - 1 : i_lo);   // u==1 reads past the end
+    i_hi = i_hi > d.size - 1 ? d.size - 1 : (i_hi < 0 ? 0 : i_hi);   // in the reference; clamp
+    const double x_lo = (double)i_lo * d.du;
+    const double y_lo = d.ppf[i_lo];
+    const double y_hi = d.ppf[i_hi];
+    const double slope = (y_hi - y_lo) / d.du;
+    return slope * (u - x_lo) + y_lo;
+}
+
+// `prior.interp(utheta, n)` of the simple kinds, lanes = components
+__device__ __forceinline__ void d_simple_interp(const PriorProg &pp, int kind, int dist, int p_ix,
+                                                double value, double *u, int n, int lane) {
+    const int ix = p_ix * n;
+    if (kind == NFA_PRIOR_CONSTANT) {                         // core.pyx:233-238
+        if (lane < n) u[ix + lane] = value;
+    } else if (kind == NFA_PRIOR_ORDERED) {                   // core.pyx:242-258
+        if (lane == 0) {
+            double umin = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const double uu = umin + (1 - umin) * u[ix + i];
+                umin = uu;
+                u[ix + i] = d_ppf_interp(pp.ds[dist], uu);
+            }
+        }
+    } else {                                                  // core.pyx:192-197
+        if (lane < n) u[ix + lane] = d_ppf_interp(pp.ds[dist], u[ix + lane]);
+    }
+    wave_lds_sync();
+}
+
+__device__ __forceinline__ double cdf_scale(int i, int ilo, double inv_delta_i, double sfact) {
+    const double base = 1.0 - (double)(i - ilo) * inv_delta_i;   // core.pyx:143-154
+    if (sfact == 0.0) return 1.0;
+    if (sfact == 1.0) return base;
+    if (sfact == 2.0) return base * base;
+    return slow_pow(base, sfact);
+}
+
+// Distribution.cdf_over_interval + cdf_interp (core.pyx:65-161), general form:
+// materialises the rewritten, normalised CDF in LDS like the reference rewrites
+// its table, then searches it.  Used for the degenerate intervals.
+__device__ __attribute__((noinline)) double d_placement_draw_general(const DistDev &d, double *cdf, int ilo,
+                                                                      int ihi, double sfact, double u,
+                                                                      int lane) {
+    const int size = d.size;
+    const int L = ihi - ilo - 1;
+    const int ch = (L + 63) / 64;
+    const int k0 = ilo + 1 + lane * ch;
+    const int k1 = min(k0 + ch, ihi);
+    const double inv_delta_i = 1.0 / (double)(ihi - ilo);
+    double local = 0.0;
+    for (int i = k0; i < k1; ++i)
+        local += 0.5 * (d.pdf[i] + d.pdf[i - 1]) * cdf_scale(i, ilo, inv_delta_i, sfact);
+    double csum;
+    double run = wave_excl_scan(local, lane, &csum);
+    for (int i = lane; i < ilo; i += 64) cdf[i] = 0.0;
+    for (int i = ihi + lane; i < size; i += 64) cdf[i] = 1.0;
+    if (L <= 0) {
+        if (lane == 0) cdf[ilo] = 1.0 / csum;                 // csum == 0: inf like the reference
+    } else {
+        if (lane == 0) cdf[ilo] = 0.0 / csum;
+        for (int i = k0; i < k1; ++i) {
+            run += 0.5 * (d.pdf[i] + d.pdf[i - 1]) * cdf_scale(i, ilo, inv_delta_i, sfact);
+            cdf[i] = run / csum;
+        }
+    }
+    wave_lds_sync();
+    if (u <= cdf[0]) u = 1e-64;                               // core.pyx:83-84
+    int lo = 0, hi = size, i = hi / 2;                        // core.pyx:86-94
+    while (i != lo) {
+        if (u > cdf[i]) lo = i; else hi = i;
+        i = (hi + lo) / 2;
+    }
+    int j_lo = i < size ? i : size - 1;
+    int j_hi = j_lo + 1;
+    if (j_hi > size - 1) j_hi = size - 1;                     // reference reads cdf[size] here
+    const double xl = d.xax[j_lo];
+    const double y_lo = cdf[j_lo];
+    const double y_hi = cdf[j_hi];
+    const double slope = (y_hi - y_lo) / d.dx;
+    const double res = 1 / slope * (u - y_lo) + xl;
+    wave_lds_sync();
+    return res;
+}
+
+// Same draw for the regular case (interval of >= 2 cells, finite positive mass):
+// the rewritten CDF is monotone, 0 up to i_lo and 1 from i_hi, so the bisection of
+// cdf_interp lands on the last entry below u.  Lanes own contiguous chunks of the
+// interval; only raw running sums go to LDS, the entry is located by counting
+// against u*csum and then settled with the reference's own comparison
+// u > run/csum on its neighbours (two or three divisions instead of `size`).
+__device__ double d_placement_draw(const DistDev &d, double *run_lds, double x_lo, double x_hi,
+                                   double sfact, double u, int lane) {
+    if (x_lo > x_hi) { const double t = x_lo; x_lo = x_hi; x_hi = t; }     // core.pyx:116-117
+    const int size = d.size;
+    long i_lo = (long)((x_lo - d.xmin) / d.dx);                            // core.pyx:120-131
+    if (i_lo >= size) i_lo = size - 1; else if (i_lo < 0) i_lo = 0;
+    long i_hi = (long)((x_hi - d.xmin) / d.dx);
+    if (i_hi == i_lo) i_hi = i_lo + 1;
+    if (i_hi > size) i_hi = size; else if (i_hi < 0) i_hi = 1;
+    const int ilo = (int)i_lo, ihi = (int)i_hi;
+    const int L = ihi - ilo - 1;
+    const int ch = (L + 63) / 64;
+    const int k0 = ilo + 1 + lane * ch;
+    const int k1 = min(k0 + ch, ihi);
+    const double inv_delta_i = 1.0 / (double)(ihi - ilo);
+    double local = 0.0;
+    for (int i = k0; i < k1; ++i)
+        local += 0.5 * (d.pdf[i] + d.pdf[i - 1]) * cdf_scale(i, ilo, inv_delta_i, sfact);
+    double csum;
+    double run = wave_excl_scan(local, lane, &csum);
+    if (!(L > 0 && csum > 0.0 && csum < INFINITY))
+        return d_placement_draw_general(d, run_lds, ilo, ihi, sfact, u, lane);
+    const double uu = (u <= 0.0) ? 1e-64 : u;                 // cdf[0] == 0 here (core.pyx:83-84)
+    const double target = uu * csum;
+    int below = 0;
+    for (int i = k0; i < k1; ++i) {
+        run += 0.5 * (d.pdf[i] + d.pdf[i - 1]) * cdf_scale(i, ilo, inv_delta_i, sfact);
+        run_lds[i] = run;
+        below += (run < target) ? 1 : 0;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) below += __shfl_xor(below, m, 64);
+    wave_lds_sync();
+    // cdf(k): 0 for k <= ilo, run/csum inside, 1 from ihi
+    int i = ilo + below;                                      // last entry believed below u
+    while (i + 1 < ihi && uu > run_lds[i + 1] / csum) ++i;
+    while (i > ilo && !(uu > run_lds[i] / csum)) --i;
+    const int j_lo = i;
+    const int j_hi = min(i + 1, size - 1);
+    const double y_lo = (j_lo <= ilo) ? 0.0 / csum : run_lds[j_lo] / csum;
+    const double y_hi = (j_hi >= ihi) ? 1.0 : ((j_hi <= ilo) ? 0.0 / csum : run_lds[j_hi] / csum);
+    const double xl = d.xax[j_lo];
+    const double slope = (y_hi - y_lo) / d.dx;                // core.pyx:102-107
+    const double res = 1 / slope * (uu - y_lo) + xl;
+    wave_lds_sync();
+    return res;
+}
+
+// PriorTransformer.c_transform (core.pyx:459-476) of one unit-cube row held in
+// LDS (u[n_param*n]), in place; `scratch` holds max_size doubles.
+__device__ __forceinline__ void prior_transform_item(const PriorProg &pp, double *u, double *scratch,
+                                                     int n, int lane) {
+    for (int k = 0; k < pp.n_prior; ++k) {
+        const nfa_prior_desc &p = pp.pr[k];
+        const int ix = p.p_ix * n;
+        switch (p.kind) {
+        case NFA_PRIOR_SIMPLE:
+        case NFA_PRIOR_CONSTANT:
+        case NFA_PRIOR_ORDERED:
+            d_simple_interp(pp, p.kind, p.dist0, p.p_ix, p.value, u, n, lane);
+            break;
+        case NFA_PRIOR_DUPLICATE:                             // core.pyx:211-221
+            if (lane < n) {
+                const double v = d_ppf_interp(pp.ds[p.dist0], u[ix + lane]);
+                u[ix + lane] = v;
+                u[p.p_ix2 * n + lane] = v;
+            }
+            wave_lds_sync();
+            break;
+        case NFA_PRIOR_SPACED:                                // core.pyx:280-292
+            if (lane == 0) {
+                double v = d_ppf_interp(pp.ds[p.dist0], u[ix]);
+                u[ix] = v;
+                for (int i = 1; i < n; ++i) {
+                    v = v + d_ppf_interp(pp.ds[p.dist1], u[ix + i]);
+                    u[ix + i] = v;
+                }
+            }
+            wave_lds_sync();
+            break;
+        case NFA_PRIOR_CENSEP:                                // core.pyx:305-318
+            if (lane == 0) {
+                const double vcen = d_ppf_interp(pp.ds[p.dist0], u[ix]);
+                if (n == 1) u[ix] = vcen;
+                else if (n == 2) {
+                    const double vsep = d_ppf_interp(pp.ds[p.dist1], u[ix + 1]);
+                    u[ix]     = vcen - 0.5 * vsep;
+                    u[ix + 1] = vcen + 0.5 * vsep;
+                }
+            }
+            wave_lds_sync();
+            break;
+        case NFA_PRIOR_RESOLVED_CENSEP: {                     // core.pyx:347-366
+            const int ix_s = p.p_ix2 * n;
+            d_simple_interp(pp, p.sub_kind, p.dist2, p.p_ix2, p.value, u, n, lane);
+            if (lane == 0) {
+                const double vcen = d_ppf_interp(pp.ds[p.dist0], u[ix]);
+                if (n == 1) u[ix] = vcen;
+                else if (n == 2) {
+                    double vsep = d_ppf_interp(pp.ds[p.dist1], u[ix + 1]);
+                    const double min_sep = p.sep_scale * sqrt(u[ix_s] * u[ix_s + 1]);
+                    if (min_sep > vsep) vsep = min_sep;
+                    u[ix]     = vcen - 0.5 * vsep;
+                    u[ix + 1] = vcen + 0.5 * vsep;
+                }
+            }
+            wave_lds_sync();
+        } break;
+        case NFA_PRIOR_RESOLVED_PLACEMENT: {                  // core.pyx:391-435
+            if (n > MAXCOMP) break;
+            const DistDev &vd = pp.ds[p.dist0];
+            const int ix_s = p.p_ix2 * n;
+            double v_lo = vd.xmin, v_hi = vd.xmax;
+            d_simple_interp(pp, p.sub_kind, p.dist2, p.p_ix2, p.value, u, n, lane);
+            if (n == 1) {
+                if (lane == 0) u[ix] = d_ppf_interp(vd, u[ix]);
+                wave_lds_sync();
+                break;
+            }
+            // every lane carries the same scalars
+            double min_seps[MAXCOMP];
+            double sep_tot = 0.0;
+            min_seps[0] = 0.0;
+#pragma unroll
+            for (int i = 1; i < MAXCOMP; ++i) {
+                double sep = 0.0;
+                if (i < n) {
+                    sep = p.sep_scale * sqrt(u[ix_s + i] * u[ix_s + i - 1]);
+                    sep_tot += sep;
+                }
+                min_seps[i] = sep;
+            }
+            if (sep_tot > v_hi - v_lo) {
+                const double overf = (v_hi - v_lo) / sep_tot;
+                sep_tot = 0.0;
+#pragma unroll
+                for (int i = 0; i < MAXCOMP; ++i) {
+                    if (i < n) { min_seps[i] *= overf; sep_tot += min_seps[i]; }
+                }
+            }
+            v_hi -= sep_tot;
+#pragma unroll
+            for (int i = 0; i < MAXCOMP; ++i) {
+                if (i < n) {
+                    const double sep = min_seps[i];
+                    v_lo += sep;
+                    v_hi += sep;
+                    const double uu = u[ix + i];
+                    v_lo = d_placement_draw(vd, scratch, v_lo, v_hi, (double)(n - 1 - i), uu, lane);
+                    if (lane == 0) u[ix + i] = v_lo;
+                }
+            }
+            wave_lds_sync();
+        } break;
+        default: break;
+        }
+    }
+}
+
+// prior_kernel: transform only (PriorTransformer.transform, core.pyx:478-483)
+__global__ void __launch_bounds__(256) prior_kernel(const PriorProg *__restrict__ ppp, double *__restrict__ U,
+                                                    long B, int n, int wave_doubles) {
+    const PriorProg &pp = *ppp;            // lives in device memory: indexed through scalar loads
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ndim = pp.n_param * n;
+    double *u = smem + (size_t)wave * wave_doubles;       // [ndim]
+    double *scratch = u + ((ndim + 1) & ~1);               // [max_size]
+    const long gw = (long)blockIdx.x * waves + wave, nw = (long)gridDim.x * waves;
+    for (long b = gw; b < B; b += nw) {
+        for (int k = lane; k < ndim; k += 64) u[k] = U[b * ndim + k];
+        wave_lds_sync();
+        prior_transform_item(pp, u, scratch, n, lane);
+        for (int k = lane; k < ndim; k += 64) U[b * ndim + k] = u[k];
+        wave_lds_sync();
+    }
+}
+
+// setup_kernel: first kernel of a likelihood batch.  One wave per item:
+// [unit cube -> theta, written back in place like the reference mutates utheta]
+// -> derived record D[b].  With HAS_PRIOR = false U already holds theta (predict).
+template <int MODE, bool HAS_PRIOR>
+__global__ void __launch_bounds__(256) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
+                                                    double *__restrict__ U, double *__restrict__ D, long B,
+                                                    int wave_doubles, const double *__restrict__ g_tabs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int n_shared;
+    const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
+    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ncomp = S.ncomp, ndim = NFA_N_PARAMS * ncomp;
+    const int drec = drec_size(ncomp, S.n_spec);
+    double *w_theta = smem + n_shared + (size_t)wave * wave_doubles;
+    double *w_comp = w_theta + ((ndim + 1) & ~1);           // [ncomp][COMP_STRIDE]
+    double *w_zlev = w_comp + ncomp * COMP_STRIDE;          // [ncomp][9]
+    double *scratch = w_zlev + ((ncomp * NFA_N_LEVELS + 1) & ~1);   // [max_size] (priors only)
+    const long gw = (long)blockIdx.x * waves + wave, nw = (long)gridDim.x * waves;
+    for (long b = gw; b < B; b += nw) {
+        for (int k = lane; k < ndim; k += 64) w_theta[k] = U[b * ndim + k];
+        wave_lds_sync();
+        if (HAS_PRIOR) {
+            prior_transform_item(*ppp, w_theta, scratch, ncomp, lane);
+            for (int k = lane; k < ndim; k += 64) U[b * ndim + k] = w_theta[k];
+        }
+        derive_item<MODE>(S, w_theta, w_comp, w_zlev, D + b * drec, sm, g_tabs, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------
+//  set-up kernels
+// ---------------------------------------------------------------------------
+__global__ void prep_kernel(const double *__restrict__ x, double *__restrict__ t0,
+                            double *__restrict__ tbg, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double T0 = NFA_H * x[i] / NFA_KB;                  // hyperfine.pyx:106
+    t0[i] = T0;
+    tbg[i] = 1.0 / expm1(T0 / NFA_TCMB);                      // ammonia.pyx:274-277
+}
+
+// null_lnZ[pix][spec] = -sum(data^2)/(2 noise^2): Spectrum.c_loglikelihood with
+// pred == 0 (core.pyx:517-530).  One wave per (pixel, spectrum).
+__global__ void null_lnz_kernel(SpecDev S, long n_pix, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long w = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= n_pix * S.n_spec) return;
+    const long p = w / S.n_spec;
+    const int s = (int)(w - p * S.n_spec);
+    const double *d = S.data + p * S.chan_tot + S.off[s];
+    double acc = 0.0;
+    for (int j = lane; j < S.size[s]; j += 64) { const double dev = d[j] - 0.0; acc += dev * dev; }
+    acc = wave_sum(acc);
+    const double noise = S.noise[p * S.n_spec + s];
+    if (lane == 0) out[w] = -acc / (2 * (noise * noise));
+}
+
+// ---------------------------------------------------------------------------
+//  unit-test kernels (device evaluation of the scalar building blocks)
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void test_fastexp_kernel(const double *x, double *out, long n, const double *g_tabs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int n_shared;
+    const double *sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ((n + 63) & ~63L);
+         i += (long)gridDim.x * blockDim.x) {
+        const double xi = i < n ? x[i] : 1.0;
+        double v;
+        if (MODE == 2) v = (double)exp_neg_f32((float)xi);
+        else v = nf_fastexp<MODE == 2 ? 1 : MODE>(xi, sm);
+        if (i < n) out[i] = v;
+    }
+}
+
+// 1 - FastExp(tau) as the fast mode evaluates it
+__global__ void test_one_minus_fastexp_kernel(const double *x, double *out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = one_minus_fastexp_f32((float)x[i]);
+}
+
+__global__ void test_iemtex_kernel(const double *x, double *out, long n, const double *g_tabs,
+                                   double xmin, double xmax, double inv_dx) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x)
+        out[i] = nf_iemtex(x[i], g_tabs + SM_T0X, g_tabs + SM_T0Y, xmin, xmax, inv_dx);
+}
+
+template <int MODE>
+__global__ void test_partition_kernel(const double *trot, double *qpara, double *qorth, long n,
+                                      const double *g_tabs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int n_shared;
+    const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
+    const int lane = threadIdx.x & 63;
+    const long w = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= n) return;
+    double lev = 0.0;
+    if (lane < NFA_NPART) lev = nf_partition_level<MODE>(lane, trot[w], sm);
+    const bool is_orth = (lane % 3) == 0;
+    const double qp = wave_sum((lane < NFA_NPART && !is_orth) ? lev : 0.0);
+    const double qo = wave_sum((lane < NFA_NPART && is_orth) ? 2 * lev : 0.0);
+    if (lane == 0) { qpara[w] = qp; qorth[w] = qo; }
+}
+
+__global__ void test_windows_kernel(SpecDev S, int s, double voff, double sigm, int *lo, int *hi) {
+    const int t = S.trans[s] - 1, i = threadIdx.x;
+    if (i >= c_nhf[t]) return;
+    const LineConst lc = nf_line(t, i, voff / NFA_CKMS, sigm / NFA_CKMS, c_nu[t], S.nu_min[s], S.nu_chan[s],
+                                 S.size[s]);
+    lo[i] = lc.lo; hi[i] = lc.hi;
+}

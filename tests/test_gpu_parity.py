@@ -15,8 +15,17 @@ from nestfit_amd.synth import TRUTH_1COMP, TRUTH_2COMP, TRUTH_3COMP, freq_axis
 pytestmark = pytest.mark.gpu
 
 TB_RTOL = 1e-6          # north_star tolerance on floating-point Tb
-TIGHT = 1e-11           # what the fp64 engine is expected to reach
-MODES = ['table', 'poly']
+MODES = ['table', 'poly', 'fast']
+# what each mode is expected to reach on Tb (pinned so that regressions show)
+TIGHT = {'table': 1e-11, 'poly': 1e-11, 'fast': 5e-7}
+# relative tolerance on lnL / theta-dependent scalars per mode
+LNL_RTOL = {'table': 1e-9, 'poly': 1e-9, 'fast': 1e-6}
+# The reference evaluates 1 - FastExp(tau) as 1 - (1 - tau + ...): for tau below ~1e-9 its own
+# result is quantised at the 1e-7 .. 1e-4 relative level (1.1e-16 / tau).  The exact modes
+# reproduce tau to ~1e-16 and therefore that rounding; the fast mode (tau to ~1e-7) cannot, so
+# its per-channel check carries an absolute floor of a few quantisation steps of the reference,
+# T0 (y - tbg) 2^-53 ~ 1e-15 K (fifteen orders below the noise), next to the 1e-6 relative bar.
+TB_ATOL_K = {'table': 0.0, 'poly': 0.0, 'fast': 4e-15}
 
 
 def _test_fastexp(engine, x, mode):
@@ -24,7 +33,7 @@ def _test_fastexp(engine, x, mode):
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.empty_like(x)
     _ffi.check(_ffi.engine().nfa_test_fastexp(_ffi.dptr(x), _ffi.dptr(out), x.size,
-                                              {'table': 0, 'poly': 1}[mode]))
+                                              {'table': 0, 'poly': 1, 'fast': 2, '1m': 3}[mode]))
     return out
 
 
@@ -65,6 +74,26 @@ def test_fastexp_poly_mode(engine, nfo):
     assert np.array_equal(got[small].view(np.uint64), want[small].view(np.uint64))
 
 
+def test_fastexp_fast_mode(engine, nfo):
+    """fp32 split-exponent exp on the float-narrowed argument: zero pattern exact, <= 2e-7."""
+    x = _fastexp_inputs()
+    x = x[~(x < 0)]                                   # FastExp(x<0) = exp(|x|): checked below
+    got = _test_fastexp(engine, x, 'fast')
+    want = nfo.fast_expn(x)
+    assert np.array_equal(got == 0, want == 0)        # exact cut at 32, NaN -> 0
+    ok = want != 0
+    assert np.max(np.abs(got[ok] - want[ok]) / want[ok]) < 2e-7
+    neg = np.array([-0.5, -1.0, -20.0])
+    np.testing.assert_allclose(_test_fastexp(engine, neg, 'fast'), nfo.fast_expn(neg), rtol=3e-7)
+    # 1 - FastExp(tau) for fp32 tau, all three branches
+    tau = np.concatenate([10 ** np.random.default_rng(5).uniform(-8, 1.6, 200_000),
+                          [0.03125, np.nextafter(np.float32(0.03125), np.float32(0)), 0.5, 32.0, 40.0]])
+    tau = tau.astype(np.float32).astype(np.float64)
+    got = _test_fastexp(engine, tau, '1m')
+    want = 1.0 - nfo.fast_expn(tau)
+    assert np.max(np.abs(got - want) / want) < 3e-7
+
+
 def test_iemtex_and_partition(engine, nfo):
     from nestfit_amd import _ffi
     lib = _ffi.engine()
@@ -77,7 +106,7 @@ def test_iemtex_and_partition(engine, nfo):
     inside = (x > lo) & (x < hi)
     assert np.array_equal(out[inside].view(np.uint64), want[inside].view(np.uint64))  # same index, same lerp
     np.testing.assert_allclose(out[~inside], want[~inside], rtol=1e-15)               # expm1 branch
-    for mode in MODES:
+    for mode in ('table', 'poly'):
         engine.set_exp_mode(mode)
         trot = np.concatenate([np.linspace(3, 300, 500), [2.0, 7.0, 1000.0]])
         qp, qo = np.empty_like(trot), np.empty_like(trot)
@@ -146,11 +175,13 @@ def test_amm_predict_grid(engine, nfo, mode):
                         assert np.array_equal(pg == 0, pc == 0), (trans, n, ncomp, cold, lte)
                         nz = pc != 0
                         if nz.any():
-                            err = np.max(np.abs(pg[nz] - pc[nz]) / np.abs(pc[nz]))
-                            worst = max(worst, err)
-                            assert err < TB_RTOL
-                        assert sg.loglikelihood == pytest.approx(sc.loglikelihood, rel=1e-9)
-    assert worst < TIGHT, worst
+                            assert (np.abs(pg - pc) <= TB_RTOL * np.abs(pc) + TB_ATOL_K[mode]).all()
+                            big = np.abs(pc) > 1e-6
+                            if big.any():
+                                worst = max(worst, np.max(np.abs(pg[big] - pc[big]) / np.abs(pc[big])))
+                        assert sg.loglikelihood == pytest.approx(sc.loglikelihood, rel=LNL_RTOL[mode])
+    print(f'{mode}: worst relative Tb error (channels above 1e-6 K) {worst:.2e}')
+    assert worst < TIGHT[mode], worst
     engine.set_exp_mode('table')
 
 
@@ -164,10 +195,11 @@ def test_survey_known_answers_on_device(engine, kat, mode):
         p = s.get_spec()
         assert int((p != 0).sum()) == c['nnz']
         assert p[-1] == 0.0
-        assert s.max_spec == pytest.approx(c['max'], rel=1e-11)
+        tol = 1e-11 if mode != 'fast' else 1e-6
+        assert s.max_spec == pytest.approx(c['max'], rel=tol)
         if 'sum' in c:
-            assert s.sum_spec == pytest.approx(c['sum'], rel=1e-11)
-        assert s.loglikelihood == pytest.approx(c['lnL'], rel=1e-11)
+            assert s.sum_spec == pytest.approx(c['sum'], rel=tol)
+        assert s.loglikelihood == pytest.approx(c['lnL'], rel=tol)
     engine.set_exp_mode('table')
 
 
@@ -209,7 +241,7 @@ def test_runner_loglikelihood_irdc_and_synth(engine, nfo, kat, mode):
         lg = gpu.loglikelihood_batch(Ug)
         lc = cpu.loglikelihood_batch(Uc)
         np.testing.assert_allclose(Ug, Uc, rtol=1e-11, atol=1e-13)
-        np.testing.assert_allclose(lg, lc, rtol=1e-9)
+        np.testing.assert_allclose(lg, lc, rtol=LNL_RTOL[mode])
         # single-point API mutates utheta in place and returns a float
         u1 = U[7].copy()
         l1 = gpu.loglikelihood(u1)
@@ -226,7 +258,7 @@ def test_runner_loglikelihood_irdc_and_synth(engine, nfo, kat, mode):
         u = np.full(12, c['u'])
         lnl = run.loglikelihood(u)
         np.testing.assert_allclose(u, c['theta'], rtol=1e-12)
-        assert lnl == pytest.approx(lnl_ref, rel=1e-11)
+        assert lnl == pytest.approx(lnl_ref, rel=1e-11 if mode != 'fast' else 1e-6)
     engine.set_exp_mode('table')
 
 
@@ -364,7 +396,7 @@ def test_full_size_configs(engine, nfo, mode):
         sub = np.arange(0, 4096, 64)
         Uc = U[sub].copy()
         lc = cpu.loglikelihood_batch(Uc)
-        np.testing.assert_allclose(l1[sub], lc, rtol=1e-9)
+        np.testing.assert_allclose(l1[sub], lc, rtol=LNL_RTOL[mode])
         np.testing.assert_allclose(U1[sub], Uc, rtol=1e-11, atol=1e-13)
         perm = np.random.default_rng(8).permutation(4096)
         U2 = U[perm].copy()
