@@ -105,9 +105,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='rows per step (default: workload B)')
-    ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'table'),
+    ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'fast'),
                     choices=['table', 'poly', 'fast'])
     ap.add_argument('--nparts', type=int, default=0, help='engine A/B knob: waves per spectrum (0 = auto)')
+    ap.add_argument('--ablate', type=int, default=0, help='timing experiment: 1 skip Tb, 2 skip lines, 3 both (INVALID results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile-events', action='store_true',
                     help='do not record per-kernel HIP events inside the timed region')
@@ -125,6 +126,8 @@ def main():
     na.set_exp_mode(args.exp_mode)
     if args.nparts:
         _ffi.set_option('nparts', args.nparts)
+    if args.ablate:
+        _ffi.set_option('ablate', args.ablate)
     lib = _ffi.engine()
 
     dist = None

@@ -38,7 +38,7 @@ int nfa_set_device(int device);              /* one process per GPU: call first 
 int nfa_device_synchronize(void);
 int nfa_device_name(char *buf, int buflen);
 
-/* Numerical mode of the FastExp replacement (per process):
+/* Numerical mode of the FastExp replacement (per process; default 2):
  *   0 = "table": the reference's three-table product held in LDS
  *       (nestfit/core/fastexp.c:234-283), bit-identical table indices;
  *   1 = "poly" : exp(-(double)(float)x) by fp64 range reduction + polynomial,
@@ -49,8 +49,11 @@ int nfa_device_name(char *buf, int buflen);
  *       <= 1e-6 relative on brightness temperature (the metric's tolerance). */
 int nfa_set_exp_mode(int mode);
 int nfa_get_exp_mode(void);
-/* Engine tuning knobs for A/B measurements: "nparts" = waves per spectrum of
- * one item in the likelihood kernel (0 = automatic). */
+/* Engine tuning knobs for A/B measurements: "nparts" = waves per spectrum of one
+ * item in the likelihood kernel (0 = default 2); "overlap" = 1 puts the set-up and
+ * the likelihood kernel of runners created afterwards on two streams; "ablate"
+ * (timing experiments only, results invalid) = 1 skip the Tb pass, 2 skip the
+ * hyperfine-line loop, 3 both. */
 int nfa_set_option(const char *key, int value);
 
 /* 1/(e^x-1) interpolation table.  The reference builds T0_X, T0_Y with numpy at

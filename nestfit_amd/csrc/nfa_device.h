@@ -92,6 +92,7 @@ struct LnlGeom {
     int nparts;        // interleaved row parts per spectrum
     int wpi;           // waves per item = n_spec * nparts
     int ipb;           // items per workgroup
+    int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 3 both
 };
 
 // ---------------------------------------------------------------------------
@@ -495,6 +496,7 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                     unsigned long long mask = __ballot(win.y > win.x && win.x < r0 + 64 && win.y > r0);
                     if (mask == 0ull) continue;
                     tau_t tau = 0;
+                    if (G.ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); } else {
                     // software-pipelined walk over the lines that touch this row: the
                     // record of the next line is in flight while the current one is used
                     int i = __builtin_ctzll(mask);
@@ -528,9 +530,11 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                         if (!more) break;
                         rec = nxt;
                     }
+                    }
                     const bool live = valid && !(tau == 0);           // hyperfine.pyx:104-105
                     if (__ballot(live) == 0ull) continue;
                     double tb;
+                    if (G.ablate & 1) { if (live) pred += (double)tau; continue; }
                     const double *dk = w_d + 4 * ncomp + (c * nspec + s) * DREC_CS;
                     if (MODE == 2 && dk[DK_KIND] != 0.0) {
                         const bool up = !(T0 < dk[DK_SPLIT]);

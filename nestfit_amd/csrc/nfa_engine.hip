@@ -39,8 +39,10 @@ struct Engine {
     bool   init = false;
     int    device = 0;
     int    n_cu = 256;
-    int    exp_mode = 0;
+    int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
     int    nparts_override = 0;
+    int    ablate = 0;
+    int    overlap = 0;
     bool   have_t0 = false;
     double *d_tabs = nullptr;                      // SM_END_TABLE doubles
     double t0_xmin = 0, t0_xmax = 0, t0_inv_dx = 0;
@@ -97,9 +99,16 @@ struct nfa_runner {
     nfa_specset *ss = nullptr;
     nfa_priors  *pr = nullptr;
     int ncomp = 1, cold = 0, lte = 0, ndim = 6;
-    hipStream_t stream = nullptr;
-    double *d_U = nullptr, *d_lnL = nullptr, *d_spec = nullptr, *d_D = nullptr;
-    int64_t cap_D = 0;
+    // Two streams: the set-up kernel of batch k+1 (latency bound: table look-ups, libm)
+    // overlaps the likelihood kernel of batch k (VALU bound).  The derived-parameter
+    // records are double buffered; events order the hand-offs.
+    hipStream_t stream = nullptr;            // likelihood kernel, device->host copies
+    hipStream_t stream_setup = nullptr;      // host->device copies, set-up kernel
+    hipEvent_t  ev_setup_done[2] = {nullptr, nullptr}, ev_lnl_done[2] = {nullptr, nullptr};
+    uint64_t    n_calls = 0;
+    double *d_U = nullptr, *d_lnL = nullptr, *d_spec = nullptr;
+    double *d_D[2] = {nullptr, nullptr};
+    int64_t cap_D[2] = {0, 0};
     int    *d_pix = nullptr;
     int64_t cap_B = 0, cap_spec = 0;
     // optional per-kernel timing (HIP events on the runner's stream)
@@ -147,6 +156,8 @@ int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "nparts") && value >= 0 && value <= 16) { g_eng.nparts_override = value; return NFA_OK; }
+    if (key && !strcmp(key, "ablate") && value >= 0 && value <= 3) { g_eng.ablate = value; return NFA_OK; }
+    if (key && !strcmp(key, "overlap") && (value == 0 || value == 1)) { g_eng.overlap = value; return NFA_OK; }
     return fail(NFA_ERR_ARG, "unknown option");
 }
 
@@ -344,15 +355,27 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors, int
     r->ss = ss; r->pr = priors; r->ncomp = ncomp; r->cold = cold ? 1 : 0; r->lte = lte ? 1 : 0;
     r->ndim = NFA_N_PARAMS * ncomp;
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    // measured on MI355X: running the set-up kernel of batch k+1 beside the likelihood kernel
+    // of batch k slows both by the same amount (the likelihood kernel already owns every wave
+    // slot), so by default both kernels share one stream; "overlap" = 1 splits them.
+    if (g_eng.overlap) HIP_TRY(hipStreamCreateWithFlags(&r->stream_setup, hipStreamNonBlocking));
+    else r->stream_setup = r->stream;
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_setup_done[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_lnl_done[k], hipEventDisableTiming));
+    }
     *out = r;
     return NFA_OK;
 }
 
 int nfa_runner_destroy(nfa_runner *r) {
     if (!r) return NFA_OK;
+    (void)hipStreamSynchronize(r->stream_setup);
     (void)hipStreamSynchronize(r->stream);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
-    (void)hipFree(r->d_D);
+    (void)hipFree(r->d_D[0]); (void)hipFree(r->d_D[1]);
+    for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(r->ev_setup_done[k]); (void)hipEventDestroy(r->ev_lnl_done[k]); }
+    if (r->stream_setup != r->stream) (void)hipStreamDestroy(r->stream_setup);
     for (hipEvent_t x : r->ev) (void)hipEventDestroy(x);
     (void)hipStreamDestroy(r->stream);
     delete r;
@@ -390,15 +413,16 @@ static SpecDev runner_specdev(const nfa_runner *r) {
 
 // First kernel of a batch: [unit cube -> theta in place] -> derived records r->d_D
 template <int MODE, bool HAS_PRIOR>
-static int launch_setup_t(nfa_runner *r, double *d_U, int64_t B) {
+static int launch_setup_t(nfa_runner *r, double *d_U, int64_t B, int slot) {
     const SpecDev S = runner_specdev(r);
     const int drec = drec_size(r->ncomp, S.n_spec);
-    if (B > r->cap_D) {                      // grown outside any timed loop
+    if (B > r->cap_D[slot]) {                // grown outside any timed loop
+        HIP_TRY(hipStreamSynchronize(r->stream_setup));
         HIP_TRY(hipStreamSynchronize(r->stream));
-        (void)hipFree(r->d_D); r->d_D = nullptr; r->cap_D = 0;
+        (void)hipFree(r->d_D[slot]); r->d_D[slot] = nullptr; r->cap_D[slot] = 0;
         const int64_t cap = std::max<int64_t>(B, 4096);
-        HIP_TRY(hipMalloc(&r->d_D, sizeof(double) * cap * drec));
-        r->cap_D = cap;
+        HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec));
+        r->cap_D[slot] = cap;
     }
     const PriorProg *d_pp = HAS_PRIOR ? r->pr->d_prog : nullptr;
     const int max_size = HAS_PRIOR ? r->pr->prog.max_size : 0;
@@ -412,26 +436,28 @@ static int launch_setup_t(nfa_runner *r, double *d_U, int64_t B) {
     auto kern = setup_kernel<MODE, HAS_PRIOR>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, r->stream, d_pp, S, d_U, r->d_D,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, r->stream_setup, d_pp, S, d_U,
+                       r->d_D[slot],
                        (long)B, wd, (const double *)g_eng.d_tabs);
     HIP_TRY(hipGetLastError());
     return NFA_OK;
 }
 
-static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior) {
+static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot) {
     const int m = g_eng.exp_mode == 0 ? 0 : 1;          // the fast mode derives like "poly"
-    if (m == 0) return has_prior ? launch_setup_t<0, true>(r, d_U, B) : launch_setup_t<0, false>(r, d_U, B);
-    return has_prior ? launch_setup_t<1, true>(r, d_U, B) : launch_setup_t<1, false>(r, d_U, B);
+    if (m == 0)
+        return has_prior ? launch_setup_t<0, true>(r, d_U, B, slot) : launch_setup_t<0, false>(r, d_U, B, slot);
+    return has_prior ? launch_setup_t<1, true>(r, d_U, B, slot) : launch_setup_t<1, false>(r, d_U, B, slot);
 }
 
 static int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
 template <int MODE, bool WS>
-static int launch_lnl_t(nfa_runner *r, const int *d_pix, const double *d_theta, double *d_lnL,
+static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL,
                         double *d_spec, int64_t B) {
     const SpecDev S = runner_specdev(r);
-    (void)d_theta;                               // theta enters through the records of launch_setup
     LnlGeom G;
+    G.ablate = g_eng.ablate;
     G.nhf_max = r->ss->nhf_max;
     const int drec = drec_size(r->ncomp, S.n_spec);
     // LDS per item slot: D record + for every spectrum the line table (32-B records + windows)
@@ -458,25 +484,58 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, const double *d_theta, 
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, r->stream, S, d_pix,
-                       (const double *)r->d_D, d_lnL, d_spec, (long)B, G, (const double *)g_eng.d_tabs);
+                       (const double *)r->d_D[slot], d_lnL, d_spec, (long)B, G, (const double *)g_eng.d_tabs);
     HIP_TRY(hipGetLastError());
     return NFA_OK;
 }
 
-static int launch_lnl(nfa_runner *r, const int *d_pix, const double *d_theta, double *d_lnL,
-                      double *d_spec, int64_t B) {
-    if (!g_eng.have_t0) return fail(NFA_ERR_STATE, "nfa_set_iemtex_table has not been called");
+static int launch_lnl(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, double *d_spec, int64_t B) {
     switch (g_eng.exp_mode) {
     case 0:
-        return d_spec ? launch_lnl_t<0, true>(r, d_pix, d_theta, d_lnL, d_spec, B)
-                      : launch_lnl_t<0, false>(r, d_pix, d_theta, d_lnL, d_spec, B);
+        return d_spec ? launch_lnl_t<0, true>(r, d_pix, slot, d_lnL, d_spec, B)
+                      : launch_lnl_t<0, false>(r, d_pix, slot, d_lnL, d_spec, B);
     case 1:
-        return d_spec ? launch_lnl_t<1, true>(r, d_pix, d_theta, d_lnL, d_spec, B)
-                      : launch_lnl_t<1, false>(r, d_pix, d_theta, d_lnL, d_spec, B);
+        return d_spec ? launch_lnl_t<1, true>(r, d_pix, slot, d_lnL, d_spec, B)
+                      : launch_lnl_t<1, false>(r, d_pix, slot, d_lnL, d_spec, B);
     default:
-        return d_spec ? launch_lnl_t<2, true>(r, d_pix, d_theta, d_lnL, d_spec, B)
-                      : launch_lnl_t<2, false>(r, d_pix, d_theta, d_lnL, d_spec, B);
+        return d_spec ? launch_lnl_t<2, true>(r, d_pix, slot, d_lnL, d_spec, B)
+                      : launch_lnl_t<2, false>(r, d_pix, slot, d_lnL, d_spec, B);
     }
+}
+
+// One batch: set-up kernel on stream_setup, likelihood kernel on stream, ordered by events;
+// batch k+1's set-up may run beside batch k's likelihood kernel.  d_U must be ready on
+// stream_setup (host->device copies are enqueued there).
+static int run_batch(nfa_runner *r, const int *d_pix, double *d_U, double *d_lnL, double *d_spec,
+                     int64_t B, bool has_prior) {
+    if (!g_eng.have_t0) return fail(NFA_ERR_STATE, "nfa_set_iemtex_table has not been called");
+    const int slot = (int)(r->n_calls & 1);
+    hipEvent_t *e = nullptr;
+    if (r->profiling) {
+        if (r->ev_used + 4 > r->ev.size()) {
+            for (int k = 0; k < 4; ++k) { hipEvent_t x; HIP_TRY(hipEventCreate(&x)); r->ev.push_back(x); }
+        }
+        e = &r->ev[r->ev_used];
+        r->ev_used += 4;
+    }
+    // the records of this slot are free once the likelihood kernel of call k-2 is done
+    const bool two = r->stream_setup != r->stream;
+    if (two && r->n_calls >= 2) HIP_TRY(hipStreamWaitEvent(r->stream_setup, r->ev_lnl_done[slot], 0));
+    if (e) HIP_TRY(hipEventRecord(e[0], r->stream_setup));
+    int rc = launch_setup(r, d_U, B, has_prior, slot);
+    if (rc) return rc;
+    if (e) HIP_TRY(hipEventRecord(e[1], r->stream_setup));
+    if (two) {
+        HIP_TRY(hipEventRecord(r->ev_setup_done[slot], r->stream_setup));
+        HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_setup_done[slot], 0));
+    }
+    if (e) HIP_TRY(hipEventRecord(e[2], r->stream));
+    rc = launch_lnl(r, d_pix, slot, d_lnL, d_spec, B);
+    if (rc) return rc;
+    if (e) HIP_TRY(hipEventRecord(e[3], r->stream));
+    if (two) HIP_TRY(hipEventRecord(r->ev_lnl_done[slot], r->stream));
+    r->n_calls++;
+    return NFA_OK;
 }
 
 extern "C" {
@@ -493,26 +552,12 @@ int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_
     if (!r || !d_U || !d_lnL) return fail(NFA_ERR_ARG, "null argument");
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     if (B <= 0) return NFA_OK;
-    hipEvent_t *e = nullptr;
-    if (r->profiling) {
-        if (r->ev_used + 3 > r->ev.size()) {
-            for (int k = 0; k < 3; ++k) { hipEvent_t x; HIP_TRY(hipEventCreate(&x)); r->ev.push_back(x); }
-        }
-        e = &r->ev[r->ev_used];
-        r->ev_used += 3;
-        HIP_TRY(hipEventRecord(e[0], r->stream));
-    }
-    int rc = launch_setup(r, d_U, B, true);
-    if (rc) return rc;
-    if (e) HIP_TRY(hipEventRecord(e[1], r->stream));
-    rc = launch_lnl(r, d_pix, d_U, d_lnL, nullptr, B);
-    if (rc) return rc;
-    if (e) HIP_TRY(hipEventRecord(e[2], r->stream));
-    return NFA_OK;
+    return run_batch(r, d_pix, d_U, d_lnL, nullptr, B, true);
 }
 
 int nfa_runner_set_profiling(nfa_runner *r, int on) {
     if (!r) return fail(NFA_ERR_ARG, "null runner");
+    HIP_TRY(hipStreamSynchronize(r->stream_setup));
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->profiling = on != 0;
     r->ev_used = 0;
@@ -521,20 +566,22 @@ int nfa_runner_set_profiling(nfa_runner *r, int on) {
 
 int nfa_runner_get_profile(nfa_runner *r, double *prior_ms, double *lnl_ms, int64_t *calls) {
     if (!r || !prior_ms || !lnl_ms || !calls) return fail(NFA_ERR_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize(r->stream_setup));
     HIP_TRY(hipStreamSynchronize(r->stream));
     double a = 0, b = 0;
-    for (size_t k = 0; k + 2 < r->ev_used + 0 && k + 2 < r->ev.size() + 0; k += 3) {
+    for (size_t k = 0; k + 3 < r->ev_used + 0 && k + 3 < r->ev.size() + 0; k += 4) {
         float t = 0;
         HIP_TRY(hipEventElapsedTime(&t, r->ev[k], r->ev[k + 1])); a += t;
-        HIP_TRY(hipEventElapsedTime(&t, r->ev[k + 1], r->ev[k + 2])); b += t;
+        HIP_TRY(hipEventElapsedTime(&t, r->ev[k + 2], r->ev[k + 3])); b += t;
     }
-    *prior_ms = a; *lnl_ms = b; *calls = (int64_t)(r->ev_used / 3);
+    *prior_ms = a; *lnl_ms = b; *calls = (int64_t)(r->ev_used / 4);
     r->ev_used = 0;
     return NFA_OK;
 }
 
 int nfa_runner_synchronize(nfa_runner *r) {
     if (!r) return fail(NFA_ERR_ARG, "null runner");
+    HIP_TRY(hipStreamSynchronize(r->stream_setup));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return NFA_OK;
 }
@@ -544,9 +591,12 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
     if (B <= 0) return NFA_OK;
     int rc = check_pix(r, pix, B); if (rc) return rc;
     rc = runner_reserve(r, B, false); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(r->d_U, U, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, r->stream));
-    if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, r->stream));
-    rc = nfa_runner_loglike_batch_dev(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, B);
+    if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
+    // the staging buffers may still be read by an earlier likelihood kernel
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpyAsync(r->d_U, U, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, r->stream_setup));
+    if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, r->stream_setup));
+    rc = run_batch(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, nullptr, B, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(U, r->d_U, sizeof(double) * B * r->ndim, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipMemcpyAsync(lnL, r->d_lnL, sizeof(double) * B, hipMemcpyDeviceToHost, r->stream));
@@ -560,11 +610,10 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
     if (B <= 0) return NFA_OK;
     int rc = check_pix(r, pix, B); if (rc) return rc;
     rc = runner_reserve(r, B, spectra_out != nullptr); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(r->d_U, theta, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, r->stream));
-    if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, r->stream));
-    rc = launch_setup(r, r->d_U, B, false);
-    if (rc) return rc;
-    rc = launch_lnl(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, spectra_out ? r->d_spec : nullptr, B);
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpyAsync(r->d_U, theta, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, r->stream_setup));
+    if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, r->stream_setup));
+    rc = run_batch(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, spectra_out ? r->d_spec : nullptr, B, false);
     if (rc) return rc;
     if (spectra_out)
         HIP_TRY(hipMemcpyAsync(spectra_out, r->d_spec, sizeof(double) * B * r->ss->dev.chan_tot,

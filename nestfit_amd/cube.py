@@ -1,0 +1,96 @@
+"""Pixel sharding of a cube over GPUs (one process per GPU) and the device-
+resident multi-pixel runner.
+
+The reference fits map pixels independently and stripes them over processes with
+``(lon_ix[i::nproc], lat_ix[i::nproc])`` (nestfit/main.py:565-571); each process
+writes its own chunk file and nothing is exchanged while sampling
+(nestfit/main.py:423-474, docs/store_spec.rst:12-32).  Here rank r owns the same
+stripe, uploads its pixels once and evaluates batches of (pixel, unit-cube row)
+items.  The only collective is the end-of-run gather of fixed-size per-pixel
+records (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .ammonia import _RunnerHandle, _SpecSet
+from .core import _as_inplace_matrix
+
+
+def get_multiproc_indices(shape, nproc):
+    """Same striping as the reference (nestfit/main.py:565-571)."""
+    lon_ix, lat_ix = np.indices(shape)
+    return [(lon_ix[i::nproc, ...].flatten(), lat_ix[i::nproc, ...].flatten()) for i in range(nproc)]
+
+
+def shard_pixels(shape, rank, world):
+    """(lon, lat) index arrays of the pixels owned by `rank` (i_lon % world == rank)."""
+    if min(shape) < 1 or not (0 <= rank < world):
+        raise ValueError('invalid shard request')
+    return get_multiproc_indices(shape, world)[rank]
+
+
+class CubeRunner:
+    """AmmoniaRunner semantics for many pixels that share their frequency axes.
+
+    Parameters
+    ----------
+    xarrs : list of 1-D frequency axes (Hz, ascending), one per transition
+    trans_ids : list of int
+    data : array [n_pix, sum(len(x) for x in xarrs)], K, spectra concatenated per pixel
+    noise : array [n_pix, n_spec], K
+    utrans : PriorTransformer
+    """
+
+    def __init__(self, xarrs, trans_ids, data, noise, utrans, ncomp=1, cold=False, lte=False):
+        assert ncomp > 0
+        self._ss = _SpecSet(xarrs, trans_ids, data, noise)
+        self._run = _RunnerHandle(self._ss, utrans, ncomp, cold, lte)
+        self.utrans = utrans
+        self.ncomp = int(ncomp)
+        self.n_model = 6
+        self.n_params = self.ndim = 6 * self.ncomp
+        self.n_pix = self._ss.n_pix
+        self.n_spec = self._ss.n_spec
+        self.n_chan_tot = self._ss.chan_tot
+        self.null_lnZ = self._ss.null_lnZ().sum(axis=1)      # per pixel
+
+    def loglikelihood_batch(self, pix, U):
+        """lnL[B] of unit-cube rows U[B, ndim] against pixels pix[B]; U is overwritten
+        with the physical parameters (like Runner.loglikelihood, core.pyx:558-561)."""
+        U = _as_inplace_matrix(U)
+        if U.shape[1] != self.ndim:
+            raise ValueError(f'Invalid shape for ncomp={self.ncomp}: {U.shape[1]}')
+        pix = np.ascontiguousarray(pix, dtype=np.int32)
+        if pix.shape != (U.shape[0],):
+            raise ValueError('one pixel index per row is required')
+        lnL = np.empty(U.shape[0])
+        _ffi.check(_ffi.load().nfa_runner_loglike_batch(self._run.handle, pix.ctypes.data_as(_ffi._ip),
+                                                        _ffi.dptr(U), _ffi.dptr(lnL), U.shape[0]))
+        return lnL
+
+
+def gather_pixel_records(records, group=None):
+    """All-gather fixed-size per-pixel result records (float64 [n_local, width]) from
+    every rank; returns the concatenation in rank order.  Ranks may own different
+    numbers of pixels (stripes of a cube whose width is not a multiple of world)."""
+    import torch
+    import torch.distributed as dist
+    records = np.ascontiguousarray(records, dtype=np.float64)
+    assert records.ndim == 2
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    n_local = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    width = records.shape[1]
+    n_max = max(counts)
+    padded = torch.zeros((n_max, width), dtype=torch.float64, device=dev)
+    if records.shape[0]:
+        padded[:records.shape[0]] = torch.from_numpy(records).to(dev)
+    out = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    return np.concatenate([o[:n].cpu().numpy() for o, n in zip(out, counts)], axis=0)

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""usage: traffic_summary.py <mode> <FETCH_SIZE counter csv> <WRITE_SIZE counter csv> [out.json]
+
+Per-launch HBM traffic of the likelihood kernel from rocprofv3 PMC passes, corrected as
+/opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE / WRITE_SIZE are in KiB;
+FETCH_SIZE under-counts reads on gfx950 by a factor that depends on the access width, so it
+is calibrated on a stream of known size issued with the engine's own pattern
+(null_lnz_kernel over a 256 MiB cube, see traffic_probe.py)."""
+import csv, json, sys
+mode, fcsv, wcsv = sys.argv[1:4]
+out = sys.argv[4] if len(sys.argv) > 4 else None
+
+def rows(path, counter):
+    r = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row['Counter_Name'] == counter:
+                r.append((row['Kernel_Name'], int(row['Grid_Size']), float(row['Counter_Value'])))
+    return r
+
+fetch, write = rows(fcsv, 'FETCH_SIZE'), rows(wcsv, 'WRITE_SIZE')
+cal = [v for k, g, v in fetch if 'null_lnz_kernel' in k and g >= 16384 * 2 * 64]
+cal_bytes = 16384 * 2048 * 8
+factor = cal_bytes / (max(cal) * 1024.0)
+lnl_f = [v for k, g, v in fetch if 'lnl_kernel' in k and g >= 4096 * 64]
+lnl_w = [v for k, g, v in write if 'lnl_kernel' in k and g >= 4096 * 64]
+half = len(lnl_f) // 2
+res = {
+    'fetch_calibration_factor': factor,
+    'one_pixel': {'fetch_bytes': sum(lnl_f[:half]) / half * 1024 * factor, 'write_bytes': sum(lnl_w[:half]) / half * 1024},
+    'pixel_per_item': {'fetch_bytes': sum(lnl_f[half:]) / (len(lnl_f) - half) * 1024 * factor,
+                       'write_bytes': sum(lnl_w[half:]) / (len(lnl_w) - half) * 1024},
+}
+for k in ('one_pixel', 'pixel_per_item'):
+    res[k]['total_bytes'] = res[k]['fetch_bytes'] + res[k]['write_bytes']
+print(json.dumps(res, indent=1))
+if out:
+    try:
+        allres = json.load(open(out))
+    except Exception:
+        allres = {}
+    allres.setdefault('C2', {})[mode] = res['one_pixel']['total_bytes']
+    allres.setdefault('detail', {})[mode] = res
+    json.dump(allres, open(out, 'w'), indent=1)

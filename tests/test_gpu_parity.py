@@ -14,6 +14,15 @@ from nestfit_amd.synth import TRUTH_1COMP, TRUTH_2COMP, TRUTH_3COMP, freq_axis
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _exact_mode_unless_stated(engine):
+    """Tests that do not pick a mode run in the bit-faithful table mode; the engine's
+    own default ("fast") is restored afterwards."""
+    engine.set_exp_mode('table')
+    yield
+    engine.set_exp_mode('fast')
+
 TB_RTOL = 1e-6          # north_star tolerance on floating-point Tb
 MODES = ['table', 'poly', 'fast']
 # what each mode is expected to reach on Tb (pinned so that regressions show)
@@ -113,7 +122,6 @@ def test_iemtex_and_partition(engine, nfo):
         _ffi.check(lib.nfa_test_partition(_ffi.dptr(trot), _ffi.dptr(qp), _ffi.dptr(qo), trot.size))
         np.testing.assert_allclose(qp, [nfo.partition_func(True, t) for t in trot], rtol=1e-14)
         np.testing.assert_allclose(qo, [nfo.partition_func(False, t) for t in trot], rtol=1e-14)
-    engine.set_exp_mode('table')
 
 
 def test_hyperfine_window_indices_bit_exact(engine, nfo):
@@ -182,7 +190,6 @@ def test_amm_predict_grid(engine, nfo, mode):
                         assert sg.loglikelihood == pytest.approx(sc.loglikelihood, rel=LNL_RTOL[mode])
     print(f'{mode}: worst relative Tb error (channels above 1e-6 K) {worst:.2e}')
     assert worst < TIGHT[mode], worst
-    engine.set_exp_mode('table')
 
 
 @pytest.mark.parametrize('mode', MODES)
@@ -200,7 +207,6 @@ def test_survey_known_answers_on_device(engine, kat, mode):
         if 'sum' in c:
             assert s.sum_spec == pytest.approx(c['sum'], rel=tol)
         assert s.loglikelihood == pytest.approx(c['lnL'], rel=tol)
-    engine.set_exp_mode('table')
 
 
 def _runner_pair(engine, nfo, ut, trans, n, ncomp, rng, cold=False, lte=False, truth=None, noise=0.2):
@@ -259,7 +265,6 @@ def test_runner_loglikelihood_irdc_and_synth(engine, nfo, kat, mode):
         lnl = run.loglikelihood(u)
         np.testing.assert_allclose(u, c['theta'], rtol=1e-12)
         assert lnl == pytest.approx(lnl_ref, rel=1e-11 if mode != 'fast' else 1e-6)
-    engine.set_exp_mode('table')
 
 
 def test_all_prior_kinds(engine, nfo):
@@ -409,4 +414,44 @@ def test_full_size_configs(engine, nfo, mode):
         spec, lp = gpu.predict_batch(U1[:256])
         assert np.array_equal(lp, l1[:256])
         assert spec.shape == (256, n * len(trans))
-    engine.set_exp_mode('table')
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_cube_runner_multi_pixel(engine, nfo, mode):
+    """Config-3 shape in miniature: a 6 x 4 cube, items = (pixel, unit-cube row)."""
+    from nestfit_amd.cube import CubeRunner, shard_pixels
+    from nestfit_amd.synth import param_sampler_draw
+    engine.set_exp_mode(mode)
+    rng = np.random.default_rng(11)
+    shape, n, noise = (6, 4), 512, 0.2
+    axes = [freq_axis(t, n) for t in (1, 2)]
+    n_pix = shape[0] * shape[1]
+    data = np.empty((n_pix, 2 * n))
+    for p in range(n_pix):
+        truth = param_sampler_draw(rng)
+        for k, t in enumerate((1, 2)):
+            s = nfo.AmmoniaSpectrum(axes[k], np.zeros(n), noise, t)
+            nfo.amm_predict(s, truth)
+            data[p, k * n:(k + 1) * n] = s.get_spec() + rng.normal(0, noise, n)
+    ut = engine.get_irdc_priors()
+    # this "rank" owns stripe 1 of 2 (i_lon % 2 == 1), like one GPU of a 2-GPU run
+    lon, lat = shard_pixels(shape, 1, 2)
+    mine = lon * shape[1] + lat
+    cube = CubeRunner(axes, (1, 2), data[mine], np.full((mine.size, 2), noise), ut, ncomp=2)
+    assert cube.n_pix == mine.size and cube.n_chan_tot == 2 * n
+    B = 600
+    pix = rng.integers(0, mine.size, B).astype(np.int32)
+    U = rng.uniform(size=(B, 12))
+    Ug = U.copy()
+    lg = cube.loglikelihood_batch(pix, Ug)
+    ps = nfo.PriorSet(ut.lower())
+    for b in range(0, B, 7):
+        p = mine[pix[b]]
+        run = nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(axes[k], data[p, k * n:(k + 1) * n], noise, t)
+                                 for k, t in enumerate((1, 2))], ps, ncomp=2)
+        u = U[b].copy()
+        assert lg[b] == pytest.approx(run.loglikelihood(u), rel=LNL_RTOL[mode])
+        np.testing.assert_allclose(Ug[b], u, rtol=1e-11, atol=1e-13)
+        assert cube.null_lnZ[pix[b]] == pytest.approx(run.null_lnZ, rel=1e-12)
+    with pytest.raises(engine.EngineError):
+        cube.loglikelihood_batch(np.full(B, mine.size, dtype=np.int32), U.copy())   # pixel out of range
