@@ -50,8 +50,9 @@ int nfa_device_name(char *buf, int buflen);
 int nfa_set_exp_mode(int mode);
 int nfa_get_exp_mode(void);
 /* Engine tuning knobs for A/B measurements: "nparts" = waves per spectrum of one
- * item in the likelihood kernel (0 = default 2); "overlap" = 1 puts the set-up and
- * the likelihood kernel of runners created afterwards on two streams; "ablate"
+ * item in the likelihood kernel (0 = default 2); "streams" = number of HIP streams
+ * ("lanes", 1..8, default 2) that runners created afterwards spread consecutive
+ * nfa_runner_loglike_batch_dev calls over; "persistent" = 1 device-sized grid; "ablate"
  * (timing experiments only, results invalid) = 1 skip the Tb pass, 2 skip the
  * hyperfine-line loop, 3 both. */
 int nfa_set_option(const char *key, int value);
@@ -148,16 +149,21 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
                              int64_t B, double *spectra_out, double *lnL_out);
 
 /* Same as nfa_runner_loglike_batch with every buffer already resident in device
- * memory (from nfa_malloc); enqueued on the runner's stream, returns without
- * synchronising.  d_pix may be NULL. */
+ * memory (from nfa_malloc); enqueued, returns without synchronising.  d_pix may be
+ * NULL.  Consecutive calls go to different HIP streams of the runner (round
+ * robin) and may overlap on the device: the buffers of calls that are in flight
+ * together must not alias.  nfa_runner_synchronize waits for all of them. */
 int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_U,
                                  double *d_lnL, int64_t B);
 int nfa_runner_synchronize(nfa_runner *r);
 /* Per-kernel timing of nfa_runner_loglike_batch_dev with HIP events recorded on
- * the runner's stream: summed milliseconds of the prior-transform kernel and of
- * the likelihood kernel over the calls made since profiling was switched on. */
+ * the stream each kernel is launched on, over the calls made since profiling was
+ * switched on.  out[0], out[1]: summed milliseconds of the set-up kernel and of the
+ * likelihood kernel; out[2], out[3]: milliseconds during which at least one set-up /
+ * likelihood kernel was running (union of the launch intervals: with several stream
+ * lanes launches overlap and the plain sum counts that time more than once). */
 int nfa_runner_set_profiling(nfa_runner *r, int on);
-int nfa_runner_get_profile(nfa_runner *r, double *prior_ms, double *lnl_ms, int64_t *calls);
+int nfa_runner_get_profile(nfa_runner *r, double *out, int64_t *calls);
 
 /* MultiNest `LogLike` (nestfit/core/cmultinest.pxd:27-28; the reference's
  * trampoline is mn_loglikelihood, nestfit/core/core.pyx:622-624).  Pass the

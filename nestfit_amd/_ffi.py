@@ -66,7 +66,7 @@ SIGNATURES = {
                                                C.c_int64]),
     'nfa_runner_synchronize': (C.c_int, [C.c_void_p]),
     'nfa_runner_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
-    'nfa_runner_get_profile': (C.c_int, [C.c_void_p, _dp, _dp, _lp]),
+    'nfa_runner_get_profile': (C.c_int, [C.c_void_p, _dp, _lp]),
     'nfa_loglike_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
     'nfa_malloc': (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     'nfa_free': (C.c_int, [C.c_void_p]),

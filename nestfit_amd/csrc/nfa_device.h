@@ -92,7 +92,8 @@ struct LnlGeom {
     int nparts;        // interleaved row parts per spectrum
     int wpi;           // waves per item = n_spec * nparts
     int ipb;           // items per workgroup
-    int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 3 both
+    int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 4 skip rows, 8 skip line setup
+    int wave_info[16]; // per wave of a workgroup: item slot | spectrum << 8 | row part << 16
 };
 
 // ---------------------------------------------------------------------------
@@ -105,10 +106,26 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Wave-wide sum with DPP lane permutations (no LDS traffic): butterfly inside each row of
+// 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row sums
+// are read through SGPRs.  Fixed order: bitwise reproducible; every lane gets the total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
 __device__ __forceinline__ double wave_excl_scan(double v, int lane, double *total) {
@@ -402,6 +419,8 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
     return (t < 0.03125f) ? w_small : (double)wf;
 }
 
+#define DREG_MAX 4           // D record doubles per lane held in flight (drec <= 256)
+
 template <int MODE, bool WRITE_SPEC>
 __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restrict__ pix,
                                                    const double *__restrict__ D,
@@ -410,8 +429,9 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                                                    const double *__restrict__ g_tabs) {
     typedef typename std::conditional<MODE == 2, float, double>::type tau_t;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    int n_shared;
-    const double *sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);
+    int n_shared = 0;
+    const double *sm = smem;
+    if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);   // fast: no tables
     const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
 
     // everything derived from the wave index is wave-uniform: keep it in SGPRs so that the
@@ -420,36 +440,53 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ncomp = S.ncomp, nspec = S.n_spec;
     const int drec = drec_size(ncomp, nspec);
-    const int il = wave / G.wpi, part = wave - il * G.wpi;   // item slot in the block, part of the item
-    const int s = part / G.nparts, rp = part - s * G.nparts;
-    // LDS: [tables][red: waves][per item slot: D record, then per spectrum the line table]
+    const int winfo = G.wave_info[wave];
+    const int il = winfo & 0xff, s = (winfo >> 8) & 0xff, rp = winfo >> 16;   // item slot, spectrum, row part
+    const int part = s * G.nparts + rp;
+    // LDS: [tables][red: waves][per item slot: 2 D records (double buffer), then per spectrum
+    // the line table]
     double *red = smem + n_shared;                            // [waves] partial chi^2
     double *slot = red + ((waves + 1) & ~1) + (size_t)il * G.wave_doubles;   // wave_doubles = per item slot
-    double *w_d = slot;
+    const int drec2 = (drec + 1) & ~1;
     const int P = ncomp * G.nhf_max;
-    LineRec *w_line = (LineRec *)(slot + ((drec + 1) & ~1)) + (size_t)s * P;
-    int2 *w_win = (int2 *)((LineRec *)(slot + ((drec + 1) & ~1)) + (size_t)nspec * P) + (size_t)s * P;
+    LineRec *w_line = (LineRec *)(slot + 2 * drec2) + (size_t)s * P;
+    // windows (lo, hi) again, 64 per component so that a whole wave can read them unguarded
+    int2 *w_win = (int2 *)((LineRec *)(slot + 2 * drec2) + (size_t)nspec * P) + (size_t)s * ncomp * 64;
 
     const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
     const int nhf = c_nhf[t];
     const double nu0 = c_nu[t];
     const double *xs = S.xarr + off, *t0s = S.t0 + off, *tbgs = S.tbg + off;
+    const int row_step = 64 * G.nparts;
 
-    for (long b0 = (long)blockIdx.x * G.ipb; b0 < B; b0 += (long)gridDim.x * G.ipb) {
+    // persistent workgroups: the grid covers the device once, every workgroup walks its
+    // items; the record of the next item is already in flight while the current one runs
+    const long stride = (long)gridDim.x * G.ipb;
+    long b0 = (long)blockIdx.x * G.ipb;
+    if (part == 0 && b0 + il < B)
+        for (int k = lane; k < drec; k += 64) slot[k] = D[(b0 + il) * drec + k];
+    __syncthreads();
+    int cur = 0;
+    for (; b0 < B; b0 += stride, cur ^= 1) {
         const long b = b0 + il;
         const bool item = b < B;
+        const double *w_d = slot + cur * drec2;
+        double dreg[DREG_MAX];
+        const long bn = b + stride;
+        if (part == 0 && bn < B) {
+#pragma unroll
+            for (int q = 0; q < DREG_MAX; ++q) {
+                const int k = lane + 64 * q;
+                dreg[q] = (k < drec) ? D[bn * drec + k] : 0.0;
+            }
+        }
         double acc = 0.0;
         long p_ix = 0;
         if (item) {
             p_ix = pix ? (long)pix[b] : 0;
-            // the item's record: loaded by its first wave
-            if (part == 0) for (int k = lane; k < drec; k += 64) w_d[k] = D[b * drec + k];
-        }
-        __syncthreads();
-        if (item) {
             // --- line constants + windows of spectrum s, lanes = (component, line) pairs,
             //     shared by the nparts waves of the spectrum (hyperfine.pyx:68-91)
-            for (int p = rp * 64 + lane; p < ncomp * nhf; p += 64 * G.nparts) {
+            for (int p = rp * 64 + lane; p < ncomp * nhf && !(G.ablate & 8); p += 64 * G.nparts) {
                 const int c = p / nhf, i = p - c * nhf;
                 const LineConst lc = nf_line(t, i, w_d[c * 4 + 2], w_d[c * 4 + 1], nu0, S.nu_min[s],
                                              S.nu_chan[s], N);
@@ -472,44 +509,34 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                 rec.lo = lo;
                 rec.len = hi > lo ? hi - lo : 0;
                 w_line[c * G.nhf_max + i] = rec;
-                w_win[c * G.nhf_max + i] = make_int2(lo, hi > lo ? hi : lo);
+                w_win[c * 64 + i] = make_int2(lo, hi > lo ? hi : lo);
             }
+            // lanes beyond the last line: empty windows (written once per item by the same waves)
+            for (int q = rp * 64 + lane; q < ncomp * 64; q += 64 * G.nparts)
+                if ((q & 63) >= nhf) w_win[q] = make_int2(0, 0);
         }
         __syncthreads();
         if (item) {
             // --- rows of 64 channels: tau profile, Tb, chi^2
             //     (hyperfine.pyx:93-113, core.pyx:522-530); this wave owns rows rp, rp+nparts, ...
             const double *ds = S.data + p_ix * S.chan_tot + off;
-            for (int r0 = rp * 64; r0 < N; r0 += 64 * G.nparts) {
+            for (int r0 = rp * 64; r0 < N && !(G.ablate & 4); r0 += row_step) {
                 const int j = r0 + lane;
                 const bool valid = j < N;
                 const int jj = valid ? j : N - 1;
-                const double xj = xs[jj];
-                const double dj = ds[jj];
-                const double T0 = t0s[jj];
-                const double tbg = tbgs[jj];
+                const double xj = xs[jj], dj = ds[jj], T0 = t0s[jj], tbg = tbgs[jj];
                 double pred = 0.0;
                 for (int c = 0; c < ncomp; ++c) {
                     const LineRec *lines = w_line + c * G.nhf_max;
-                    int2 win = make_int2(0, 0);
-                    if (lane < nhf) win = w_win[c * G.nhf_max + lane];
-                    unsigned long long mask = __ballot(win.y > win.x && win.x < r0 + 64 && win.y > r0);
+                    const int2 win = w_win[c * 64 + lane];
+                    unsigned long long mask = __ballot(win.x < r0 + 64 && win.y > r0 && win.y > win.x);
                     if (mask == 0ull) continue;
                     tau_t tau = 0;
                     if (G.ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); } else {
-                    // software-pipelined walk over the lines that touch this row: the
-                    // record of the next line is in flight while the current one is used
-                    int i = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    LineRec rec = lines[i];
-                    while (true) {
-                        const bool more = mask != 0ull;
-                        LineRec nxt = rec;
-                        if (more) {
-                            i = __builtin_ctzll(mask);
-                            mask &= mask - 1;
-                            nxt = lines[i];
-                        }
+                    while (mask) {
+                        const int i = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        const LineRec rec = lines[i];
                         const double nu = xj - rec.nucen;
                         const double tau_exp = nu * nu * rec.idenom;
                         const bool inwin = (unsigned)(j - rec.lo) < (unsigned)rec.len;
@@ -527,8 +554,6 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                             const double e = nf_fastexp<MODE>(tau_exp, sm);
                             tau = inwin ? __builtin_fma(rec.htau, e, (double)tau) : tau;
                         }
-                        if (!more) break;
-                        rec = nxt;
                     }
                     }
                     const bool live = valid && !(tau == 0);           // hyperfine.pyx:104-105
@@ -557,8 +582,17 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
             }
             acc = wave_sum(acc);
         }
-        // --- the item's partial sums meet in LDS; fixed order (core.pyx:530, ammonia.pyx:429-432)
+        // --- the item's partial sums meet in LDS; fixed order (core.pyx:530, ammonia.pyx:429-432).
+        //     The same barrier publishes the next item's record.
         if (lane == 0) red[wave] = acc;
+        if (part == 0 && bn < B) {
+            double *w_dn = slot + (cur ^ 1) * drec2;
+#pragma unroll
+            for (int q = 0; q < DREG_MAX; ++q) {
+                const int k = lane + 64 * q;
+                if (k < drec) w_dn[k] = dreg[q];
+            }
+        }
         __syncthreads();
         if (item && part == 0 && lane == 0 && lnL) {
             double tot = 0.0;
@@ -732,6 +766,9 @@ __device__ double d_placement_draw(const DistDev &d, double *run_lds, double x_l
     return res;
 }
 
+// scratch layout: [0, size) running sums / CDF copy, then MAXCOMP separations
+__device__ __forceinline__ int d_scratch_seps_offset(int size) { return (size + 1) & ~1; }
+
 // PriorTransformer.c_transform (core.pyx:459-476) of one unit-cube row held in
 // LDS (u[n_param*n]), in place; `scratch` holds max_size doubles.
 __device__ __forceinline__ void prior_transform_item(const PriorProg &pp, double *u, double *scratch,
@@ -803,38 +840,28 @@ __device__ __forceinline__ void prior_transform_item(const PriorProg &pp, double
                 wave_lds_sync();
                 break;
             }
-            // every lane carries the same scalars
-            double min_seps[MAXCOMP];
+            // minimum separations: lane i-1 -> component i (core.pyx:409-415); kept in LDS
+            double *min_seps = scratch + d_scratch_seps_offset(vd.size);
+            if (lane < n) min_seps[lane] = (lane == 0) ? 0.0
+                                                       : p.sep_scale * sqrt(u[ix_s + lane] * u[ix_s + lane - 1]);
+            wave_lds_sync();
             double sep_tot = 0.0;
-            min_seps[0] = 0.0;
-#pragma unroll
-            for (int i = 1; i < MAXCOMP; ++i) {
-                double sep = 0.0;
-                if (i < n) {
-                    sep = p.sep_scale * sqrt(u[ix_s + i] * u[ix_s + i - 1]);
-                    sep_tot += sep;
-                }
-                min_seps[i] = sep;
-            }
-            if (sep_tot > v_hi - v_lo) {
-                const double overf = (v_hi - v_lo) / sep_tot;
+            for (int i = 1; i < n; ++i) sep_tot += min_seps[i];
+            double overf = 1.0;
+            const bool shrink = sep_tot > v_hi - v_lo;            // core.pyx:418-423
+            if (shrink) {
+                overf = (v_hi - v_lo) / sep_tot;
                 sep_tot = 0.0;
-#pragma unroll
-                for (int i = 0; i < MAXCOMP; ++i) {
-                    if (i < n) { min_seps[i] *= overf; sep_tot += min_seps[i]; }
-                }
+                for (int i = 0; i < n; ++i) sep_tot += min_seps[i] * overf;
             }
             v_hi -= sep_tot;
-#pragma unroll
-            for (int i = 0; i < MAXCOMP; ++i) {
-                if (i < n) {
-                    const double sep = min_seps[i];
-                    v_lo += sep;
-                    v_hi += sep;
-                    const double uu = u[ix + i];
-                    v_lo = d_placement_draw(vd, scratch, v_lo, v_hi, (double)(n - 1 - i), uu, lane);
-                    if (lane == 0) u[ix + i] = v_lo;
-                }
+            for (int i = 0; i < n; ++i) {                          // core.pyx:427-435
+                const double sep = shrink ? min_seps[i] * overf : min_seps[i];
+                v_lo += sep;
+                v_hi += sep;
+                const double uu = u[ix + i];
+                v_lo = d_placement_draw(vd, scratch, v_lo, v_hi, (double)(n - 1 - i), uu, lane);
+                if (lane == 0) u[ix + i] = v_lo;
             }
             wave_lds_sync();
         } break;
@@ -873,6 +900,16 @@ __global__ void __launch_bounds__(256) setup_kernel(const PriorProg *__restrict_
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int n_shared;
     const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
+    // the prior program (descriptors + table pointers, ~2 KB) is walked field by field by
+    // every wave: keep a copy in LDS instead of chasing it through global memory
+    const int pp_doubles = HAS_PRIOR ? (int)((sizeof(PriorProg) + 7) / 8) : 0;
+    if (HAS_PRIOR) {
+        const double *src = (const double *)ppp;
+        for (int i = threadIdx.x; i < pp_doubles; i += blockDim.x) smem[n_shared + i] = src[i];
+        __syncthreads();
+    }
+    const PriorProg *pp_lds = (const PriorProg *)(smem + n_shared);
+    n_shared += (pp_doubles + 1) & ~1;
     const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ncomp = S.ncomp, ndim = NFA_N_PARAMS * ncomp;
@@ -886,7 +923,7 @@ __global__ void __launch_bounds__(256) setup_kernel(const PriorProg *__restrict_
         for (int k = lane; k < ndim; k += 64) w_theta[k] = U[b * ndim + k];
         wave_lds_sync();
         if (HAS_PRIOR) {
-            prior_transform_item(*ppp, w_theta, scratch, ncomp, lane);
+            prior_transform_item(*pp_lds, w_theta, scratch, ncomp, lane);
             for (int k = lane; k < ndim; k += 64) U[b * ndim + k] = w_theta[k];
         }
         derive_item<MODE>(S, w_theta, w_comp, w_zlev, D + b * drec, sm, g_tabs, lane);

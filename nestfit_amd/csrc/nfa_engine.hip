@@ -42,7 +42,8 @@ struct Engine {
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
     int    nparts_override = 0;
     int    ablate = 0;
-    int    overlap = 0;
+    int    streams = 2;              // stream lanes of new runners
+    int    persistent = 0;
     bool   have_t0 = false;
     double *d_tabs = nullptr;                      // SM_END_TABLE doubles
     double t0_xmin = 0, t0_xmax = 0, t0_inv_dx = 0;
@@ -95,20 +96,22 @@ struct nfa_priors {
     std::vector<double *> d_arrays;
 };
 
+#define NFA_MAX_LANES 8
 struct nfa_runner {
     nfa_specset *ss = nullptr;
     nfa_priors  *pr = nullptr;
     int ncomp = 1, cold = 0, lte = 0, ndim = 6;
-    // Two streams: the set-up kernel of batch k+1 (latency bound: table look-ups, libm)
-    // overlaps the likelihood kernel of batch k (VALU bound).  The derived-parameter
-    // records are double buffered; events order the hand-offs.
-    hipStream_t stream = nullptr;            // likelihood kernel, device->host copies
-    hipStream_t stream_setup = nullptr;      // host->device copies, set-up kernel
-    hipEvent_t  ev_setup_done[2] = {nullptr, nullptr}, ev_lnl_done[2] = {nullptr, nullptr};
+    // Stream lanes: consecutive batches go to different HIP streams (round robin), so the
+    // tail of one batch (few workgroups left, SIMDs draining) overlaps the start of the
+    // next; inside a lane the set-up kernel and the likelihood kernel run in order and own
+    // the lane's derived-parameter records.
+    int         n_lanes = 1;
+    hipStream_t lanes[NFA_MAX_LANES] = {};
+    double     *d_D[NFA_MAX_LANES] = {};
+    int64_t     cap_D[NFA_MAX_LANES] = {};
+    hipStream_t stream = nullptr;            // lane 0: also the stream of the host-pointer entry points
     uint64_t    n_calls = 0;
     double *d_U = nullptr, *d_lnL = nullptr, *d_spec = nullptr;
-    double *d_D[2] = {nullptr, nullptr};
-    int64_t cap_D[2] = {0, 0};
     int    *d_pix = nullptr;
     int64_t cap_B = 0, cap_spec = 0;
     // optional per-kernel timing (HIP events on the runner's stream)
@@ -156,8 +159,9 @@ int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "nparts") && value >= 0 && value <= 16) { g_eng.nparts_override = value; return NFA_OK; }
-    if (key && !strcmp(key, "ablate") && value >= 0 && value <= 3) { g_eng.ablate = value; return NFA_OK; }
-    if (key && !strcmp(key, "overlap") && (value == 0 || value == 1)) { g_eng.overlap = value; return NFA_OK; }
+    if (key && !strcmp(key, "ablate") && value >= 0 && value <= 15) { g_eng.ablate = value; return NFA_OK; }
+    if (key && !strcmp(key, "streams") && value >= 1 && value <= NFA_MAX_LANES) { g_eng.streams = value; return NFA_OK; }
+    if (key && !strcmp(key, "persistent") && (value == 0 || value == 1)) { g_eng.persistent = value; return NFA_OK; }
     return fail(NFA_ERR_ARG, "unknown option");
 }
 
@@ -309,7 +313,7 @@ int nfa_priors_destroy(nfa_priors *p) {
 
 static int launch_priors(const nfa_priors *p, double *d_U, int64_t B, int ncomp, hipStream_t st) {
     const int ndim = p->prog.n_param * ncomp;
-    const int wave_doubles = ((ndim + 1) & ~1) + ((p->prog.max_size + 1) & ~1);
+    const int wave_doubles = ((ndim + 1) & ~1) + ((p->prog.max_size + 1) & ~1) + MAXCOMP + 2;
     const int waves = 4;
     const size_t lds = sizeof(double) * wave_doubles * waves;
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "distribution tables too large for LDS scratch");
@@ -354,30 +358,20 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors, int
     nfa_runner *r = new nfa_runner();
     r->ss = ss; r->pr = priors; r->ncomp = ncomp; r->cold = cold ? 1 : 0; r->lte = lte ? 1 : 0;
     r->ndim = NFA_N_PARAMS * ncomp;
-    HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-    // measured on MI355X: running the set-up kernel of batch k+1 beside the likelihood kernel
-    // of batch k slows both by the same amount (the likelihood kernel already owns every wave
-    // slot), so by default both kernels share one stream; "overlap" = 1 splits them.
-    if (g_eng.overlap) HIP_TRY(hipStreamCreateWithFlags(&r->stream_setup, hipStreamNonBlocking));
-    else r->stream_setup = r->stream;
-    for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipEventCreateWithFlags(&r->ev_setup_done[k], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&r->ev_lnl_done[k], hipEventDisableTiming));
-    }
+    r->n_lanes = std::max(1, std::min(g_eng.streams, NFA_MAX_LANES));
+    for (int k = 0; k < r->n_lanes; ++k) HIP_TRY(hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking));
+    r->stream = r->lanes[0];
     *out = r;
     return NFA_OK;
 }
 
 int nfa_runner_destroy(nfa_runner *r) {
     if (!r) return NFA_OK;
-    (void)hipStreamSynchronize(r->stream_setup);
-    (void)hipStreamSynchronize(r->stream);
+    for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamSynchronize(r->lanes[k]);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
-    (void)hipFree(r->d_D[0]); (void)hipFree(r->d_D[1]);
-    for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(r->ev_setup_done[k]); (void)hipEventDestroy(r->ev_lnl_done[k]); }
-    if (r->stream_setup != r->stream) (void)hipStreamDestroy(r->stream_setup);
+    for (int k = 0; k < r->n_lanes; ++k) (void)hipFree(r->d_D[k]);
     for (hipEvent_t x : r->ev) (void)hipEventDestroy(x);
-    (void)hipStreamDestroy(r->stream);
+    for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamDestroy(r->lanes[k]);
     delete r;
     return NFA_OK;
 }
@@ -417,8 +411,7 @@ static int launch_setup_t(nfa_runner *r, double *d_U, int64_t B, int slot) {
     const SpecDev S = runner_specdev(r);
     const int drec = drec_size(r->ncomp, S.n_spec);
     if (B > r->cap_D[slot]) {                // grown outside any timed loop
-        HIP_TRY(hipStreamSynchronize(r->stream_setup));
-        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(hipStreamSynchronize(r->lanes[slot]));
         (void)hipFree(r->d_D[slot]); r->d_D[slot] = nullptr; r->cap_D[slot] = 0;
         const int64_t cap = std::max<int64_t>(B, 4096);
         HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec));
@@ -429,14 +422,15 @@ static int launch_setup_t(nfa_runner *r, double *d_U, int64_t B, int slot) {
     const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : 32;
     const int waves = 4;
     int wd = ((r->ndim + 1) & ~1) + r->ncomp * COMP_STRIDE + ((r->ncomp * NFA_N_LEVELS + 1) & ~1);
-    if (HAS_PRIOR) wd += (max_size + 1) & ~1;
-    const size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)wd * waves);
+    if (HAS_PRIOR) wd += ((max_size + 1) & ~1) + MAXCOMP + 2;
+    const size_t pp_doubles = HAS_PRIOR ? (((sizeof(PriorProg) + 7) / 8 + 1) & ~(size_t)1) : 0;
+    const size_t lds = sizeof(double) * ((size_t)n_shared + pp_doubles + (size_t)wd * waves);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "distribution tables too large for LDS scratch");
     const int64_t blocks = std::min<int64_t>((B + waves - 1) / waves, (int64_t)g_eng.n_cu * 8);
     auto kern = setup_kernel<MODE, HAS_PRIOR>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, r->stream_setup, d_pp, S, d_U,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, r->lanes[slot], d_pp, S, d_U,
                        r->d_D[slot],
                        (long)B, wd, (const double *)g_eng.d_tabs);
     HIP_TRY(hipGetLastError());
@@ -460,8 +454,10 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     G.ablate = g_eng.ablate;
     G.nhf_max = r->ss->nhf_max;
     const int drec = drec_size(r->ncomp, S.n_spec);
-    // LDS per item slot: D record + for every spectrum the line table (32-B records + windows)
-    G.wave_doubles = ((drec + 1) & ~1) + S.n_spec * r->ncomp * G.nhf_max * ((int)(sizeof(LineRec) / sizeof(double)) + 1);
+    // LDS per item slot: two D records (double buffer) + for every spectrum the line table
+    // (32-B records + windows)
+    if (drec > 64 * DREG_MAX) return fail(NFA_ERR_ARG, "ncomp x n_spec too large for the record prefetch");
+    G.wave_doubles = 2 * ((drec + 1) & ~1) + S.n_spec * r->ncomp * (G.nhf_max * (int)(sizeof(LineRec) / sizeof(double)) + 64);
     int min_rows = 1 << 30;
     for (int s = 0; s < S.n_spec; ++s) min_rows = std::min(min_rows, (S.size[s] + 63) / 64);
     // Every item is cut into n_spec x nparts waves.  nparts depends on the runner's shape
@@ -475,15 +471,31 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     const int target_waves = MODE == 0 ? 16 : 4;
     G.ipb = std::max(1, target_waves / G.wpi);
     const int waves = G.wpi * G.ipb;
-    const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : 32;
+    if (waves > 16) return fail(NFA_ERR_ARG, "too many spectra for one workgroup");
+    for (int w = 0; w < 16; ++w) {
+        const int il = w / G.wpi, part = w % G.wpi;
+        G.wave_info[w] = il | ((part / G.nparts) << 8) | ((part % G.nparts) << 16);
+    }
+    const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
     const size_t lds = sizeof(double) * ((size_t)n_shared + ((waves + 1) & ~1) + (size_t)G.wave_doubles * G.ipb);
     if (lds > 160 * 1024 || waves > 16)
         return fail(NFA_ERR_ARG, "ncomp / n_spec too large for the LDS line table");
-    const int64_t blocks = std::min<int64_t>((B + G.ipb - 1) / G.ipb, (int64_t)g_eng.n_cu * 256);
     auto kern = lnl_kernel<MODE, WS>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, r->stream, S, d_pix,
+    // One workgroup per ipb items, dispatched by the hardware as slots free up (measured:
+    // a device-sized persistent grid with static striding loses ~25 % to the 2-vs-3 items
+    // per workgroup imbalance at B = 4096); "persistent" = 1 switches to the device-sized grid.
+    int64_t blocks = std::min<int64_t>((B + G.ipb - 1) / G.ipb, (int64_t)g_eng.n_cu * 256);
+    if (g_eng.persistent) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 64 * waves, lds));
+        const int64_t capacity = (int64_t)g_eng.n_cu * std::max(1, per_cu);
+        const int64_t groups = (B + G.ipb - 1) / G.ipb;
+        const int64_t per_block = (groups + capacity - 1) / capacity;      // same count for every workgroup
+        blocks = (groups + per_block - 1) / per_block;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, r->lanes[slot], S, d_pix,
                        (const double *)r->d_D[slot], d_lnL, d_spec, (long)B, G, (const double *)g_eng.d_tabs);
     HIP_TRY(hipGetLastError());
     return NFA_OK;
@@ -503,42 +515,37 @@ static int launch_lnl(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, 
     }
 }
 
-// One batch: set-up kernel on stream_setup, likelihood kernel on stream, ordered by events;
-// batch k+1's set-up may run beside batch k's likelihood kernel.  d_U must be ready on
-// stream_setup (host->device copies are enqueued there).
+// One batch on the next stream lane: set-up kernel, then likelihood kernel.  `lane_out`
+// receives the lane (stream) the batch was enqueued on.
 static int run_batch(nfa_runner *r, const int *d_pix, double *d_U, double *d_lnL, double *d_spec,
-                     int64_t B, bool has_prior) {
+                     int64_t B, bool has_prior, int force_lane, int *lane_out) {
     if (!g_eng.have_t0) return fail(NFA_ERR_STATE, "nfa_set_iemtex_table has not been called");
-    const int slot = (int)(r->n_calls & 1);
+    const int slot = force_lane >= 0 ? force_lane : (int)(r->n_calls % (uint64_t)r->n_lanes);
+    hipStream_t st = r->lanes[slot];
     hipEvent_t *e = nullptr;
     if (r->profiling) {
-        if (r->ev_used + 4 > r->ev.size()) {
-            for (int k = 0; k < 4; ++k) { hipEvent_t x; HIP_TRY(hipEventCreate(&x)); r->ev.push_back(x); }
+        if (r->ev_used + 3 > r->ev.size()) {
+            for (int k = 0; k < 3; ++k) { hipEvent_t x; HIP_TRY(hipEventCreate(&x)); r->ev.push_back(x); }
         }
         e = &r->ev[r->ev_used];
-        r->ev_used += 4;
+        r->ev_used += 3;
+        HIP_TRY(hipEventRecord(e[0], st));
     }
-    // the records of this slot are free once the likelihood kernel of call k-2 is done
-    const bool two = r->stream_setup != r->stream;
-    if (two && r->n_calls >= 2) HIP_TRY(hipStreamWaitEvent(r->stream_setup, r->ev_lnl_done[slot], 0));
-    if (e) HIP_TRY(hipEventRecord(e[0], r->stream_setup));
     int rc = launch_setup(r, d_U, B, has_prior, slot);
     if (rc) return rc;
-    if (e) HIP_TRY(hipEventRecord(e[1], r->stream_setup));
-    if (two) {
-        HIP_TRY(hipEventRecord(r->ev_setup_done[slot], r->stream_setup));
-        HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_setup_done[slot], 0));
-    }
-    if (e) HIP_TRY(hipEventRecord(e[2], r->stream));
+    if (e) HIP_TRY(hipEventRecord(e[1], st));
     rc = launch_lnl(r, d_pix, slot, d_lnL, d_spec, B);
     if (rc) return rc;
-    if (e) HIP_TRY(hipEventRecord(e[3], r->stream));
-    if (two) HIP_TRY(hipEventRecord(r->ev_lnl_done[slot], r->stream));
+    if (e) HIP_TRY(hipEventRecord(e[2], st));
     r->n_calls++;
+    if (lane_out) *lane_out = slot;
     return NFA_OK;
 }
 
-extern "C" {
+static int sync_all_lanes(nfa_runner *r) {
+    for (int k = 0; k < r->n_lanes; ++k) HIP_TRY(hipStreamSynchronize(r->lanes[k]));
+    return NFA_OK;
+}
 
 static int check_pix(const nfa_runner *r, const int32_t *pix, int64_t B) {
     if (!pix) return NFA_OK;
@@ -547,60 +554,82 @@ static int check_pix(const nfa_runner *r, const int32_t *pix, int64_t B) {
     return NFA_OK;
 }
 
+extern "C" {
+
 int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_U, double *d_lnL,
                                  int64_t B) {
     if (!r || !d_U || !d_lnL) return fail(NFA_ERR_ARG, "null argument");
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     if (B <= 0) return NFA_OK;
-    return run_batch(r, d_pix, d_U, d_lnL, nullptr, B, true);
+    return run_batch(r, d_pix, d_U, d_lnL, nullptr, B, true, -1, nullptr);
 }
 
 int nfa_runner_set_profiling(nfa_runner *r, int on) {
     if (!r) return fail(NFA_ERR_ARG, "null runner");
-    HIP_TRY(hipStreamSynchronize(r->stream_setup));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    int rc = sync_all_lanes(r); if (rc) return rc;
     r->profiling = on != 0;
     r->ev_used = 0;
     return NFA_OK;
 }
 
-int nfa_runner_get_profile(nfa_runner *r, double *prior_ms, double *lnl_ms, int64_t *calls) {
-    if (!r || !prior_ms || !lnl_ms || !calls) return fail(NFA_ERR_ARG, "null argument");
-    HIP_TRY(hipStreamSynchronize(r->stream_setup));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    double a = 0, b = 0;
-    for (size_t k = 0; k + 3 < r->ev_used + 0 && k + 3 < r->ev.size() + 0; k += 4) {
-        float t = 0;
-        HIP_TRY(hipEventElapsedTime(&t, r->ev[k], r->ev[k + 1])); a += t;
-        HIP_TRY(hipEventElapsedTime(&t, r->ev[k + 2], r->ev[k + 3])); b += t;
+// length of the union of intervals [a_k, b_k] (milliseconds)
+static double union_length(std::vector<std::pair<double, double>> iv) {
+    std::sort(iv.begin(), iv.end());
+    double tot = 0, cur_a = 0, cur_b = -1;
+    for (auto &p : iv) {
+        if (cur_b < cur_a || p.first > cur_b) {
+            if (cur_b >= cur_a) tot += cur_b - cur_a;
+            cur_a = p.first; cur_b = p.second;
+        } else if (p.second > cur_b) cur_b = p.second;
     }
-    *prior_ms = a; *lnl_ms = b; *calls = (int64_t)(r->ev_used / 4);
+    if (cur_b >= cur_a) tot += cur_b - cur_a;
+    return tot;
+}
+
+int nfa_runner_get_profile(nfa_runner *r, double *out, int64_t *calls) {
+    if (!r || !out || !calls) return fail(NFA_ERR_ARG, "null argument");
+    int rc = sync_all_lanes(r); if (rc) return rc;
+    double a = 0, b = 0;
+    std::vector<std::pair<double, double>> iv_setup, iv_lnl;
+    const size_t n = std::min(r->ev_used, r->ev.size()) / 3;
+    for (size_t k = 0; k < n; ++k) {
+        float t0 = 0, t1 = 0, t2 = 0;          // times since the first recorded event
+        HIP_TRY(hipEventElapsedTime(&t0, r->ev[0], r->ev[3 * k]));
+        HIP_TRY(hipEventElapsedTime(&t1, r->ev[0], r->ev[3 * k + 1]));
+        HIP_TRY(hipEventElapsedTime(&t2, r->ev[0], r->ev[3 * k + 2]));
+        a += t1 - t0; b += t2 - t1;
+        iv_setup.emplace_back(t0, t1);
+        iv_lnl.emplace_back(t1, t2);
+    }
+    out[0] = a;                          // sum of set-up kernel durations
+    out[1] = b;                          // sum of likelihood kernel durations
+    out[2] = union_length(iv_setup);     // time during which >= 1 set-up kernel was running
+    out[3] = union_length(iv_lnl);       // time during which >= 1 likelihood kernel was running
+    *calls = (int64_t)n;
     r->ev_used = 0;
     return NFA_OK;
 }
 
 int nfa_runner_synchronize(nfa_runner *r) {
     if (!r) return fail(NFA_ERR_ARG, "null runner");
-    HIP_TRY(hipStreamSynchronize(r->stream_setup));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    return NFA_OK;
+    return sync_all_lanes(r);
 }
 
 int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, double *lnL, int64_t B) {
     if (!r || !U || !lnL) return fail(NFA_ERR_ARG, "null argument");
     if (B <= 0) return NFA_OK;
     int rc = check_pix(r, pix, B); if (rc) return rc;
-    rc = runner_reserve(r, B, false); if (rc) return rc;
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
-    // the staging buffers may still be read by an earlier likelihood kernel
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    HIP_TRY(hipMemcpyAsync(r->d_U, U, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, r->stream_setup));
-    if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, r->stream_setup));
-    rc = run_batch(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, nullptr, B, true);
+    rc = sync_all_lanes(r); if (rc) return rc;           // the staging buffers are shared
+    rc = runner_reserve(r, B, false); if (rc) return rc;
+    hipStream_t st = r->lanes[0];
+    HIP_TRY(hipMemcpyAsync(r->d_U, U, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, st));
+    if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, st));
+    rc = run_batch(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, nullptr, B, true, 0, nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(U, r->d_U, sizeof(double) * B * r->ndim, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipMemcpyAsync(lnL, r->d_lnL, sizeof(double) * B, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpyAsync(U, r->d_U, sizeof(double) * B * r->ndim, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(lnL, r->d_lnL, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return NFA_OK;
 }
 
@@ -609,18 +638,20 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
     if (!r || !theta) return fail(NFA_ERR_ARG, "null argument");
     if (B <= 0) return NFA_OK;
     int rc = check_pix(r, pix, B); if (rc) return rc;
+    rc = sync_all_lanes(r); if (rc) return rc;
     rc = runner_reserve(r, B, spectra_out != nullptr); if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    HIP_TRY(hipMemcpyAsync(r->d_U, theta, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, r->stream_setup));
-    if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, r->stream_setup));
-    rc = run_batch(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, spectra_out ? r->d_spec : nullptr, B, false);
+    hipStream_t st = r->lanes[0];
+    HIP_TRY(hipMemcpyAsync(r->d_U, theta, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, st));
+    if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, st));
+    rc = run_batch(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, spectra_out ? r->d_spec : nullptr, B,
+                   false, 0, nullptr);
     if (rc) return rc;
     if (spectra_out)
         HIP_TRY(hipMemcpyAsync(spectra_out, r->d_spec, sizeof(double) * B * r->ss->dev.chan_tot,
-                               hipMemcpyDeviceToHost, r->stream));
+                               hipMemcpyDeviceToHost, st));
     if (lnL_out)
-        HIP_TRY(hipMemcpyAsync(lnL_out, r->d_lnL, sizeof(double) * B, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(hipMemcpyAsync(lnL_out, r->d_lnL, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return NFA_OK;
 }
 
