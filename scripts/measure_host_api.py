@@ -1,0 +1,27 @@
+"""PCIe-inclusive rate of the host-pointer entry point (GPU box): U and lnL travel over
+PCIe on every call, nfa_runner_loglike_batch synchronises before returning."""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import nestfit_amd as na
+from nestfit_amd.synth import TRUTH_2COMP, freq_axis
+n = 1024
+rng = np.random.default_rng(5)
+axes = [freq_axis(t, n) for t in (1, 2)]
+spec = []
+for t, x in zip((1, 2), axes):
+    s = na.AmmoniaSpectrum(x, np.zeros(n), 0.2, t)
+    na.amm_predict(s, TRUTH_2COMP)
+    spec.append([x, s.get_spec() + rng.normal(0, 0.2, n), 0.2, t])
+run = na.AmmoniaRunner.from_data(spec, na.get_irdc_priors(), ncomp=2)
+for B in (1, 400, 4096, 65536):
+    U = rng.uniform(size=(B, 12))
+    run.loglikelihood_batch(U.copy())
+    reps = 200 if B <= 4096 else 20
+    bufs = [U.copy() for _ in range(reps)]
+    t0 = time.perf_counter()
+    for b in bufs:
+        run.loglikelihood_batch(b)
+    dt = (time.perf_counter() - t0) / reps
+    print(f'host API B={B}: {dt*1e6:.1f} us per call, {B/dt/1e6:.3f} M evals/s (PCIe + sync inclusive)')
