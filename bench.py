@@ -270,7 +270,7 @@ def main():
                 'workload': f'{args.workload}: B={B} live-point draws per step per GPU, '
                             f'NH3 {"+".join(f"({t},{t})" for t in trans)}, {n_chan} ch, '
                             f'{ncomp} comp, get_irdc_priors(size=500)',
-                'exp_mode': args.exp_mode, 'stream_lanes': args.streams or 2, 'pixels_per_gpu': 1, 'sharding': 'pixel stripes, no collective',
+                'exp_mode': args.exp_mode, 'stream_lanes': args.streams or 3, 'pixels_per_gpu': 1, 'sharding': 'pixel stripes, no collective',
                 'device': name.value.decode(),
             },
             'roofline': roof, 'cpu_baseline': cpu,

@@ -1,10 +1,10 @@
 // nfa_device.h -- device code of the MI355X (gfx950) NH3 log-likelihood engine.
 //
 // Hot path of autocorr/nestfit v0.2 (AmmoniaRunner.c_loglikelihood,
-// nestfit/models/ammonia.pyx:423-432) as two kernels per batch:
+// nestfit/models/ammonia.pyx:423-432):
 //
-//   setup_kernel    unit cube -> theta            core/core.pyx:459-476
-//                   theta -> channel-independent  models/ammonia.pyx:337-361
+//   set-up stage    unit cube -> theta            core/core.pyx:459-476
+//   (nfa_setup.h)   theta -> channel-independent  models/ammonia.pyx:337-361
 //                   scalars (Trot/Tex, partition sums, main-line tau)
 //   lnl_kernel      model spectrum + chi^2        models/hyperfine.pyx:52-118,
 //                                                 core/core.pyx:522-530
@@ -63,7 +63,7 @@ struct SpecDev {
     double  t0_xmin, t0_xmax, t0_inv_dx;
 };
 
-// derived-parameter record of one item (doubles), written by setup_kernel:
+// derived-parameter record of one item (doubles), written by derive_kernel (nfa_setup.h):
 //   [c*4 + 0] tex  [c*4 + 1] sigm/CKMS  [c*4 + 2] voff/CKMS  [c*4 + 3] 1/tex
 //   [4*ncomp + (c*nspec + s)*DREC_CS + 0] main-line optical depth of (component, spectrum)
 //                                    + 1 kind, + 2.. the y(T0) = 1/(e^(T0/tex)-1) model:
@@ -287,107 +287,6 @@ __device__ __forceinline__ const double *stage_exp_tables(double *smem, const do
 }
 
 // ---------------------------------------------------------------------------
-//  derive_item: everything of c_amm_predict that does not depend on the channel
-//  (ammonia.pyx:337-361), one wave per item.  The heavy libm calls live here
-//  (setup_kernel) so that lnl_kernel stays lean.
-// ---------------------------------------------------------------------------
-#define COMP_STRIDE 8        // LDS per component: trot, tex, qpara, qorth, 10**ntot, spare x3
-
-// One item: theta (LDS, w_theta[ndim]) -> record Db.  w_comp[ncomp*COMP_STRIDE] and
-// w_zlev[ncomp*9] are LDS scratch of the wave.
-template <int MODE>
-__device__ __forceinline__ void derive_item(const SpecDev &S, const double *w_theta, double *w_comp,
-                                            double *w_zlev, double *__restrict__ Db, const double *sm,
-                                            const double *__restrict__ g_tabs, int lane) {
-    const int ncomp = S.ncomp, nspec = S.n_spec;
-    if (lane < ncomp) {                                      // ammonia.pyx:337-346, 351
-        double trot = w_theta[ncomp + lane];
-        double tex  = w_theta[2 * ncomp + lane];
-        if (S.cold) trot = nf_swift(trot);
-        if (S.lte) tex = trot;
-        double *cc = w_comp + lane * COMP_STRIDE;
-        cc[0] = trot;
-        cc[1] = tex;
-        cc[4] = slow_pow(10.0, w_theta[3 * ncomp + lane]);
-        double *d = Db + lane * 4;
-        d[0] = tex;
-        d[1] = w_theta[4 * ncomp + lane] / NFA_CKMS;         // hyperfine.pyx:72
-        d[2] = w_theta[lane] / NFA_CKMS;                     // hyperfine.pyx:73
-        d[3] = 1.0 / tex;
-    }
-    wave_lds_sync();
-    for (int c = 0; c < ncomp; ++c) {                        // ammonia.pyx:304-315, 347-348
-        const double trot = w_comp[c * COMP_STRIDE];
-        const int j = lane;
-        double lev = 0.0;
-        if (j < NFA_NPART) lev = nf_partition_level<MODE>(j, trot, sm);
-        const bool is_orth = (j % 3) == 0;
-        const double qp = wave_sum((j < NFA_NPART && !is_orth) ? lev : 0.0);
-        const double qo = wave_sum((j < NFA_NPART && is_orth) ? 2 * lev : 0.0);
-        if (lane == 0) { w_comp[c * COMP_STRIDE + 2] = qp; w_comp[c * COMP_STRIDE + 3] = qo; }
-        if (j >= 1 && j <= NFA_N_LEVELS) w_zlev[c * NFA_N_LEVELS + (j - 1)] = lev;
-    }
-    wave_lds_sync();
-    for (int k = lane; k < ncomp * nspec; k += 64) {         // ammonia.pyx:349-361
-        const int c = k / nspec, s = k - c * nspec;
-        const int t = S.trans[s] - 1;
-        const double nu0 = c_nu[t];
-        const bool para = ((t + 1) % 3) != 0;
-        const double *cc = w_comp + c * COMP_STRIDE;
-        const double tex = cc[1];
-        const double sigm = w_theta[4 * ncomp + c];
-        const double orth = w_theta[5 * ncomp + c];
-        const double zlev = w_zlev[c * NFA_N_LEVELS + t];
-        const double qtot = para ? cc[2] : cc[3];
-        const double species_frac = para ? 1.0 - orth : orth;
-        const double pop_rotstate = cc[4] * species_frac * zlev / qtot;
-        const double ex = slow_exp(-NFA_H * nu0 / (NFA_KB * tex));
-        const double expterm = (1.0 - ex) / (1.0 + ex);
-        const double fracterm = (NFA_CCMS * NFA_CCMS) * c_ea[t] / (8 * M_PI * (nu0 * nu0));
-        const double widthterm = NFA_CKMS / (sigm * nu0 * sqrt(2 * M_PI));
-        const double tau_main = pop_rotstate * fracterm * expterm * widthterm;
-        double *dk = Db + 4 * ncomp + k * DREC_CS;
-        dk[DK_TMAIN] = slow_pow(10.0, slow_log10(tau_main));         // ammonia.pyx:361, hyperfine.pyx:63
-        // y(T0) model over the spectrum's band (used by the fast mode only)
-        const double T0a = S.t0[S.off[s]], T0b = S.t0[S.off[s] + S.size[s] - 1];
-        const double inv_tex = 1.0 / tex;
-        const double xa = T0a * inv_tex, xb = T0b * inv_tex;
-        const bool ina = S.t0_xmin < xa && xa < S.t0_xmax, inb = S.t0_xmin < xb && xb < S.t0_xmax;
-        double kind = 0.0, A0 = 0.0, B0 = 0.0, A1 = 0.0, B1 = 0.0, split = INFINITY, m = 0.0, q = 0.0;
-        const double *t0x = g_tabs + SM_T0X, *t0y = g_tabs + SM_T0Y;
-        if (ina && inb) {
-            const long ia = (long)((xa - S.t0_xmin) * S.t0_inv_dx);
-            const long ib = (long)((xb - S.t0_xmin) * S.t0_inv_dx);
-            if (ia >= 0 && ib <= T0_SIZE - 2 && ib - ia <= 1) {
-                const double sl0 = (t0y[ia + 1] - t0y[ia]) * S.t0_inv_dx;
-                A0 = t0y[ia] - sl0 * t0x[ia];
-                B0 = sl0 * inv_tex;
-                A1 = A0; B1 = B0;
-                kind = 1.0;
-                if (ib != ia) {
-                    const double sl1 = (t0y[ib + 1] - t0y[ib]) * S.t0_inv_dx;
-                    A1 = t0y[ib] - sl1 * t0x[ib];
-                    B1 = sl1 * inv_tex;
-                    split = t0x[ib] * tex;
-                    kind = 2.0;
-                }
-            }
-        } else if (!ina && !inb && ((xa <= S.t0_xmin && xb <= S.t0_xmin) || (xa >= S.t0_xmax && xb >= S.t0_xmax))) {
-            m = 0.5 * (T0a + T0b);
-            const double y = slow_inv_expm1(m * inv_tex);
-            A0 = y;
-            B0 = -y * (1.0 + y) * inv_tex;
-            q = 0.5 * (1.0 + 2.0 * y) * y * (1.0 + y) * inv_tex * inv_tex;
-            A1 = A0; B1 = B0;
-            kind = 3.0;
-        }
-        dk[DK_KIND] = kind; dk[DK_A0] = A0; dk[DK_B0] = B0; dk[DK_A1] = A1; dk[DK_B1] = B1;
-        dk[DK_SPLIT] = split; dk[DK_M] = m; dk[DK_Q] = q; dk[9] = 0.0;
-    }
-    wave_lds_sync();
-}
-
-// ---------------------------------------------------------------------------
 //  lnl_kernel
 // ---------------------------------------------------------------------------
 struct __attribute__((aligned(16))) LineRec {
@@ -607,328 +506,7 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
     }
 }
 
-// ---------------------------------------------------------------------------
-//  prior_kernel: PriorTransformer.c_transform (core.pyx:459-476), one wave per
-//  unit-cube row, in place.
-// ---------------------------------------------------------------------------
-struct DistDev {
-    int     size, pad;
-    double  du, dx, xmin, xmax;
-    const double *xax, *pdf, *cdf, *ppf;
-};
-#define MAXPRIOR 16
-#define MAXDIST  16
-struct PriorProg {
-    int n_prior, n_dist, n_param, max_size;
-    nfa_prior_desc pr[MAXPRIOR];
-    DistDev        ds[MAXDIST];
-};
-
-__device__ __forceinline__ double d_ppf_interp(const DistDev &d, double u) {   // core.pyx:47-63
-    long i_lo = (long)((double)(d.size - 1) * u);
-    long i_hi = i_lo + 1;
-    i_lo = i_lo < 0 ? 0 : (i_lo > d.size - 1 ? d.size - 1 : i_lo);   // u==1 reads past the end
-    i_hi = i_hi > d.size - 1 ? d.size - 1 : (i_hi < 0 ? 0 : i_hi);   // in the reference; clamp
-    const double x_lo = (double)i_lo * d.du;
-    const double y_lo = d.ppf[i_lo];
-    const double y_hi = d.ppf[i_hi];
-    const double slope = (y_hi - y_lo) / d.du;
-    return slope * (u - x_lo) + y_lo;
-}
-
-// `prior.interp(utheta, n)` of the simple kinds, lanes = components
-__device__ __forceinline__ void d_simple_interp(const PriorProg &pp, int kind, int dist, int p_ix,
-                                                double value, double *u, int n, int lane) {
-    const int ix = p_ix * n;
-    if (kind == NFA_PRIOR_CONSTANT) {                         // core.pyx:233-238
-        if (lane < n) u[ix + lane] = value;
-    } else if (kind == NFA_PRIOR_ORDERED) {                   // core.pyx:242-258
-        if (lane == 0) {
-            double umin = 0.0;
-            for (int i = 0; i < n; ++i) {
-                const double uu = umin + (1 - umin) * u[ix + i];
-                umin = uu;
-                u[ix + i] = d_ppf_interp(pp.ds[dist], uu);
-            }
-        }
-    } else {                                                  // core.pyx:192-197
-        if (lane < n) u[ix + lane] = d_ppf_interp(pp.ds[dist], u[ix + lane]);
-    }
-    wave_lds_sync();
-}
-
-__device__ __forceinline__ double cdf_scale(int i, int ilo, double inv_delta_i, double sfact) {
-    const double base = 1.0 - (double)(i - ilo) * inv_delta_i;   // core.pyx:143-154
-    if (sfact == 0.0) return 1.0;
-    if (sfact == 1.0) return base;
-    if (sfact == 2.0) return base * base;
-    return slow_pow(base, sfact);
-}
-
-// Distribution.cdf_over_interval + cdf_interp (core.pyx:65-161), general form:
-// materialises the rewritten, normalised CDF in LDS like the reference rewrites
-// its table, then searches it.  Used for the degenerate intervals.
-__device__ __attribute__((noinline)) double d_placement_draw_general(const DistDev &d, double *cdf, int ilo,
-                                                                      int ihi, double sfact, double u,
-                                                                      int lane) {
-    const int size = d.size;
-    const int L = ihi - ilo - 1;
-    const int ch = (L + 63) / 64;
-    const int k0 = ilo + 1 + lane * ch;
-    const int k1 = min(k0 + ch, ihi);
-    const double inv_delta_i = 1.0 / (double)(ihi - ilo);
-    double local = 0.0;
-    for (int i = k0; i < k1; ++i)
-        local += 0.5 * (d.pdf[i] + d.pdf[i - 1]) * cdf_scale(i, ilo, inv_delta_i, sfact);
-    double csum;
-    double run = wave_excl_scan(local, lane, &csum);
-    for (int i = lane; i < ilo; i += 64) cdf[i] = 0.0;
-    for (int i = ihi + lane; i < size; i += 64) cdf[i] = 1.0;
-    if (L <= 0) {
-        if (lane == 0) cdf[ilo] = 1.0 / csum;                 // csum == 0: inf like the reference
-    } else {
-        if (lane == 0) cdf[ilo] = 0.0 / csum;
-        for (int i = k0; i < k1; ++i) {
-            run += 0.5 * (d.pdf[i] + d.pdf[i - 1]) * cdf_scale(i, ilo, inv_delta_i, sfact);
-            cdf[i] = run / csum;
-        }
-    }
-    wave_lds_sync();
-    if (u <= cdf[0]) u = 1e-64;                               // core.pyx:83-84
-    int lo = 0, hi = size, i = hi / 2;                        // core.pyx:86-94
-    while (i != lo) {
-        if (u > cdf[i]) lo = i; else hi = i;
-        i = (hi + lo) / 2;
-    }
-    int j_lo = i < size ? i : size - 1;
-    int j_hi = j_lo + 1;
-    if (j_hi > size - 1) j_hi = size - 1;                     // reference reads cdf[size] here
-    const double xl = d.xax[j_lo];
-    const double y_lo = cdf[j_lo];
-    const double y_hi = cdf[j_hi];
-    const double slope = (y_hi - y_lo) / d.dx;
-    const double res = 1 / slope * (u - y_lo) + xl;
-    wave_lds_sync();
-    return res;
-}
-
-// Same draw for the regular case (interval of >= 2 cells, finite positive mass):
-// the rewritten CDF is monotone, 0 up to i_lo and 1 from i_hi, so the bisection of
-// cdf_interp lands on the last entry below u.  Lanes own contiguous chunks of the
-// interval; only raw running sums go to LDS, the entry is located by counting
-// against u*csum and then settled with the reference's own comparison
-// u > run/csum on its neighbours (two or three divisions instead of `size`).
-__device__ double d_placement_draw(const DistDev &d, double *run_lds, double x_lo, double x_hi,
-                                   double sfact, double u, int lane) {
-    if (x_lo > x_hi) { const double t = x_lo; x_lo = x_hi; x_hi = t; }     // core.pyx:116-117
-    const int size = d.size;
-    long i_lo = (long)((x_lo - d.xmin) / d.dx);                            // core.pyx:120-131
-    if (i_lo >= size) i_lo = size - 1; else if (i_lo < 0) i_lo = 0;
-    long i_hi = (long)((x_hi - d.xmin) / d.dx);
-    if (i_hi == i_lo) i_hi = i_lo + 1;
-    if (i_hi > size) i_hi = size; else if (i_hi < 0) i_hi = 1;
-    const int ilo = (int)i_lo, ihi = (int)i_hi;
-    const int L = ihi - ilo - 1;
-    const int ch = (L + 63) / 64;
-    const int k0 = ilo + 1 + lane * ch;
-    const int k1 = min(k0 + ch, ihi);
-    const double inv_delta_i = 1.0 / (double)(ihi - ilo);
-    double local = 0.0;
-    for (int i = k0; i < k1; ++i)
-        local += 0.5 * (d.pdf[i] + d.pdf[i - 1]) * cdf_scale(i, ilo, inv_delta_i, sfact);
-    double csum;
-    double run = wave_excl_scan(local, lane, &csum);
-    if (!(L > 0 && csum > 0.0 && csum < INFINITY))
-        return d_placement_draw_general(d, run_lds, ilo, ihi, sfact, u, lane);
-    const double uu = (u <= 0.0) ? 1e-64 : u;                 // cdf[0] == 0 here (core.pyx:83-84)
-    const double target = uu * csum;
-    int below = 0;
-    for (int i = k0; i < k1; ++i) {
-        run += 0.5 * (d.pdf[i] + d.pdf[i - 1]) * cdf_scale(i, ilo, inv_delta_i, sfact);
-        run_lds[i] = run;
-        below += (run < target) ? 1 : 0;
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) below += __shfl_xor(below, m, 64);
-    wave_lds_sync();
-    // cdf(k): 0 for k <= ilo, run/csum inside, 1 from ihi
-    int i = ilo + below;                                      // last entry believed below u
-    while (i + 1 < ihi && uu > run_lds[i + 1] / csum) ++i;
-    while (i > ilo && !(uu > run_lds[i] / csum)) --i;
-    const int j_lo = i;
-    const int j_hi = min(i + 1, size - 1);
-    const double y_lo = (j_lo <= ilo) ? 0.0 / csum : run_lds[j_lo] / csum;
-    const double y_hi = (j_hi >= ihi) ? 1.0 : ((j_hi <= ilo) ? 0.0 / csum : run_lds[j_hi] / csum);
-    const double xl = d.xax[j_lo];
-    const double slope = (y_hi - y_lo) / d.dx;                // core.pyx:102-107
-    const double res = 1 / slope * (uu - y_lo) + xl;
-    wave_lds_sync();
-    return res;
-}
-
-// scratch layout: [0, size) running sums / CDF copy, then MAXCOMP separations
-__device__ __forceinline__ int d_scratch_seps_offset(int size) { return (size + 1) & ~1; }
-
-// PriorTransformer.c_transform (core.pyx:459-476) of one unit-cube row held in
-// LDS (u[n_param*n]), in place; `scratch` holds max_size doubles.
-__device__ __forceinline__ void prior_transform_item(const PriorProg &pp, double *u, double *scratch,
-                                                     int n, int lane) {
-    for (int k = 0; k < pp.n_prior; ++k) {
-        const nfa_prior_desc &p = pp.pr[k];
-        const int ix = p.p_ix * n;
-        switch (p.kind) {
-        case NFA_PRIOR_SIMPLE:
-        case NFA_PRIOR_CONSTANT:
-        case NFA_PRIOR_ORDERED:
-            d_simple_interp(pp, p.kind, p.dist0, p.p_ix, p.value, u, n, lane);
-            break;
-        case NFA_PRIOR_DUPLICATE:                             // core.pyx:211-221
-            if (lane < n) {
-                const double v = d_ppf_interp(pp.ds[p.dist0], u[ix + lane]);
-                u[ix + lane] = v;
-                u[p.p_ix2 * n + lane] = v;
-            }
-            wave_lds_sync();
-            break;
-        case NFA_PRIOR_SPACED:                                // core.pyx:280-292
-            if (lane == 0) {
-                double v = d_ppf_interp(pp.ds[p.dist0], u[ix]);
-                u[ix] = v;
-                for (int i = 1; i < n; ++i) {
-                    v = v + d_ppf_interp(pp.ds[p.dist1], u[ix + i]);
-                    u[ix + i] = v;
-                }
-            }
-            wave_lds_sync();
-            break;
-        case NFA_PRIOR_CENSEP:                                // core.pyx:305-318
-            if (lane == 0) {
-                const double vcen = d_ppf_interp(pp.ds[p.dist0], u[ix]);
-                if (n == 1) u[ix] = vcen;
-                else if (n == 2) {
-                    const double vsep = d_ppf_interp(pp.ds[p.dist1], u[ix + 1]);
-                    u[ix]     = vcen - 0.5 * vsep;
-                    u[ix + 1] = vcen + 0.5 * vsep;
-                }
-            }
-            wave_lds_sync();
-            break;
-        case NFA_PRIOR_RESOLVED_CENSEP: {                     // core.pyx:347-366
-            const int ix_s = p.p_ix2 * n;
-            d_simple_interp(pp, p.sub_kind, p.dist2, p.p_ix2, p.value, u, n, lane);
-            if (lane == 0) {
-                const double vcen = d_ppf_interp(pp.ds[p.dist0], u[ix]);
-                if (n == 1) u[ix] = vcen;
-                else if (n == 2) {
-                    double vsep = d_ppf_interp(pp.ds[p.dist1], u[ix + 1]);
-                    const double min_sep = p.sep_scale * sqrt(u[ix_s] * u[ix_s + 1]);
-                    if (min_sep > vsep) vsep = min_sep;
-                    u[ix]     = vcen - 0.5 * vsep;
-                    u[ix + 1] = vcen + 0.5 * vsep;
-                }
-            }
-            wave_lds_sync();
-        } break;
-        case NFA_PRIOR_RESOLVED_PLACEMENT: {                  // core.pyx:391-435
-            if (n > MAXCOMP) break;
-            const DistDev &vd = pp.ds[p.dist0];
-            const int ix_s = p.p_ix2 * n;
-            double v_lo = vd.xmin, v_hi = vd.xmax;
-            d_simple_interp(pp, p.sub_kind, p.dist2, p.p_ix2, p.value, u, n, lane);
-            if (n == 1) {
-                if (lane == 0) u[ix] = d_ppf_interp(vd, u[ix]);
-                wave_lds_sync();
-                break;
-            }
-            // minimum separations: lane i-1 -> component i (core.pyx:409-415); kept in LDS
-            double *min_seps = scratch + d_scratch_seps_offset(vd.size);
-            if (lane < n) min_seps[lane] = (lane == 0) ? 0.0
-                                                       : p.sep_scale * sqrt(u[ix_s + lane] * u[ix_s + lane - 1]);
-            wave_lds_sync();
-            double sep_tot = 0.0;
-            for (int i = 1; i < n; ++i) sep_tot += min_seps[i];
-            double overf = 1.0;
-            const bool shrink = sep_tot > v_hi - v_lo;            // core.pyx:418-423
-            if (shrink) {
-                overf = (v_hi - v_lo) / sep_tot;
-                sep_tot = 0.0;
-                for (int i = 0; i < n; ++i) sep_tot += min_seps[i] * overf;
-            }
-            v_hi -= sep_tot;
-            for (int i = 0; i < n; ++i) {                          // core.pyx:427-435
-                const double sep = shrink ? min_seps[i] * overf : min_seps[i];
-                v_lo += sep;
-                v_hi += sep;
-                const double uu = u[ix + i];
-                v_lo = d_placement_draw(vd, scratch, v_lo, v_hi, (double)(n - 1 - i), uu, lane);
-                if (lane == 0) u[ix + i] = v_lo;
-            }
-            wave_lds_sync();
-        } break;
-        default: break;
-        }
-    }
-}
-
-// prior_kernel: transform only (PriorTransformer.transform, core.pyx:478-483)
-__global__ void __launch_bounds__(256) prior_kernel(const PriorProg *__restrict__ ppp, double *__restrict__ U,
-                                                    long B, int n, int wave_doubles) {
-    const PriorProg &pp = *ppp;            // lives in device memory: indexed through scalar loads
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ndim = pp.n_param * n;
-    double *u = smem + (size_t)wave * wave_doubles;       // [ndim]
-    double *scratch = u + ((ndim + 1) & ~1);               // [max_size]
-    const long gw = (long)blockIdx.x * waves + wave, nw = (long)gridDim.x * waves;
-    for (long b = gw; b < B; b += nw) {
-        for (int k = lane; k < ndim; k += 64) u[k] = U[b * ndim + k];
-        wave_lds_sync();
-        prior_transform_item(pp, u, scratch, n, lane);
-        for (int k = lane; k < ndim; k += 64) U[b * ndim + k] = u[k];
-        wave_lds_sync();
-    }
-}
-
-// setup_kernel: first kernel of a likelihood batch.  One wave per item:
-// [unit cube -> theta, written back in place like the reference mutates utheta]
-// -> derived record D[b].  With HAS_PRIOR = false U already holds theta (predict).
-template <int MODE, bool HAS_PRIOR>
-__global__ void __launch_bounds__(256) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
-                                                    double *__restrict__ U, double *__restrict__ D, long B,
-                                                    int wave_doubles, const double *__restrict__ g_tabs) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    int n_shared;
-    const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
-    // the prior program (descriptors + table pointers, ~2 KB) is walked field by field by
-    // every wave: keep a copy in LDS instead of chasing it through global memory
-    const int pp_doubles = HAS_PRIOR ? (int)((sizeof(PriorProg) + 7) / 8) : 0;
-    if (HAS_PRIOR) {
-        const double *src = (const double *)ppp;
-        for (int i = threadIdx.x; i < pp_doubles; i += blockDim.x) smem[n_shared + i] = src[i];
-        __syncthreads();
-    }
-    const PriorProg *pp_lds = (const PriorProg *)(smem + n_shared);
-    n_shared += (pp_doubles + 1) & ~1;
-    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ncomp = S.ncomp, ndim = NFA_N_PARAMS * ncomp;
-    const int drec = drec_size(ncomp, S.n_spec);
-    double *w_theta = smem + n_shared + (size_t)wave * wave_doubles;
-    double *w_comp = w_theta + ((ndim + 1) & ~1);           // [ncomp][COMP_STRIDE]
-    double *w_zlev = w_comp + ncomp * COMP_STRIDE;          // [ncomp][9]
-    double *scratch = w_zlev + ((ncomp * NFA_N_LEVELS + 1) & ~1);   // [max_size] (priors only)
-    const long gw = (long)blockIdx.x * waves + wave, nw = (long)gridDim.x * waves;
-    for (long b = gw; b < B; b += nw) {
-        for (int k = lane; k < ndim; k += 64) w_theta[k] = U[b * ndim + k];
-        wave_lds_sync();
-        if (HAS_PRIOR) {
-            prior_transform_item(*pp_lds, w_theta, scratch, ncomp, lane);
-            for (int k = lane; k < ndim; k += 64) U[b * ndim + k] = w_theta[k];
-        }
-        derive_item<MODE>(S, w_theta, w_comp, w_zlev, D + b * drec, sm, g_tabs, lane);
-    }
-}
+#include "nfa_setup.h"
 
 // ---------------------------------------------------------------------------
 //  set-up kernels

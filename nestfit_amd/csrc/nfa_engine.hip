@@ -42,7 +42,7 @@ struct Engine {
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
     int    nparts_override = 0;
     int    ablate = 0;
-    int    streams = 2;              // stream lanes of new runners
+    int    streams = 3;              // stream lanes of new runners
     int    persistent = 0;
     bool   have_t0 = false;
     double *d_tabs = nullptr;                      // SM_END_TABLE doubles
@@ -108,6 +108,7 @@ struct nfa_runner {
     int         n_lanes = 1;
     hipStream_t lanes[NFA_MAX_LANES] = {};
     double     *d_D[NFA_MAX_LANES] = {};
+    double     *d_Q[NFA_MAX_LANES] = {};     // partition sums, QREC doubles per (item, component)
     int64_t     cap_D[NFA_MAX_LANES] = {};
     hipStream_t stream = nullptr;            // lane 0: also the stream of the host-pointer entry points
     uint64_t    n_calls = 0;
@@ -295,6 +296,25 @@ int nfa_priors_create(nfa_priors **out, const nfa_prior_desc *priors, int n_prio
             p->d_arrays.push_back(dp);
             *dst[q] = dp;
         }
+        // prefix moments of the trapezoid terms (long double accumulation, one rounding each)
+        std::vector<double> m0(s.size), m1(s.size), m2(s.size);
+        long double a0 = 0, a1 = 0, a2 = 0;
+        m0[0] = m1[0] = m2[0] = 0.0;
+        for (int64_t i = 1; i < s.size; ++i) {
+            const long double ti = 0.5L * ((long double)s.pdf[i] + (long double)s.pdf[i - 1]);
+            const long double ic = (long double)(i - s.size / 2);
+            a0 += ti; a1 += ti * ic; a2 += ti * ic * ic;
+            m0[i] = (double)a0; m1[i] = (double)a1; m2[i] = (double)a2;
+        }
+        const double *msrc[3] = {m0.data(), m1.data(), m2.data()};
+        const double **mdst[3] = {&d.m0, &d.m1, &d.m2};
+        for (int q = 0; q < 3; ++q) {
+            double *dp = nullptr;
+            HIP_TRY(hipMalloc(&dp, sizeof(double) * s.size));
+            HIP_TRY(hipMemcpy(dp, msrc[q], sizeof(double) * s.size, hipMemcpyHostToDevice));
+            p->d_arrays.push_back(dp);
+            *mdst[q] = dp;
+        }
         g.max_size = std::max(g.max_size, (int)s.size);
     }
     HIP_TRY(hipMalloc(&p->d_prog, sizeof(PriorProg)));
@@ -313,18 +333,10 @@ int nfa_priors_destroy(nfa_priors *p) {
 
 static int launch_priors(const nfa_priors *p, double *d_U, int64_t B, int ncomp, hipStream_t st) {
     const int ndim = p->prog.n_param * ncomp;
-    const int wave_doubles = ((ndim + 1) & ~1) + ((p->prog.max_size + 1) & ~1) + MAXCOMP + 2;
-    const int waves = 4;
-    const size_t lds = sizeof(double) * wave_doubles * waves;
-    if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "distribution tables too large for LDS scratch");
-    int64_t blocks = (B + waves - 1) / waves;
-    const int64_t cap = (int64_t)g_eng.n_cu * 8;
-    if (blocks > cap) blocks = cap;
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)prior_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(prior_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, st,
-                       (const PriorProg *)p->d_prog, d_U,
-                       (long)B, ncomp, wave_doubles);
+    const size_t lds = sizeof(double) * 64 * (size_t)ndim;          // theta transposed, one lane per item
+    if (lds > 64 * 1024) return fail(NFA_ERR_ARG, "too many parameters for the prior kernel");
+    hipLaunchKernelGGL(prior_items_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), lds, st,
+                       (const PriorProg *)p->d_prog, d_U, (long)B, ncomp);
     HIP_TRY(hipGetLastError());
     return NFA_OK;
 }
@@ -369,7 +381,7 @@ int nfa_runner_destroy(nfa_runner *r) {
     if (!r) return NFA_OK;
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamSynchronize(r->lanes[k]);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
-    for (int k = 0; k < r->n_lanes; ++k) (void)hipFree(r->d_D[k]);
+    for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_Q[k]); }
     for (hipEvent_t x : r->ev) (void)hipEventDestroy(x);
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamDestroy(r->lanes[k]);
     delete r;
@@ -405,43 +417,47 @@ static SpecDev runner_specdev(const nfa_runner *r) {
     return S;
 }
 
-// First kernel of a batch: [unit cube -> theta in place] -> derived records r->d_D
-template <int MODE, bool HAS_PRIOR>
-static int launch_setup_t(nfa_runner *r, double *d_U, int64_t B, int slot) {
+// Set-up stage of a batch on stream lane `slot`: [unit cube -> theta in place] ->
+// partition sums -> derived records r->d_D[slot]   (kernels: nfa_setup.h)
+static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot) {
     const SpecDev S = runner_specdev(r);
     const int drec = drec_size(r->ncomp, S.n_spec);
+    hipStream_t st = r->lanes[slot];
     if (B > r->cap_D[slot]) {                // grown outside any timed loop
-        HIP_TRY(hipStreamSynchronize(r->lanes[slot]));
-        (void)hipFree(r->d_D[slot]); r->d_D[slot] = nullptr; r->cap_D[slot] = 0;
+        HIP_TRY(hipStreamSynchronize(st));
+        (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_Q[slot]);
+        r->d_D[slot] = nullptr; r->d_Q[slot] = nullptr; r->cap_D[slot] = 0;
         const int64_t cap = std::max<int64_t>(B, 4096);
         HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec));
+        HIP_TRY(hipMalloc(&r->d_Q[slot], sizeof(double) * cap * r->ncomp * QREC));
         r->cap_D[slot] = cap;
     }
-    const PriorProg *d_pp = HAS_PRIOR ? r->pr->d_prog : nullptr;
-    const int max_size = HAS_PRIOR ? r->pr->prog.max_size : 0;
-    const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : 32;
-    const int waves = 4;
-    int wd = ((r->ndim + 1) & ~1) + r->ncomp * COMP_STRIDE + ((r->ncomp * NFA_N_LEVELS + 1) & ~1);
-    if (HAS_PRIOR) wd += ((max_size + 1) & ~1) + MAXCOMP + 2;
-    const size_t pp_doubles = HAS_PRIOR ? (((sizeof(PriorProg) + 7) / 8 + 1) & ~(size_t)1) : 0;
-    const size_t lds = sizeof(double) * ((size_t)n_shared + pp_doubles + (size_t)wd * waves);
-    if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "distribution tables too large for LDS scratch");
-    const int64_t blocks = std::min<int64_t>((B + waves - 1) / waves, (int64_t)g_eng.n_cu * 8);
-    auto kern = setup_kernel<MODE, HAS_PRIOR>;
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, r->lanes[slot], d_pp, S, d_U,
-                       r->d_D[slot],
-                       (long)B, wd, (const double *)g_eng.d_tabs);
-    HIP_TRY(hipGetLastError());
+    if (has_prior) {
+        int rc = launch_priors(r->pr, d_U, B, r->ncomp, st);
+        if (rc) return rc;
+    }
+    {   // partition sums: lane = (item, component, quarter of the J levels)
+        const int64_t lanes = B * r->ncomp * 4;
+        const unsigned blocks = (unsigned)((lanes + 255) / 256);
+        if (g_eng.exp_mode == 0) {
+            const size_t lds = sizeof(double) * (SM_END_TABLE - SM_EXP2);
+            HIP_TRY(hipFuncSetAttribute((const void *)qsum_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(qsum_kernel<0>, dim3(blocks), dim3(256), lds, st, (const double *)d_U, r->d_Q[slot],
+                               (long)B, r->ncomp, r->cold, (const double *)g_eng.d_tabs);
+        } else {
+            hipLaunchKernelGGL(qsum_kernel<1>, dim3(blocks), dim3(256), sizeof(double) * 32, st, (const double *)d_U,
+                               r->d_Q[slot], (long)B, r->ncomp, r->cold, (const double *)g_eng.d_tabs);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    {   // derived records: lane = (item, component, spectrum)
+        const int64_t lanes = B * r->ncomp * S.n_spec;
+        hipLaunchKernelGGL(derive_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, S,
+                           (const double *)d_U, (const double *)r->d_Q[slot], r->d_D[slot], (long)B,
+                           (const double *)g_eng.d_tabs);
+        HIP_TRY(hipGetLastError());
+    }
     return NFA_OK;
-}
-
-static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot) {
-    const int m = g_eng.exp_mode == 0 ? 0 : 1;          // the fast mode derives like "poly"
-    if (m == 0)
-        return has_prior ? launch_setup_t<0, true>(r, d_U, B, slot) : launch_setup_t<0, false>(r, d_U, B, slot);
-    return has_prior ? launch_setup_t<1, true>(r, d_U, B, slot) : launch_setup_t<1, false>(r, d_U, B, slot);
 }
 
 static int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }

