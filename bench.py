@@ -18,6 +18,7 @@ of per-pixel summaries.
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
 import argparse
+import contextlib
 import ctypes as C
 import json
 import multiprocessing as mp
@@ -98,6 +99,21 @@ def cpu_baseline(spec_data, program, ncomp, U, budget_s=12.0):
     }
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on stdout when the first communicator is created; the
+    contract is ONE JSON line on stdout, so native stdout goes to stderr meanwhile."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -122,6 +138,13 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
+    use_dist = world > 1 or os.environ.get('NFA_BENCH_FORCE_DIST') == '1'
+    if use_dist:
+        # torch ships its own HIP runtime (same soname as /opt/rocm's): it has to be the one
+        # that is loaded first, otherwise torch finds "no HIP GPUs" after the engine's init
+        import torch
+        torch.cuda.set_device(local_rank)
+        torch.cuda.init()
     import nestfit_amd as na
     from nestfit_amd import _ffi, synth
     na.set_device(local_rank)                 # one process per GPU, before any other call
@@ -137,11 +160,12 @@ def main():
     lib = _ffi.engine()
 
     dist = None
-    if world > 1:
-        import torch
+    if use_dist:                              # one rank per GPU over RCCL
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        with stdout_to_stderr():
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.barrier()                    # creates the communicator (and prints the banner)
+            torch.cuda.synchronize()
 
     trans, n_chan, vhalf, ncomp, truth_key, B = WORKLOADS[args.workload]
     if args.batch:

@@ -193,7 +193,7 @@ __device__ __forceinline__ double nf_fastexp(double xd, const double *sm) {
         r = exp_neg_poly((double)x, sm);                      // out-of-range lanes are replaced below
     }
     const bool special = (l < 0) || (l >= 10) || (x < 0.0f);
-    if (__ballot(special) != 0ull) {
+    if (__builtin_amdgcn_ballot_w64(special) != 0ull) {
         const double t = (double)x;                           // fastexp.c:264-270; x == 0 gives exactly 1
         double ty = 1.0 - t * (1.0 / 3.0);
         ty = 1.0 - (t * ty) * 0.5;
@@ -428,14 +428,14 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                 for (int c = 0; c < ncomp; ++c) {
                     const LineRec *lines = w_line + c * G.nhf_max;
                     const int2 win = w_win[c * 64 + lane];
-                    unsigned long long mask = __ballot(win.x < r0 + 64 && win.y > r0 && win.y > win.x);
+                    unsigned long long mask = __builtin_amdgcn_ballot_w64(win.x < r0 + 64 && win.y > r0 && win.y > win.x);
                     if (mask == 0ull) continue;
                     tau_t tau = 0;
                     if (G.ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); } else {
                     while (mask) {
                         const int i = __builtin_ctzll(mask);
                         mask &= mask - 1;
-                        const LineRec rec = lines[i];
+                        const LineRec rec = lines[i];                     // two 16-byte broadcast reads
                         const double nu = xj - rec.nucen;
                         const double tau_exp = nu * nu * rec.idenom;
                         const bool inwin = (unsigned)(j - rec.lo) < (unsigned)rec.len;
@@ -448,7 +448,9 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                             yl = __builtin_fmaf(x, NEG_L2E_LO, yl);
                             float e = __builtin_amdgcn_exp2f(yh);
                             e = __builtin_fmaf(e * 0.693147180559945f, yl, e);
-                            tau = inwin ? __builtin_fmaf(rec.htau_f, e, (float)tau) : tau;
+                            // predicate the weight, not the arithmetic: straight-line code
+                            const float h = inwin ? rec.htau_f : 0.0f;
+                            tau = __builtin_fmaf(h, e, (float)tau);
                         } else {
                             const double e = nf_fastexp<MODE>(tau_exp, sm);
                             tau = inwin ? __builtin_fma(rec.htau, e, (double)tau) : tau;
@@ -456,7 +458,7 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                     }
                     }
                     const bool live = valid && !(tau == 0);           // hyperfine.pyx:104-105
-                    if (__ballot(live) == 0ull) continue;
+                    if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;
                     double tb;
                     if (G.ablate & 1) { if (live) pred += (double)tau; continue; }
                     const double *dk = w_d + 4 * ncomp + (c * nspec + s) * DREC_CS;

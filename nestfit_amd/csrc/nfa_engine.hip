@@ -478,8 +478,9 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     for (int s = 0; s < S.n_spec; ++s) min_rows = std::min(min_rows, (S.size[s] + 63) / 64);
     // Every item is cut into n_spec x nparts waves.  nparts depends on the runner's shape
     // only (never on the batch size), so that a row's result does not depend on which
-    // batch it travelled in; 2 parts give a 4096-row batch of 2 spectra 16 waves per SIMD.
-    int nparts = g_eng.nparts_override > 0 ? g_eng.nparts_override : 2;
+    // batch it travelled in.  Default 1 (one wave per spectrum): with stream lanes hiding the
+    // tail of a batch, fewer and longer waves win (measured: 74 vs 70 M evals/s at B = 4096).
+    int nparts = g_eng.nparts_override > 0 ? g_eng.nparts_override : 1;
     nparts = std::max(1, std::min(nparts, std::min(min_rows, 16 / S.n_spec)));
     G.nparts = pow2_floor(nparts);
     G.wpi = S.n_spec * G.nparts;

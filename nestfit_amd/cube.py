@@ -8,6 +8,11 @@ writes its own chunk file and nothing is exchanged while sampling
 stripe, uploads its pixels once and evaluates batches of (pixel, unit-cube row)
 items.  The only collective is the end-of-run gather of fixed-size per-pixel
 records (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
+
+Loader note: torch bundles its own HIP runtime under the same soname as /opt/rocm's.  A
+process that uses both the engine and torch's GPU side (the "nccl" gather) must
+``import torch; torch.cuda.init()`` BEFORE the first engine call, so that one runtime
+serves both (bench.py does this); the other order leaves torch with "no HIP GPUs".
 """
 import ctypes as C
 
