@@ -123,8 +123,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='rows per step (default: workload B)')
     ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'fast'),
                     choices=['table', 'poly', 'fast'])
-    ap.add_argument('--nparts', type=int, default=0, help='engine A/B knob: waves per spectrum (0 = auto)')
-    ap.add_argument('--persistent', type=int, default=0, help='engine A/B knob')
+    ap.add_argument('--wpb', type=int, default=0, help='engine A/B knob: waves per workgroup (0 = default)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
     ap.add_argument('--ablate', type=int, default=0, help='timing experiment: 1 skip Tb, 2 skip lines, 3 both (INVALID results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -149,12 +148,10 @@ def main():
     from nestfit_amd import _ffi, synth
     na.set_device(local_rank)                 # one process per GPU, before any other call
     na.set_exp_mode(args.exp_mode)
-    if args.nparts:
-        _ffi.set_option('nparts', args.nparts)
+    if args.wpb:
+        _ffi.set_option('wpb', args.wpb)
     if args.ablate:
         _ffi.set_option('ablate', args.ablate)
-    if args.persistent:
-        _ffi.set_option('persistent', args.persistent)
     if args.streams:
         _ffi.set_option('streams', args.streams)
     lib = _ffi.engine()

@@ -49,8 +49,8 @@ int nfa_device_name(char *buf, int buflen);
  *       <= 1e-6 relative on brightness temperature (the metric's tolerance). */
 int nfa_set_exp_mode(int mode);
 int nfa_get_exp_mode(void);
-/* Engine tuning knobs for A/B measurements: "nparts" = waves per spectrum of one
- * item in the likelihood kernel (0 = default 2); "streams" = number of HIP streams
+/* Engine tuning knobs for A/B measurements: "wpb" = waves per workgroup of the
+ * likelihood kernel (1..16); "streams" = number of HIP streams
  * ("lanes", 1..8, default 2) that runners created afterwards spread consecutive
  * nfa_runner_loglike_batch_dev calls over; "persistent" = 1 device-sized grid; "ablate"
  * (timing experiments only, results invalid) = 1 skip the Tb pass, 2 skip the

@@ -10,17 +10,16 @@
 //                                                 core/core.pyx:522-530
 //
 // lnl_kernel execution model (wave = 64 lanes):
-//   * a work item is one (theta, pixel); it is cut into WPI = n_spec x n_parts
-//     wavefronts, one per (spectrum, interleaved row part), so that a batch of a
-//     few thousand live points still puts >= 8 waves on every SIMD;
+//   * a work item is one (theta, pixel); each of its spectra is one independent
+//     wavefront (a 4096-row batch of 2 spectra puts 8 waves on every SIMD);
 //   * inside a wave lanes are frequency channels: a row is 64 consecutive
 //     channels (coalesced 512-B loads of x, data, T0, tbg); the optical depth of
 //     the row lives in one register per lane;
 //   * the (component, hyperfine line) constants of the wave's spectrum are formed
 //     with lanes = lines, kept in the wave's LDS slice and broadcast-read in the
 //     row loop; a ballot over the line windows selects the lines that touch a row;
-//   * chi^2 is reduced with wave shuffles, the WPI partial sums of an item meet in
-//     LDS at one workgroup barrier (fixed summation order: bitwise reproducible).
+//   * chi^2 is reduced with DPP lane permutes; the per-spectrum terms of an item are
+//     added in spectrum order by lnl_sum_kernel (bitwise reproducible).
 // No MFMA: the path is elementwise fp64/fp32 plus reductions.
 //
 // Numerical modes (template MODE): 0 "table" and 1 "poly" evaluate FastExp like
@@ -89,11 +88,7 @@ __host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncom
 struct LnlGeom {
     int nhf_max;       // lines per component slot in the LDS line table
     int wave_doubles;  // LDS doubles per wave
-    int nparts;        // interleaved row parts per spectrum
-    int wpi;           // waves per item = n_spec * nparts
-    int ipb;           // items per workgroup
-    int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 4 skip rows, 8 skip line setup
-    int wave_info[16]; // per wave of a workgroup: item slot | spectrum << 8 | row part << 16
+    int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 4 skip rows, 8 skip line set-up
 };
 
 // ---------------------------------------------------------------------------
@@ -295,37 +290,48 @@ struct __attribute__((aligned(16))) LineRec {
     int lo, len;                                 // window [lo, lo+len)
 };
 
-// 1 - FastExp(tau) of the reference for fp32 tau (MODE 2): the reference's cubic
-// below 2^-5 (fastexp.c:264-270) including its 1 - (1 - q) rounding, which decides
-// where a faint channel comes out exactly 0; tau*P8(tau) below 0.5; 1 - exp(-tau)
-// above (exactly 1 from 32 and for NaN).
+// 1 - FastExp(tau) of the reference for fp32 tau (MODE 2):
+//   tau < 2^-5   the reference's cubic  tau (1 - tau/2 (1 - tau/3))   (fastexp.c:264-270)
+//   tau < 0.25   tau * P6(tau), truncation < 2e-9
+//   otherwise    1 - exp(-tau) (6e-8 e/(1-e) <= 2.2e-7; exactly 1 from 32 and for NaN)
+// Below 1e-8 the reference's own evaluation 1 - (1 - q) is quantised in steps of 2^-53 (it
+// even returns exactly 0 below 1.1e-16, which decides the zero pattern of faint channels):
+// those lanes repeat that rounding in fp64, under a wave-uniform branch that is rarely taken.
 __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
     const float r3 = __builtin_fmaf(t, -1.0f / 3.0f, 1.0f);
-    const float r2 = __builtin_fmaf(t * r3, -0.5f, 1.0f);
-    const double r1 = 1.0 - (double)(t * r2);
-    const double w_small = 1.0 - r1;
-    float p = 1.0f / 362880.0f;                               // (1 - e^-t)/t = sum (-t)^k/(k+1)!
-    p = __builtin_fmaf(p, t, -1.0f / 40320.0f);
-    p = __builtin_fmaf(p, t, 1.0f / 5040.0f);
+    const float pc = __builtin_fmaf(t * r3, -0.5f, 1.0f);
+    float p = 1.0f / 5040.0f;                                 // (1 - e^-t)/t = sum (-t)^k/(k+1)!
     p = __builtin_fmaf(p, t, -1.0f / 720.0f);
     p = __builtin_fmaf(p, t, 1.0f / 120.0f);
     p = __builtin_fmaf(p, t, -1.0f / 24.0f);
     p = __builtin_fmaf(p, t, 1.0f / 6.0f);
     p = __builtin_fmaf(p, t, -0.5f);
     p = __builtin_fmaf(p, t, 1.0f);
+    p = (t < 0.03125f) ? pc : p;
     const float w_big = 1.0f - exp_neg_f32(t);
-    const float wf = (t < 0.5f) ? t * p : w_big;
-    return (t < 0.03125f) ? w_small : (double)wf;
+    double w = (double)((t < 0.25f) ? t * p : w_big);
+    const bool tiny = t < 1e-8f;
+    if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) {
+        const double r1 = 1.0 - (double)(t * pc);
+        w = tiny ? 1.0 - r1 : w;
+    }
+    return w;
 }
 
-#define DREG_MAX 4           // D record doubles per lane held in flight (drec <= 256)
-
+// ---------------------------------------------------------------------------
+//  lnl_kernel: one wavefront per (item, spectrum) unit, no coupling between waves.
+//  Every wave loads the item's record, forms the line constants of its spectrum in
+//  its own LDS slice, walks the rows and writes the spectrum's log-likelihood term;
+//  lnl_sum_kernel adds the terms of an item in spectrum order (ammonia.pyx:429-432).
+//  (A workgroup-per-item version with the partial sums meeting at a barrier lost
+//  ~20 % of the SIMD time to waves waiting for their slower siblings.)
+// ---------------------------------------------------------------------------
 template <int MODE, bool WRITE_SPEC>
 __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restrict__ pix,
-                                                   const double *__restrict__ D,
-                                                   double *__restrict__ lnL,
-                                                   double *__restrict__ spec_out, long B, LnlGeom G,
-                                                   const double *__restrict__ g_tabs) {
+                                                  const double *__restrict__ D,
+                                                  double *__restrict__ part,
+                                                  double *__restrict__ spec_out, long B, LnlGeom G,
+                                                  const double *__restrict__ g_tabs) {
     typedef typename std::conditional<MODE == 2, float, double>::type tau_t;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int n_shared = 0;
@@ -333,179 +339,141 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
     if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);   // fast: no tables
     const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
 
-    // everything derived from the wave index is wave-uniform: keep it in SGPRs so that the
-    // SpecDev fields it selects come through scalar loads and the loops stay uniform
+    // wave-uniform values live in SGPRs: SpecDev fields come through scalar loads
     const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ncomp = S.ncomp, nspec = S.n_spec;
     const int drec = drec_size(ncomp, nspec);
-    const int winfo = G.wave_info[wave];
-    const int il = winfo & 0xff, s = (winfo >> 8) & 0xff, rp = winfo >> 16;   // item slot, spectrum, row part
-    const int part = s * G.nparts + rp;
-    // LDS: [tables][red: waves][per item slot: 2 D records (double buffer), then per spectrum
-    // the line table]
-    double *red = smem + n_shared;                            // [waves] partial chi^2
-    double *slot = red + ((waves + 1) & ~1) + (size_t)il * G.wave_doubles;   // wave_doubles = per item slot
-    const int drec2 = (drec + 1) & ~1;
-    const int P = ncomp * G.nhf_max;
-    LineRec *w_line = (LineRec *)(slot + 2 * drec2) + (size_t)s * P;
-    // windows (lo, hi) again, 64 per component so that a whole wave can read them unguarded
-    int2 *w_win = (int2 *)((LineRec *)(slot + 2 * drec2) + (size_t)nspec * P) + (size_t)s * ncomp * 64;
+    double *w_d = smem + n_shared + (size_t)wave * G.wave_doubles;
+    LineRec *w_line = (LineRec *)(w_d + ((drec + 1) & ~1));
+    int2 *w_win = (int2 *)(w_line + ncomp * G.nhf_max);       // 64 windows per component (padded)
 
-    const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
-    const int nhf = c_nhf[t];
-    const double nu0 = c_nu[t];
-    const double *xs = S.xarr + off, *t0s = S.t0 + off, *tbgs = S.tbg + off;
-    const int row_step = 64 * G.nparts;
-
-    // persistent workgroups: the grid covers the device once, every workgroup walks its
-    // items; the record of the next item is already in flight while the current one runs
-    const long stride = (long)gridDim.x * G.ipb;
-    long b0 = (long)blockIdx.x * G.ipb;
-    if (part == 0 && b0 + il < B)
-        for (int k = lane; k < drec; k += 64) slot[k] = D[(b0 + il) * drec + k];
-    __syncthreads();
-    int cur = 0;
-    for (; b0 < B; b0 += stride, cur ^= 1) {
-        const long b = b0 + il;
-        const bool item = b < B;
-        const double *w_d = slot + cur * drec2;
-        double dreg[DREG_MAX];
-        const long bn = b + stride;
-        if (part == 0 && bn < B) {
-#pragma unroll
-            for (int q = 0; q < DREG_MAX; ++q) {
-                const int k = lane + 64 * q;
-                dreg[q] = (k < drec) ? D[bn * drec + k] : 0.0;
+    const long units = B * nspec;
+    for (long unit = (long)blockIdx.x * waves + wave; unit < units; unit += (long)gridDim.x * waves) {
+        const long b = unit / nspec;
+        const int s = (int)(unit - b * nspec);
+        const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
+        const int nhf = c_nhf[t];
+        const double nu0 = c_nu[t];
+        const double *xs = S.xarr + off, *t0s = S.t0 + off, *tbgs = S.tbg + off;
+        const long p_ix = pix ? (long)pix[b] : 0;
+        for (int k = lane; k < drec; k += 64) w_d[k] = D[b * drec + k];
+        wave_lds_sync();
+        // --- line constants + windows, lanes = (component, line) pairs (hyperfine.pyx:68-91)
+        for (int p = lane; p < ncomp * nhf && !(G.ablate & 8); p += 64) {
+            const int c = p / nhf, i = p - c * nhf;
+            const LineConst lc = nf_line(t, i, w_d[c * 4 + 2], w_d[c * 4 + 1], nu0, S.nu_min[s],
+                                         S.nu_chan[s], N);
+            int lo = lc.lo;
+            const int hi = lc.hi;
+            // Only the first channel of a window can lie beyond the point where FastExp
+            // returns exactly 0 (float argument >= 32, fastexp.c:272-273; also NaN): it then
+            // adds nothing, so the hot loop starts one channel later and needs no cut-off test.
+            if (hi > lo) {
+                const double nu = xs[lo] - lc.nucen;
+                const float a = (float)(nu * nu * lc.idenom);
+                if (!(a < 32.0f)) lo += 1;
             }
+            LineRec rec;
+            rec.nucen = lc.nucen;
+            rec.idenom = lc.idenom;
+            const double htau = w_d[4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
+            if (MODE == 2) { rec.htau = 0.0; rec.htau_f = (float)htau; } else rec.htau = htau;
+            rec.lo = lo;
+            rec.len = hi > lo ? hi - lo : 0;
+            w_line[c * G.nhf_max + i] = rec;
+            w_win[c * 64 + i] = make_int2(lo, hi > lo ? hi : lo);
         }
+        for (int q = lane; q < ncomp * 64; q += 64)
+            if ((q & 63) >= nhf) w_win[q] = make_int2(0, 0);      // lanes beyond the last line
+        wave_lds_sync();
+        // --- rows of 64 channels: tau profile, Tb, chi^2 (hyperfine.pyx:93-113, core.pyx:522-530)
+        const double *ds = S.data + p_ix * S.chan_tot + off;
         double acc = 0.0;
-        long p_ix = 0;
-        if (item) {
-            p_ix = pix ? (long)pix[b] : 0;
-            // --- line constants + windows of spectrum s, lanes = (component, line) pairs,
-            //     shared by the nparts waves of the spectrum (hyperfine.pyx:68-91)
-            for (int p = rp * 64 + lane; p < ncomp * nhf && !(G.ablate & 8); p += 64 * G.nparts) {
-                const int c = p / nhf, i = p - c * nhf;
-                const LineConst lc = nf_line(t, i, w_d[c * 4 + 2], w_d[c * 4 + 1], nu0, S.nu_min[s],
-                                             S.nu_chan[s], N);
-                int lo = lc.lo;
-                const int hi = lc.hi;
-                // Only the first channel of a window can lie beyond the point where
-                // FastExp returns exactly 0 (float argument >= 32, fastexp.c:272-273; also
-                // NaN): it then adds nothing, so the hot loop starts one channel later and
-                // needs no cut-off test.
-                if (hi > lo) {
-                    const double nu = xs[lo] - lc.nucen;
-                    const float a = (float)(nu * nu * lc.idenom);
-                    if (!(a < 32.0f)) lo += 1;
+        for (int r0 = 0; r0 < N && !(G.ablate & 4); r0 += 64) {
+            const int j = r0 + lane;
+            const bool valid = j < N;
+            const int jj = valid ? j : N - 1;
+            const double xj = xs[jj], dj = ds[jj], T0 = t0s[jj], tbg = tbgs[jj];
+            double pred = 0.0;
+            for (int c = 0; c < ncomp; ++c) {
+                const LineRec *lines = w_line + c * G.nhf_max;
+                const int2 win = w_win[c * 64 + lane];
+                const bool hit = (win.x < r0 + 64) & (win.y > r0) & (win.y > win.x);
+                unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (mask == 0ull) continue;
+                tau_t tau = 0;
+                if (G.ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); } else {
+                while (mask) {
+                    const int i = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const LineRec rec = lines[i];                     // two 16-byte broadcast reads
+                    const double nu = xj - rec.nucen;
+                    const double tau_exp = nu * nu * rec.idenom;
+                    const bool inwin = (unsigned)(j - rec.lo) < (unsigned)rec.len;
+                    if (MODE == 2) {
+                        const float x = (float)tau_exp;               // math.pxd:17 narrowing
+                        const float NEG_L2E_HI = -1.44269502162933349609375f;
+                        const float NEG_L2E_LO = -1.925963033500011e-08f;
+                        const float yh = x * NEG_L2E_HI;
+                        float yl = __builtin_fmaf(x, NEG_L2E_HI, -yh);
+                        yl = __builtin_fmaf(x, NEG_L2E_LO, yl);
+                        float e = __builtin_amdgcn_exp2f(yh);
+                        e = __builtin_fmaf(e * 0.693147180559945f, yl, e);
+                        // predicate the weight, not the arithmetic: straight-line code
+                        const float h = inwin ? rec.htau_f : 0.0f;
+                        tau = __builtin_fmaf(h, e, (float)tau);
+                    } else {
+                        const double e = nf_fastexp<MODE>(tau_exp, sm);
+                        tau = inwin ? __builtin_fma(rec.htau, e, (double)tau) : tau;
+                    }
                 }
-                LineRec rec;
-                rec.nucen = lc.nucen;
-                rec.idenom = lc.idenom;
-                const double htau = w_d[4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
-                if (MODE == 2) { rec.htau = 0.0; rec.htau_f = (float)htau; } else rec.htau = htau;
-                rec.lo = lo;
-                rec.len = hi > lo ? hi - lo : 0;
-                w_line[c * G.nhf_max + i] = rec;
-                w_win[c * 64 + i] = make_int2(lo, hi > lo ? hi : lo);
-            }
-            // lanes beyond the last line: empty windows (written once per item by the same waves)
-            for (int q = rp * 64 + lane; q < ncomp * 64; q += 64 * G.nparts)
-                if ((q & 63) >= nhf) w_win[q] = make_int2(0, 0);
-        }
-        __syncthreads();
-        if (item) {
-            // --- rows of 64 channels: tau profile, Tb, chi^2
-            //     (hyperfine.pyx:93-113, core.pyx:522-530); this wave owns rows rp, rp+nparts, ...
-            const double *ds = S.data + p_ix * S.chan_tot + off;
-            for (int r0 = rp * 64; r0 < N && !(G.ablate & 4); r0 += row_step) {
-                const int j = r0 + lane;
-                const bool valid = j < N;
-                const int jj = valid ? j : N - 1;
-                const double xj = xs[jj], dj = ds[jj], T0 = t0s[jj], tbg = tbgs[jj];
-                double pred = 0.0;
-                for (int c = 0; c < ncomp; ++c) {
-                    const LineRec *lines = w_line + c * G.nhf_max;
-                    const int2 win = w_win[c * 64 + lane];
-                    unsigned long long mask = __builtin_amdgcn_ballot_w64(win.x < r0 + 64 && win.y > r0 && win.y > win.x);
-                    if (mask == 0ull) continue;
-                    tau_t tau = 0;
-                    if (G.ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); } else {
-                    while (mask) {
-                        const int i = __builtin_ctzll(mask);
-                        mask &= mask - 1;
-                        const LineRec rec = lines[i];                     // two 16-byte broadcast reads
-                        const double nu = xj - rec.nucen;
-                        const double tau_exp = nu * nu * rec.idenom;
-                        const bool inwin = (unsigned)(j - rec.lo) < (unsigned)rec.len;
-                        if (MODE == 2) {
-                            const float x = (float)tau_exp;               // math.pxd:17 narrowing
-                            const float NEG_L2E_HI = -1.44269502162933349609375f;
-                            const float NEG_L2E_LO = -1.925963033500011e-08f;
-                            const float yh = x * NEG_L2E_HI;
-                            float yl = __builtin_fmaf(x, NEG_L2E_HI, -yh);
-                            yl = __builtin_fmaf(x, NEG_L2E_LO, yl);
-                            float e = __builtin_amdgcn_exp2f(yh);
-                            e = __builtin_fmaf(e * 0.693147180559945f, yl, e);
-                            // predicate the weight, not the arithmetic: straight-line code
-                            const float h = inwin ? rec.htau_f : 0.0f;
-                            tau = __builtin_fmaf(h, e, (float)tau);
-                        } else {
-                            const double e = nf_fastexp<MODE>(tau_exp, sm);
-                            tau = inwin ? __builtin_fma(rec.htau, e, (double)tau) : tau;
-                        }
-                    }
-                    }
-                    const bool live = valid && !(tau == 0);           // hyperfine.pyx:104-105
-                    if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;
-                    double tb;
-                    if (G.ablate & 1) { if (live) pred += (double)tau; continue; }
-                    const double *dk = w_d + 4 * ncomp + (c * nspec + s) * DREC_CS;
-                    if (MODE == 2 && dk[DK_KIND] != 0.0) {
+                }
+                const bool live = valid && !(tau == 0);               // hyperfine.pyx:104-105
+                if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;
+                double tb;
+                if (G.ablate & 1) { if (live) pred += (double)tau; continue; }
+                const double *dk = w_d + 4 * ncomp + (c * nspec + s) * DREC_CS;
+                if (MODE == 2 && dk[DK_KIND] != 0.0) {
+                    double y;
+                    if (dk[DK_KIND] == 1.0) {                         // one table cell over the band (usual)
+                        y = __builtin_fma(dk[DK_B0], T0, dk[DK_A0]);
+                    } else {
                         const bool up = !(T0 < dk[DK_SPLIT]);
                         const double dT = T0 - dk[DK_M];
                         const double ya = up ? dk[DK_A1] : dk[DK_A0];
                         const double yb = up ? dk[DK_B1] : dk[DK_B0];
-                        const double y = __builtin_fma(__builtin_fma(dk[DK_Q], dT, yb), dT, ya);
-                        tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
-                    } else {
-                        const double y = nf_iemtex(T0 / w_d[c * 4], g_t0x, g_t0y, S.t0_xmin, S.t0_xmax,
-                                                   S.t0_inv_dx);
-                        if (MODE == 2) tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
-                        else tb = (T0 * (y - tbg)) * (1.0 - nf_fastexp<MODE>((double)tau, sm));
+                        y = __builtin_fma(__builtin_fma(dk[DK_Q], dT, yb), dT, ya);
                     }
-                    if (live) pred += tb;
+                    tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
+                } else {
+                    const double y = nf_iemtex(T0 / w_d[c * 4], g_t0x, g_t0y, S.t0_xmin, S.t0_xmax,
+                                               S.t0_inv_dx);
+                    if (MODE == 2) tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
+                    else tb = (T0 * (y - tbg)) * (1.0 - nf_fastexp<MODE>((double)tau, sm));
                 }
-                if (WRITE_SPEC) { if (valid) spec_out[b * S.chan_tot + off + j] = pred; }
-                const double dev = dj - pred;
-                if (valid) acc = __builtin_fma(dev, dev, acc);
+                if (live) pred += tb;
             }
-            acc = wave_sum(acc);
+            if (WRITE_SPEC) { if (valid) spec_out[b * S.chan_tot + off + j] = pred; }
+            const double dev = dj - pred;
+            if (valid) acc = __builtin_fma(dev, dev, acc);
         }
-        // --- the item's partial sums meet in LDS; fixed order (core.pyx:530, ammonia.pyx:429-432).
-        //     The same barrier publishes the next item's record.
-        if (lane == 0) red[wave] = acc;
-        if (part == 0 && bn < B) {
-            double *w_dn = slot + (cur ^ 1) * drec2;
-#pragma unroll
-            for (int q = 0; q < DREG_MAX; ++q) {
-                const int k = lane + 64 * q;
-                if (k < drec) w_dn[k] = dreg[q];
-            }
+        acc = wave_sum(acc);
+        if (lane == 0 && part) {
+            const double noise = S.noise[p_ix * nspec + s];
+            part[unit] = -acc / (2 * (noise * noise));                // core.pyx:530
         }
-        __syncthreads();
-        if (item && part == 0 && lane == 0 && lnL) {
-            double tot = 0.0;
-            for (int ss = 0; ss < nspec; ++ss) {
-                double a = 0.0;
-                for (int q = 0; q < G.nparts; ++q) a += red[il * G.wpi + ss * G.nparts + q];
-                const double noise = S.noise[p_ix * nspec + ss];
-                tot += -a / (2 * (noise * noise));
-            }
-            lnL[b] = tot;
-        }
+        wave_lds_sync();
     }
+}
+
+// lnL[b] = sum over the spectra of the item, in order (ammonia.pyx:425-432)
+__global__ void lnl_sum_kernel(const double *__restrict__ part, double *__restrict__ lnL, long B, int nspec) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double tot = 0.0;
+    for (int s = 0; s < nspec; ++s) tot += part[b * nspec + s];
+    lnL[b] = tot;
 }
 
 #include "nfa_setup.h"

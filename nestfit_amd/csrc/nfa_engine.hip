@@ -40,10 +40,9 @@ struct Engine {
     int    device = 0;
     int    n_cu = 256;
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
-    int    nparts_override = 0;
+    int    wpb = 4;                  // waves per workgroup of the likelihood kernel
     int    ablate = 0;
     int    streams = 3;              // stream lanes of new runners
-    int    persistent = 0;
     bool   have_t0 = false;
     double *d_tabs = nullptr;                      // SM_END_TABLE doubles
     double t0_xmin = 0, t0_xmax = 0, t0_inv_dx = 0;
@@ -109,6 +108,7 @@ struct nfa_runner {
     hipStream_t lanes[NFA_MAX_LANES] = {};
     double     *d_D[NFA_MAX_LANES] = {};
     double     *d_Q[NFA_MAX_LANES] = {};     // partition sums, QREC doubles per (item, component)
+    double     *d_part[NFA_MAX_LANES] = {};  // per (item, spectrum) log-likelihood terms
     int64_t     cap_D[NFA_MAX_LANES] = {};
     hipStream_t stream = nullptr;            // lane 0: also the stream of the host-pointer entry points
     uint64_t    n_calls = 0;
@@ -159,10 +159,9 @@ int nfa_set_exp_mode(int mode) {
 int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
-    if (key && !strcmp(key, "nparts") && value >= 0 && value <= 16) { g_eng.nparts_override = value; return NFA_OK; }
+    if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }
     if (key && !strcmp(key, "ablate") && value >= 0 && value <= 15) { g_eng.ablate = value; return NFA_OK; }
     if (key && !strcmp(key, "streams") && value >= 1 && value <= NFA_MAX_LANES) { g_eng.streams = value; return NFA_OK; }
-    if (key && !strcmp(key, "persistent") && (value == 0 || value == 1)) { g_eng.persistent = value; return NFA_OK; }
     return fail(NFA_ERR_ARG, "unknown option");
 }
 
@@ -381,7 +380,7 @@ int nfa_runner_destroy(nfa_runner *r) {
     if (!r) return NFA_OK;
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamSynchronize(r->lanes[k]);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
-    for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_Q[k]); }
+    for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_Q[k]); (void)hipFree(r->d_part[k]); }
     for (hipEvent_t x : r->ev) (void)hipEventDestroy(x);
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamDestroy(r->lanes[k]);
     delete r;
@@ -425,11 +424,12 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     hipStream_t st = r->lanes[slot];
     if (B > r->cap_D[slot]) {                // grown outside any timed loop
         HIP_TRY(hipStreamSynchronize(st));
-        (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_Q[slot]);
-        r->d_D[slot] = nullptr; r->d_Q[slot] = nullptr; r->cap_D[slot] = 0;
+        (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_Q[slot]); (void)hipFree(r->d_part[slot]);
+        r->d_D[slot] = nullptr; r->d_Q[slot] = nullptr; r->d_part[slot] = nullptr; r->cap_D[slot] = 0;
         const int64_t cap = std::max<int64_t>(B, 4096);
         HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec));
         HIP_TRY(hipMalloc(&r->d_Q[slot], sizeof(double) * cap * r->ncomp * QREC));
+        HIP_TRY(hipMalloc(&r->d_part[slot], sizeof(double) * cap * S.n_spec));
         r->cap_D[slot] = cap;
     }
     if (has_prior) {
@@ -460,7 +460,6 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     return NFA_OK;
 }
 
-static int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
 template <int MODE, bool WS>
 static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL,
@@ -470,51 +469,29 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     G.ablate = g_eng.ablate;
     G.nhf_max = r->ss->nhf_max;
     const int drec = drec_size(r->ncomp, S.n_spec);
-    // LDS per item slot: two D records (double buffer) + for every spectrum the line table
-    // (32-B records + windows)
-    if (drec > 64 * DREG_MAX) return fail(NFA_ERR_ARG, "ncomp x n_spec too large for the record prefetch");
-    G.wave_doubles = 2 * ((drec + 1) & ~1) + S.n_spec * r->ncomp * (G.nhf_max * (int)(sizeof(LineRec) / sizeof(double)) + 64);
-    int min_rows = 1 << 30;
-    for (int s = 0; s < S.n_spec; ++s) min_rows = std::min(min_rows, (S.size[s] + 63) / 64);
-    // Every item is cut into n_spec x nparts waves.  nparts depends on the runner's shape
-    // only (never on the batch size), so that a row's result does not depend on which
-    // batch it travelled in.  Default 1 (one wave per spectrum): with stream lanes hiding the
-    // tail of a batch, fewer and longer waves win (measured: 74 vs 70 M evals/s at B = 4096).
-    int nparts = g_eng.nparts_override > 0 ? g_eng.nparts_override : 1;
-    nparts = std::max(1, std::min(nparts, std::min(min_rows, 16 / S.n_spec)));
-    G.nparts = pow2_floor(nparts);
-    G.wpi = S.n_spec * G.nparts;
-    // table mode shares 51 KB of product tables: fat workgroups; otherwise 4 waves
-    const int target_waves = MODE == 0 ? 16 : 4;
-    G.ipb = std::max(1, target_waves / G.wpi);
-    const int waves = G.wpi * G.ipb;
-    if (waves > 16) return fail(NFA_ERR_ARG, "too many spectra for one workgroup");
-    for (int w = 0; w < 16; ++w) {
-        const int il = w / G.wpi, part = w % G.wpi;
-        G.wave_info[w] = il | ((part / G.nparts) << 8) | ((part % G.nparts) << 16);
-    }
+    // LDS per wave: the item's record + the line table of one spectrum (32-B records + 64 windows
+    // per component)
+    G.wave_doubles = ((drec + 1) & ~1) + r->ncomp * (G.nhf_max * (int)(sizeof(LineRec) / sizeof(double)) + 64);
+    // table mode shares 51 KB of product tables: fat workgroups; otherwise g_eng.wpb waves
+    const int waves = MODE == 0 ? 4 : std::max(1, std::min(g_eng.wpb, 16));
     const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
-    const size_t lds = sizeof(double) * ((size_t)n_shared + ((waves + 1) & ~1) + (size_t)G.wave_doubles * G.ipb);
-    if (lds > 160 * 1024 || waves > 16)
-        return fail(NFA_ERR_ARG, "ncomp / n_spec too large for the LDS line table");
+    const size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * waves);
+    if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "ncomp too large for the LDS line table");
     auto kern = lnl_kernel<MODE, WS>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // One workgroup per ipb items, dispatched by the hardware as slots free up (measured:
-    // a device-sized persistent grid with static striding loses ~25 % to the 2-vs-3 items
-    // per workgroup imbalance at B = 4096); "persistent" = 1 switches to the device-sized grid.
-    int64_t blocks = std::min<int64_t>((B + G.ipb - 1) / G.ipb, (int64_t)g_eng.n_cu * 256);
-    if (g_eng.persistent) {
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 64 * waves, lds));
-        const int64_t capacity = (int64_t)g_eng.n_cu * std::max(1, per_cu);
-        const int64_t groups = (B + G.ipb - 1) / G.ipb;
-        const int64_t per_block = (groups + capacity - 1) / capacity;      // same count for every workgroup
-        blocks = (groups + per_block - 1) / per_block;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, r->lanes[slot], S, d_pix,
-                       (const double *)r->d_D[slot], d_lnL, d_spec, (long)B, G, (const double *)g_eng.d_tabs);
+    const int64_t units = B * S.n_spec;
+    const int64_t blocks = std::min<int64_t>((units + waves - 1) / waves, (int64_t)g_eng.n_cu * 1024);
+    hipStream_t st = r->lanes[slot];
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, st, S, d_pix,
+                       (const double *)r->d_D[slot], d_lnL ? r->d_part[slot] : nullptr, d_spec, (long)B, G,
+                       (const double *)g_eng.d_tabs);
     HIP_TRY(hipGetLastError());
+    if (d_lnL) {
+        hipLaunchKernelGGL(lnl_sum_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st,
+                           (const double *)r->d_part[slot], d_lnL, (long)B, S.n_spec);
+        HIP_TRY(hipGetLastError());
+    }
     return NFA_OK;
 }
 
