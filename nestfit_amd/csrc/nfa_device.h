@@ -312,6 +312,7 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
     double w = (double)((t < 0.25f) ? t * p : w_big);
     const bool tiny = t < 1e-8f;
     if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) {
+        asm volatile("" ::: "memory");            // keep the rare path a branch (no if-conversion)
         const double r1 = 1.0 - (double)(t * pc);
         w = tiny ? 1.0 - r1 : w;
     }
@@ -398,6 +399,8 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
             double pred = 0.0;
             for (int c = 0; c < ncomp; ++c) {
                 const LineRec *lines = w_line + c * G.nhf_max;
+                const double *dk = w_d + 4 * ncomp + (c * nspec + s) * DREC_CS;
+                const double dk_kind = dk[DK_KIND], dk_a0 = dk[DK_A0], dk_b0 = dk[DK_B0];
                 const int2 win = w_win[c * 64 + lane];
                 const bool hit = (win.x < r0 + 64) & (win.y > r0) & (win.y > win.x);
                 unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
@@ -433,16 +436,15 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                 if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;
                 double tb;
                 if (G.ablate & 1) { if (live) pred += (double)tau; continue; }
-                const double *dk = w_d + 4 * ncomp + (c * nspec + s) * DREC_CS;
-                if (MODE == 2 && dk[DK_KIND] != 0.0) {
+                if (MODE == 2 && dk_kind != 0.0) {
                     double y;
-                    if (dk[DK_KIND] == 1.0) {                         // one table cell over the band (usual)
-                        y = __builtin_fma(dk[DK_B0], T0, dk[DK_A0]);
+                    if (dk_kind == 1.0) {                             // one table cell over the band (usual)
+                        y = __builtin_fma(dk_b0, T0, dk_a0);
                     } else {
                         const bool up = !(T0 < dk[DK_SPLIT]);
                         const double dT = T0 - dk[DK_M];
-                        const double ya = up ? dk[DK_A1] : dk[DK_A0];
-                        const double yb = up ? dk[DK_B1] : dk[DK_B0];
+                        const double ya = up ? dk[DK_A1] : dk_a0;
+                        const double yb = up ? dk[DK_B1] : dk_b0;
                         y = __builtin_fma(__builtin_fma(dk[DK_Q], dT, yb), dT, ya);
                     }
                     tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
