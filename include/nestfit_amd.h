@@ -50,11 +50,12 @@ int nfa_device_name(char *buf, int buflen);
 int nfa_set_exp_mode(int mode);
 int nfa_get_exp_mode(void);
 /* Engine tuning knobs for A/B measurements: "wpb" = waves per workgroup of the
- * likelihood kernel (1..16); "streams" = number of HIP streams
- * ("lanes", 1..8, default 2) that runners created afterwards spread consecutive
- * nfa_runner_loglike_batch_dev calls over; "persistent" = 1 device-sized grid; "ablate"
- * (timing experiments only, results invalid) = 1 skip the Tb pass, 2 skip the
- * hyperfine-line loop, 3 both. */
+ * likelihood kernel (1..16, default 4); "occ" = resident waves per SIMD the fast-mode
+ * likelihood kernel is capped to (0 = no cap, default 7); "streams" = number of HIP
+ * streams ("lanes", 1..8, default 3) that runners created afterwards spread consecutive
+ * nfa_runner_loglike_batch_dev calls over; "ablate" (only in builds with -DNFA_ABLATE,
+ * timing experiments, results invalid) = bit mask: 1 skip the Tb pass, 2 skip the
+ * hyperfine-line loop, 4 skip the rows, 8 skip the line set-up. */
 int nfa_set_option(const char *key, int value);
 
 /* 1/(e^x-1) interpolation table.  The reference builds T0_X, T0_Y with numpy at

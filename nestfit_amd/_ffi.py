@@ -3,6 +3,7 @@
 There is deliberately no CPU fallback: if the HIP library is missing or no
 gfx950 device is visible, every compute entry point raises `EngineError`.
 """
+import os
 import ctypes as C
 from pathlib import Path
 
@@ -96,7 +97,8 @@ def load():
         raise EngineError(
             f'{LIB_PATH} is missing: build it with `python -m nestfit_amd.build` '
             '(the engine has no CPU fallback)')
-    lib = C.CDLL(str(LIB_PATH))
+    # NFA_ENGINE_LIB: development override for A/B runs of two engine builds
+    lib = C.CDLL(os.environ.get('NFA_ENGINE_LIB') or str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -10,7 +10,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 SRC = HERE / 'csrc' / 'nfa_engine.hip'
-DEPS = [SRC, HERE / 'csrc' / 'nh3_data.h', HERE.parent / 'include' / 'nestfit_amd.h']
+DEPS = sorted((HERE / 'csrc').glob('*.h*')) + [HERE.parent / 'include' / 'nestfit_amd.h']
 OUT = HERE / 'lib' / 'libnestfit_amd.so'
 
 FLAGS = [

@@ -341,6 +341,11 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
     const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
 
     // wave-uniform values live in SGPRs: SpecDev fields come through scalar loads
+#ifdef NFA_ABLATE
+    const int ablate = G.ablate;      // timing experiments (build with -DNFA_ABLATE)
+#else
+    const int ablate = 0;
+#endif
     const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ncomp = S.ncomp, nspec = S.n_spec;
@@ -350,7 +355,12 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
     int2 *w_win = (int2 *)(w_line + ncomp * G.nhf_max);       // 64 windows per component (padded)
 
     const long units = B * nspec;
-    for (long unit = (long)blockIdx.x * waves + wave; unit < units; unit += (long)gridDim.x * waves) {
+    // one unit per wave; the grid covers them all.  Waves of a workgroup land on the SIMDs of a CU
+    // in order, so the unit -> wave assignment is rotated per workgroup: otherwise one SIMD would
+    // only ever see the spectrum with the most hyperfine lines.
+    const int rot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 0x9E3779B1u) >> 28));
+    const long unit = (long)blockIdx.x * waves + (wave + rot) % waves;
+    if (unit < units) {
         const long b = unit / nspec;
         const int s = (int)(unit - b * nspec);
         const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
@@ -361,7 +371,7 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
         for (int k = lane; k < drec; k += 64) w_d[k] = D[b * drec + k];
         wave_lds_sync();
         // --- line constants + windows, lanes = (component, line) pairs (hyperfine.pyx:68-91)
-        for (int p = lane; p < ncomp * nhf && !(G.ablate & 8); p += 64) {
+        for (int p = lane; p < ncomp * nhf && !(ablate & 8); p += 64) {
             const int c = p / nhf, i = p - c * nhf;
             const LineConst lc = nf_line(t, i, w_d[c * 4 + 2], w_d[c * 4 + 1], nu0, S.nu_min[s],
                                          S.nu_chan[s], N);
@@ -379,7 +389,8 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
             rec.nucen = lc.nucen;
             rec.idenom = lc.idenom;
             const double htau = w_d[4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
-            if (MODE == 2) { rec.htau = 0.0; rec.htau_f = (float)htau; } else rec.htau = htau;
+            // fast mode keeps the weight as a float in the low word (no union store: that goes through scratch)
+            rec.htau = MODE == 2 ? __longlong_as_double((long long)__float_as_uint((float)htau)) : htau;
             rec.lo = lo;
             rec.len = hi > lo ? hi - lo : 0;
             w_line[c * G.nhf_max + i] = rec;
@@ -391,7 +402,7 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
         // --- rows of 64 channels: tau profile, Tb, chi^2 (hyperfine.pyx:93-113, core.pyx:522-530)
         const double *ds = S.data + p_ix * S.chan_tot + off;
         double acc = 0.0;
-        for (int r0 = 0; r0 < N && !(G.ablate & 4); r0 += 64) {
+        for (int r0 = 0; r0 < N && !(ablate & 4); r0 += 64) {
             const int j = r0 + lane;
             const bool valid = j < N;
             const int jj = valid ? j : N - 1;
@@ -406,7 +417,7 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                 unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
                 if (mask == 0ull) continue;
                 tau_t tau = 0;
-                if (G.ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); } else {
+                if (ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); } else {
                 while (mask) {
                     const int i = __builtin_ctzll(mask);
                     mask &= mask - 1;
@@ -435,7 +446,7 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                 const bool live = valid && !(tau == 0);               // hyperfine.pyx:104-105
                 if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;
                 double tb;
-                if (G.ablate & 1) { if (live) pred += (double)tau; continue; }
+                if (ablate & 1) { if (live) pred += (double)tau; continue; }
                 if (MODE == 2 && dk_kind != 0.0) {
                     double y;
                     if (dk_kind == 1.0) {                             // one table cell over the band (usual)

@@ -24,6 +24,10 @@ cal_bytes = 16384 * 2048 * 8
 factor = cal_bytes / (max(cal) * 1024.0)
 lnl_f = [v for k, g, v in fetch if 'lnl_kernel' in k and g >= 4096 * 64]
 lnl_w = [v for k, g, v in write if 'lnl_kernel' in k and g >= 4096 * 64]
+# lnl_sum_kernel (adds the per-spectrum terms) belongs to the same launch: 4096 threads
+sum_f = [v for k, g, v in fetch if 'lnl_sum_kernel' in k and g == 4096] or [0.0]
+sum_w = [v for k, g, v in write if 'lnl_sum_kernel' in k and g == 4096] or [0.0]
+sum_bytes = sum(sum_f) / len(sum_f) * 1024 * factor + sum(sum_w) / len(sum_w) * 1024
 half = len(lnl_f) // 2
 res = {
     'fetch_calibration_factor': factor,
@@ -32,7 +36,8 @@ res = {
                        'write_bytes': sum(lnl_w[half:]) / (len(lnl_w) - half) * 1024},
 }
 for k in ('one_pixel', 'pixel_per_item'):
-    res[k]['total_bytes'] = res[k]['fetch_bytes'] + res[k]['write_bytes']
+    res[k]['lnl_sum_bytes'] = sum_bytes
+    res[k]['total_bytes'] = res[k]['fetch_bytes'] + res[k]['write_bytes'] + sum_bytes
 print(json.dumps(res, indent=1))
 if out:
     try:
