@@ -75,6 +75,22 @@ int nfa_set_iemtex_table(const double *t0_x, const double *t0_y, int64_t n);
 int nfa_specset_create(nfa_specset **out, int n_spec, const int64_t *sizes,
                        const int32_t *trans_ids, const double *const *xarr,
                        int64_t n_pix, const double *data, const double *noise);
+/* The same for the sibling models on the same kernels:
+ *   model 0 = ammonia (as above);
+ *   model 1 = N2H+, DiazenyliumSpectrum.__init__ (nestfit/models/diazenylium.pyx:108-136),
+ *             trans_ids 1..3 = J 1-0, 2-1, 3-2; parameters per component voff, tex, ltau, sigm
+ *             (c_nnhp_predict, diazenylium.pyx:138-154);
+ *   model 2 = Gaussian on a plain Spectrum (nestfit/core/core.pyx:486-520 with rest_freq;
+ *             c_gauss_predict, nestfit/models/gaussian.pyx:17-50): n_spec must be 1,
+ *             trans_ids is ignored, rest_freqs[0] = Spectrum.rest_freq in Hz (NULL = 0 like
+ *             the reference's default); parameters per component voff, sigm, peak. */
+#define NFA_MODEL_AMMONIA      0
+#define NFA_MODEL_DIAZENYLIUM  1
+#define NFA_MODEL_GAUSSIAN     2
+int nfa_specset_create_model(nfa_specset **out, int model, int n_spec, const int64_t *sizes,
+                             const int32_t *trans_ids, const double *rest_freqs,
+                             const double *const *xarr, int64_t n_pix, const double *data,
+                             const double *noise);
 int nfa_specset_destroy(nfa_specset *ss);
 int nfa_specset_set_data(nfa_specset *ss, int64_t pix, const double *data);
 /* null_lnZ[n_pix][n_spec] = -sum(data^2)/(2 noise^2)   (core.pyx:517-520) */

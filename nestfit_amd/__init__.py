@@ -8,6 +8,12 @@ from ._ffi import EngineError, device_count, get_exp_mode, set_device, set_exp_m
 from .core import (ConstantPrior, CenSepPrior, Distribution, DuplicatePrior, OrderedPrior, Prior,
                    PriorTransformer, ResolvedCenSepPrior, ResolvedPlacementPrior, SpacedPrior)
 from .ammonia import AmmoniaRunner, AmmoniaSpectrum, amm_predict
+from .diazenylium import DiazenyliumRunner, DiazenyliumSpectrum, nnhp_predict
+from .gaussian import GaussianRunner, gauss_predict
+from . import ammonia, diazenylium, gaussian
+
+# registry like nestfit/models/__init__.py:3-7
+MODELS = {m.NAME: m for m in (ammonia, diazenylium, gaussian)}
 from .prior_constructors import get_irdc_priors, get_synth_priors
 
 __all__ = [
@@ -15,4 +21,6 @@ __all__ = [
     'Distribution', 'Prior', 'ConstantPrior', 'DuplicatePrior', 'OrderedPrior', 'SpacedPrior',
     'CenSepPrior', 'ResolvedCenSepPrior', 'ResolvedPlacementPrior', 'PriorTransformer',
     'AmmoniaSpectrum', 'AmmoniaRunner', 'amm_predict', 'get_irdc_priors', 'get_synth_priors',
+    'DiazenyliumSpectrum', 'DiazenyliumRunner', 'nnhp_predict', 'GaussianRunner', 'gauss_predict',
+    'MODELS',
 ]

@@ -48,6 +48,8 @@ SIGNATURES = {
     'nfa_set_iemtex_table': (C.c_int, [_dp, _dp, C.c_int64]),
     'nfa_specset_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _lp, _ip,
                                      C.POINTER(_dp), C.c_int64, _dp, _dp]),
+    'nfa_specset_create_model': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, _lp, _ip, _dp,
+                                           C.POINTER(_dp), C.c_int64, _dp, _dp]),
     'nfa_specset_destroy': (C.c_int, [C.c_void_p]),
     'nfa_specset_set_data': (C.c_int, [C.c_void_p, C.c_int64, _dp]),
     'nfa_specset_null_lnz': (C.c_int, [C.c_void_p, _dp]),

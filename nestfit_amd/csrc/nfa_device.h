@@ -47,14 +47,22 @@
 #define SM_END_POLY   2032
 #define SM_END_TABLE  (SM_FEC + 2560)   // 8432 doubles
 
-__constant__ int    c_nhf[NFA_N_LEVELS];
-__constant__ double c_nu[NFA_N_LEVELS];
+// Transition tables of every model in one index space: 0..8 NH3 (1,1)..(9,9), 9..11 N2H+
+// 1-0, 2-1, 3-2, 12 the Gaussian model's single "line" (offset 0, weight 1, rest frequency
+// from the spectrum).  SpecDev.trans holds index + 1.
+#define NFA_T_N2HP   NFA_N_LEVELS
+#define NFA_T_GAUSS  (NFA_N_LEVELS + NFA_N2HP_LEVELS)
+#define NFA_T_ALL    (NFA_T_GAUSS + 1)
+__constant__ int    c_nhf[NFA_T_ALL];
+__constant__ double c_nu[NFA_T_ALL];
 __constant__ double c_ea[NFA_N_LEVELS];
-__constant__ double c_voff[NFA_N_LEVELS][NFA_MAX_HF_N];
-__constant__ double c_tauw[NFA_N_LEVELS][NFA_MAX_HF_N];
+__constant__ double c_voff[NFA_T_ALL][NFA_MAX_HF_N];
+__constant__ double c_tauw[NFA_T_ALL][NFA_MAX_HF_N];
 
 struct SpecDev {
     int     n_spec, ncomp, cold, lte;
+    int     model, npar;                 // NFA_MODEL_*, parameters per component (6 / 4 / 3)
+    double  rest[MAXSPEC];               // line rest frequency (tables, or Spectrum.rest_freq)
     int     size[MAXSPEC], trans[MAXSPEC], off[MAXSPEC];
     double  nu_min[MAXSPEC], nu_chan[MAXSPEC];
     int64_t chan_tot;
@@ -254,7 +262,8 @@ __device__ __forceinline__ LineConst nf_line(int t, int i, double v_over_c, doub
     const double hf_freq   = (1.0 - c_voff[t][i] / NFA_CKMS) * nu0;
     const double hf_width  = s_over_c * hf_freq;             // (sigm / CKMS) * hf_freq
     const double hf_offset = v_over_c * hf_freq;             // (voff / CKMS) * hf_freq
-    const double hf_nucen  = hf_freq - hf_offset;
+    // the Gaussian model forms its centre as rest_freq * (1 - voff / CKMS) (gaussian.pyx:33)
+    const double hf_nucen  = t == NFA_T_GAUSS ? nu0 * (1 - v_over_c) : hf_freq - hf_offset;
     const double hf_idenom = 0.5 / (hf_width * hf_width);
     const double nu_cutoff = sqrt(12.5 / hf_idenom);
     const double nu_lo = (hf_nucen - nu_min - nu_cutoff);
@@ -327,7 +336,8 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
 //  (A workgroup-per-item version with the partial sums meeting at a barrier lost
 //  ~20 % of the SIMD time to waves waiting for their slower siblings.)
 // ---------------------------------------------------------------------------
-template <int MODE, bool WRITE_SPEC>
+// WIDE (fast mode only): the spectra set holds a transition with more than 26 lines (N2H+)
+template <int MODE, bool WRITE_SPEC, bool WIDE>
 __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restrict__ pix,
                                                   const double *__restrict__ D,
                                                   double *__restrict__ part,
@@ -365,7 +375,7 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
         const int s = (int)(unit - b * nspec);
         const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
         const int nhf = c_nhf[t];
-        const double nu0 = c_nu[t];
+        const double nu0 = S.rest[s];
         const double *xs = S.xarr + off, *t0s = S.t0 + off, *tbgs = S.tbg + off;
         const long p_ix = pix ? (long)pix[b] : 0;
         for (int k = lane; k < drec; k += 64) w_d[k] = D[b * drec + k];
@@ -417,7 +427,30 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                 unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
                 if (mask == 0ull) continue;
                 tau_t tau = 0;
-                if (ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); } else {
+                if (ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); }
+                else if (MODE == 2 && WIDE) {
+                    // N2H+ 2-1 / 3-2 stack up to 45 overlapping lines: a float running sum could
+                    // drift past the 1e-6 bar, so the sum (only the sum) is kept in fp64
+                    double td = 0.0;
+                    while (mask) {
+                        const int i = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        const LineRec rec = lines[i];
+                        const double nu = xj - rec.nucen;
+                        const float x = (float)(nu * nu * rec.idenom);
+                        const float NEG_L2E_HI = -1.44269502162933349609375f;
+                        const float NEG_L2E_LO = -1.925963033500011e-08f;
+                        const float yh = x * NEG_L2E_HI;
+                        float yl = __builtin_fmaf(x, NEG_L2E_HI, -yh);
+                        yl = __builtin_fmaf(x, NEG_L2E_LO, yl);
+                        float e = __builtin_amdgcn_exp2f(yh);
+                        e = __builtin_fmaf(e * 0.693147180559945f, yl, e);
+                        const bool inwin = (unsigned)(j - rec.lo) < (unsigned)rec.len;
+                        const float h = inwin ? rec.htau_f : 0.0f;
+                        td = __builtin_fma((double)h, (double)e, td);
+                    }
+                    tau = (tau_t)td;
+                } else {
                 while (mask) {
                     const int i = __builtin_ctzll(mask);
                     mask &= mask - 1;
@@ -446,7 +479,10 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                 const bool live = valid && !(tau == 0);               // hyperfine.pyx:104-105
                 if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;
                 double tb;
-                if (ablate & 1) { if (live) pred += (double)tau; continue; }
+                if ((ablate & 1) || S.model == NFA_MODEL_GAUSSIAN) {      // gaussian.pyx:50: pred += peak * e
+                    if (live) pred += (double)tau;
+                    continue;
+                }
                 if (MODE == 2 && dk_kind != 0.0) {
                     double y;
                     if (dk_kind == 1.0) {                             // one table cell over the band (usual)
@@ -570,7 +606,7 @@ __global__ void test_partition_kernel(const double *trot, double *qpara, double 
 __global__ void test_windows_kernel(SpecDev S, int s, double voff, double sigm, int *lo, int *hi) {
     const int t = S.trans[s] - 1, i = threadIdx.x;
     if (i >= c_nhf[t]) return;
-    const LineConst lc = nf_line(t, i, voff / NFA_CKMS, sigm / NFA_CKMS, c_nu[t], S.nu_min[s], S.nu_chan[s],
+    const LineConst lc = nf_line(t, i, voff / NFA_CKMS, sigm / NFA_CKMS, S.rest[s], S.nu_min[s], S.nu_chan[s],
                                  S.size[s]);
     lo[i] = lc.lo; hi[i] = lc.hi;
 }

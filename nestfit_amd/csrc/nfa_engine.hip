@@ -18,6 +18,7 @@
 
 #define NFA_DATA_QUAL static const
 #include "nh3_data.h"
+#include "n2hp_data.h"
 #include "nfa_device.h"
 
 // ---------------------------------------------------------------------------
@@ -60,11 +61,26 @@ static int engine_init() {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, g_eng.device));
     g_eng.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_nhf), nfa_nhf, sizeof(nfa_nhf)));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_nu), nfa_nu, sizeof(nfa_nu)));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_ea), nfa_ea, sizeof(nfa_ea)));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_voff), nfa_voff, sizeof(nfa_voff)));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_tauw), nfa_tau_wts, sizeof(nfa_tau_wts)));
+    {   // transition tables of all models in one index space (nfa_device.h)
+        static int h_nhf[NFA_T_ALL];
+        static double h_nu[NFA_T_ALL], h_voff[NFA_T_ALL][NFA_MAX_HF_N], h_tauw[NFA_T_ALL][NFA_MAX_HF_N];
+        memset(h_voff, 0, sizeof(h_voff)); memset(h_tauw, 0, sizeof(h_tauw));
+        for (int t = 0; t < NFA_N_LEVELS; ++t) {
+            h_nhf[t] = nfa_nhf[t]; h_nu[t] = nfa_nu[t];
+            memcpy(h_voff[t], nfa_voff[t], sizeof(h_voff[t])); memcpy(h_tauw[t], nfa_tau_wts[t], sizeof(h_tauw[t]));
+        }
+        for (int t = 0; t < NFA_N2HP_LEVELS; ++t) {
+            const int g = NFA_T_N2HP + t;
+            h_nhf[g] = nfa_n2hp_nhf[t]; h_nu[g] = nfa_n2hp_nu[t];
+            memcpy(h_voff[g], nfa_n2hp_voff[t], sizeof(h_voff[g])); memcpy(h_tauw[g], nfa_n2hp_tau_wts[t], sizeof(h_tauw[g]));
+        }
+        h_nhf[NFA_T_GAUSS] = 1; h_nu[NFA_T_GAUSS] = 0.0; h_tauw[NFA_T_GAUSS][0] = 1.0;
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_nhf), h_nhf, sizeof(h_nhf)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_nu), h_nu, sizeof(h_nu)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_ea), nfa_ea, sizeof(nfa_ea)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_voff), h_voff, sizeof(h_voff)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_tauw), h_tauw, sizeof(h_tauw)));
+    }
     std::vector<double> tabs(SM_END_TABLE, 0.0);
     // 2^(i/32)
     for (int i = 0; i < 32; ++i) tabs[SM_EXP2 + i] = (double)exp2l((long double)i / 32.0L);
@@ -183,30 +199,60 @@ int nfa_set_iemtex_table(const double *t0_x, const double *t0_y, int64_t n) {
 int nfa_specset_create(nfa_specset **out, int n_spec, const int64_t *sizes,
                        const int32_t *trans_ids, const double *const *xarr,
                        int64_t n_pix, const double *data, const double *noise) {
-    if (!out || !sizes || !trans_ids || !xarr || !data || !noise)
-        return fail(NFA_ERR_ARG, "null argument");
+    return nfa_specset_create_model(out, NFA_MODEL_AMMONIA, n_spec, sizes, trans_ids, nullptr, xarr, n_pix,
+                                    data, noise);
+}
+
+int nfa_specset_create_model(nfa_specset **out, int model, int n_spec, const int64_t *sizes,
+                             const int32_t *trans_ids, const double *rest_freqs,
+                             const double *const *xarr, int64_t n_pix, const double *data,
+                             const double *noise) {
+    if (!out || !sizes || !xarr || !data || !noise) return fail(NFA_ERR_ARG, "null argument");
+    if (model < NFA_MODEL_AMMONIA || model > NFA_MODEL_GAUSSIAN) return fail(NFA_ERR_ARG, "unknown model");
+    if (model != NFA_MODEL_GAUSSIAN && !trans_ids) return fail(NFA_ERR_ARG, "null argument");
+    if (model == NFA_MODEL_GAUSSIAN && n_spec != 1)                     // gaussian.pyx:57-89
+        return fail(NFA_ERR_ARG, "the Gaussian model takes one spectrum");
     if (n_spec < 1 || n_spec > MAXSPEC) return fail(NFA_ERR_ARG, "n_spec must be in 1..16");
     if (n_pix < 1) return fail(NFA_ERR_ARG, "n_pix must be >= 1");
     int rc = engine_init(); if (rc) return rc;
     nfa_specset *ss = new nfa_specset();
     SpecDev &d = ss->dev;
     d.n_spec = n_spec;
+    d.model = model;
+    d.npar = model == NFA_MODEL_DIAZENYLIUM ? NFA_N2HP_PARAMS : model == NFA_MODEL_GAUSSIAN ? NFA_GAUSS_PARAMS
+                                                                                          : NFA_N_PARAMS;
     int64_t tot = 0;
     for (int s = 0; s < n_spec; ++s) {
         if (sizes[s] < 2 || sizes[s] > (1 << 24)) { delete ss; return fail(NFA_ERR_ARG, "spectrum size out of range"); }
-        if (trans_ids[s] < 1 || trans_ids[s] > NFA_N_LEVELS) {          // ammonia.pyx:268
-            delete ss; return fail(NFA_ERR_ARG, "trans_id must be in 1..9");
+        int tglob;                                                      // index into the device tables
+        if (model == NFA_MODEL_AMMONIA) {
+            if (trans_ids[s] < 1 || trans_ids[s] > NFA_N_LEVELS) {      // ammonia.pyx:268
+                delete ss; return fail(NFA_ERR_ARG, "trans_id must be in 1..9");
+            }
+            tglob = trans_ids[s] - 1;
+            d.rest[s] = nfa_nu[tglob];
+            ss->nhf_max = std::max(ss->nhf_max, nfa_nhf[tglob]);
+        } else if (model == NFA_MODEL_DIAZENYLIUM) {
+            if (trans_ids[s] < 1 || trans_ids[s] > NFA_N2HP_LEVELS) {   // diazenylium.pyx:128
+                delete ss; return fail(NFA_ERR_ARG, "trans_id must be in 1..3");
+            }
+            tglob = NFA_T_N2HP + trans_ids[s] - 1;
+            d.rest[s] = nfa_n2hp_nu[trans_ids[s] - 1];
+            ss->nhf_max = std::max(ss->nhf_max, nfa_n2hp_nhf[trans_ids[s] - 1]);
+        } else {
+            tglob = NFA_T_GAUSS;
+            d.rest[s] = rest_freqs ? rest_freqs[s] : 0.0;               // core.pyx:510
+            ss->nhf_max = std::max(ss->nhf_max, 1);
         }
         const double nu_chan = xarr[s][1] - xarr[s][0];
         if (!(nu_chan > 0)) {                                           // core.pyx:503-504
             delete ss; return fail(NFA_ERR_ARG, "frequency axis must be ascending");
         }
         d.size[s] = (int)sizes[s];
-        d.trans[s] = trans_ids[s];
+        d.trans[s] = tglob + 1;
         d.off[s] = (int)tot;
         d.nu_min[s] = xarr[s][0];
         d.nu_chan[s] = nu_chan;
-        ss->nhf_max = std::max(ss->nhf_max, nfa_nhf[trans_ids[s] - 1]);
         tot += sizes[s];
     }
     for (int64_t i = 0; i < n_pix * n_spec; ++i)
@@ -365,12 +411,12 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors, int
                       int cold, int lte) {
     if (!out || !ss) return fail(NFA_ERR_ARG, "null argument");
     if (ncomp < 1 || ncomp > MAXCOMP) return fail(NFA_ERR_ARG, "ncomp must be in 1..10");   // ammonia.pyx:401
-    if (priors && priors->prog.n_param != NFA_N_PARAMS)
-        return fail(NFA_ERR_ARG, "prior program must cover the 6 ammonia parameters");
+    if (priors && priors->prog.n_param != ss->dev.npar)
+        return fail(NFA_ERR_ARG, "prior program must cover the model's parameters (6 NH3, 4 N2H+, 3 Gaussian)");
     int rc = engine_init(); if (rc) return rc;
     nfa_runner *r = new nfa_runner();
     r->ss = ss; r->pr = priors; r->ncomp = ncomp; r->cold = cold ? 1 : 0; r->lte = lte ? 1 : 0;
-    r->ndim = NFA_N_PARAMS * ncomp;
+    r->ndim = ss->dev.npar * ncomp;
     r->n_lanes = std::max(1, std::min(g_eng.streams, NFA_MAX_LANES));
     for (int k = 0; k < r->n_lanes; ++k) HIP_TRY(hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking));
     r->stream = r->lanes[0];
@@ -438,6 +484,13 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
         int rc = launch_priors(r->pr, d_U, B, r->ncomp, st);
         if (rc) return rc;
     }
+    if (S.model != NFA_MODEL_AMMONIA) {     // sibling models: theta goes to c_hf_predict as it is
+        const int64_t lanes = B * r->ncomp * S.n_spec;
+        hipLaunchKernelGGL(derive_simple_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, S,
+                           (const double *)d_U, r->d_D[slot], (long)B, (const double *)g_eng.d_tabs);
+        HIP_TRY(hipGetLastError());
+        return NFA_OK;
+    }
     {   // partition sums: lane = (item, component, quarter of the J levels)
         const int64_t lanes = B * r->ncomp * 4;
         const unsigned blocks = (unsigned)((lanes + 255) / 256);
@@ -463,7 +516,7 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
 }
 
 
-template <int MODE, bool WS>
+template <int MODE, bool WS, bool WIDE>
 static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL,
                         double *d_spec, int64_t B) {
     const SpecDev S = runner_specdev(r);
@@ -486,7 +539,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
         lds = std::max(lds, per_block - 256);
     }
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "ncomp too large for the LDS line table");
-    auto kern = lnl_kernel<MODE, WS>;
+    auto kern = lnl_kernel<MODE, WS, WIDE>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t units = B * S.n_spec;
@@ -508,14 +561,17 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
 static int launch_lnl(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, double *d_spec, int64_t B) {
     switch (g_eng.exp_mode) {
     case 0:
-        return d_spec ? launch_lnl_t<0, true>(r, d_pix, slot, d_lnL, d_spec, B)
-                      : launch_lnl_t<0, false>(r, d_pix, slot, d_lnL, d_spec, B);
+        return d_spec ? launch_lnl_t<0, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
+                      : launch_lnl_t<0, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
     case 1:
-        return d_spec ? launch_lnl_t<1, true>(r, d_pix, slot, d_lnL, d_spec, B)
-                      : launch_lnl_t<1, false>(r, d_pix, slot, d_lnL, d_spec, B);
+        return d_spec ? launch_lnl_t<1, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
+                      : launch_lnl_t<1, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
     default:
-        return d_spec ? launch_lnl_t<2, true>(r, d_pix, slot, d_lnL, d_spec, B)
-                      : launch_lnl_t<2, false>(r, d_pix, slot, d_lnL, d_spec, B);
+        if (r->ss->nhf_max > 26)        // more lines than any NH3 transition: fp64 running sum of tau
+            return d_spec ? launch_lnl_t<2, true, true>(r, d_pix, slot, d_lnL, d_spec, B)
+                          : launch_lnl_t<2, false, true>(r, d_pix, slot, d_lnL, d_spec, B);
+        return d_spec ? launch_lnl_t<2, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
+                      : launch_lnl_t<2, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
     }
 }
 
@@ -771,7 +827,8 @@ int nfa_test_partition(const double *trot, double *qpara, double *qorth, int64_t
 int nfa_test_windows(nfa_runner *r, int spec, double voff, double sigm, int32_t *lo, int32_t *hi) {
     if (!r || spec < 0 || spec >= r->ss->dev.n_spec) return fail(NFA_ERR_ARG, "bad spectrum index");
     int *dl = nullptr, *dh = nullptr;
-    const int nhf = nfa_nhf[r->ss->dev.trans[spec] - 1];
+    const int tg = r->ss->dev.trans[spec] - 1;          // index into the combined tables
+    const int nhf = tg < NFA_T_N2HP ? nfa_nhf[tg] : tg < NFA_T_GAUSS ? nfa_n2hp_nhf[tg - NFA_T_N2HP] : 1;
     HIP_TRY(hipMalloc(&dl, sizeof(int) * 64));
     HIP_TRY(hipMalloc(&dh, sizeof(int) * 64));
     hipLaunchKernelGGL(test_windows_kernel, dim3(1), dim3(64), 0, 0, r->ss->dev, spec, voff, sigm, dl, dh);

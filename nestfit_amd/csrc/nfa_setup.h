@@ -272,6 +272,48 @@ __global__ void __launch_bounds__(256) qsum_kernel(const double *__restrict__ th
     if (on && chunk == 0) { qrec[0] = qp; qrec[1] = qo; qrec[2] = trot; }
 }
 
+// y(T0) = 1/(e^(T0/tex) - 1) over the band of spectrum s, as the fast mode evaluates it:
+// kind 1 / 2 = the reference's table cell(s) (hyperfine.pyx:30-45) written as a line in T0,
+// kind 3 = band entirely outside the table (exact function there): quadratic about the band
+// centre, kind 0 = anything else (per-lane nf_iemtex).
+__device__ __forceinline__ void write_y_model(double *dk, const SpecDev &S, int s, double tex,
+                                              const double *__restrict__ g_tabs) {
+    const double T0a = S.t0[S.off[s]], T0b = S.t0[S.off[s] + S.size[s] - 1];
+    const double inv_tex = 1.0 / tex;
+    const double xa = T0a * inv_tex, xb = T0b * inv_tex;
+    const bool ina = S.t0_xmin < xa && xa < S.t0_xmax, inb = S.t0_xmin < xb && xb < S.t0_xmax;
+    double kind = 0.0, A0 = 0.0, B0 = 0.0, A1 = 0.0, B1 = 0.0, split = INFINITY, m = 0.0, q = 0.0;
+    const double *t0x = g_tabs + SM_T0X, *t0y = g_tabs + SM_T0Y;
+    if (ina && inb) {
+        const long ia = (long)((xa - S.t0_xmin) * S.t0_inv_dx);
+        const long ib = (long)((xb - S.t0_xmin) * S.t0_inv_dx);
+        if (ia >= 0 && ib <= T0_SIZE - 2 && ib - ia <= 1) {
+            const double sl0 = (t0y[ia + 1] - t0y[ia]) * S.t0_inv_dx;
+            A0 = t0y[ia] - sl0 * t0x[ia];
+            B0 = sl0 * inv_tex;
+            A1 = A0; B1 = B0;
+            kind = 1.0;
+            if (ib != ia) {
+                const double sl1 = (t0y[ib + 1] - t0y[ib]) * S.t0_inv_dx;
+                A1 = t0y[ib] - sl1 * t0x[ib];
+                B1 = sl1 * inv_tex;
+                split = t0x[ib] * tex;
+                kind = 2.0;
+            }
+        }
+    } else if (!ina && !inb && ((xa <= S.t0_xmin && xb <= S.t0_xmin) || (xa >= S.t0_xmax && xb >= S.t0_xmax))) {
+        m = 0.5 * (T0a + T0b);
+        const double y = 1.0 / expm1(m * inv_tex);
+        A0 = y;
+        B0 = -y * (1.0 + y) * inv_tex;
+        q = 0.5 * (1.0 + 2.0 * y) * y * (1.0 + y) * inv_tex * inv_tex;
+        A1 = A0; B1 = B0;
+        kind = 3.0;
+    }
+    dk[DK_KIND] = kind; dk[DK_A0] = A0; dk[DK_B0] = B0; dk[DK_A1] = A1; dk[DK_B1] = B1;
+    dk[DK_SPLIT] = split; dk[DK_M] = m; dk[DK_Q] = q; dk[9] = 0.0;
+}
+
 // ---------------------------------------------------------------------------
 //  derive_kernel: lane = (item, component, spectrum); ammonia.pyx:337-361
 // ---------------------------------------------------------------------------
@@ -316,39 +358,44 @@ __global__ void __launch_bounds__(256) derive_kernel(SpecDev S, const double *__
     }
     double *dk = Db + 4 * ncomp + k * DREC_CS;
     dk[DK_TMAIN] = pow(10.0, log10(tau_main));                // ammonia.pyx:361, hyperfine.pyx:63
-    // y(T0) = 1/(e^(T0/tex) - 1) over the spectrum's band (used by the fast mode only)
-    const double T0a = S.t0[S.off[s]], T0b = S.t0[S.off[s] + S.size[s] - 1];
-    const double inv_tex = 1.0 / tex;
-    const double xa = T0a * inv_tex, xb = T0b * inv_tex;
-    const bool ina = S.t0_xmin < xa && xa < S.t0_xmax, inb = S.t0_xmin < xb && xb < S.t0_xmax;
-    double kind = 0.0, A0 = 0.0, B0 = 0.0, A1 = 0.0, B1 = 0.0, split = INFINITY, m = 0.0, q = 0.0;
-    const double *t0x = g_tabs + SM_T0X, *t0y = g_tabs + SM_T0Y;
-    if (ina && inb) {
-        const long ia = (long)((xa - S.t0_xmin) * S.t0_inv_dx);
-        const long ib = (long)((xb - S.t0_xmin) * S.t0_inv_dx);
-        if (ia >= 0 && ib <= T0_SIZE - 2 && ib - ia <= 1) {
-            const double sl0 = (t0y[ia + 1] - t0y[ia]) * S.t0_inv_dx;
-            A0 = t0y[ia] - sl0 * t0x[ia];
-            B0 = sl0 * inv_tex;
-            A1 = A0; B1 = B0;
-            kind = 1.0;
-            if (ib != ia) {
-                const double sl1 = (t0y[ib + 1] - t0y[ib]) * S.t0_inv_dx;
-                A1 = t0y[ib] - sl1 * t0x[ib];
-                B1 = sl1 * inv_tex;
-                split = t0x[ib] * tex;
-                kind = 2.0;
-            }
-        }
-    } else if (!ina && !inb && ((xa <= S.t0_xmin && xb <= S.t0_xmin) || (xa >= S.t0_xmax && xb >= S.t0_xmax))) {
-        m = 0.5 * (T0a + T0b);
-        const double y = 1.0 / expm1(m * inv_tex);
-        A0 = y;
-        B0 = -y * (1.0 + y) * inv_tex;
-        q = 0.5 * (1.0 + 2.0 * y) * y * (1.0 + y) * inv_tex * inv_tex;
-        A1 = A0; B1 = B0;
-        kind = 3.0;
+    write_y_model(dk, S, s, tex, g_tabs);
+}
+
+// ---------------------------------------------------------------------------
+//  derive_simple_kernel: the sibling models hand c_hf_predict its arguments directly.
+//  N2H+ (diazenylium.pyx:138-154): voff, tex, ltau, sigm -> tau_main = 10**ltau (hyperfine.pyx:63)
+//  Gaussian (gaussian.pyx:17-35): voff, sigm, peak -> one line of weight `peak`, no Tb pass
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) derive_simple_kernel(SpecDev S, const double *__restrict__ theta,
+                                                            double *__restrict__ D, long B,
+                                                            const double *__restrict__ g_tabs) {
+    const int ncomp = S.ncomp, nspec = S.n_spec, ndim = S.npar * ncomp;
+    const int drec = drec_size(ncomp, nspec);
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_item = ncomp * nspec;
+    if (gid >= B * per_item) return;
+    const long b = gid / per_item;
+    const int k = (int)(gid - b * per_item);
+    const int c = k / nspec, s = k - c * nspec;
+    const double *th = theta + b * ndim;
+    const bool gauss = S.model == NFA_MODEL_GAUSSIAN;
+    const double voff = th[c];
+    const double tex  = gauss ? 1.0 : th[ncomp + c];
+    const double sigm = gauss ? th[ncomp + c] : th[3 * ncomp + c];
+    const double amp  = gauss ? th[2 * ncomp + c] : pow(10.0, th[2 * ncomp + c]);
+    double *Db = D + b * drec;
+    if (s == 0) {
+        double *d = Db + c * 4;
+        d[0] = tex;
+        d[1] = sigm / NFA_CKMS;
+        d[2] = voff / NFA_CKMS;
+        d[3] = 1.0 / tex;
     }
-    dk[DK_KIND] = kind; dk[DK_A0] = A0; dk[DK_B0] = B0; dk[DK_A1] = A1; dk[DK_B1] = B1;
-    dk[DK_SPLIT] = split; dk[DK_M] = m; dk[DK_Q] = q; dk[9] = 0.0;
+    double *dk = Db + 4 * ncomp + k * DREC_CS;
+    dk[DK_TMAIN] = amp;
+    if (gauss) {
+        for (int q = 1; q < DREC_CS; ++q) dk[q] = 0.0;
+    } else {
+        write_y_model(dk, S, s, tex, g_tabs);
+    }
 }

@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from .ammonia import _RunnerHandle, _SpecSet
+from ._model import _RunnerHandle, _SpecSet
 from .core import _as_inplace_matrix
 
 
@@ -48,14 +48,16 @@ class CubeRunner:
     utrans : PriorTransformer
     """
 
-    def __init__(self, xarrs, trans_ids, data, noise, utrans, ncomp=1, cold=False, lte=False):
+    def __init__(self, xarrs, trans_ids, data, noise, utrans, ncomp=1, cold=False, lte=False,
+                 model=0, rest_freqs=None):
+        """model: 0 ammonia (default), 1 diazenylium, 2 gaussian (then `rest_freqs` = [Hz])."""
         assert ncomp > 0
-        self._ss = _SpecSet(xarrs, trans_ids, data, noise)
+        self._ss = _SpecSet(xarrs, trans_ids, data, noise, model=model, rest_freqs=rest_freqs)
         self._run = _RunnerHandle(self._ss, utrans, ncomp, cold, lte)
         self.utrans = utrans
         self.ncomp = int(ncomp)
-        self.n_model = 6
-        self.n_params = self.ndim = 6 * self.ncomp
+        self.n_model = {0: 6, 1: 4, 2: 3}[int(model)]
+        self.n_params = self.ndim = self.n_model * self.ncomp
         self.n_pix = self._ss.n_pix
         self.n_spec = self._ss.n_spec
         self.n_chan_tot = self._ss.chan_tot

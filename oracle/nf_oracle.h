@@ -28,7 +28,10 @@ double nfo_partition_level(long j, double trot);
 double nfo_partition_func(int para, double trot);
 
 /* spectra */
+enum { NFO_MODEL_AMMONIA = 0, NFO_MODEL_DIAZENYLIUM = 1, NFO_MODEL_GAUSSIAN = 2 };
 typedef struct nfo_spectrum nfo_spectrum;
+nfo_spectrum *nfo_spectrum_new_model(const double *xarr, const double *data, long n,
+                                     double noise, int model, int trans_id, double rest_freq);
 nfo_spectrum *nfo_spectrum_new(const double *xarr, const double *data, long n,
                                double noise, int trans_id);
 void   nfo_spectrum_free(nfo_spectrum *s);
@@ -43,6 +46,8 @@ void   nfo_hf_windows(const nfo_spectrum *s, double voff, double sigm,
                       long *lo, long *hi);
 void   nfo_amm_predict(nfo_spectrum *s, const double *params, long ndim,
                        int cold, int lte);
+void   nfo_nnhp_predict(nfo_spectrum *s, const double *params, long ndim);   /* diazenylium.pyx:138-154 */
+void   nfo_gauss_predict(nfo_spectrum *s, const double *params, long ndim);  /* gaussian.pyx:17-50 */
 
 /* priors */
 enum {
@@ -100,6 +105,10 @@ double nfo_trans_nu(int trans_id);
 double nfo_trans_ea(int trans_id);
 double nfo_trans_voff(int trans_id, int i);
 double nfo_trans_tau_wt(int trans_id, int i);
+int    nfo_n2hp_nhf(int trans_id);
+double nfo_n2hp_nu(int trans_id);
+double nfo_n2hp_voff(int trans_id, int i);
+double nfo_n2hp_tau_wt(int trans_id, int i);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,16 @@ def _load(name):
     lib.nfo_partition_func.argtypes = [C.c_int, C.c_double]
     lib.nfo_spectrum_new.restype = C.c_void_p
     lib.nfo_spectrum_new.argtypes = [_dp, _dp, C.c_long, C.c_double, C.c_int]
+    lib.nfo_spectrum_new_model.restype = C.c_void_p
+    lib.nfo_spectrum_new_model.argtypes = [_dp, _dp, C.c_long, C.c_double, C.c_int, C.c_int, C.c_double]
+    lib.nfo_nnhp_predict.argtypes = [C.c_void_p, _dp, C.c_long]
+    lib.nfo_gauss_predict.argtypes = [C.c_void_p, _dp, C.c_long]
+    lib.nfo_n2hp_nhf.argtypes = [C.c_int]
+    lib.nfo_n2hp_nu.restype = C.c_double
+    lib.nfo_n2hp_nu.argtypes = [C.c_int]
+    for f in ('nfo_n2hp_voff', 'nfo_n2hp_tau_wt'):
+        getattr(lib, f).restype = C.c_double
+        getattr(lib, f).argtypes = [C.c_int, C.c_int]
     lib.nfo_spectrum_free.argtypes = [C.c_void_p]
     lib.nfo_spectrum_size.restype = C.c_long
     lib.nfo_spectrum_size.argtypes = [C.c_void_p]
@@ -198,10 +208,14 @@ def partition_func(para, trot):
     return lib().nfo_partition_func(int(bool(para)), float(trot))
 
 
+MODEL_AMMONIA, MODEL_DIAZENYLIUM, MODEL_GAUSSIAN = 0, 1, 2
+
+
 class AmmoniaSpectrum:
     """Oracle twin of nestfit.models.ammonia.AmmoniaSpectrum (ammonia.pyx:244-277)."""
+    MODEL = MODEL_AMMONIA
 
-    def __init__(self, xarr, data, noise, trans_id=1, native=False):
+    def __init__(self, xarr, data, noise, trans_id=1, native=False, rest_freq=0.0):
         self._lib = lib(native)
         xarr = np.ascontiguousarray(xarr, dtype=np.float64)
         data = np.ascontiguousarray(data, dtype=np.float64)
@@ -209,8 +223,9 @@ class AmmoniaSpectrum:
         self.size = xarr.size
         self.trans_id = int(trans_id)
         self.noise = float(noise)
-        self._h = self._lib.nfo_spectrum_new(_p(xarr), _p(data), xarr.size, float(noise),
-                                             int(trans_id))
+        self.rest_freq = float(rest_freq)
+        self._h = self._lib.nfo_spectrum_new_model(_p(xarr), _p(data), xarr.size, float(noise),
+                                                   self.MODEL, int(trans_id), float(rest_freq))
         if not self._h:
             raise AssertionError('invalid spectrum arguments')
 
@@ -255,7 +270,8 @@ class AmmoniaSpectrum:
         self._lib.nfo_spectrum_set_data(self._h, _p(data))
 
     def hf_windows(self, voff, sigm):
-        n = self._lib.nfo_trans_nhf(self.trans_id)
+        n = (self._lib.nfo_n2hp_nhf if self.MODEL == MODEL_DIAZENYLIUM
+             else self._lib.nfo_trans_nhf)(self.trans_id)
         lo = np.zeros(n, dtype=np.int64)
         hi = np.zeros(n, dtype=np.int64)
         self._lib.nfo_hf_windows(self._h, float(voff), float(sigm),
@@ -266,6 +282,30 @@ class AmmoniaSpectrum:
 def amm_predict(s, params, cold=False, lte=False):
     params = np.ascontiguousarray(params, dtype=np.float64)
     s._lib.nfo_amm_predict(s._h, _p(params), params.size, int(cold), int(lte))
+
+
+class DiazenyliumSpectrum(AmmoniaSpectrum):
+    """Oracle twin of nestfit.models.diazenylium.DiazenyliumSpectrum (diazenylium.pyx:108-136)."""
+    MODEL = MODEL_DIAZENYLIUM
+
+
+class Spectrum(AmmoniaSpectrum):
+    """Oracle twin of nestfit.core.core.Spectrum as the Gaussian model uses it (core.pyx:486-530)."""
+    MODEL = MODEL_GAUSSIAN
+
+    def __init__(self, xarr, data, noise, rest_freq=None, trans_id=None, native=False):
+        super().__init__(xarr, data, noise, trans_id=-1 if trans_id is None else trans_id,
+                         native=native, rest_freq=0.0 if rest_freq is None else rest_freq)
+
+
+def nnhp_predict(s, params):
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    s._lib.nfo_nnhp_predict(s._h, _p(params), params.size)
+
+
+def gauss_predict(s, params):
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    s._lib.nfo_gauss_predict(s._h, _p(params), params.size)
 
 
 class PriorSet:
@@ -302,6 +342,7 @@ class PriorSet:
 
 class AmmoniaRunner:
     """Oracle twin of nestfit.models.ammonia.AmmoniaRunner (ammonia.pyx:369-447)."""
+    N_MODEL = 6
 
     def __init__(self, spectra, priorset, ncomp=1, cold=False, lte=False, native=False):
         assert ncomp > 0
@@ -310,7 +351,7 @@ class AmmoniaRunner:
         self.priorset = priorset
         self.ncomp, self.cold, self.lte = int(ncomp), bool(cold), bool(lte)
         self.n_spec = len(self.spectra)
-        self.ndim = self.n_params = 6 * self.ncomp
+        self.ndim = self.n_params = self.N_MODEL * self.ncomp
         self.null_lnZ = sum(s.null_lnZ for s in self.spectra)
         self.n_chan_tot = sum(s.size for s in self.spectra)
         self._handles = (C.c_void_p * self.n_spec)(*[s._h for s in self.spectra])
@@ -336,4 +377,29 @@ class AmmoniaRunner:
         if params.shape[0] != self.ndim:
             raise ValueError(f'Invalid shape for ncomp={self.ncomp}: {params.shape[0]}')
         for s in self.spectra:
-            amm_predict(s, params, self.cold, self.lte)
+            self._predict_one(s, params)
+
+    def _predict_one(self, s, params):
+        amm_predict(s, params, self.cold, self.lte)
+
+
+class DiazenyliumRunner(AmmoniaRunner):
+    """Oracle twin of nestfit.models.diazenylium.DiazenyliumRunner (diazenylium.pyx:161-231)."""
+    N_MODEL = 4
+
+    def __init__(self, spectra, priorset, ncomp=1, native=False):
+        super().__init__(spectra, priorset, ncomp=ncomp, native=native)
+
+    def _predict_one(self, s, params):
+        nnhp_predict(s, params)
+
+
+class GaussianRunner(AmmoniaRunner):
+    """Oracle twin of nestfit.models.gaussian.GaussianRunner (gaussian.pyx:57-112)."""
+    N_MODEL = 3
+
+    def __init__(self, spectrum, priorset, ncomp=1, native=False):
+        super().__init__([spectrum], priorset, ncomp=ncomp, native=native)
+
+    def _predict_one(self, s, params):
+        gauss_predict(s, params)
