@@ -187,6 +187,28 @@ int nfa_runner_get_profile(nfa_runner *r, double *out, int64_t *calls);
  * nfa_runner* as MultiNest's `context`. */
 void nfa_loglike_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx);
 
+/* ---- callback-coalescing broker -------------------------------
+ * MultiNest evaluates one point per LogLike call (cmultinest.pxd:27-28); the broker
+ * gathers concurrent calls of many sampler threads into GPU batches.
+ * nfa_broker_loglike blocks the calling thread until its batch has run: `cube` (ndim
+ * doubles in the unit cube) is overwritten with the physical parameters and *lnew set,
+ * exactly like mn_loglikelihood -> c_loglikelihood (core.pyx:622-624,
+ * ammonia.pyx:423-432); pix < 0 = the runner's only pixel.  A generation's first caller
+ * leads it: it launches when n_clients requests (0 = unknown) or max_batch are queued, or
+ * after max_wait_us.  Results are bitwise those of nfa_runner_loglike_batch.
+ * nfa_broker_callback has MultiNest's LogLike signature; its context is an
+ * nfa_broker_client (broker + pixel).  The runner must not be used directly while a
+ * broker serves it. */
+typedef struct nfa_broker nfa_broker;
+typedef struct { nfa_broker *broker; int32_t pix; } nfa_broker_client;
+int  nfa_broker_create(nfa_broker **out, nfa_runner *r, int max_batch, int64_t max_wait_us, int n_clients);
+int  nfa_broker_destroy(nfa_broker *b);
+int  nfa_broker_set_clients(nfa_broker *b, int n_clients);
+int  nfa_broker_loglike(nfa_broker *b, int32_t pix, double *cube, double *lnew);
+void nfa_broker_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx);
+/* out[0] batches launched, out[1] evaluations served, out[2] largest batch */
+int  nfa_broker_stats(nfa_broker *b, int64_t *out);
+
 /* ---- device memory + events (for harnesses that keep inputs in HBM) ------- */
 int nfa_malloc(void **dptr, int64_t bytes);
 int nfa_free(void *dptr);

@@ -71,6 +71,12 @@ SIGNATURES = {
     'nfa_runner_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'nfa_runner_get_profile': (C.c_int, [C.c_void_p, _dp, _lp]),
     'nfa_loglike_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
+    'nfa_broker_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int64, C.c_int]),
+    'nfa_broker_destroy': (C.c_int, [C.c_void_p]),
+    'nfa_broker_set_clients': (C.c_int, [C.c_void_p, C.c_int]),
+    'nfa_broker_loglike': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+    'nfa_broker_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
+    'nfa_broker_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'nfa_malloc': (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     'nfa_free': (C.c_int, [C.c_void_p]),
     'nfa_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

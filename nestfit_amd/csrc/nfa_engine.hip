@@ -840,3 +840,5 @@ int nfa_test_windows(nfa_runner *r, int spec, double voff, double sigm, int32_t 
 }
 
 }  // extern "C"
+
+#include "nfa_broker.h"
