@@ -208,6 +208,11 @@ int  nfa_broker_loglike(nfa_broker *b, int32_t pix, double *cube, double *lnew);
 void nfa_broker_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx);
 /* out[0] batches launched, out[1] evaluations served, out[2] largest batch */
 int  nfa_broker_stats(nfa_broker *b, int64_t *out);
+/* test / measurement support: n_threads native threads (one per would-be serial sampler, thread
+ * k bound to pixel pix[k], NULL = the only pixel) each make n_calls blocking calls on their own
+ * rows of U[n_threads][n_calls][ndim] (overwritten); lnL[n_threads][n_calls]; wall time out. */
+int  nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int32_t *pix, double *U,
+                           double *lnL, double *seconds_out);
 
 /* ---- device memory + events (for harnesses that keep inputs in HBM) ------- */
 int nfa_malloc(void **dptr, int64_t bytes);

@@ -77,6 +77,7 @@ SIGNATURES = {
     'nfa_broker_loglike': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
     'nfa_broker_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
     'nfa_broker_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'nfa_test_broker_storm': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp]),
     'nfa_malloc': (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     'nfa_free': (C.c_int, [C.c_void_p]),
     'nfa_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

@@ -10,18 +10,23 @@
 #pragma once
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 struct nfa_broker {
     nfa_runner *r = nullptr;
     int      max_batch = 4096;
     int      n_clients = 0;            // 0 = unknown: the leader always waits max_wait_us
     int64_t  max_wait_us = 200;
-    struct Req { double *cube; int pix; double lnl; int rc; bool done; };
+    // one generation = the requests that will share a launch; followers sleep on their own
+    // generation's condition variable, so a finished batch wakes only its members
+    struct Gen { std::mutex m; std::condition_variable cv; bool done = false; };
+    struct Req { double *cube; int pix; double lnl; int rc; };
     std::mutex m;                      // queue state
     std::condition_variable cv_full;   // leader: enough requests queued
-    std::condition_variable cv_done;   // followers: results are in
     std::vector<Req *> queue;
+    std::shared_ptr<Gen> gen;          // generation being filled
     bool leader_present = false;
     std::mutex run_m;                  // the runner is used by one batch at a time
     std::vector<double> U, lnL;        // staging (guarded by run_m)
@@ -70,21 +75,27 @@ static bool broker_ready(const nfa_broker *b) {
 // single pixel.
 int nfa_broker_loglike(nfa_broker *b, int32_t pix, double *cube, double *lnew) {
     if (!b || !cube || !lnew) return fail(NFA_ERR_ARG, "null argument");
-    nfa_broker::Req rq{cube, pix, NAN, NFA_OK, false};
+    nfa_broker::Req rq{cube, pix, NAN, NFA_OK};
     std::unique_lock<std::mutex> lk(b->m);
     b->queue.push_back(&rq);
     if (b->leader_present) {
+        std::shared_ptr<nfa_broker::Gen> g = b->gen;
         if (broker_ready(b)) b->cv_full.notify_one();
-        b->cv_done.wait(lk, [&] { return rq.done; });
+        lk.unlock();
+        std::unique_lock<std::mutex> gl(g->m);
+        g->cv.wait(gl, [&] { return g->done; });
         *lnew = rq.lnl;
         return rq.rc == NFA_OK ? NFA_OK : fail(rq.rc, "broker batch failed");
     }
     b->leader_present = true;
+    std::shared_ptr<nfa_broker::Gen> g = std::make_shared<nfa_broker::Gen>();
+    b->gen = g;
     if (b->max_wait_us > 0 && !broker_ready(b))
         b->cv_full.wait_for(lk, std::chrono::microseconds(b->max_wait_us), [&] { return broker_ready(b); });
     std::vector<nfa_broker::Req *> batch;
     batch.swap(b->queue);
     b->leader_present = false;         // the next arrival leads the next generation
+    b->gen.reset();
     lk.unlock();
 
     const int ndim = b->r->ndim;
@@ -107,10 +118,11 @@ int nfa_broker_loglike(nfa_broker *b, int32_t pix, double *cube, double *lnew) {
         }
         b->n_batches += 1; b->n_evals += (uint64_t)B; b->max_seen = std::max<uint64_t>(b->max_seen, (uint64_t)B);
     }
-    lk.lock();
-    for (auto *q : batch) q->done = true;
-    lk.unlock();
-    b->cv_done.notify_all();
+    {
+        std::lock_guard<std::mutex> gl(g->m);
+        g->done = true;
+    }
+    g->cv.notify_all();
     *lnew = rq.lnl;
     return rc;
 }
@@ -131,6 +143,31 @@ int nfa_broker_stats(nfa_broker *b, int64_t *out) {
     if (!b || !out) return fail(NFA_ERR_ARG, "null argument");
     std::lock_guard<std::mutex> run(b->run_m);
     out[0] = (int64_t)b->n_batches; out[1] = (int64_t)b->n_evals; out[2] = (int64_t)b->max_seen;
+    return NFA_OK;
+}
+
+// Measurement / test support: n_threads native threads, each a stand-in for one serial sampler,
+// make n_calls blocking nfa_broker_loglike calls on their own rows of U[n_threads][n_calls][ndim]
+// (overwritten with theta); lnL[n_threads][n_calls].  Returns the wall time in *seconds_out.
+int nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int32_t *pix, double *U,
+                          double *lnL, double *seconds_out) {
+    if (!b || !U || !lnL || n_threads < 1 || n_calls < 1) return fail(NFA_ERR_ARG, "bad argument");
+    const int ndim = b->r->ndim;
+    std::vector<std::thread> th;
+    std::vector<int> rcs((size_t)n_threads, NFA_OK);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < n_threads; ++k)
+        th.emplace_back([=, &rcs] {
+            for (int j = 0; j < n_calls; ++j) {
+                const size_t row = (size_t)k * n_calls + j;
+                const int rc = nfa_broker_loglike(b, pix ? pix[k] : -1, U + row * ndim, lnL + row);
+                if (rc != NFA_OK) rcs[k] = rc;
+            }
+        });
+    for (auto &t : th) t.join();
+    if (seconds_out)
+        *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int rc : rcs) if (rc != NFA_OK) return rc;
     return NFA_OK;
 }
 
