@@ -1,0 +1,333 @@
+"""Built-in batched nested sampler: the stand-in for MultiNest when
+``libmultinest`` is not available, built so that the GPU sees batches.
+
+The reference drives one serial MultiNest instance per pixel
+(``run_multinest``, nestfit/core/core.pyx:727-823; pixel loop nestfit/main.py:452-469), one
+likelihood per callback.  Here every pixel of a cube is a nested-sampling run of its own, but all
+runs advance in lock-step: each iteration proposes ``k`` candidates per active pixel from the
+bounding ellipsoid of its live points (the idea of MultiNest's ellipsoidal rejection sampling,
+Feroz et al. 2009, without the mode clustering), all candidates of all pixels go to the device in
+ONE likelihood batch, and every pixel whose batch contains a point above its current threshold
+replaces its worst live point (Skilling 2006 bookkeeping).  The outputs follow what the
+reference's ``mn_dump`` stores (core.pyx:627-687): posterior rows ``[theta..., -2 lnL, weight]``,
+``param_constr`` rows 2, 3 = best-fit and MAP, global lnZ and its error, max log-likelihood.
+
+This is not MultiNest: the random streams differ and there is no multi-ellipsoid decomposition,
+so evidences agree with a MultiNest run only within their sampling error.  What can be checked
+bit-for-bit is the likelihood it is fed (tests drive the same sampler with the CPU oracle).
+"""
+import numpy as np
+
+LOG_ZERO = -1e100
+
+
+class NestedResult:
+    """Per-pixel outcome, named like the quantities MultiNest hands to ``mn_dump``."""
+
+    def __init__(self, posterior, lnZ, lnZ_err, max_loglike, n_live, n_evals, n_iter, information):
+        self.posterior = posterior                  # (n_samples, n_params + 2)
+        self.n_samples = int(posterior.shape[0])
+        self.n_params = int(posterior.shape[1] - 2)
+        self.lnZ = float(lnZ)
+        self.lnZ_err = float(lnZ_err)
+        self.max_loglike = float(max_loglike)
+        self.n_live = int(n_live)
+        self.n_evals = int(n_evals)
+        self.n_iter = int(n_iter)
+        self.information = float(information)
+        w = posterior[:, -1]
+        th = posterior[:, :-2]
+        mean = w @ th
+        var = np.maximum(w @ (th - mean) ** 2, 0.0)
+        best = th[np.argmin(posterior[:, -2])]      # max likelihood
+        mapp = th[np.argmax(w)]                     # largest posterior mass
+        self.param_constr = np.stack([mean, np.sqrt(var), best, mapp])    # (4, n_params)
+
+
+def _ball(rng, shape, ndim):
+    """Uniform points in the unit ndim-ball, shape (..., ndim)."""
+    g = rng.standard_normal(shape + (ndim,))
+    g /= np.linalg.norm(g, axis=-1, keepdims=True)
+    return g * rng.uniform(size=shape + (1,)) ** (1.0 / ndim)
+
+
+def _fit_ellipsoids(U, enlarge):
+    """Bounding ellipsoid of live points U[P, nlive, ndim]: centre, and a matrix A with
+    {c + A z : |z| <= 1} containing every live point, its volume scaled by `enlarge`."""
+    P, nlive, ndim = U.shape
+    c = U.mean(axis=1)
+    d = U - c[:, None, :]
+    cov = np.einsum('pni,pnj->pij', d, d) / (nlive - 1)
+    cov += 1e-12 * np.eye(ndim)[None] * np.maximum(np.trace(cov, axis1=1, axis2=2), 1e-30)[:, None, None]
+    L = np.linalg.cholesky(cov)
+    y = np.linalg.solve(L, d.transpose(0, 2, 1))               # (P, ndim, nlive)
+    r2 = np.max(np.sum(y * y, axis=1), axis=1)                 # largest Mahalanobis distance^2
+    scale = np.sqrt(r2) * enlarge ** (1.0 / ndim)
+    return c, L * scale[:, None, None]
+
+
+def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
+               n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, progress=None):
+    """Nested sampling of `n_pix` independent problems in lock-step.
+
+    Parameters
+    ----------
+    loglike : callable(pix[B] int32, U[B, ndim] float64) -> lnL[B]
+        Evaluates unit-cube rows against pixels; must overwrite U with the physical parameters
+        (the convention of Runner.loglikelihood, core.pyx:558-561).
+    nlive, tol, efr, seed, maxiter : as in ``run_multinest`` (core.pyx:727-744): live points,
+        evidence tolerance, target sampling efficiency (sets the ellipsoid enlargement 1/efr in
+        volume), RNG seed (-1 = from the OS), iteration cap per pixel.
+    n_cand : candidates per pixel and iteration (default ceil(2 / efr)).
+    upd_frac : the ellipsoids are refitted after this fraction of nlive replacements.
+
+    Returns a list of `NestedResult`, one per pixel.
+    """
+    assert ndim > 0 and nlive > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
+    rng = np.random.default_rng(None if seed is None or seed < 0 else seed)
+    K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
+    P = int(n_pix)
+    all_pix = np.arange(P, dtype=np.int32)
+
+    def evaluate(pix, U):
+        out = np.empty(U.shape[0])
+        for a in range(0, U.shape[0], chunk):
+            out[a:a + chunk] = loglike(pix[a:a + chunk], U[a:a + chunk])
+        return np.where(np.isfinite(out), out, log_zero)
+
+    # live points: unit-cube positions, physical parameters, log-likelihoods
+    Ulive = rng.uniform(size=(P, nlive, ndim))
+    Tlive = Ulive.reshape(-1, ndim).copy()
+    Llive = evaluate(np.repeat(all_pix, nlive), Tlive).reshape(P, nlive)
+    Tlive = Tlive.reshape(P, nlive, ndim)
+    n_evals = np.full(P, nlive, dtype=np.int64)
+    n_iter = np.zeros(P, dtype=np.int64)
+    lnZ = np.full(P, -np.inf)
+    H = np.zeros(P)
+    ln_shrink = np.log1p(-np.exp(-1.0 / nlive))                 # ln(X_i - X_{i+1}) - ln X_i
+    active = np.full(P, maxiter > 0)
+    since_fit = np.zeros(P, dtype=np.int64)
+    upd = max(1, int(upd_frac * nlive))
+    centre, axes = _fit_ellipsoids(Ulive, 1.0 / efr)
+    dead_T, dead_L, dead_lnw, dead_pix = [], [], [], []
+
+    while active.any():
+        idx = np.flatnonzero(active)
+        n = idx.size
+        worst = np.argmin(Llive[idx], axis=1)
+        Lmin = Llive[idx, worst]
+        # candidates from the bounding ellipsoids; outside the unit cube = outside the prior
+        z = _ball(rng, (n, K), ndim)
+        cand = centre[idx, None, :] + np.einsum('pij,pkj->pki', axes[idx], z)
+        inside = np.all((cand >= 0.0) & (cand < 1.0), axis=2)
+        flat = np.flatnonzero(inside.ravel())
+        Lc = np.full(n * K, -np.inf)
+        Tc = cand.reshape(n * K, ndim).copy()
+        if flat.size:
+            Tsub = Tc[flat]
+            Lc[flat] = evaluate(np.repeat(idx, K).astype(np.int32)[flat], Tsub)
+            Tc[flat] = Tsub
+            np.add.at(n_evals, np.repeat(idx, K)[flat], 1)
+        Lc = Lc.reshape(n, K)
+        ok = Lc > Lmin[:, None]
+        hit = ok.any(axis=1)
+        first = np.argmax(ok, axis=1)
+        adv = np.flatnonzero(hit)                               # pixels that advance this round
+        if adv.size:
+            p = idx[adv]
+            w = worst[adv]
+            lnX = -n_iter[p] / nlive
+            lnw = lnX + ln_shrink
+            lnwL = lnw + Lmin[adv]
+            lnZ_new = np.logaddexp(lnZ[p], lnwL)
+            with np.errstate(invalid='ignore', over='ignore'):
+                old = np.where(np.isfinite(lnZ[p]), np.exp(lnZ[p] - lnZ_new) * (H[p] + lnZ[p]), 0.0)
+                H[p] = np.exp(lnwL - lnZ_new) * Lmin[adv] + old - lnZ_new
+            lnZ[p] = lnZ_new
+            dead_T.append(Tlive[p, w].copy()); dead_L.append(Lmin[adv].copy())
+            dead_lnw.append(lnw); dead_pix.append(p)
+            sel = adv * K + first[adv]
+            Ulive[p, w] = cand.reshape(n * K, ndim)[sel]
+            Tlive[p, w] = Tc[sel]
+            Llive[p, w] = Lc.reshape(-1)[sel]
+            n_iter[p] += 1
+            since_fit[p] += 1
+            # termination (MultiNest's tol): the live points cannot add more than tol to lnZ
+            lnX_next = -n_iter[p] / nlive
+            remain = Llive[p].max(axis=1) + lnX_next
+            done = (np.logaddexp(lnZ[p], remain) - lnZ[p] < tol) | (n_iter[p] >= maxiter)
+            active[p[done]] = False
+            refit = p[(since_fit[p] >= upd) & ~done]
+            if refit.size:
+                centre[refit], axes[refit] = _fit_ellipsoids(Ulive[refit], 1.0 / efr)
+                since_fit[refit] = 0
+        if progress is not None:
+            progress(int(active.sum()), int(n_iter.max()))
+
+    # assemble per pixel: dead points + the final live points, each with mass X_final / nlive
+    dead_pix = np.concatenate(dead_pix) if dead_pix else np.zeros(0, dtype=np.int64)
+    dead_T = np.concatenate(dead_T) if dead_T else np.zeros((0, ndim))
+    dead_L = np.concatenate(dead_L) if dead_L else np.zeros(0)
+    dead_lnw = np.concatenate(dead_lnw) if dead_lnw else np.zeros(0)
+    order = np.argsort(dead_pix, kind='stable')
+    bounds = np.searchsorted(dead_pix[order], np.arange(P + 1))
+    results = []
+    for p in range(P):
+        sl = order[bounds[p]:bounds[p + 1]]
+        lnw_live = np.full(nlive, -n_iter[p] / nlive - np.log(nlive))
+        T = np.concatenate([dead_T[sl], Tlive[p]])
+        L = np.concatenate([dead_L[sl], Llive[p]])
+        lnw = np.concatenate([dead_lnw[sl], lnw_live])
+        lnZ_tot = np.logaddexp.reduce(lnw + L)
+        wt = np.exp(lnw + L - lnZ_tot)
+        # information including the live-point term, for the error estimate sqrt(H / nlive)
+        with np.errstate(invalid='ignore'):
+            Hp = float(np.sum(np.where(wt > 0, wt * (L - lnZ_tot), 0.0)))
+        post = np.empty((T.shape[0], ndim + 2))
+        post[:, :ndim] = T
+        post[:, ndim] = -2.0 * L
+        post[:, ndim + 1] = wt
+        results.append(NestedResult(post, lnZ_tot, np.sqrt(max(Hp, 0.0) / nlive), L.max(), nlive,
+                                    n_evals[p], n_iter[p], Hp))
+    return results
+
+
+# ---------------------------------------------------------------------------
+#  reference-shaped front end: Dumper + run_multinest (core.pyx:564-823)
+# ---------------------------------------------------------------------------
+class MemoryGroup:
+    """Minimal stand-in for an ``h5py.Group`` (attrs + datasets) when h5py is absent."""
+
+    class _File:
+        def flush(self):
+            pass
+
+    def __init__(self):
+        self.attrs = {}
+        self.datasets = {}
+        self.file = MemoryGroup._File()
+
+    def create_dataset(self, name, data=None):
+        self.datasets[name] = np.array(data)
+        return self.datasets[name]
+
+    def __getitem__(self, name):
+        return self.datasets[name]
+
+
+class Dumper:
+    """Same constructor, quantiles and column names as the reference's ``Dumper``
+    (core.pyx:564-612); `group` is an h5py group or a `MemoryGroup`."""
+
+    def __init__(self, group, no_dump=False):
+        self.group = group
+        self.no_dump = no_dump
+        self.n_calls = 0
+        self.n_samples = -1
+        self.quantiles = np.array([
+            0.00, 0.01, 0.10, 0.25, 0.50, 0.75, 0.90, 0.99, 1.00,
+            1.58655254e-1, 0.84134475,  # 1-sigma credible interval
+            2.27501319e-2, 0.97724987,  # 2-sigma credible interval
+            1.34989803e-3, 0.99865010,  # 3-sigma credible interval
+        ])
+        self.marginal_cols = [
+            'min', 'p01', 'p10', 'p25', 'p50', 'p75', 'p90', 'p99', 'max',
+            '1s_lo', '1s_hi', '2s_lo', '2s_hi', '3s_lo', '3s_hi',
+        ]
+
+    def calc_marginals(self, posteriors):
+        # The last two columns of the posterior array are -2*lnL and X*L/Z
+        return np.quantile(posteriors[:, :-2], self.quantiles, axis=0)
+
+    def flush(self):
+        self.group.file.flush()
+
+    def append_attributes(self, **kwargs):
+        for name, value in kwargs.items():
+            self.group.attrs[name] = value
+
+    def append_datasets(self, **kwargs):
+        for name, data in kwargs.items():
+            self.group.create_dataset(name, data=data)
+
+    def dump(self, runner, res):
+        """What ``mn_dump`` writes on its final call (core.pyx:627-687)."""
+        self.n_calls += 1
+        self.n_samples = res.n_samples
+        runner.run_lnZ = res.lnZ
+        if self.no_dump:
+            return
+        group = self.group
+        group.attrs['ncomp'] = runner.ncomp
+        group.attrs['null_lnZ'] = runner.null_lnZ
+        group.attrs['n_chan_tot'] = runner.n_chan_tot
+        group.attrs['n_samples'] = res.n_samples
+        group.attrs['n_live'] = res.n_live
+        group.attrs['n_params'] = res.n_params
+        group.attrs['global_lnZ'] = res.lnZ
+        group.attrs['global_lnZ_err'] = res.lnZ_err
+        group.attrs['max_loglike'] = res.max_loglike
+        group.attrs['marg_cols'] = self.marginal_cols
+        group.attrs['marg_quantiles'] = self.quantiles
+        n = float(runner.n_chan_tot)
+        k = float(runner.n_params)
+        nullL = runner.null_lnZ
+        maxL = res.max_loglike
+        bic = np.log(n) * k - 2 * maxL
+        aic = 2 * k - 2 * maxL
+        aicc = aic + (2 * k**2 + 2 * k) / (n - k - 1)
+        null_bic = np.log(n) * k - 2 * nullL
+        null_aic = 2 * k - 2 * nullL
+        null_aicc = null_aic + (2 * k**2 + 2 * k) / (n - k - 1)
+        group.attrs['BIC'] = bic
+        group.attrs['AIC'] = aic
+        group.attrs['AICc'] = aicc
+        group.attrs['null_BIC'] = null_bic
+        group.attrs['null_AIC'] = null_aic
+        group.attrs['null_AICc'] = null_aicc
+        group.create_dataset('posteriors', data=res.posterior.astype('float32'))
+        group.create_dataset('marginals', data=self.calc_marginals(res.posterior))
+        group.create_dataset('bestfit_params', data=res.param_constr[2])
+        group.create_dataset('map_params', data=res.param_constr[3])
+
+
+def run_multinest(runner, dumper, IS=False, mmodal=True, ceff=False, nlive=400, tol=0.5, efr=0.3,
+                  nClsPar=None, maxModes=100, updInt=10, Ztol=-1e90, root='results', seed=-1,
+                  pWrap=None, fb=False, resume=False, initMPI=False, outfile=False, logZero=-1e100,
+                  maxiter=int(1e6)):
+    """Signature of the reference's ``run_multinest`` (core.pyx:727-823) on the built-in sampler,
+    for one runner (one pixel).  Options that only concern MultiNest's mode separation, importance
+    sampling or its output files are accepted and ignored; the argument checks are the
+    reference's."""
+    assert runner.ndim > 0
+    assert nlive > 0
+    assert tol > 0
+    assert 0 < efr <= 1
+    assert maxModes > 0
+    assert updInt > 0
+    assert Ztol is not None and np.isfinite(Ztol)
+    assert logZero is not None and np.isfinite(logZero)
+    assert maxiter >= 0
+    if nClsPar is None:
+        nClsPar = runner.n_params
+    if nClsPar > runner.n_params:
+        raise ValueError('Number of clustering parameters must be less than total.')
+
+    def loglike(pix, U):
+        return runner.loglikelihood_batch(U)
+
+    res = run_nested(loglike, runner.ndim, 1, nlive=nlive, tol=tol, efr=efr, seed=seed,
+                     maxiter=maxiter, log_zero=logZero)[0]
+    dumper.dump(runner, res)
+    return res
+
+
+def fit_pixels(cube_runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), **kwargs):
+    """All pixels `pix` of a `CubeRunner` in one lock-step run; returns a list of NestedResult."""
+    pix = np.ascontiguousarray(pix, dtype=np.int32)
+
+    def loglike(k, U):
+        return cube_runner.loglikelihood_batch(pix[k], U)
+
+    return run_nested(loglike, cube_runner.ndim, pix.size, nlive=nlive, tol=tol, efr=efr, seed=seed,
+                      maxiter=maxiter, **kwargs)

@@ -1,0 +1,206 @@
+"""Built-in batched nested sampler.
+
+CPU part: analytic evidences, reproducibility, the reference-shaped Dumper / run_multinest front
+end.  GPU part: the same sampler, same seed, fed by the HIP engine and by the CPU oracle."""
+import numpy as np
+import pytest
+
+from nestfit_amd import sampler
+from nestfit_amd.synth import freq_axis
+
+
+def _gauss_problem(centres, sigma):
+    centres = np.atleast_2d(centres)
+
+    def loglike(pix, U):
+        d2 = ((U[:, None, :] - centres[None]) ** 2).sum(axis=2)
+        return np.logaddexp.reduce(-0.5 * d2 / sigma ** 2, axis=1)
+    return loglike
+
+
+def test_gaussian_evidence_and_posterior():
+    ndim, sigma, P = 4, 0.05, 8
+    res = sampler.run_nested(_gauss_problem(np.full(ndim, 0.5), sigma), ndim, P, nlive=200, tol=0.1,
+                             efr=0.5, seed=12)
+    truth = ndim * np.log(sigma * np.sqrt(2 * np.pi))
+    lnZ = np.array([r.lnZ for r in res])
+    err = np.array([r.lnZ_err for r in res])
+    assert np.all(np.abs(lnZ - truth) < 4 * err + 0.05), (lnZ, truth, err)
+    assert abs(lnZ.mean() - truth) < 4 * err.mean() / np.sqrt(P) + 0.03
+    # the sample scatter of lnZ over the runs is what lnZ_err claims
+    assert 0.4 < lnZ.std(ddof=1) / err.mean() < 2.0
+    for r in res:
+        assert r.posterior.shape == (r.n_samples, ndim + 2)
+        assert r.posterior[:, -1].sum() == pytest.approx(1.0, abs=1e-12)
+        assert r.n_samples == r.n_iter + r.n_live
+        mean, sig, best, mapp = r.param_constr
+        np.testing.assert_allclose(mean, 0.5, atol=0.01)
+        np.testing.assert_allclose(sig, sigma, rtol=0.2)
+        np.testing.assert_allclose(best, 0.5, atol=0.03)
+        assert r.max_loglike == pytest.approx(-0.5 * r.posterior[:, -2].min())
+        assert r.information == pytest.approx(-truth - ndim / 2, abs=0.5)     # H of a Gaussian in a box
+
+
+def test_two_modes_in_one_ellipsoid():
+    ndim, sigma = 3, 0.04
+    centres = np.array([[0.3, 0.3, 0.3], [0.7, 0.7, 0.7]])
+    res = sampler.run_nested(_gauss_problem(centres, sigma), ndim, 4, nlive=300, tol=0.1, efr=0.3, seed=5)
+    truth = np.log(2) + ndim * np.log(sigma * np.sqrt(2 * np.pi))
+    for r in res:
+        assert abs(r.lnZ - truth) < 4 * r.lnZ_err + 0.05
+        w, x = r.posterior[:, -1], r.posterior[:, 0]
+        assert w[x < 0.5].sum() == pytest.approx(0.5, abs=0.15)               # both modes populated
+
+
+def test_seed_reproducibility_and_independent_pixels():
+    f = _gauss_problem(np.full(3, 0.4), 0.1)
+    a = sampler.run_nested(f, 3, 3, nlive=60, seed=7)
+    b = sampler.run_nested(f, 3, 3, nlive=60, seed=7)
+    c = sampler.run_nested(f, 3, 3, nlive=60, seed=8)
+    for x, y in zip(a, b):
+        assert x.lnZ == y.lnZ and np.array_equal(x.posterior, y.posterior)
+    assert a[0].lnZ != c[0].lnZ
+    assert len({r.lnZ for r in a}) == 3
+
+
+def test_maxiter_and_logzero():
+    f = _gauss_problem(np.full(2, 0.5), 0.1)
+    r = sampler.run_nested(f, 2, 2, nlive=50, maxiter=30, seed=1)
+    assert all(x.n_iter == 30 and x.n_samples == 80 for x in r)
+    r0 = sampler.run_nested(f, 2, 1, nlive=50, maxiter=0, seed=1)[0]
+    assert r0.n_iter == 0 and r0.n_samples == 50
+
+    def nan_loglike(pix, U):
+        out = _gauss_problem(np.full(2, 0.5), 0.1)(pix, U)
+        out[U[:, 0] < 0.2] = np.nan                                           # treated as logZero
+        return out
+    r = sampler.run_nested(nan_loglike, 2, 1, nlive=80, seed=3)[0]
+    assert np.isfinite(r.lnZ) and r.posterior[r.posterior[:, -1] > 1e-6, 0].min() >= 0.2
+
+
+class _FakeRunner:
+    ndim = n_params = 3
+    ncomp = 1
+    null_lnZ = -50.0
+    n_chan_tot = 100
+    run_lnZ = float('nan')
+
+    def loglikelihood_batch(self, U):
+        return _gauss_problem(np.full(3, 0.5), 0.1)(None, U)
+
+
+def test_run_multinest_front_end_writes_the_reference_layout():
+    """Attributes and datasets of mn_dump (core.pyx:627-687, docs/store_spec.rst)."""
+    group = sampler.MemoryGroup()
+    dumper = sampler.Dumper(group)
+    runner = _FakeRunner()
+    res = sampler.run_multinest(runner, dumper, nlive=80, tol=0.5, efr=0.5, seed=4)
+    assert runner.run_lnZ == res.lnZ
+    for key in ('ncomp', 'null_lnZ', 'n_chan_tot', 'n_samples', 'n_live', 'n_params', 'global_lnZ',
+                'global_lnZ_err', 'max_loglike', 'marg_cols', 'marg_quantiles', 'BIC', 'AIC', 'AICc',
+                'null_BIC', 'null_AIC', 'null_AICc'):
+        assert key in group.attrs, key
+    k, n = 3.0, 100.0
+    assert group.attrs['BIC'] == pytest.approx(np.log(n) * k - 2 * res.max_loglike)
+    assert group.attrs['null_AICc'] == pytest.approx(2 * k + 100.0 + (2 * k * k + 2 * k) / (n - k - 1))
+    assert group['posteriors'].dtype == np.float32
+    assert group['posteriors'].shape == (res.n_samples, 5)
+    assert group['marginals'].shape == (15, 3)
+    assert len(group.attrs['marg_cols']) == 15
+    np.testing.assert_allclose(group['marginals'][4], 0.5, atol=0.2)          # p50 row, unweighted like the reference
+    assert group['bestfit_params'].shape == (3,) and group['map_params'].shape == (3,)
+    dumper.append_attributes(extra=1)
+    dumper.append_datasets(extra=np.arange(3))
+    dumper.flush()
+    assert group.attrs['extra'] == 1 and group['extra'].tolist() == [0, 1, 2]
+    quiet = sampler.Dumper(sampler.MemoryGroup(), no_dump=True)
+    sampler.run_multinest(runner, quiet, nlive=60, seed=4)
+    assert not quiet.group.attrs and not quiet.group.datasets
+    with pytest.raises(AssertionError):
+        sampler.run_multinest(runner, dumper, nlive=0)
+    with pytest.raises(AssertionError):
+        sampler.run_multinest(runner, dumper, efr=1.5)
+    with pytest.raises(ValueError, match='clustering parameters'):
+        sampler.run_multinest(runner, dumper, nClsPar=4)
+
+
+# ---------------------------------------------------------------------------- GPU
+def _cube(engine, nfo, n_pix, seed):
+    """Small synthetic cube: NH3 (1,1)+(2,2), 1 component, 256 channels, varying amplitude."""
+    from nestfit_amd.cube import CubeRunner
+    rng = np.random.default_rng(seed)
+    n, noise = 256, 0.15
+    axes = [freq_axis(1, n), freq_axis(2, n)]
+    truths = []
+    data = np.empty((n_pix, 2 * n))
+    cpu_runners = []
+    ut = engine.get_irdc_priors(size=300, vsys=0.0)
+    ps = nfo.PriorSet(ut.lower())
+    for p in range(n_pix):
+        th = np.array([rng.uniform(-1, 1), rng.uniform(10, 18), rng.uniform(4, 8), rng.uniform(14.2, 14.8),
+                       rng.uniform(0.3, 0.8), 0.0])
+        truths.append(th)
+        specs = []
+        for k, t in enumerate((1, 2)):
+            s = nfo.AmmoniaSpectrum(axes[k], np.zeros(n), noise, t)
+            nfo.amm_predict(s, th)
+            d = s.get_spec() + rng.normal(0, noise, n)
+            data[p, k * n:(k + 1) * n] = d
+            specs.append(nfo.AmmoniaSpectrum(axes[k], d, noise, t))
+        cpu_runners.append(nfo.AmmoniaRunner(specs, ps, ncomp=1))
+    cube = CubeRunner(axes, (1, 2), data, np.full((n_pix, 2), noise), ut, ncomp=1)
+    return cube, cpu_runners, np.array(truths), data, axes
+
+
+@pytest.mark.gpu
+def test_sampler_on_gpu_matches_the_same_sampler_on_the_oracle(engine, nfo):
+    """Same seed, same proposals: in the bit-faithful table mode the likelihoods agree to ~1e-13, so
+    every accept/reject decision and hence the whole run is the same; in fast mode (1e-7) the
+    evidences still agree far inside their error."""
+    n_pix = 3
+    cube, cpu_runners, truths, _, _ = _cube(engine, nfo, n_pix, seed=21)
+
+    def cpu_loglike(pix, U):
+        out = np.empty(U.shape[0])
+        for p in np.unique(pix):
+            m = pix == p
+            sub = U[m]
+            out[m] = cpu_runners[p].loglikelihood_batch(sub)
+            U[m] = sub
+        return out
+
+    kw = dict(nlive=60, tol=0.5, efr=0.3, seed=33)
+    ref = sampler.run_nested(cpu_loglike, cube.ndim, n_pix, **kw)
+    try:
+        engine.set_exp_mode('table')
+        got = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
+        for g, r in zip(got, ref):
+            assert g.n_iter == r.n_iter and g.n_evals == r.n_evals
+            assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
+            np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
+        engine.set_exp_mode('fast')
+        fast = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
+        for g, r in zip(fast, ref):
+            assert abs(g.lnZ - r.lnZ) < 0.5 * r.lnZ_err + 1e-3
+    finally:
+        engine.set_exp_mode('fast')
+    null = cube.null_lnZ
+    for p, r in enumerate(ref):
+        assert r.lnZ - null[p] > 11                                   # main.py:464-469 threshold: a detection
+        mean, sig = r.param_constr[0], r.param_constr[1]
+        assert abs(mean[0] - truths[p, 0]) < 5 * sig[0] + 0.02        # velocity recovered
+
+
+@pytest.mark.gpu
+def test_run_multinest_front_end_on_the_engine(engine, nfo):
+    cube, cpu_runners, truths, data, axes = _cube(engine, nfo, 1, seed=5)
+    n = 256
+    spec_data = [[axes[k], data[0, k * n:(k + 1) * n], 0.15, t] for k, t in enumerate((1, 2))]
+    ut = engine.get_irdc_priors(size=300, vsys=0.0)
+    runner = engine.AmmoniaRunner.from_data(spec_data, ut, ncomp=1)
+    group = sampler.MemoryGroup()
+    res = sampler.run_multinest(runner, sampler.Dumper(group), nlive=60, seed=2)
+    assert group.attrs['ncomp'] == 1 and group.attrs['n_params'] == 6
+    assert group.attrs['global_lnZ'] == res.lnZ == runner.run_lnZ
+    assert res.lnZ - runner.null_lnZ > 11
+    assert group['posteriors'].shape[1] == 8
