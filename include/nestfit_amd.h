@@ -214,6 +214,28 @@ int  nfa_broker_stats(nfa_broker *b, int64_t *out);
 int  nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int32_t *pix, double *U,
                            double *lnL, double *seconds_out);
 
+/* ---- device-resident batched nested sampler --------------------
+ * Stand-in for one serial MultiNest run per pixel (run_multinest, nestfit/core/core.pyx:727-823,
+ * pixel loop nestfit/main.py:452-469) when libmultinest is absent: all pixels' runs advance in
+ * lock-step rounds with their state in HBM; a round = n_cand candidates per active pixel from
+ * its bounding ellipsoid, one likelihood batch over all of them, one wave per pixel doing the
+ * replace / evidence / stop / refit step.  pix[n_pix]: cube pixel of each run.  cap_iter: dead
+ * point slots per pixel (a run stops when they are full).  tol, efr, seed, maxiter as
+ * run_multinest; upd = replacements between ellipsoid refits; log_zero replaces non-finite
+ * likelihoods; check_every = rounds between two compactions of the active-pixel list.
+ * Outputs are the raw material of what mn_dump stores (core.pyx:627-687): dead points with
+ * their ln-weights, the final live points, iteration and evaluation counts; nestfit_amd/sampler.py
+ * assembles posteriors / lnZ from them and holds the bit-compatible host twin of the algorithm. */
+typedef struct nfa_sampler nfa_sampler;
+int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int64_t n_pix, int nlive,
+                       int n_cand, int64_t cap_iter);
+int nfa_sampler_destroy(nfa_sampler *s);
+int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
+                    double log_zero, int check_every);
+int nfa_sampler_counts(nfa_sampler *s, int64_t *n_iter, int64_t *n_evals, int64_t *rounds);
+int nfa_sampler_dead(nfa_sampler *s, int64_t p, int64_t n, double *theta, double *lnL, double *lnw);
+int nfa_sampler_live(nfa_sampler *s, double *theta, double *lnL);
+
 /* ---- device memory + events (for harnesses that keep inputs in HBM) ------- */
 int nfa_malloc(void **dptr, int64_t bytes);
 int nfa_free(void *dptr);

@@ -78,6 +78,14 @@ SIGNATURES = {
     'nfa_broker_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
     'nfa_broker_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'nfa_test_broker_storm': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp]),
+    'nfa_sampler_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, _ip, C.c_int64, C.c_int, C.c_int,
+                                     C.c_int64]),
+    'nfa_sampler_destroy': (C.c_int, [C.c_void_p]),
+    'nfa_sampler_run': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int,
+                                  C.c_double, C.c_int]),
+    'nfa_sampler_counts': (C.c_int, [C.c_void_p, _lp, _lp, _lp]),
+    'nfa_sampler_dead': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp, _dp]),
+    'nfa_sampler_live': (C.c_int, [C.c_void_p, _dp, _dp]),
     'nfa_malloc': (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     'nfa_free': (C.c_int, [C.c_void_p]),
     'nfa_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

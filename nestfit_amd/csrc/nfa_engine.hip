@@ -842,3 +842,4 @@ int nfa_test_windows(nfa_runner *r, int spec, double voff, double sigm, int32_t 
 }  // extern "C"
 
 #include "nfa_broker.h"
+#include "nfa_sampler.h"

@@ -1,0 +1,433 @@
+// nfa_sampler.h -- device-resident batched nested sampler.
+//
+// Stand-in for the serial MultiNest run per pixel of the reference (run_multinest,
+// nestfit/core/core.pyx:727-823; pixel loop nestfit/main.py:452-469) when libmultinest is not
+// available, laid out for the GPU: every pixel is an independent nested-sampling run, all runs
+// advance in lock-step rounds and their whole state (live points, bounding ellipsoids, evidence
+// accumulators, dead points) stays in HBM.  One round =
+//     ns_propose_kernel   K candidates per active pixel, uniform in the pixel's bounding ellipsoid
+//                         (counter-based RNG, so the host twin in nestfit_amd/sampler.py draws
+//                         the very same candidates)
+//     set-up + lnl kernels the engine's likelihood batch over all candidates of all pixels
+//     ns_update_kernel    one wave per pixel: scan the K candidates in order, every one above the
+//                         pixel's current threshold replaces the worst live point (Skilling's
+//                         bookkeeping: dead point, ln w, running lnZ), stop test, ellipsoid refit
+// The host only counts rounds and, every few rounds, compacts the list of still-active pixels.
+#pragma once
+
+#define NS_MAXD      60          // 6 parameters x MAXCOMP
+#define NS_TAG_LIVE  (1ull << 62)
+#define NS_B_RADIUS  255ull
+
+__host__ __device__ inline uint64_t ns_mix(uint64_t x) {             // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// uniform in (0, 1), a pure function of (seed, pixel, a, b)
+__host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t a, uint64_t b) {
+    const uint64_t h = ns_mix(ns_mix(ns_mix(ns_mix(seed) + p) + a) + b);
+    return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+struct NsDev {
+    int     P, N, D, K;                 // pixels, live points, dimensions, candidates per round
+    long    cap;                        // dead-point slots per pixel
+    double  tol, ln_shrink, enl_pow, log_zero;
+    long    maxiter;
+    int     upd;
+    uint64_t seed;
+    const int *pixmap;                  // sampler pixel -> cube pixel
+    double *Ulive, *Tlive, *Llive;      // [P][N][D], [P][N][D], [P][N]
+    double *centre, *axes;              // [P][D], [P][D][D] (lower triangular, scaled)
+    long   *n_iter, *n_evals;           // [P]
+    double *lnZ;                        // [P] running evidence of the dead points
+    int    *active, *since_fit;         // [P]
+    double *deadT, *deadL, *deadlnw;    // [P][cap][D], [P][cap], [P][cap]
+    double *candU, *candT, *candL;      // [P*K][D], [P*K][D], [P*K]
+    int    *candpix, *valid;            // [P*K]
+    const int *actlist;                 // [n_act] active pixels of this round
+};
+
+// ---- live points -------------------------------------------------------------------------
+__global__ void ns_init_live_kernel(NsDev S, int *__restrict__ livepix) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = (long)S.P * S.N * S.D;
+    if (gid >= tot) return;
+    const long pi = gid / S.D;
+    const int j = (int)(gid - pi * S.D);
+    const long p = pi / S.N;
+    const long i = pi - p * S.N;
+    const double u = ns_uniform(S.seed, (uint64_t)p, NS_TAG_LIVE + (uint64_t)i, (uint64_t)j);
+    S.Ulive[gid] = u;
+    S.Tlive[gid] = u;
+    if (j == 0) livepix[pi] = S.pixmap[p];
+}
+
+__global__ void ns_sanitize_kernel(double *__restrict__ L, long n, double log_zero) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < n) { const double v = L[gid]; L[gid] = isfinite(v) ? v : log_zero; }
+}
+
+// ---- candidates --------------------------------------------------------------------------
+__global__ void ns_propose_kernel(NsDev S, int n_act, long round) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)n_act * S.K) return;
+    const int q = (int)(gid / S.K), k = (int)(gid - (long)q * S.K);
+    const int p = S.actlist[q];
+    const int D = S.D;
+    double *cu = S.candU + gid * D, *ct = S.candT + gid * D;
+    S.candpix[gid] = S.pixmap[p];
+    if (!S.active[p]) {                 // finished since the last compaction: harmless dummy row
+        for (int j = 0; j < D; ++j) { cu[j] = 0.5; ct[j] = 0.5; }
+        S.valid[gid] = 0;
+        return;
+    }
+    const uint64_t a = (uint64_t)round * (uint64_t)S.K + (uint64_t)k;
+    double z[NS_MAXD];
+    double n2 = 0.0;
+    for (int m = 0; m < D; m += 2) {    // Box-Muller pairs
+        const double u1 = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)m);
+        const double u2 = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)(m + 1));
+        const double r = sqrt(-2.0 * log(u1));
+        const double ang = 6.283185307179586 * u2;
+        z[m] = r * cos(ang);
+        n2 += z[m] * z[m];
+        if (m + 1 < D) { z[m + 1] = r * sin(ang); n2 += z[m + 1] * z[m + 1]; }
+    }
+    const double ur = ns_uniform(S.seed, (uint64_t)p, a, NS_B_RADIUS);
+    const double f = exp(log(ur) / D) / sqrt(n2);         // uniform in the unit ball
+    const double *c = S.centre + (long)p * D, *A = S.axes + (long)p * D * D;
+    bool ok = true;
+    for (int j = 0; j < D; ++j) {
+        double v = c[j];
+        for (int i = 0; i <= j; ++i) v += A[j * D + i] * (z[i] * f);
+        ok = ok && (v >= 0.0) && (v < 1.0);
+        cu[j] = v;
+    }
+    for (int j = 0; j < D; ++j) ct[j] = ok ? cu[j] : 0.5;   // outside the prior: not a candidate
+    S.valid[gid] = ok ? 1 : 0;
+}
+
+// ---- wave helpers (one 64-lane wave per pixel; nothing here is hot) -------------------------
+__device__ __forceinline__ double ns_wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double ns_wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// minimum with the lowest index among equals (numpy.argmin)
+__device__ __forceinline__ void ns_wave_argmin(double &v, int &ix) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(ix, o);
+        if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+    }
+}
+__device__ __forceinline__ double ns_logaddexp(double a, double b) {
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const double m = fmax(a, b);
+    return m + log1p(exp(-fabs(a - b)));
+}
+
+// Bounding ellipsoid of the live points of pixel p (same arithmetic as _fit_ellipsoids in
+// nestfit_amd/sampler.py): centre = mean, A = chol(cov) * sqrt(max Mahalanobis^2) * enl^(1/D).
+// sA: D*D doubles of LDS, sc: D doubles.
+__device__ void ns_refit(const NsDev &S, int p, double *sA, double *sc, int lane) {
+    const int N = S.N, D = S.D;
+    const double *U = S.Ulive + (long)p * N * D;
+    for (int j = 0; j < D; ++j) {
+        double s = 0.0;
+        for (int i = lane; i < N; i += 64) s += U[(long)i * D + j];
+        s = ns_wave_sum(s);
+        if (lane == 0) sc[j] = s / N;
+    }
+    wave_lds_sync();
+    double tr = 0.0;
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b <= a; ++b) {
+            double s = 0.0;
+            for (int i = lane; i < N; i += 64) s += (U[(long)i * D + a] - sc[a]) * (U[(long)i * D + b] - sc[b]);
+            s = ns_wave_sum(s) / (N - 1);
+            if (lane == 0) sA[a * D + b] = s;
+            if (a == b) tr += s;
+        }
+    wave_lds_sync();
+    if (lane == 0) {                    // Cholesky, lower triangle in place
+        const double eps = 1e-12 * fmax(tr, 1e-30);
+        for (int a = 0; a < D; ++a) sA[a * D + a] += eps;
+        for (int j = 0; j < D; ++j) {
+            double d = sA[j * D + j];
+            for (int k = 0; k < j; ++k) d -= sA[j * D + k] * sA[j * D + k];
+            d = sqrt(fmax(d, 1e-300));
+            sA[j * D + j] = d;
+            for (int i = j + 1; i < D; ++i) {
+                double v = sA[i * D + j];
+                for (int k = 0; k < j; ++k) v -= sA[i * D + k] * sA[j * D + k];
+                sA[i * D + j] = v / d;
+            }
+        }
+    }
+    wave_lds_sync();
+    double r2 = 0.0;
+    for (int i = lane; i < N; i += 64) {           // y = L^-1 (u_i - c), forward substitution
+        double y[NS_MAXD];
+        double s2 = 0.0;
+        for (int a = 0; a < D; ++a) {
+            double v = U[(long)i * D + a] - sc[a];
+            for (int k = 0; k < a; ++k) v -= sA[a * D + k] * y[k];
+            y[a] = v / sA[a * D + a];
+            s2 += y[a] * y[a];
+        }
+        r2 = fmax(r2, s2);
+    }
+    r2 = ns_wave_max(r2);
+    const double scale = sqrt(r2) * S.enl_pow;
+    double *A = S.axes + (long)p * D * D, *c = S.centre + (long)p * D;
+    for (int e = lane; e < D * D; e += 64) {
+        const int a = e / D, b = e - a * D;
+        A[e] = b <= a ? sA[e] * scale : 0.0;
+    }
+    for (int j = lane; j < D; j += 64) c[j] = sc[j];
+    wave_lds_sync();
+}
+
+// ---- one wave per pixel: accept / replace / evidence / stop / refit ------------------------
+// q indexes actlist (force_refit: q indexes pixels directly, no candidates: initial ellipsoids)
+__global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int force_refit) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= n_act) return;
+    const int p = force_refit ? q : S.actlist[q];
+    const int N = S.N, D = S.D, K = S.K;
+    double *sL = smem;                              // live log-likelihoods of the pixel
+    double *sA = sL + ((N + 1) & ~1);               // D*D
+    double *sc = sA + D * D;                        // D
+    if (force_refit) { ns_refit(S, p, sA, sc, lane); return; }
+    if (!S.active[p]) return;
+    double *Ll = S.Llive + (long)p * N;
+    for (int i = lane; i < N; i += 64) sL[i] = Ll[i];
+    wave_lds_sync();
+    auto extremes = [&](double &lmin, int &w, double &lmax) {
+        double mn = INFINITY, mx = -INFINITY;
+        int ix = 0x7fffffff;
+        for (int i = lane; i < N; i += 64) {
+            const double v = sL[i];
+            if (v < mn) { mn = v; ix = i; }         // ascending i: first occurrence per lane
+            mx = fmax(mx, v);
+        }
+        ns_wave_argmin(mn, ix);
+        lmin = mn; w = ix; lmax = ns_wave_max(mx);
+    };
+    double Lmin, Lmax;
+    int w;
+    extremes(Lmin, w, Lmax);
+    long it = S.n_iter[p], evals = S.n_evals[p];
+    double lnZ = S.lnZ[p];
+    int since = S.since_fit[p];
+    bool done = false;
+    for (int k = 0; k < K && !done; ++k) {
+        const long g = (long)q * K + k;
+        if (!S.valid[g]) continue;
+        evals += 1;
+        double Lk = S.candL[g];
+        if (!isfinite(Lk)) Lk = S.log_zero;
+        if (!(Lk > Lmin)) continue;
+        // the worst live point dies with prior mass X_it - X_(it+1)
+        const double lnw = -(double)it / N + S.ln_shrink;
+        lnZ = ns_logaddexp(lnZ, lnw + Lmin);
+        if (it < S.cap) {
+            double *dT = S.deadT + ((long)p * S.cap + it) * D;
+            const double *Tw = S.Tlive + ((long)p * N + w) * D;
+            for (int j = lane; j < D; j += 64) dT[j] = Tw[j];
+            if (lane == 0) { S.deadL[(long)p * S.cap + it] = Lmin; S.deadlnw[(long)p * S.cap + it] = lnw; }
+        }
+        wave_lds_sync();
+        for (int j = lane; j < D; j += 64) {
+            S.Ulive[((long)p * N + w) * D + j] = S.candU[g * D + j];
+            S.Tlive[((long)p * N + w) * D + j] = S.candT[g * D + j];
+        }
+        if (lane == 0) { sL[w] = Lk; Ll[w] = Lk; }
+        wave_lds_sync();
+        it += 1; since += 1;
+        extremes(Lmin, w, Lmax);
+        const double remain = Lmax - (double)it / N;
+        done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= S.cap;
+    }
+    if (lane == 0) {
+        S.n_iter[p] = it; S.n_evals[p] = evals; S.lnZ[p] = lnZ;
+        if (done) S.active[p] = 0;
+    }
+    if (!done && since >= S.upd) {
+        __threadfence();                            // the wave's own stores to Ulive, then its loads
+        ns_refit(S, p, sA, sc, lane);
+        since = 0;
+    }
+    if (lane == 0) S.since_fit[p] = since;
+}
+
+// ---- host side -----------------------------------------------------------------------------
+struct nfa_sampler {
+    nfa_runner *r = nullptr;
+    NsDev d = {};
+    int *d_pixmap = nullptr, *d_actlist = nullptr, *d_livepix = nullptr;
+    std::vector<int> h_active, h_act;
+    long rounds = 0;
+    bool ran = false;
+};
+
+extern "C" {
+
+int nfa_sampler_destroy(nfa_sampler *s) {
+    if (!s) return NFA_OK;
+    NsDev &d = s->d;
+    void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.lnZ, d.active,
+                    d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid,
+                    s->d_pixmap, s->d_actlist, s->d_livepix};
+    for (void *p : ptrs) (void)hipFree(p);
+    delete s;
+    return NFA_OK;
+}
+
+// Device-resident nested sampling of n_pix pixels of the runner's spectra set in lock-step.
+// pix[n_pix] = cube pixel per run (NULL: 0..n_pix-1 must all be the runner's pixel 0 -> only
+// n_pix = 1 makes sense then).  cap_iter = dead-point slots per pixel (a run stops there).
+int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int64_t n_pix, int nlive,
+                       int n_cand, int64_t cap_iter) {
+    if (!out || !r) return fail(NFA_ERR_ARG, "null argument");
+    if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
+    if (n_pix < 1 || n_pix > (1 << 24)) return fail(NFA_ERR_ARG, "n_pix out of range");
+    if (nlive < r->ndim + 2 || nlive > 8192) return fail(NFA_ERR_ARG, "nlive must be in ndim+2..8192");
+    if (n_cand < 1 || n_cand > 1024) return fail(NFA_ERR_ARG, "n_cand must be in 1..1024");
+    if (cap_iter < 1) return fail(NFA_ERR_ARG, "cap_iter must be >= 1");
+    if (r->ndim > NS_MAXD) return fail(NFA_ERR_ARG, "too many dimensions");
+    int rc = check_pix(r, pix, n_pix); if (rc) return rc;
+    nfa_sampler *s = new nfa_sampler();
+    s->r = r;
+    NsDev &d = s->d;
+    d.P = (int)n_pix; d.N = nlive; d.D = r->ndim; d.K = n_cand; d.cap = (long)cap_iter;
+    const size_t P = (size_t)n_pix, N = (size_t)nlive, D = (size_t)r->ndim, K = (size_t)n_cand, C = (size_t)cap_iter;
+    std::vector<int> pm(P);
+    for (size_t p = 0; p < P; ++p) pm[p] = pix ? pix[p] : 0;
+#define NS_ALLOC(ptr, type, count) \
+    if (hipMalloc((void **)&(ptr), sizeof(type) * (count)) != hipSuccess) { \
+        nfa_sampler_destroy(s); return fail(NFA_ERR_DEVICE, "out of device memory for the sampler state"); }
+    NS_ALLOC(s->d_pixmap, int, P); NS_ALLOC(s->d_actlist, int, P); NS_ALLOC(s->d_livepix, int, P * N);
+    NS_ALLOC(d.Ulive, double, P * N * D); NS_ALLOC(d.Tlive, double, P * N * D); NS_ALLOC(d.Llive, double, P * N);
+    NS_ALLOC(d.centre, double, P * D); NS_ALLOC(d.axes, double, P * D * D);
+    NS_ALLOC(d.n_iter, long, P); NS_ALLOC(d.n_evals, long, P); NS_ALLOC(d.lnZ, double, P);
+    NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P);
+    NS_ALLOC(d.deadT, double, P * C * D); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
+    NS_ALLOC(d.candU, double, P * K * D); NS_ALLOC(d.candT, double, P * K * D); NS_ALLOC(d.candL, double, P * K);
+    NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K);
+#undef NS_ALLOC
+    HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
+    d.pixmap = s->d_pixmap; d.actlist = s->d_actlist;
+    *out = s;
+    return NFA_OK;
+}
+
+// tol, efr, seed, maxiter as run_multinest (core.pyx:727-744); upd = replacements between
+// ellipsoid refits; check_every = rounds between two looks at the set of active pixels.
+int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
+                    double log_zero, int check_every) {
+    if (!s) return fail(NFA_ERR_ARG, "null sampler");
+    if (!(tol > 0) || !(efr > 0 && efr <= 1) || maxiter < 0 || upd < 1 || check_every < 1)
+        return fail(NFA_ERR_ARG, "bad sampler options");
+    nfa_runner *r = s->r;
+    NsDev &d = s->d;
+    const int P = d.P, N = d.N, D = d.D, K = d.K;
+    d.tol = tol; d.maxiter = (long)maxiter; d.upd = upd; d.seed = (uint64_t)seed; d.log_zero = log_zero;
+    d.ln_shrink = log1p(-exp(-1.0 / N));
+    d.enl_pow = pow(1.0 / efr, 1.0 / D);
+    hipStream_t st = r->lanes[0];
+    HIP_TRY(hipMemsetAsync(d.n_iter, 0, sizeof(long) * P, st));
+    HIP_TRY(hipMemsetAsync(d.since_fit, 0, sizeof(int) * P, st));
+    {   // live points
+        const long tot = (long)P * N * D;
+        hipLaunchKernelGGL(ns_init_live_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, s->d_livepix);
+        HIP_TRY(hipGetLastError());
+        int rc = run_batch(r, s->d_livepix, d.Tlive, d.Llive, nullptr, (int64_t)P * N, true, 0, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ns_sanitize_kernel, dim3((unsigned)(((long)P * N + 255) / 256)), dim3(256), 0, st,
+                           d.Llive, (long)P * N, log_zero);
+        HIP_TRY(hipGetLastError());
+    }
+    std::vector<long> h_evals((size_t)P, (long)N);
+    std::vector<double> h_lnz((size_t)P, -INFINITY);
+    s->h_active.assign((size_t)P, maxiter > 0 ? 1 : 0);
+    HIP_TRY(hipMemcpyAsync(d.n_evals, h_evals.data(), sizeof(long) * P, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d.lnZ, h_lnz.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d.active, s->h_active.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
+    const size_t lds = sizeof(double) * ((size_t)((N + 1) & ~1) + (size_t)D * D + (size_t)D);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), lds, st, d, P, 1);   // first ellipsoids
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    s->rounds = 0;
+    int n_act = maxiter > 0 ? P : 0;
+    s->h_act.resize((size_t)P);
+    for (int p = 0; p < P; ++p) s->h_act[p] = p;
+    if (n_act) HIP_TRY(hipMemcpy(s->d_actlist, s->h_act.data(), sizeof(int) * P, hipMemcpyHostToDevice));
+    // every pixel needs at most maxiter accepted rounds, but a round may accept nothing: bound the
+    // loop by a generous multiple so that a stuck run cannot spin forever
+    const long max_rounds = 200 * (std::min<long>((long)maxiter, d.cap) + 1000);
+    while (n_act > 0 && s->rounds < max_rounds) {
+        for (int c = 0; c < check_every; ++c) {
+            const long B = (long)n_act * K;
+            hipLaunchKernelGGL(ns_propose_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, d, n_act, s->rounds);
+            HIP_TRY(hipGetLastError());
+            int rc = run_batch(r, d.candpix, d.candT, d.candL, nullptr, B, true, 0, nullptr);
+            if (rc) return rc;
+            hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_act), dim3(64), lds, st, d, n_act, 0);
+            HIP_TRY(hipGetLastError());
+            s->rounds += 1;
+        }
+        HIP_TRY(hipMemcpyAsync(s->h_active.data(), d.active, sizeof(int) * P, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_act = 0;
+        for (int p = 0; p < P; ++p) if (s->h_active[p]) s->h_act[n_act++] = p;
+        if (n_act) HIP_TRY(hipMemcpyAsync(s->d_actlist, s->h_act.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    s->ran = true;
+    return n_act == 0 ? NFA_OK : fail(NFA_ERR_STATE, "sampler stopped at the round limit with active pixels");
+}
+
+// n_iter[P], n_evals[P], rounds (scalar)
+int nfa_sampler_counts(nfa_sampler *s, int64_t *n_iter, int64_t *n_evals, int64_t *rounds) {
+    if (!s || !s->ran || !n_iter || !n_evals) return fail(NFA_ERR_ARG, "sampler has not run");
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    HIP_TRY(hipMemcpy(n_iter, s->d.n_iter, sizeof(long) * s->d.P, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(n_evals, s->d.n_evals, sizeof(long) * s->d.P, hipMemcpyDeviceToHost));
+    if (rounds) *rounds = s->rounds;
+    return NFA_OK;
+}
+
+// dead points of pixel p: theta[n][D], lnL[n], lnw[n] with n = min(n_iter[p], cap)
+int nfa_sampler_dead(nfa_sampler *s, int64_t p, int64_t n, double *theta, double *lnL, double *lnw) {
+    if (!s || !s->ran || p < 0 || p >= s->d.P || n < 0 || n > s->d.cap) return fail(NFA_ERR_ARG, "bad argument");
+    if (n == 0) return NFA_OK;
+    const NsDev &d = s->d;
+    HIP_TRY(hipMemcpy(theta, d.deadT + (size_t)p * d.cap * d.D, sizeof(double) * n * d.D, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lnL, d.deadL + (size_t)p * d.cap, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lnw, d.deadlnw + (size_t)p * d.cap, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return NFA_OK;
+}
+
+// final live points: theta[P][N][D], lnL[P][N]
+int nfa_sampler_live(nfa_sampler *s, double *theta, double *lnL) {
+    if (!s || !s->ran || !theta || !lnL) return fail(NFA_ERR_ARG, "sampler has not run");
+    const NsDev &d = s->d;
+    HIP_TRY(hipMemcpy(theta, d.Tlive, sizeof(double) * (size_t)d.P * d.N * d.D, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lnL, d.Llive, sizeof(double) * (size_t)d.P * d.N, hipMemcpyDeviceToHost));
+    return NFA_OK;
+}
+
+}  // extern "C"

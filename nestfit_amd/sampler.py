@@ -12,6 +12,10 @@ replaces its worst live point (Skilling 2006 bookkeeping).  The outputs follow w
 reference's ``mn_dump`` stores (core.pyx:627-687): posterior rows ``[theta..., -2 lnL, weight]``,
 ``param_constr`` rows 2, 3 = best-fit and MAP, global lnZ and its error, max log-likelihood.
 
+Two implementations of one algorithm live side by side: `run_nested` (numpy, any likelihood
+callable) and `run_nested_device` (state and per-round logic on the GPU, csrc/nfa_sampler.h); they
+share a counter-based random stream, so the same seed gives the same run.
+
 This is not MultiNest: the random streams differ and there is no multi-ellipsoid decomposition,
 so evidences agree with a MultiNest run only within their sampling error.  What can be checked
 bit-for-bit is the likelihood it is fed (tests drive the same sampler with the CPU oracle).
@@ -44,21 +48,59 @@ class NestedResult:
         self.param_constr = np.stack([mean, np.sqrt(var), best, mapp])    # (4, n_params)
 
 
-def _ball(rng, shape, ndim):
-    """Uniform points in the unit ndim-ball, shape (..., ndim)."""
-    g = rng.standard_normal(shape + (ndim,))
-    g /= np.linalg.norm(g, axis=-1, keepdims=True)
-    return g * rng.uniform(size=shape + (1,)) ** (1.0 / ndim)
+# ---- counter-based random numbers, shared bit for bit with csrc/nfa_sampler.h -------------
+_U64 = np.uint64
+_TAG_LIVE = _U64(1 << 62)
+_B_RADIUS = _U64(255)
+
+
+def _mix(x):
+    """splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)."""
+    with np.errstate(over='ignore'):
+        x = x + _U64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> _U64(27))) * _U64(0x94D049BB133111EB)
+        return z ^ (z >> _U64(31))
+
+
+def _uniform(seed, p, a, b):
+    """Uniform in (0, 1): a pure function of (seed, pixel, a, b) (ns_uniform on the device)."""
+    with np.errstate(over='ignore'):
+        h = _mix(_mix(_mix(_mix(np.asarray(seed, dtype=_U64)) + np.asarray(p, dtype=_U64))
+                      + np.asarray(a, dtype=_U64)) + np.asarray(b, dtype=_U64))
+    return ((h >> _U64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def _candidates(seed, pix, rnd, K, centre, axes):
+    """K candidates per pixel of `pix`, uniform in the bounding ellipsoids (ns_propose_kernel)."""
+    n, D = len(pix), centre.shape[1]
+    p = np.asarray(pix, dtype=_U64)[:, None, None]
+    a = (_U64(rnd) * _U64(K) + np.arange(K, dtype=_U64))[None, :, None]
+    z = np.empty((n, K, D))
+    for m in range(0, D, 2):
+        u1 = _uniform(seed, p, a, _U64(m))[..., 0]
+        u2 = _uniform(seed, p, a, _U64(m + 1))[..., 0]
+        r = np.sqrt(-2.0 * np.log(u1))
+        ang = 6.283185307179586 * u2
+        z[:, :, m] = r * np.cos(ang)
+        if m + 1 < D:
+            z[:, :, m + 1] = r * np.sin(ang)
+    ur = _uniform(seed, p, a, _B_RADIUS)[..., 0]
+    f = np.exp(np.log(ur) / D) / np.sqrt((z * z).sum(axis=2))
+    cand = centre[:, None, :] + np.einsum('pji,pki->pkj', axes, z * f[:, :, None])
+    return cand
 
 
 def _fit_ellipsoids(U, enlarge):
-    """Bounding ellipsoid of live points U[P, nlive, ndim]: centre, and a matrix A with
-    {c + A z : |z| <= 1} containing every live point, its volume scaled by `enlarge`."""
+    """Bounding ellipsoid of live points U[P, nlive, ndim]: centre, and a lower-triangular A with
+    {c + A z : |z| <= 1} containing every live point, its volume scaled by `enlarge` (ns_refit)."""
     P, nlive, ndim = U.shape
-    c = U.mean(axis=1)
+    c = U.sum(axis=1) / nlive
     d = U - c[:, None, :]
     cov = np.einsum('pni,pnj->pij', d, d) / (nlive - 1)
-    cov += 1e-12 * np.eye(ndim)[None] * np.maximum(np.trace(cov, axis1=1, axis2=2), 1e-30)[:, None, None]
+    tr = np.trace(cov, axis1=1, axis2=2)
+    cov = cov + (1e-12 * np.maximum(tr, 1e-30))[:, None, None] * np.eye(ndim)[None]
     L = np.linalg.cholesky(cov)
     y = np.linalg.solve(L, d.transpose(0, 2, 1))               # (P, ndim, nlive)
     r2 = np.max(np.sum(y * y, axis=1), axis=1)                 # largest Mahalanobis distance^2
@@ -66,121 +108,19 @@ def _fit_ellipsoids(U, enlarge):
     return c, L * scale[:, None, None]
 
 
-def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
-               n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, progress=None):
-    """Nested sampling of `n_pix` independent problems in lock-step.
-
-    Parameters
-    ----------
-    loglike : callable(pix[B] int32, U[B, ndim] float64) -> lnL[B]
-        Evaluates unit-cube rows against pixels; must overwrite U with the physical parameters
-        (the convention of Runner.loglikelihood, core.pyx:558-561).
-    nlive, tol, efr, seed, maxiter : as in ``run_multinest`` (core.pyx:727-744): live points,
-        evidence tolerance, target sampling efficiency (sets the ellipsoid enlargement 1/efr in
-        volume), RNG seed (-1 = from the OS), iteration cap per pixel.
-    n_cand : candidates per pixel and iteration (default ceil(2 / efr)).
-    upd_frac : the ellipsoids are refitted after this fraction of nlive replacements.
-
-    Returns a list of `NestedResult`, one per pixel.
-    """
-    assert ndim > 0 and nlive > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
-    rng = np.random.default_rng(None if seed is None or seed < 0 else seed)
-    K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
-    P = int(n_pix)
-    all_pix = np.arange(P, dtype=np.int32)
-
-    def evaluate(pix, U):
-        out = np.empty(U.shape[0])
-        for a in range(0, U.shape[0], chunk):
-            out[a:a + chunk] = loglike(pix[a:a + chunk], U[a:a + chunk])
-        return np.where(np.isfinite(out), out, log_zero)
-
-    # live points: unit-cube positions, physical parameters, log-likelihoods
-    Ulive = rng.uniform(size=(P, nlive, ndim))
-    Tlive = Ulive.reshape(-1, ndim).copy()
-    Llive = evaluate(np.repeat(all_pix, nlive), Tlive).reshape(P, nlive)
-    Tlive = Tlive.reshape(P, nlive, ndim)
-    n_evals = np.full(P, nlive, dtype=np.int64)
-    n_iter = np.zeros(P, dtype=np.int64)
-    lnZ = np.full(P, -np.inf)
-    H = np.zeros(P)
-    ln_shrink = np.log1p(-np.exp(-1.0 / nlive))                 # ln(X_i - X_{i+1}) - ln X_i
-    active = np.full(P, maxiter > 0)
-    since_fit = np.zeros(P, dtype=np.int64)
-    upd = max(1, int(upd_frac * nlive))
-    centre, axes = _fit_ellipsoids(Ulive, 1.0 / efr)
-    dead_T, dead_L, dead_lnw, dead_pix = [], [], [], []
-
-    while active.any():
-        idx = np.flatnonzero(active)
-        n = idx.size
-        worst = np.argmin(Llive[idx], axis=1)
-        Lmin = Llive[idx, worst]
-        # candidates from the bounding ellipsoids; outside the unit cube = outside the prior
-        z = _ball(rng, (n, K), ndim)
-        cand = centre[idx, None, :] + np.einsum('pij,pkj->pki', axes[idx], z)
-        inside = np.all((cand >= 0.0) & (cand < 1.0), axis=2)
-        flat = np.flatnonzero(inside.ravel())
-        Lc = np.full(n * K, -np.inf)
-        Tc = cand.reshape(n * K, ndim).copy()
-        if flat.size:
-            Tsub = Tc[flat]
-            Lc[flat] = evaluate(np.repeat(idx, K).astype(np.int32)[flat], Tsub)
-            Tc[flat] = Tsub
-            np.add.at(n_evals, np.repeat(idx, K)[flat], 1)
-        Lc = Lc.reshape(n, K)
-        ok = Lc > Lmin[:, None]
-        hit = ok.any(axis=1)
-        first = np.argmax(ok, axis=1)
-        adv = np.flatnonzero(hit)                               # pixels that advance this round
-        if adv.size:
-            p = idx[adv]
-            w = worst[adv]
-            lnX = -n_iter[p] / nlive
-            lnw = lnX + ln_shrink
-            lnwL = lnw + Lmin[adv]
-            lnZ_new = np.logaddexp(lnZ[p], lnwL)
-            with np.errstate(invalid='ignore', over='ignore'):
-                old = np.where(np.isfinite(lnZ[p]), np.exp(lnZ[p] - lnZ_new) * (H[p] + lnZ[p]), 0.0)
-                H[p] = np.exp(lnwL - lnZ_new) * Lmin[adv] + old - lnZ_new
-            lnZ[p] = lnZ_new
-            dead_T.append(Tlive[p, w].copy()); dead_L.append(Lmin[adv].copy())
-            dead_lnw.append(lnw); dead_pix.append(p)
-            sel = adv * K + first[adv]
-            Ulive[p, w] = cand.reshape(n * K, ndim)[sel]
-            Tlive[p, w] = Tc[sel]
-            Llive[p, w] = Lc.reshape(-1)[sel]
-            n_iter[p] += 1
-            since_fit[p] += 1
-            # termination (MultiNest's tol): the live points cannot add more than tol to lnZ
-            lnX_next = -n_iter[p] / nlive
-            remain = Llive[p].max(axis=1) + lnX_next
-            done = (np.logaddexp(lnZ[p], remain) - lnZ[p] < tol) | (n_iter[p] >= maxiter)
-            active[p[done]] = False
-            refit = p[(since_fit[p] >= upd) & ~done]
-            if refit.size:
-                centre[refit], axes[refit] = _fit_ellipsoids(Ulive[refit], 1.0 / efr)
-                since_fit[refit] = 0
-        if progress is not None:
-            progress(int(active.sum()), int(n_iter.max()))
-
-    # assemble per pixel: dead points + the final live points, each with mass X_final / nlive
-    dead_pix = np.concatenate(dead_pix) if dead_pix else np.zeros(0, dtype=np.int64)
-    dead_T = np.concatenate(dead_T) if dead_T else np.zeros((0, ndim))
-    dead_L = np.concatenate(dead_L) if dead_L else np.zeros(0)
-    dead_lnw = np.concatenate(dead_lnw) if dead_lnw else np.zeros(0)
-    order = np.argsort(dead_pix, kind='stable')
-    bounds = np.searchsorted(dead_pix[order], np.arange(P + 1))
+def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive):
+    """NestedResult per pixel from dead points (theta, lnL, lnw per pixel) and final live points:
+    every live point carries the mass X_final / nlive."""
     results = []
-    for p in range(P):
-        sl = order[bounds[p]:bounds[p + 1]]
+    for p in range(len(n_iter)):
+        dT, dL, dlnw = dead[p]
         lnw_live = np.full(nlive, -n_iter[p] / nlive - np.log(nlive))
-        T = np.concatenate([dead_T[sl], Tlive[p]])
-        L = np.concatenate([dead_L[sl], Llive[p]])
-        lnw = np.concatenate([dead_lnw[sl], lnw_live])
+        T = np.concatenate([dT, Tlive[p]])
+        L = np.concatenate([dL, Llive[p]])
+        lnw = np.concatenate([dlnw, lnw_live])
         lnZ_tot = np.logaddexp.reduce(lnw + L)
         wt = np.exp(lnw + L - lnZ_tot)
-        # information including the live-point term, for the error estimate sqrt(H / nlive)
+        # information H = sum w (lnL - lnZ), for the error estimate sqrt(H / nlive)
         with np.errstate(invalid='ignore'):
             Hp = float(np.sum(np.where(wt > 0, wt * (L - lnZ_tot), 0.0)))
         post = np.empty((T.shape[0], ndim + 2))
@@ -190,6 +130,165 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         results.append(NestedResult(post, lnZ_tot, np.sqrt(max(Hp, 0.0) / nlive), L.max(), nlive,
                                     n_evals[p], n_iter[p], Hp))
     return results
+
+
+def _resolve_seed(seed):
+    if seed is None or seed < 0:                                # like MultiNest: from the system
+        return int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> np.uint64(1))
+    return int(seed)
+
+
+def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
+               n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
+               progress=None):
+    """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
+    device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
+
+    Parameters
+    ----------
+    loglike : callable(pix[B] int32, U[B, ndim] float64) -> lnL[B]
+        Evaluates unit-cube rows against pixels; must overwrite U with the physical parameters
+        (the convention of Runner.loglikelihood, core.pyx:558-561).
+    nlive, tol, efr, seed, maxiter : as in ``run_multinest`` (core.pyx:727-744): live points,
+        evidence tolerance, target sampling efficiency (sets the ellipsoid enlargement 1/efr in
+        volume), RNG seed (-1 = from the OS), iteration cap per pixel.
+    n_cand : candidates per pixel and round (default ceil(2 / efr)); they are scanned in order
+        and every one above the pixel's current threshold replaces its worst live point.
+    upd_frac : the ellipsoids are refitted after this fraction of nlive replacements.
+    cap_iter : dead-point slots per pixel (default: no other cap than maxiter).
+
+    Returns a list of `NestedResult`, one per pixel.
+    """
+    assert ndim > 0 and nlive > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
+    seed = _resolve_seed(seed)
+    K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
+    P = int(n_pix)
+    cap = int(maxiter if cap_iter is None else min(cap_iter, maxiter) if maxiter > 0 else cap_iter)
+    all_pix = np.arange(P, dtype=np.int32)
+
+    def evaluate(pix, U):
+        out = np.empty(U.shape[0])
+        for a in range(0, U.shape[0], chunk):
+            out[a:a + chunk] = loglike(pix[a:a + chunk], U[a:a + chunk])
+        return np.where(np.isfinite(out), out, log_zero)
+
+    # live points: unit-cube positions, physical parameters, log-likelihoods
+    Ulive = _uniform(seed, all_pix[:, None, None], _TAG_LIVE + np.arange(nlive, dtype=_U64)[None, :, None],
+                     np.arange(ndim, dtype=_U64)[None, None, :])
+    Tlive = Ulive.reshape(-1, ndim).copy()
+    Llive = evaluate(np.repeat(all_pix, nlive), Tlive).reshape(P, nlive)
+    Tlive = Tlive.reshape(P, nlive, ndim)
+    n_evals = np.full(P, nlive, dtype=np.int64)
+    n_iter = np.zeros(P, dtype=np.int64)
+    lnZ = np.full(P, -np.inf)
+    ln_shrink = np.log1p(-np.exp(-1.0 / nlive))                 # ln(X_i - X_{i+1}) - ln X_i
+    active = np.full(P, maxiter > 0)
+    since_fit = np.zeros(P, dtype=np.int64)
+    upd = max(1, int(upd_frac * nlive))
+    centre, axes = _fit_ellipsoids(Ulive, 1.0 / efr)
+    dead_T, dead_L, dead_lnw, dead_pix = [], [], [], []
+    rnd = 0
+    while active.any():
+        idx = np.flatnonzero(active)
+        n = idx.size
+        cand = _candidates(seed, idx, rnd, K, centre[idx], axes[idx])
+        valid = np.all((cand >= 0.0) & (cand < 1.0), axis=2)    # outside the unit cube = outside the prior
+        flat = np.flatnonzero(valid.ravel())
+        Lc = np.full(n * K, -np.inf)
+        Tc = cand.reshape(n * K, ndim).copy()
+        if flat.size:
+            Tsub = Tc[flat]
+            Lc[flat] = evaluate(np.repeat(idx, K).astype(np.int32)[flat], Tsub)
+            Tc[flat] = Tsub
+        Lc = Lc.reshape(n, K)
+        Tc = Tc.reshape(n, K, ndim)
+        going = np.ones(n, dtype=bool)                          # not finished within this round
+        for k in range(K):                                      # the wave's sequential scan
+            sel = going & valid[:, k]
+            n_evals[idx[sel]] += 1
+            worst = np.argmin(Llive[idx], axis=1)
+            Lmin = Llive[idx, worst]
+            acc = np.flatnonzero(sel & (Lc[:, k] > Lmin))
+            if not acc.size:
+                continue
+            p, w = idx[acc], worst[acc]
+            lnw = -n_iter[p] / nlive + ln_shrink
+            lnZ[p] = np.logaddexp(lnZ[p], lnw + Lmin[acc])
+            keep = n_iter[p] < cap
+            dead_T.append(Tlive[p, w][keep]); dead_L.append(Lmin[acc][keep])
+            dead_lnw.append(lnw[keep]); dead_pix.append(p[keep])
+            Ulive[p, w] = cand[acc, k]
+            Tlive[p, w] = Tc[acc, k]
+            Llive[p, w] = Lc[acc, k]
+            n_iter[p] += 1
+            since_fit[p] += 1
+            # termination (MultiNest's tol): the live points cannot add more than tol to lnZ
+            remain = Llive[p].max(axis=1) - n_iter[p] / nlive
+            done = (np.logaddexp(lnZ[p], remain) - lnZ[p] < tol) | (n_iter[p] >= maxiter) | (n_iter[p] >= cap)
+            active[p[done]] = False
+            going[acc[done]] = False
+        refit = idx[going & (since_fit[idx] >= upd)]
+        if refit.size:
+            centre[refit], axes[refit] = _fit_ellipsoids(Ulive[refit], 1.0 / efr)
+            since_fit[refit] = 0
+        rnd += 1
+        if progress is not None:
+            progress(int(active.sum()), int(n_iter.max()))
+
+    dead_pix = np.concatenate(dead_pix) if dead_pix else np.zeros(0, dtype=np.int64)
+    dead_T = np.concatenate(dead_T) if dead_T else np.zeros((0, ndim))
+    dead_L = np.concatenate(dead_L) if dead_L else np.zeros(0)
+    dead_lnw = np.concatenate(dead_lnw) if dead_lnw else np.zeros(0)
+    order = np.argsort(dead_pix, kind='stable')
+    bounds = np.searchsorted(dead_pix[order], np.arange(P + 1))
+    dead = [(dead_T[order[bounds[p]:bounds[p + 1]]], dead_L[order[bounds[p]:bounds[p + 1]]],
+             dead_lnw[order[bounds[p]:bounds[p + 1]]]) for p in range(P)]
+    res = _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive)
+    for r in res:
+        r.rounds = rnd
+    return res
+
+
+def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
+                      upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8):
+    """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
+    `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
+    work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive)."""
+    import ctypes as C
+    from . import _ffi
+    lib = _ffi.engine()
+    pix = np.ascontiguousarray(pix, dtype=np.int32)
+    P, ndim = int(pix.size), int(runner.ndim)
+    assert nlive > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
+    seed = _resolve_seed(seed)
+    K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
+    cap = int(cap_iter) if cap_iter else int(max(1, min(maxiter, 60 * nlive)))
+    h = C.c_void_p()
+    _ffi.check(lib.nfa_sampler_create(C.byref(h), runner._run.handle, pix.ctypes.data_as(_ffi._ip), P,
+                                      int(nlive), K, cap))
+    try:
+        _ffi.check(lib.nfa_sampler_run(h, float(tol), float(efr), seed, int(maxiter),
+                                       max(1, int(upd_frac * nlive)), float(log_zero), int(check_every)))
+        n_iter = np.empty(P, dtype=np.int64)
+        n_evals = np.empty(P, dtype=np.int64)
+        rounds = C.c_int64()
+        _ffi.check(lib.nfa_sampler_counts(h, n_iter.ctypes.data_as(_ffi._lp), n_evals.ctypes.data_as(_ffi._lp),
+                                          C.byref(rounds)))
+        Tlive = np.empty((P, nlive, ndim))
+        Llive = np.empty((P, nlive))
+        _ffi.check(lib.nfa_sampler_live(h, _ffi.dptr(Tlive), _ffi.dptr(Llive)))
+        dead = []
+        for p in range(P):
+            n = int(min(n_iter[p], cap))
+            dT, dL, dw = np.empty((n, ndim)), np.empty(n), np.empty(n)
+            _ffi.check(lib.nfa_sampler_dead(h, p, n, _ffi.dptr(dT), _ffi.dptr(dL), _ffi.dptr(dw)))
+            dead.append((dT, dL, dw))
+    finally:
+        lib.nfa_sampler_destroy(h)
+    res = _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive)
+    for r in res:
+        r.rounds = int(rounds.value)
+    return res
 
 
 # ---------------------------------------------------------------------------
@@ -322,9 +421,15 @@ def run_multinest(runner, dumper, IS=False, mmodal=True, ceff=False, nlive=400, 
     return res
 
 
-def fit_pixels(cube_runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), **kwargs):
-    """All pixels `pix` of a `CubeRunner` in one lock-step run; returns a list of NestedResult."""
+def fit_pixels(cube_runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), device=True,
+               **kwargs):
+    """All pixels `pix` of a `CubeRunner` in one lock-step run; returns a list of NestedResult.
+    device=True keeps the sampler state on the GPU (`run_nested_device`); device=False runs the
+    host twin and sends only the likelihood batches to the GPU."""
     pix = np.ascontiguousarray(pix, dtype=np.int32)
+    if device:
+        return run_nested_device(cube_runner, pix, nlive=nlive, tol=tol, efr=efr, seed=seed,
+                                 maxiter=maxiter, **kwargs)
 
     def loglike(k, U):
         return cube_runner.loglikelihood_batch(pix[k], U)

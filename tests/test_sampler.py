@@ -173,11 +173,14 @@ def test_sampler_on_gpu_matches_the_same_sampler_on_the_oracle(engine, nfo):
     ref = sampler.run_nested(cpu_loglike, cube.ndim, n_pix, **kw)
     try:
         engine.set_exp_mode('table')
-        got = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
-        for g, r in zip(got, ref):
-            assert g.n_iter == r.n_iter and g.n_evals == r.n_evals
-            assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
-            np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
+        # host twin (numpy rounds, GPU likelihood) and device-resident sampler, same seed
+        for device in (False, True):
+            got = sampler.fit_pixels(cube, np.arange(n_pix), device=device, **kw)
+            for g, r in zip(got, ref):
+                assert g.n_iter == r.n_iter and g.n_evals == r.n_evals, (device, g.n_iter, r.n_iter)
+                assert g.rounds == r.rounds
+                assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
+                np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
         engine.set_exp_mode('fast')
         fast = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
         for g, r in zip(fast, ref):
@@ -204,3 +207,26 @@ def test_run_multinest_front_end_on_the_engine(engine, nfo):
     assert group.attrs['global_lnZ'] == res.lnZ == runner.run_lnZ
     assert res.lnZ - runner.null_lnZ > 11
     assert group['posteriors'].shape[1] == 8
+
+
+@pytest.mark.gpu
+def test_device_sampler_limits_and_errors(engine, nfo):
+    from nestfit_amd import _ffi
+    cube, cpu_runners, truths, data, axes = _cube(engine, nfo, 4, seed=8)
+    pix = np.arange(4)
+    capped = sampler.run_nested_device(cube, pix, nlive=40, maxiter=25, seed=3)
+    assert all(r.n_iter == 25 and r.n_samples == 65 for r in capped)
+    none = sampler.run_nested_device(cube, pix, nlive=40, maxiter=0, seed=3)
+    assert all(r.n_iter == 0 and r.n_samples == 40 for r in none)
+    full = sampler.run_nested_device(cube, pix, nlive=40, cap_iter=30, seed=3)     # dead-point buffer full
+    assert all(r.n_iter == 30 for r in full)
+    twin = sampler.fit_pixels(cube, pix, nlive=40, cap_iter=30, seed=3, device=False)
+    for a, b in zip(full, twin):
+        assert a.n_evals == b.n_evals and a.lnZ == pytest.approx(b.lnZ, rel=1e-10)
+    # a subset and a permutation of pixels: every pixel's stream depends on its slot, not on company
+    sub = sampler.run_nested_device(cube, np.array([2, 0]), nlive=40, maxiter=25, seed=3)
+    assert sub[0].lnZ != capped[2].lnZ                       # slot 0 stream on pixel 2: a different run
+    with pytest.raises(engine.EngineError, match='nlive'):
+        sampler.run_nested_device(cube, pix, nlive=cube.ndim + 2 + 9000, seed=1)
+    with pytest.raises(engine.EngineError, match='pixel index'):
+        sampler.run_nested_device(cube, np.array([7]), nlive=40, seed=1)
