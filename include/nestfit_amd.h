@@ -219,7 +219,9 @@ int  nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int3
  * pixel loop nestfit/main.py:452-469) when libmultinest is absent: all pixels' runs advance in
  * lock-step rounds with their state in HBM; a round = n_cand candidates per active pixel from
  * its bounding ellipsoid, one likelihood batch over all of them, one wave per pixel doing the
- * replace / evidence / stop / refit step.  pix[n_pix]: cube pixel of each run.  cap_iter: dead
+ * replace / evidence / stop / refit step.  pix[n_pix]: cube pixel of each run.  n_cand: candidates
+ * per pixel and round at least; the number is raised (up to 1024) so that a round evaluates about
+ * batch_target candidates however few pixels are still running.  cap_iter: dead
  * point slots per pixel (a run stops when they are full).  tol, efr, seed, maxiter as
  * run_multinest; upd = replacements between ellipsoid refits; log_zero replaces non-finite
  * likelihoods; check_every = rounds between two compactions of the active-pixel list.
@@ -228,7 +230,7 @@ int  nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int3
  * assembles posteriors / lnZ from them and holds the bit-compatible host twin of the algorithm. */
 typedef struct nfa_sampler nfa_sampler;
 int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int64_t n_pix, int nlive,
-                       int n_cand, int64_t cap_iter);
+                       int n_cand, int64_t batch_target, int64_t cap_iter);
 int nfa_sampler_destroy(nfa_sampler *s);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);

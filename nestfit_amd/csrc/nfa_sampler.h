@@ -33,7 +33,7 @@ __host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t
 }
 
 struct NsDev {
-    int     P, N, D, K;                 // pixels, live points, dimensions, candidates per round
+    int     P, N, D, K;                 // pixels, live points, dimensions, candidates per round (at least)
     long    cap;                        // dead-point slots per pixel
     double  tol, ln_shrink, enl_pow, log_zero;
     long    maxiter;
@@ -43,6 +43,7 @@ struct NsDev {
     double *Ulive, *Tlive, *Llive;      // [P][N][D], [P][N][D], [P][N]
     double *centre, *axes;              // [P][D], [P][D][D] (lower triangular, scaled)
     long   *n_iter, *n_evals;           // [P]
+    long   *cand_base;                  // [P] candidates drawn so far (index into the pixel's random stream)
     double *lnZ;                        // [P] running evidence of the dead points
     int    *active, *since_fit;         // [P]
     double *deadT, *deadL, *deadlnw;    // [P][cap][D], [P][cap], [P][cap]
@@ -72,10 +73,12 @@ __global__ void ns_sanitize_kernel(double *__restrict__ L, long n, double log_ze
 }
 
 // ---- candidates --------------------------------------------------------------------------
-__global__ void ns_propose_kernel(NsDev S, int n_act, long round) {
+// Kr = candidates per pixel in this round (>= K: grows when few pixels are left, so the tail of
+// slow pixels does not cost one launch per handful of candidates)
+__global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)n_act * S.K) return;
-    const int q = (int)(gid / S.K), k = (int)(gid - (long)q * S.K);
+    if (gid >= (long)n_act * Kr) return;
+    const int q = (int)(gid / Kr), k = (int)(gid - (long)q * Kr);
     const int p = S.actlist[q];
     const int D = S.D;
     double *cu = S.candU + gid * D, *ct = S.candT + gid * D;
@@ -85,7 +88,7 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, long round) {
         S.valid[gid] = 0;
         return;
     }
-    const uint64_t a = (uint64_t)round * (uint64_t)S.K + (uint64_t)k;
+    const uint64_t a = (uint64_t)S.cand_base[p] + (uint64_t)k;
     double z[NS_MAXD];
     double n2 = 0.0;
     for (int m = 0; m < D; m += 2) {    // Box-Muller pairs
@@ -199,12 +202,12 @@ __device__ void ns_refit(const NsDev &S, int p, double *sA, double *sc, int lane
 
 // ---- one wave per pixel: accept / replace / evidence / stop / refit ------------------------
 // q indexes actlist (force_refit: q indexes pixels directly, no candidates: initial ellipsoids)
-__global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int force_refit) {
+__global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int Kr, int force_refit) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= n_act) return;
     const int p = force_refit ? q : S.actlist[q];
-    const int N = S.N, D = S.D, K = S.K;
+    const int N = S.N, D = S.D, K = Kr;
     double *sL = smem;                              // live log-likelihoods of the pixel
     double *sA = sL + ((N + 1) & ~1);               // D*D
     double *sc = sA + D * D;                        // D
@@ -231,7 +234,8 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int f
     double lnZ = S.lnZ[p];
     int since = S.since_fit[p];
     bool done = false;
-    for (int k = 0; k < K && !done; ++k) {
+    // the scan also stops after `upd` replacements: the ellipsoid is refitted before going on
+    for (int k = 0; k < K && !done && since < S.upd; ++k) {
         const long g = (long)q * K + k;
         if (!S.valid[g]) continue;
         evals += 1;
@@ -260,7 +264,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int f
         done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= S.cap;
     }
     if (lane == 0) {
-        S.n_iter[p] = it; S.n_evals[p] = evals; S.lnZ[p] = lnZ;
+        S.n_iter[p] = it; S.n_evals[p] = evals; S.lnZ[p] = lnZ; S.cand_base[p] += Kr;
         if (done) S.active[p] = 0;
     }
     if (!done && since >= S.upd) {
@@ -272,9 +276,11 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int f
 }
 
 // ---- host side -----------------------------------------------------------------------------
+#define NS_KMAX 1024            // most candidates one pixel gets in a round
 struct nfa_sampler {
     nfa_runner *r = nullptr;
     NsDev d = {};
+    long b_target = 0;          // candidates per round the sampler aims for (all pixels together)
     int *d_pixmap = nullptr, *d_actlist = nullptr, *d_livepix = nullptr;
     std::vector<int> h_active, h_act;
     long rounds = 0;
@@ -286,7 +292,7 @@ extern "C" {
 int nfa_sampler_destroy(nfa_sampler *s) {
     if (!s) return NFA_OK;
     NsDev &d = s->d;
-    void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.lnZ, d.active,
+    void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active,
                     d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid,
                     s->d_pixmap, s->d_actlist, s->d_livepix};
     for (void *p : ptrs) (void)hipFree(p);
@@ -297,21 +303,26 @@ int nfa_sampler_destroy(nfa_sampler *s) {
 // Device-resident nested sampling of n_pix pixels of the runner's spectra set in lock-step.
 // pix[n_pix] = cube pixel per run (NULL: 0..n_pix-1 must all be the runner's pixel 0 -> only
 // n_pix = 1 makes sense then).  cap_iter = dead-point slots per pixel (a run stops there).
+// batch_target = candidates per round over all pixels the sampler aims for.
 int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int64_t n_pix, int nlive,
-                       int n_cand, int64_t cap_iter) {
+                       int n_cand, int64_t batch_target, int64_t cap_iter) {
     if (!out || !r) return fail(NFA_ERR_ARG, "null argument");
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     if (n_pix < 1 || n_pix > (1 << 24)) return fail(NFA_ERR_ARG, "n_pix out of range");
     if (nlive < r->ndim + 2 || nlive > 8192) return fail(NFA_ERR_ARG, "nlive must be in ndim+2..8192");
     if (n_cand < 1 || n_cand > 1024) return fail(NFA_ERR_ARG, "n_cand must be in 1..1024");
     if (cap_iter < 1) return fail(NFA_ERR_ARG, "cap_iter must be >= 1");
+    if (batch_target < 1 || batch_target > (1 << 26)) return fail(NFA_ERR_ARG, "batch_target out of range");
     if (r->ndim > NS_MAXD) return fail(NFA_ERR_ARG, "too many dimensions");
     int rc = check_pix(r, pix, n_pix); if (rc) return rc;
     nfa_sampler *s = new nfa_sampler();
     s->r = r;
     NsDev &d = s->d;
     d.P = (int)n_pix; d.N = nlive; d.D = r->ndim; d.K = n_cand; d.cap = (long)cap_iter;
-    const size_t P = (size_t)n_pix, N = (size_t)nlive, D = (size_t)r->ndim, K = (size_t)n_cand, C = (size_t)cap_iter;
+    const size_t P = (size_t)n_pix, N = (size_t)nlive, D = (size_t)r->ndim, C = (size_t)cap_iter;
+    s->b_target = std::max<long>((long)n_pix * n_cand, (long)batch_target);
+    // rows of the candidate buffers: n_act * Kr <= max(b_target, n_act * K) <= b_target
+    const size_t K = ((size_t)s->b_target + P - 1) / P;       // so that P * K >= b_target
     std::vector<int> pm(P);
     for (size_t p = 0; p < P; ++p) pm[p] = pix ? pix[p] : 0;
 #define NS_ALLOC(ptr, type, count) \
@@ -320,7 +331,7 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(s->d_pixmap, int, P); NS_ALLOC(s->d_actlist, int, P); NS_ALLOC(s->d_livepix, int, P * N);
     NS_ALLOC(d.Ulive, double, P * N * D); NS_ALLOC(d.Tlive, double, P * N * D); NS_ALLOC(d.Llive, double, P * N);
     NS_ALLOC(d.centre, double, P * D); NS_ALLOC(d.axes, double, P * D * D);
-    NS_ALLOC(d.n_iter, long, P); NS_ALLOC(d.n_evals, long, P); NS_ALLOC(d.lnZ, double, P);
+    NS_ALLOC(d.n_iter, long, P); NS_ALLOC(d.n_evals, long, P); NS_ALLOC(d.cand_base, long, P); NS_ALLOC(d.lnZ, double, P);
     NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P);
     NS_ALLOC(d.deadT, double, P * C * D); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
     NS_ALLOC(d.candU, double, P * K * D); NS_ALLOC(d.candT, double, P * K * D); NS_ALLOC(d.candL, double, P * K);
@@ -347,6 +358,7 @@ int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_
     d.enl_pow = pow(1.0 / efr, 1.0 / D);
     hipStream_t st = r->lanes[0];
     HIP_TRY(hipMemsetAsync(d.n_iter, 0, sizeof(long) * P, st));
+    HIP_TRY(hipMemsetAsync(d.cand_base, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.since_fit, 0, sizeof(int) * P, st));
     {   // live points
         const long tot = (long)P * N * D;
@@ -367,7 +379,7 @@ int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_
     const size_t lds = sizeof(double) * ((size_t)((N + 1) & ~1) + (size_t)D * D + (size_t)D);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), lds, st, d, P, 1);   // first ellipsoids
+    hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), lds, st, d, P, 0, 1);   // first ellipsoids
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     s->rounds = 0;
@@ -379,13 +391,15 @@ int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_
     // loop by a generous multiple so that a stuck run cannot spin forever
     const long max_rounds = 200 * (std::min<long>((long)maxiter, d.cap) + 1000);
     while (n_act > 0 && s->rounds < max_rounds) {
+        // candidates per pixel: the round's batch stays near b_target however few pixels are left
+        const int Kr = (int)std::min<long>(NS_KMAX, std::max<long>(K, s->b_target / n_act));
         for (int c = 0; c < check_every; ++c) {
-            const long B = (long)n_act * K;
-            hipLaunchKernelGGL(ns_propose_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, d, n_act, s->rounds);
+            const long B = (long)n_act * Kr;
+            hipLaunchKernelGGL(ns_propose_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, d, n_act, Kr);
             HIP_TRY(hipGetLastError());
             int rc = run_batch(r, d.candpix, d.candT, d.candL, nullptr, B, true, 0, nullptr);
             if (rc) return rc;
-            hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_act), dim3(64), lds, st, d, n_act, 0);
+            hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_act), dim3(64), lds, st, d, n_act, Kr, 0);
             HIP_TRY(hipGetLastError());
             s->rounds += 1;
         }

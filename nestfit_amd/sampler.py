@@ -72,11 +72,12 @@ def _uniform(seed, p, a, b):
     return ((h >> _U64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
 
 
-def _candidates(seed, pix, rnd, K, centre, axes):
-    """K candidates per pixel of `pix`, uniform in the bounding ellipsoids (ns_propose_kernel)."""
+def _candidates(seed, pix, base, K, centre, axes):
+    """K candidates per pixel of `pix`, uniform in the bounding ellipsoids (ns_propose_kernel);
+    base[n] = how many candidates each pixel has drawn before."""
     n, D = len(pix), centre.shape[1]
     p = np.asarray(pix, dtype=_U64)[:, None, None]
-    a = (_U64(rnd) * _U64(K) + np.arange(K, dtype=_U64))[None, :, None]
+    a = (np.asarray(base, dtype=_U64)[:, None] + np.arange(K, dtype=_U64)[None, :])[:, :, None]
     z = np.empty((n, K, D))
     for m in range(0, D, 2):
         u1 = _uniform(seed, p, a, _U64(m))[..., 0]
@@ -140,7 +141,7 @@ def _resolve_seed(seed):
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
-               progress=None):
+               check_every=8, batch_target=65536, progress=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -152,9 +153,14 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     nlive, tol, efr, seed, maxiter : as in ``run_multinest`` (core.pyx:727-744): live points,
         evidence tolerance, target sampling efficiency (sets the ellipsoid enlargement 1/efr in
         volume), RNG seed (-1 = from the OS), iteration cap per pixel.
-    n_cand : candidates per pixel and round (default ceil(2 / efr)); they are scanned in order
-        and every one above the pixel's current threshold replaces its worst live point.
-    upd_frac : the ellipsoids are refitted after this fraction of nlive replacements.
+    n_cand : candidates per pixel and round (default ceil(2 / efr)), at least: every
+        `check_every` rounds the number is raised so that the round's batch stays near
+        max(n_pix * n_cand, batch_target) however few pixels are still running (at most 1024 per
+        pixel).
+        They are scanned in order and every one above the pixel's current threshold replaces its
+        worst live point.
+    upd_frac : the ellipsoids are refitted after this fraction of nlive replacements (the scan
+        of a round stops there).
     cap_iter : dead-point slots per pixel (default: no other cap than maxiter).
 
     Returns a list of `NestedResult`, one per pixel.
@@ -188,22 +194,31 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     centre, axes = _fit_ellipsoids(Ulive, 1.0 / efr)
     dead_T, dead_L, dead_lnw, dead_pix = [], [], [], []
     rnd = 0
+    b_target = max(P * K, int(batch_target))
+    cand_base = np.zeros(P, dtype=np.int64)
+    Kr = K
     while active.any():
+        if rnd % check_every == 0:                              # the device compacts its pixel list here
+            Kr = int(min(1024, max(K, b_target // int(active.sum()))))
         idx = np.flatnonzero(active)
         n = idx.size
-        cand = _candidates(seed, idx, rnd, K, centre[idx], axes[idx])
+        cand = _candidates(seed, idx, cand_base[idx], Kr, centre[idx], axes[idx])
+        cand_base[idx] += Kr
         valid = np.all((cand >= 0.0) & (cand < 1.0), axis=2)    # outside the unit cube = outside the prior
         flat = np.flatnonzero(valid.ravel())
-        Lc = np.full(n * K, -np.inf)
-        Tc = cand.reshape(n * K, ndim).copy()
+        Lc = np.full(n * Kr, -np.inf)
+        Tc = cand.reshape(n * Kr, ndim).copy()
         if flat.size:
             Tsub = Tc[flat]
-            Lc[flat] = evaluate(np.repeat(idx, K).astype(np.int32)[flat], Tsub)
+            Lc[flat] = evaluate(np.repeat(idx, Kr).astype(np.int32)[flat], Tsub)
             Tc[flat] = Tsub
-        Lc = Lc.reshape(n, K)
-        Tc = Tc.reshape(n, K, ndim)
-        going = np.ones(n, dtype=bool)                          # not finished within this round
-        for k in range(K):                                      # the wave's sequential scan
+        Lc = Lc.reshape(n, Kr)
+        Tc = Tc.reshape(n, Kr, ndim)
+        going = np.ones(n, dtype=bool)                          # still scanning in this round
+        for k in range(Kr):                                     # the wave's sequential scan
+            going &= since_fit[idx] < upd                       # refit first, then go on
+            if not going.any():
+                break
             sel = going & valid[:, k]
             n_evals[idx[sel]] += 1
             worst = np.argmin(Llive[idx], axis=1)
@@ -227,7 +242,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             done = (np.logaddexp(lnZ[p], remain) - lnZ[p] < tol) | (n_iter[p] >= maxiter) | (n_iter[p] >= cap)
             active[p[done]] = False
             going[acc[done]] = False
-        refit = idx[going & (since_fit[idx] >= upd)]
+        refit = idx[active[idx] & (since_fit[idx] >= upd)]
         if refit.size:
             centre[refit], axes[refit] = _fit_ellipsoids(Ulive[refit], 1.0 / efr)
             since_fit[refit] = 0
@@ -250,7 +265,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
 
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
-                      upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8):
+                      upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=65536):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
     work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive)."""
@@ -265,7 +280,7 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
     cap = int(cap_iter) if cap_iter else int(max(1, min(maxiter, 60 * nlive)))
     h = C.c_void_p()
     _ffi.check(lib.nfa_sampler_create(C.byref(h), runner._run.handle, pix.ctypes.data_as(_ffi._ip), P,
-                                      int(nlive), K, cap))
+                                      int(nlive), K, int(batch_target), cap))
     try:
         _ffi.check(lib.nfa_sampler_run(h, float(tol), float(efr), seed, int(maxiter),
                                        max(1, int(upd_frac * nlive)), float(log_zero), int(check_every)))
