@@ -46,6 +46,8 @@ struct NsDev {
     long   *cand_base;                  // [P] candidates drawn so far (index into the pixel's random stream)
     double *lnZ;                        // [P] running evidence of the dead points
     int    *active, *since_fit;         // [P]
+    int    *use_cube;                   // [P] 1: the ellipsoid is larger than the unit cube, draw from the cube
+    double  ln_vball;                   // ln volume of the unit D-ball
     double *deadT, *deadL, *deadlnw;    // [P][cap][D], [P][cap], [P][cap]
     double *candU, *candT, *candL;      // [P*K][D], [P*K][D], [P*K]
     int    *candpix, *valid;            // [P*K]
@@ -89,6 +91,11 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
         return;
     }
     const uint64_t a = (uint64_t)S.cand_base[p] + (uint64_t)k;
+    if (S.use_cube[p]) {                // early on the bounding ellipsoid is no better than the prior itself
+        for (int j = 0; j < D; ++j) { const double u = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)j); cu[j] = u; ct[j] = u; }
+        S.valid[gid] = 1;
+        return;
+    }
     double z[NS_MAXD];
     double n2 = 0.0;
     for (int m = 0; m < D; m += 2) {    // Box-Muller pairs
@@ -191,6 +198,11 @@ __device__ void ns_refit(const NsDev &S, int p, double *sA, double *sc, int lane
     }
     r2 = ns_wave_max(r2);
     const double scale = sqrt(r2) * S.enl_pow;
+    if (lane == 0) {                    // ln volume of the ellipsoid against ln 1 of the unit cube
+        double lnv = S.ln_vball + D * log(scale);
+        for (int a = 0; a < D; ++a) lnv += log(sA[a * D + a]);
+        S.use_cube[p] = lnv >= 0.0 ? 1 : 0;
+    }
     double *A = S.axes + (long)p * D * D, *c = S.centre + (long)p * D;
     for (int e = lane; e < D * D; e += 64) {
         const int a = e / D, b = e - a * D;
@@ -234,8 +246,9 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     double lnZ = S.lnZ[p];
     int since = S.since_fit[p];
     bool done = false;
-    // the scan also stops after `upd` replacements: the ellipsoid is refitted before going on
-    for (int k = 0; k < K && !done && since < S.upd; ++k) {
+    // every candidate of the round is used: within a round the bound only goes stale by the
+    // factor exp(-replacements / N) in volume, far cheaper than throwing evaluated points away
+    for (int k = 0; k < K && !done; ++k) {
         const long g = (long)q * K + k;
         if (!S.valid[g]) continue;
         evals += 1;
@@ -284,6 +297,8 @@ struct nfa_sampler {
     int *d_pixmap = nullptr, *d_actlist = nullptr, *d_livepix = nullptr;
     std::vector<int> h_active, h_act;
     long rounds = 0;
+    int  n_act = 0, check_every = 8;
+    size_t lds = 0;
     bool ran = false;
 };
 
@@ -292,7 +307,7 @@ extern "C" {
 int nfa_sampler_destroy(nfa_sampler *s) {
     if (!s) return NFA_OK;
     NsDev &d = s->d;
-    void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active,
+    void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
                     d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid,
                     s->d_pixmap, s->d_actlist, s->d_livepix};
     for (void *p : ptrs) (void)hipFree(p);
@@ -332,7 +347,7 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.Ulive, double, P * N * D); NS_ALLOC(d.Tlive, double, P * N * D); NS_ALLOC(d.Llive, double, P * N);
     NS_ALLOC(d.centre, double, P * D); NS_ALLOC(d.axes, double, P * D * D);
     NS_ALLOC(d.n_iter, long, P); NS_ALLOC(d.n_evals, long, P); NS_ALLOC(d.cand_base, long, P); NS_ALLOC(d.lnZ, double, P);
-    NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P);
+    NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P); NS_ALLOC(d.use_cube, int, P);
     NS_ALLOC(d.deadT, double, P * C * D); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
     NS_ALLOC(d.candU, double, P * K * D); NS_ALLOC(d.candT, double, P * K * D); NS_ALLOC(d.candL, double, P * K);
     NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K);
@@ -345,17 +360,23 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
 
 // tol, efr, seed, maxiter as run_multinest (core.pyx:727-744); upd = replacements between
 // ellipsoid refits; check_every = rounds between two looks at the set of active pixels.
-int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
-                    double log_zero, int check_every) {
+// nfa_sampler_begin draws and evaluates the live points and fits the first ellipsoids;
+// nfa_sampler_advance runs up to max_chunks groups of check_every rounds (0 = until every pixel
+// has stopped) and reports how many pixels are still running, so the caller can show progress
+// or give up; nfa_sampler_run = begin + advance to the end.
+int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
+                      double log_zero, int check_every) {
     if (!s) return fail(NFA_ERR_ARG, "null sampler");
     if (!(tol > 0) || !(efr > 0 && efr <= 1) || maxiter < 0 || upd < 1 || check_every < 1)
         return fail(NFA_ERR_ARG, "bad sampler options");
     nfa_runner *r = s->r;
     NsDev &d = s->d;
-    const int P = d.P, N = d.N, D = d.D, K = d.K;
+    const int P = d.P, N = d.N, D = d.D;
     d.tol = tol; d.maxiter = (long)maxiter; d.upd = upd; d.seed = (uint64_t)seed; d.log_zero = log_zero;
     d.ln_shrink = log1p(-exp(-1.0 / N));
     d.enl_pow = pow(1.0 / efr, 1.0 / D);
+    d.ln_vball = 0.5 * D * log(M_PI) - lgamma(0.5 * D + 1.0);
+    s->check_every = check_every;
     hipStream_t st = r->lanes[0];
     HIP_TRY(hipMemsetAsync(d.n_iter, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.cand_base, 0, sizeof(long) * P, st));
@@ -376,42 +397,58 @@ int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_
     HIP_TRY(hipMemcpyAsync(d.n_evals, h_evals.data(), sizeof(long) * P, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d.lnZ, h_lnz.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d.active, s->h_active.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
-    const size_t lds = sizeof(double) * ((size_t)((N + 1) & ~1) + (size_t)D * D + (size_t)D);
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), lds, st, d, P, 0, 1);   // first ellipsoids
+    s->lds = sizeof(double) * ((size_t)((N + 1) & ~1) + (size_t)D * D + (size_t)D);
+    if (s->lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));
+    hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), s->lds, st, d, P, 0, 1);   // first ellipsoids
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     s->rounds = 0;
-    int n_act = maxiter > 0 ? P : 0;
+    s->n_act = maxiter > 0 ? P : 0;
     s->h_act.resize((size_t)P);
     for (int p = 0; p < P; ++p) s->h_act[p] = p;
-    if (n_act) HIP_TRY(hipMemcpy(s->d_actlist, s->h_act.data(), sizeof(int) * P, hipMemcpyHostToDevice));
-    // every pixel needs at most maxiter accepted rounds, but a round may accept nothing: bound the
-    // loop by a generous multiple so that a stuck run cannot spin forever
-    const long max_rounds = 200 * (std::min<long>((long)maxiter, d.cap) + 1000);
-    while (n_act > 0 && s->rounds < max_rounds) {
+    if (s->n_act) HIP_TRY(hipMemcpy(s->d_actlist, s->h_act.data(), sizeof(int) * P, hipMemcpyHostToDevice));
+    s->ran = true;
+    return NFA_OK;
+}
+
+int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_out) {
+    if (!s || !s->ran) return fail(NFA_ERR_STATE, "nfa_sampler_begin has not been called");
+    nfa_runner *r = s->r;
+    NsDev &d = s->d;
+    const int P = d.P, K = d.K;
+    hipStream_t st = r->lanes[0];
+    for (int64_t chunk = 0; s->n_act > 0 && (max_chunks <= 0 || chunk < max_chunks); ++chunk) {
         // candidates per pixel: the round's batch stays near b_target however few pixels are left
+        const int n_act = s->n_act;
         const int Kr = (int)std::min<long>(NS_KMAX, std::max<long>(K, s->b_target / n_act));
-        for (int c = 0; c < check_every; ++c) {
+        for (int c = 0; c < s->check_every; ++c) {
             const long B = (long)n_act * Kr;
             hipLaunchKernelGGL(ns_propose_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, d, n_act, Kr);
             HIP_TRY(hipGetLastError());
             int rc = run_batch(r, d.candpix, d.candT, d.candL, nullptr, B, true, 0, nullptr);
             if (rc) return rc;
-            hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_act), dim3(64), lds, st, d, n_act, Kr, 0);
+            hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_act), dim3(64), s->lds, st, d, n_act, Kr, 0);
             HIP_TRY(hipGetLastError());
             s->rounds += 1;
         }
         HIP_TRY(hipMemcpyAsync(s->h_active.data(), d.active, sizeof(int) * P, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        n_act = 0;
-        for (int p = 0; p < P; ++p) if (s->h_active[p]) s->h_act[n_act++] = p;
-        if (n_act) HIP_TRY(hipMemcpyAsync(s->d_actlist, s->h_act.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, st));
+        s->n_act = 0;
+        for (int p = 0; p < P; ++p) if (s->h_active[p]) s->h_act[s->n_act++] = p;
+        if (s->n_act)
+            HIP_TRY(hipMemcpyAsync(s->d_actlist, s->h_act.data(), sizeof(int) * s->n_act, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
-    s->ran = true;
-    return n_act == 0 ? NFA_OK : fail(NFA_ERR_STATE, "sampler stopped at the round limit with active pixels");
+    if (n_active_out) *n_active_out = s->n_act;
+    return NFA_OK;
+}
+
+int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
+                    double log_zero, int check_every) {
+    int rc = nfa_sampler_begin(s, tol, efr, seed, maxiter, upd, log_zero, check_every);
+    if (rc) return rc;
+    return nfa_sampler_advance(s, 0, nullptr);
 }
 
 // n_iter[P], n_evals[P], rounds (scalar)

@@ -20,6 +20,8 @@ This is not MultiNest: the random streams differ and there is no multi-ellipsoid
 so evidences agree with a MultiNest run only within their sampling error.  What can be checked
 bit-for-bit is the likelihood it is fed (tests drive the same sampler with the CPU oracle).
 """
+import math
+
 import numpy as np
 
 LOG_ZERO = -1e100
@@ -72,8 +74,9 @@ def _uniform(seed, p, a, b):
     return ((h >> _U64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
 
 
-def _candidates(seed, pix, base, K, centre, axes):
-    """K candidates per pixel of `pix`, uniform in the bounding ellipsoids (ns_propose_kernel);
+def _candidates(seed, pix, base, K, centre, axes, use_cube):
+    """K candidates per pixel of `pix`, uniform in the bounding ellipsoids, or in the unit cube
+    where `use_cube` says the ellipsoid is the larger of the two (ns_propose_kernel);
     base[n] = how many candidates each pixel has drawn before."""
     n, D = len(pix), centre.shape[1]
     p = np.asarray(pix, dtype=_U64)[:, None, None]
@@ -90,6 +93,9 @@ def _candidates(seed, pix, base, K, centre, axes):
     ur = _uniform(seed, p, a, _B_RADIUS)[..., 0]
     f = np.exp(np.log(ur) / D) / np.sqrt((z * z).sum(axis=2))
     cand = centre[:, None, :] + np.einsum('pji,pki->pkj', axes, z * f[:, :, None])
+    if use_cube.any():
+        cube = _uniform(seed, p, a, np.arange(D, dtype=_U64)[None, None, :])
+        cand[use_cube] = cube[use_cube]
     return cand
 
 
@@ -106,7 +112,11 @@ def _fit_ellipsoids(U, enlarge):
     y = np.linalg.solve(L, d.transpose(0, 2, 1))               # (P, ndim, nlive)
     r2 = np.max(np.sum(y * y, axis=1), axis=1)                 # largest Mahalanobis distance^2
     scale = np.sqrt(r2) * enlarge ** (1.0 / ndim)
-    return c, L * scale[:, None, None]
+    A = L * scale[:, None, None]
+    # ln volume against ln 1 of the unit cube: a larger ellipsoid is no better than the prior itself
+    lnv = (0.5 * ndim * np.log(np.pi) - math.lgamma(0.5 * ndim + 1.0) + ndim * np.log(scale)
+           + np.log(np.diagonal(L, axis1=1, axis2=2)).sum(axis=1))
+    return c, A, lnv >= 0.0
 
 
 def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive):
@@ -159,8 +169,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         pixel).
         They are scanned in order and every one above the pixel's current threshold replaces its
         worst live point.
-    upd_frac : the ellipsoids are refitted after this fraction of nlive replacements (the scan
-        of a round stops there).
+    upd_frac : the ellipsoids are refitted at the end of a round once this fraction of nlive
+        replacements has accumulated.
     cap_iter : dead-point slots per pixel (default: no other cap than maxiter).
 
     Returns a list of `NestedResult`, one per pixel.
@@ -191,7 +201,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     active = np.full(P, maxiter > 0)
     since_fit = np.zeros(P, dtype=np.int64)
     upd = max(1, int(upd_frac * nlive))
-    centre, axes = _fit_ellipsoids(Ulive, 1.0 / efr)
+    centre, axes, use_cube = _fit_ellipsoids(Ulive, 1.0 / efr)
     dead_T, dead_L, dead_lnw, dead_pix = [], [], [], []
     rnd = 0
     b_target = max(P * K, int(batch_target))
@@ -202,7 +212,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             Kr = int(min(1024, max(K, b_target // int(active.sum()))))
         idx = np.flatnonzero(active)
         n = idx.size
-        cand = _candidates(seed, idx, cand_base[idx], Kr, centre[idx], axes[idx])
+        cand = _candidates(seed, idx, cand_base[idx], Kr, centre[idx], axes[idx], use_cube[idx])
         cand_base[idx] += Kr
         valid = np.all((cand >= 0.0) & (cand < 1.0), axis=2)    # outside the unit cube = outside the prior
         flat = np.flatnonzero(valid.ravel())
@@ -216,7 +226,6 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         Tc = Tc.reshape(n, Kr, ndim)
         going = np.ones(n, dtype=bool)                          # still scanning in this round
         for k in range(Kr):                                     # the wave's sequential scan
-            going &= since_fit[idx] < upd                       # refit first, then go on
             if not going.any():
                 break
             sel = going & valid[:, k]
@@ -244,7 +253,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             going[acc[done]] = False
         refit = idx[active[idx] & (since_fit[idx] >= upd)]
         if refit.size:
-            centre[refit], axes[refit] = _fit_ellipsoids(Ulive[refit], 1.0 / efr)
+            centre[refit], axes[refit], use_cube[refit] = _fit_ellipsoids(Ulive[refit], 1.0 / efr)
             since_fit[refit] = 0
         rnd += 1
         if progress is not None:
@@ -265,10 +274,14 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
 
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
-                      upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=65536):
+                      upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=65536,
+                      progress=None, time_limit=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
-    work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive)."""
+    work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive).  `progress`
+    (callable(n_active, rounds)) is called about once a second; after `time_limit` seconds the
+    pixels still running are stopped where they are (their results are then lower bounds)."""
+    import time
     import ctypes as C
     from . import _ffi
     lib = _ffi.engine()
@@ -282,8 +295,22 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
     _ffi.check(lib.nfa_sampler_create(C.byref(h), runner._run.handle, pix.ctypes.data_as(_ffi._ip), P,
                                       int(nlive), K, int(batch_target), cap))
     try:
-        _ffi.check(lib.nfa_sampler_run(h, float(tol), float(efr), seed, int(maxiter),
-                                       max(1, int(upd_frac * nlive)), float(log_zero), int(check_every)))
+        _ffi.check(lib.nfa_sampler_begin(h, float(tol), float(efr), seed, int(maxiter),
+                                         max(1, int(upd_frac * nlive)), float(log_zero), int(check_every)))
+        n_active = C.c_int64(P)
+        t0 = time.perf_counter()
+        chunks = 16
+        while True:
+            t1 = time.perf_counter()
+            _ffi.check(lib.nfa_sampler_advance(h, chunks, C.byref(n_active)))
+            if n_active.value == 0:
+                break
+            dt = time.perf_counter() - t1
+            chunks = int(min(4096, max(1, chunks * (1.0 / max(dt, 1e-3)))))     # about a second per call
+            if progress is not None:
+                progress(int(n_active.value), None)
+            if time_limit is not None and time.perf_counter() - t0 > time_limit:
+                break
         n_iter = np.empty(P, dtype=np.int64)
         n_evals = np.empty(P, dtype=np.int64)
         rounds = C.c_int64()

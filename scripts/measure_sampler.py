@@ -52,7 +52,10 @@ def main():
         res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=nlive, tol=0.5, efr=0.3, seed=1, device=False,
                                  progress=progress)
     else:
-        res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=nlive, tol=0.5, efr=0.3, seed=1)
+        res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=nlive, tol=0.5, efr=0.3, seed=1,
+                                 progress=lambda n_active, it: print(f'  ... {n_active} pixels active, '
+                                                                     f'{time.perf_counter() - t0:.0f} s', flush=True),
+                                 time_limit=float(sys.argv[6]) if len(sys.argv) > 6 else None)
     dt = time.perf_counter() - t0
     evals = sum(r.n_evals for r in res)
     iters = np.array([r.n_iter for r in res])
