@@ -1,0 +1,347 @@
+"""Cube ingestion without astropy / spectral_cube: a minimal FITS reader and the
+reference's ``NoiseMap`` / ``NoiseMapUniform`` / ``DataCube`` / ``CubeStack`` (reference:
+nestfit/main.py:39-223) on top of it, plus the step the GPU adds: all NaN-free pixels of a stack
+as ONE device-resident spectra set (``CubeStack.to_device``) instead of a host-to-device copy per
+pixel (nestfit/main.py:437-441, 456).
+
+Supported FITS subset (enough for the reference's own test cubes, nestfit/test/data/*.fits, and
+for what CASA / spectral_cube write): primary HDU image, BITPIX 8/16/32/64/-32/-64 with
+BSCALE/BZERO, 3 axes (or 4 with a degenerate Stokes axis), brightness unit K, spectral axis
+VRAD / VELO (radio convention) in m/s or km/s, or FREQ in Hz..GHz, with RESTFRQ / RESTFREQ.
+"""
+from collections.abc import Iterable
+
+import numpy as np
+
+CKMS = 299792.458
+_BLOCK = 2880
+_DTYPES = {8: '>u1', 16: '>i2', 32: '>i4', 64: '>i8', -32: '>f4', -64: '>f8'}
+
+
+def _parse_value(txt):
+    txt = txt.strip()
+    if not txt:
+        return None
+    if txt.startswith("'"):
+        end = 1
+        out = []
+        while end < len(txt):                       # '' inside a string is an escaped quote
+            if txt[end] == "'":
+                if end + 1 < len(txt) and txt[end + 1] == "'":
+                    out.append("'")
+                    end += 2
+                    continue
+                break
+            out.append(txt[end])
+            end += 1
+        return ''.join(out).rstrip()
+    val = txt.split('/', 1)[0].strip()
+    if val in ('T', 'F'):
+        return val == 'T'
+    try:
+        return int(val)
+    except ValueError:
+        pass
+    try:
+        return float(val.replace('D', 'E'))
+    except ValueError:
+        return val
+
+
+def read_fits(path):
+    """(header dict in card order, data array in FITS axis order [NAXISn, ..., NAXIS1]) of the
+    primary HDU.  COMMENT / HISTORY / CONTINUE cards are skipped."""
+    with open(path, 'rb') as f:
+        raw = f.read()
+    header = {}
+    pos = 0
+    done = False
+    while not done:
+        block = raw[pos:pos + _BLOCK]
+        if len(block) < _BLOCK:
+            raise ValueError(f'{path}: truncated FITS header')
+        pos += _BLOCK
+        for i in range(0, _BLOCK, 80):
+            card = block[i:i + 80].decode('ascii', 'replace')
+            key = card[:8].strip()
+            if key == 'END':
+                done = True
+                break
+            if not key or key in ('COMMENT', 'HISTORY', 'CONTINUE') or card[8:10] != '= ':
+                continue
+            header[key] = _parse_value(card[10:])
+    if not header.get('SIMPLE', False):
+        raise ValueError(f'{path}: not a standard FITS file')
+    naxis = int(header.get('NAXIS', 0))
+    shape = [int(header[f'NAXIS{k}']) for k in range(naxis, 0, -1)]
+    bitpix = int(header['BITPIX'])
+    if bitpix not in _DTYPES:
+        raise ValueError(f'{path}: unsupported BITPIX {bitpix}')
+    count = int(np.prod(shape)) if shape else 0
+    data = np.frombuffer(raw, dtype=_DTYPES[bitpix], count=count, offset=pos).reshape(shape)
+    data = data.astype(np.float64)
+    bscale, bzero = header.get('BSCALE', 1.0), header.get('BZERO', 0.0)
+    if bscale != 1.0 or bzero != 0.0:
+        data = data * float(bscale) + float(bzero)
+    return header, data
+
+
+class SimpleCube:
+    """The slice of ``spectral_cube.SpectralCube`` that ``DataCube`` needs: header, data in
+    (spectral, lat, lon) order, brightness unit, spectral axis in Hz and in km/s (radio)."""
+
+    def __init__(self, header, data):
+        data = np.asarray(data, dtype=np.float64)
+        while data.ndim > 3 and data.shape[0] == 1:        # degenerate Stokes axis
+            data = data[0]
+        if data.ndim != 3:
+            raise ValueError(f'Cannot parse shape : {data.shape}')
+        self.header = dict(header)
+        self._data = data
+        self.unit = str(header.get('BUNIT', '')).strip()
+        ctype = str(header.get('CTYPE3', '')).strip().upper()
+        n = data.shape[0]
+        crval, cdelt, crpix = float(header['CRVAL3']), float(header['CDELT3']), float(header.get('CRPIX3', 1.0))
+        world = crval + (np.arange(n) + 1.0 - crpix) * cdelt
+        cunit = str(header.get('CUNIT3', '')).strip().lower()
+        self.rest_freq = header.get('RESTFRQ', header.get('RESTFREQ'))
+        if ctype.startswith('FREQ'):
+            scale = {'hz': 1.0, 'khz': 1e3, 'mhz': 1e6, 'ghz': 1e9, '': 1.0}[cunit]
+            self._freq = world * scale
+        elif ctype.startswith('VRAD') or ctype.startswith('VELO'):
+            if ctype.startswith('VELO') and int(header.get('VELREF', 257)) < 256:
+                raise ValueError('optical-convention velocity axes are not supported')
+            if self.rest_freq is None:
+                raise ValueError('a velocity axis needs RESTFRQ')
+            scale = {'m s-1': 1e-3, 'm/s': 1e-3, 'km s-1': 1.0, 'km/s': 1.0, '': 1e-3}[cunit]
+            self._freq = float(self.rest_freq) * (1.0 - world * scale / CKMS)     # radio convention
+        else:
+            raise ValueError(f'unsupported spectral axis type {ctype!r}')
+
+    @classmethod
+    def read(cls, path):
+        return cls(*read_fits(str(path)))
+
+    @property
+    def shape(self):
+        return self._data.shape
+
+    def __getitem__(self, key):
+        """Spectral slicing only (``cube[:-1]``, ``cube[::-1]``)."""
+        if not isinstance(key, slice):
+            raise TypeError('only slices along the spectral axis are supported')
+        new = object.__new__(SimpleCube)
+        new.header, new.unit, new.rest_freq = dict(self.header), self.unit, self.rest_freq
+        new._data = self._data[key]
+        new._freq = self._freq[key]
+        return new
+
+    def spectral_axis_hz(self):
+        return self._freq.copy()
+
+    def spectral_axis_kms(self):
+        if self.rest_freq is None:
+            raise ValueError('a velocity axis needs RESTFRQ')
+        return CKMS * (1.0 - self._freq / float(self.rest_freq))
+
+
+class NoiseMap:
+    def __init__(self, data):
+        # NOTE The axes in the data cube are transposed, so these need to be as well
+        self.data = np.asarray(data).transpose()
+        self.shape = self.data.shape
+
+    @classmethod
+    def from_pbimg(cls, rms, pb_img):
+        pb_img = np.asarray(pb_img, dtype=np.float64)
+        shape = pb_img.shape
+        naxes = len(shape)
+        if naxes == 4:
+            pb_img = pb_img[0, 0]
+        elif naxes == 3:
+            pb_img = pb_img[0]
+        elif naxes == 2:
+            pass
+        else:
+            raise ValueError(f'Cannot parse shape : {shape}')
+        # A typical primary beam image will be masked with NaNs, so replace them in the noise map
+        # with Inf values.
+        with np.errstate(divide='ignore', invalid='ignore'):
+            img = rms / pb_img
+        img[~np.isfinite(img)] = np.inf
+        return cls(img)
+
+    def get_noise(self, i_lon, i_lat):
+        return self.data[i_lon, i_lat]
+
+
+class NoiseMapUniform:
+    def __init__(self, rms):
+        self.rms = rms
+        self.shape = None
+
+    def get_noise(self, i_lon, i_lat):
+        return self.rms
+
+
+class DataCube:
+    """Reference: nestfit/main.py:77-172.  `cube` is a `SimpleCube` (or anything with the same
+    attributes)."""
+
+    def __init__(self, cube, noise_map, trans_id=None):
+        if isinstance(noise_map, (float, int)):
+            self.noise_map = NoiseMapUniform(noise_map)
+        else:
+            self.noise_map = noise_map
+        self.trans_id = trans_id
+        self._header = dict(cube.header)
+        self.dv = self.get_chan_width(cube)
+        self.data, self.xarr = self.data_from_cube(cube)
+        self.varr = self.velo_axis_from_cube(cube)
+        self.shape = self.data.shape
+        # NOTE data is transposed so (s, b, l) -> (l, b, s)
+        self.spatial_shape = (self.shape[0], self.shape[1])
+        self.nchan = self.shape[2]
+        if self.noise_map.shape is not None:
+            assert self.spatial_shape == self.noise_map.shape
+
+    @property
+    def full_header(self):
+        return self._header
+
+    @property
+    def simple_header(self):
+        keys = (
+            'SIMPLE', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'WCSAXES', 'CRPIX1', 'CRPIX2', 'CDELT1',
+            'CDELT2', 'CUNIT1', 'CUNIT2', 'CTYPE1', 'CTYPE2', 'CRVAL1', 'CRVAL2', 'RADESYS', 'EQUINOX',
+        )
+        hdict = {}
+        for k in keys:
+            try:
+                hdict[k] = self._header[k]
+            except KeyError:
+                continue
+        hdict['NAXIS'] = 2
+        hdict['WCSAXES'] = 2
+        coord_sys = ('ra', 'dec', 'lon', 'lat')
+        # CTYPE's of form "RA---SIN"
+        assert hdict['CTYPE1'].split('-')[0].lower() in coord_sys
+        assert hdict['CTYPE2'].split('-')[0].lower() in coord_sys
+        return hdict
+
+    def get_chan_width(self, cube):
+        axis = cube.spectral_axis_kms()
+        return abs(axis[1] - axis[0])
+
+    def data_from_cube(self, cube):
+        # intensity units must be Kelvin (the reference converts with the beam; no beam maths here)
+        if cube.unit == '':
+            print('-- Assuming cube intensity units of K')
+        elif cube.unit != 'K':
+            raise ValueError(f'cube intensity unit {cube.unit!r}: only K is supported')
+        axis = cube.spectral_axis_hz()
+        nu_chan = axis[1] - axis[0]
+        # ensure that the frequency axis is in ascending order
+        if nu_chan < 0:
+            cube = cube[::-1]
+            axis = cube.spectral_axis_hz()
+        # data is transposed such that the frequency axis is contiguous (now the last or
+        # right-most in of the indices)
+        data = cube._data.transpose().copy()
+        return data, axis
+
+    def velo_axis_from_cube(self, cube):
+        varr = cube.spectral_axis_kms()
+        # xarr is ascending in Hz, so the matching velocity axis must be descending
+        if varr[1] > varr[0]:
+            return varr[::-1].copy()
+        return varr.copy()
+
+    def get_spec_data(self, i_lon, i_lat):
+        arr = self.data[i_lon, i_lat, :]  # axes reversed from typical cube
+        noise = self.noise_map.get_noise(i_lon, i_lat)
+        has_nans = np.isnan(arr).any() or np.isnan(noise)
+        return self.xarr, arr, noise, self.trans_id, has_nans
+
+
+class CubeStack:
+    """Reference: nestfit/main.py:175-223."""
+
+    def __init__(self, cubes):
+        assert isinstance(cubes, Iterable)
+        self.cubes = cubes
+        self.n_cubes = len(cubes)
+
+    def __iter__(self):
+        for cube in self.cubes:
+            yield cube
+
+    @property
+    def full_header(self):
+        return self.cubes[0].full_header
+
+    @property
+    def simple_header(self):
+        return self.cubes[0].simple_header
+
+    @property
+    def shape(self):
+        return self.cubes[0].shape
+
+    @property
+    def spatial_shape(self):
+        return self.cubes[0].spatial_shape
+
+    def get_arrays(self, i_lon, i_lat):
+        arrays = []
+        for dcube in self.cubes:
+            xarr, arr, *_ = dcube.get_spec_data(i_lon, i_lat)
+            arrays.append(arr)
+        return arrays
+
+    def get_spec_data(self, i_lon, i_lat):
+        all_spec_data = []
+        any_nans = False
+        for dcube in self.cubes:
+            *spec_data, has_nans = dcube.get_spec_data(i_lon, i_lat)
+            all_spec_data.append(spec_data)
+            any_nans |= has_nans
+        return all_spec_data, any_nans
+
+    def get_max_snr(self, i_lon, i_lat):
+        max_snr = 0.0
+        for dcube in self.cubes:
+            _, arr, noise, _, _ = dcube.get_spec_data(i_lon, i_lat)
+            spec_snr = np.max(arr) / noise
+            max_snr = spec_snr if spec_snr > max_snr else max_snr
+        return max_snr
+
+    # ---- what the GPU adds ----------------------------------------------------------------
+    def good_pixels(self, lon=None, lat=None):
+        """(i_lon, i_lat) of the pixels without NaNs in any cube or noise value: the ones the
+        reference's fit loop does not skip (main.py:438-441).  `lon`, `lat` restrict the search to
+        given index arrays (e.g. one rank's stripe)."""
+        if lon is None:
+            lon, lat = (a.ravel() for a in np.indices(self.spatial_shape))
+        lon, lat = np.asarray(lon), np.asarray(lat)
+        bad = np.zeros(lon.shape, dtype=bool)
+        for dcube in self.cubes:
+            bad |= np.isnan(dcube.data[lon, lat, :]).any(axis=1)
+            nm = dcube.noise_map
+            noise = np.full(lon.shape, nm.rms, dtype=np.float64) if nm.shape is None else nm.data[lon, lat]
+            bad |= ~(noise > 0) | ~np.isfinite(noise)
+        return lon[~bad], lat[~bad]
+
+    def to_device(self, utrans, ncomp=1, lon=None, lat=None, model=0, **runner_kwargs):
+        """All good pixels as one device-resident spectra set: returns (CubeRunner, i_lon, i_lat);
+        row k of the runner is pixel (i_lon[k], i_lat[k])."""
+        from .cube import CubeRunner
+        lon, lat = self.good_pixels(lon, lat)
+        data = np.concatenate([dc.data[lon, lat, :] for dc in self.cubes], axis=1)
+        noise = np.empty((lon.size, self.n_cubes))
+        for k, dc in enumerate(self.cubes):
+            nm = dc.noise_map
+            noise[:, k] = nm.rms if nm.shape is None else nm.data[lon, lat]
+        runner = CubeRunner([dc.xarr for dc in self.cubes], [dc.trans_id for dc in self.cubes], data, noise,
+                            utrans, ncomp=ncomp, model=model, **runner_kwargs)
+        return runner, lon, lat

@@ -1,0 +1,145 @@
+"""Cube driver on the batched sampler: the reference's ``CubeFitter`` (nestfit/main.py:380-526)
+with its per-pixel loop turned inside out.  The reference forks `nproc` processes, each walking
+its longitude stripe pixel by pixel and component count by component count through serial
+MultiNest runs.  Here a stripe belongs to one GPU; all its pixels with the same number of live
+points are fitted together in lock-step (`sampler.fit_pixels`), first with one component, then
+the pixels whose evidence gained at least `lnZ_thresh` with two, and so on -- the same decision
+rule per pixel (main.py:452-469), the same groups and attributes in the store.
+"""
+import inspect
+
+import numpy as np
+
+from . import sampler
+from .cube import get_multiproc_indices
+from .store import HdfStore, StoreFile
+
+_MODEL_ID = {'ammonia': 0, 'diazenylium': 1, 'gaussian': 2}
+
+
+class _RunInfo:
+    """What ``Dumper.dump`` reads from a runner (core.pyx:638-660)."""
+
+    def __init__(self, ncomp, null_lnZ, n_chan_tot, n_params):
+        self.ncomp, self.null_lnZ, self.n_chan_tot, self.n_params = ncomp, null_lnZ, n_chan_tot, n_params
+        self.run_lnZ = np.nan
+
+
+class CubeFitter:
+    mn_default_kwargs = {
+        'nlive': 100,
+        'tol': 1.0,
+        'efr': 0.3,
+        'updInt': 2000,
+    }
+
+    def __init__(self, stack, utrans, runner_cls, runner_kwargs=None, lnZ_thresh=11, ncomp_max=2,
+                 mn_kwargs=None, nlive_snr_fact=5, nlive_quantum=20):
+        """Parameters as the reference (main.py:388-420).  `nlive_quantum`: the reference gives
+        every pixel its own number of live points, nlive + int(nlive_snr_fact * snr); pixels are
+        batched by that number rounded up to a multiple of `nlive_quantum` (1 = exactly the
+        reference's value, at the price of smaller batches)."""
+        self.stack = stack
+        self.utrans = utrans
+        self.runner_cls = runner_cls
+        self.runner_kwargs = {} if runner_kwargs is None else runner_kwargs
+        self.lnZ_thresh = lnZ_thresh
+        self.ncomp_max = ncomp_max
+        self.mn_kwargs = self.mn_default_kwargs.copy()
+        if mn_kwargs is not None:
+            self.mn_kwargs.update(mn_kwargs)
+        self.nlive_snr_fact = nlive_snr_fact
+        self.nlive_quantum = max(1, int(nlive_quantum))
+        self.model_id = _MODEL_ID[inspect.getmodule(runner_cls).NAME]
+        self.n_model = inspect.getmodule(runner_cls).N
+
+    def _nlive(self, lon, lat):
+        base = int(self.mn_kwargs['nlive'])
+        out = np.empty(lon.size, dtype=np.int64)
+        for k, (i, j) in enumerate(zip(lon, lat)):
+            n = base + int(self.nlive_snr_fact * self.stack.get_max_snr(i, j))      # main.py:444-447
+            out[k] = -(-n // self.nlive_quantum) * self.nlive_quantum
+        return out
+
+    def fit(self, *args):
+        (all_lon, all_lat), chunk_path = args
+        all_lon, all_lat = np.asarray(all_lon), np.asarray(all_lat)
+        hdf = StoreFile(chunk_path, 'a')
+        lon, lat = self.stack.good_pixels(all_lon, all_lat)
+        good = set(zip(lon.tolist(), lat.tolist()))
+        for i_lon, i_lat in zip(all_lon.tolist(), all_lat.tolist()):
+            if (i_lon, i_lat) not in good:
+                print(f'-- ({i_lon}, {i_lat}) SKIP: has NaN values')
+        if lon.size:
+            nlive = self._nlive(lon, lat)
+            kw = {k: self.mn_kwargs[k] for k in ('tol', 'efr', 'seed', 'maxiter') if k in self.mn_kwargs}
+            for nl in np.unique(nlive):
+                sel = np.flatnonzero(nlive == nl)
+                self._fit_group(hdf, lon[sel], lat[sel], int(nl), kw)
+        hdf.flush()
+        hdf.close()
+
+    def _fit_group(self, hdf, lon, lat, nlive, kw):
+        old_lnZ = None
+        nbest = np.zeros(lon.size, dtype=np.int64)
+        alive = np.arange(lon.size)                      # pixels still adding components
+        ncomp = 1
+        while ncomp <= self.ncomp_max and alive.size:
+            runner, rlon, rlat = self.stack.to_device(self.utrans, ncomp=ncomp, lon=lon[alive], lat=lat[alive],
+                                                      model=self.model_id, **self.runner_kwargs)
+            assert np.array_equal(rlon, lon[alive]) and np.array_equal(rlat, lat[alive])
+            if ncomp == 1:
+                old_lnZ = runner.null_lnZ.copy()
+                assert np.isfinite(old_lnZ).all()
+            print(f'-- {alive.size} pixels, nlive = {nlive} -> N = {ncomp}')
+            res = sampler.fit_pixels(runner, np.arange(alive.size), nlive=nlive, **kw)
+            n_chan_tot = int(runner._ss.chan_tot)
+            gain = np.empty(alive.size)
+            for k, (p, r) in enumerate(zip(alive, res)):
+                group = hdf.require_group(f'/pix/{lon[p]}/{lat[p]}')
+                sub_group = group.create_group(f'{ncomp}')
+                info = _RunInfo(ncomp, float(runner.null_lnZ[k]), n_chan_tot, self.n_model * ncomp)
+                sampler.Dumper(sub_group).dump(info, r)
+                assert np.isfinite(info.run_lnZ)
+                gain[k] = info.run_lnZ - old_lnZ[p]
+            keep = gain >= self.lnZ_thresh               # main.py:464-469
+            nbest[alive[keep]] = ncomp
+            old_lnZ[alive[keep]] = np.array([r.lnZ for r in res])[keep]
+            alive = alive[keep]
+            ncomp += 1
+        for p in range(lon.size):
+            group = hdf[f'/pix/{lon[p]}/{lat[p]}']
+            group.attrs['i_lon'] = int(lon[p])
+            group.attrs['i_lat'] = int(lat[p])
+            group.attrs['nbest'] = int(nbest[p])
+
+    def fit_cube(self, store_name='run/test_cube', nproc=1, rank=None):
+        """Creates the store, fits every pixel and links the chunk files (main.py:476-526).
+        `nproc` = number of stripes / chunk files (the reference's process count: one per GPU
+        here).  With `rank` given (one process per GPU, e.g. under torch.distributed.run) this
+        process fits only stripe `rank`; the caller links the files once all ranks are done
+        (`HdfStore(store_name).link_files()`).  Without it all stripes are fitted in turn."""
+        n_lon = self.stack.spatial_shape[0]
+        if nproc > n_lon:
+            raise ValueError(
+                f'The pixel width of the image in longitude ({n_lon}) '
+                f'must be greater than or equal to the number of processes ({nproc}).')
+        indices = get_multiproc_indices(self.stack.spatial_shape, nproc)
+        if rank is not None and rank != 0:           # only rank 0 touches the table file
+            from pathlib import Path
+            from .store import check_ext
+            store_dir = Path(check_ext(str(store_name), ext='store'))
+            store_dir.mkdir(parents=True, exist_ok=True)
+            self.fit(indices[rank], store_dir / f'{HdfStore.chunk_prefix}{rank}.npz')
+            return
+        store = HdfStore(store_name, nchunks=nproc)
+        if 'simple_header' not in store.hdf:
+            store.insert_header(self.stack)
+        store.insert_fitter_pars(self)
+        store.insert_model_metadata(self.runner_cls)
+        todo = range(store.nchunks) if rank is None else [0]
+        for k in todo:
+            self.fit(indices[k], store.chunk_paths[k])
+        if rank is None:
+            store.link_files()
+        store.close()
