@@ -220,8 +220,9 @@ int  nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int3
  * lock-step rounds with their state in HBM; a round = n_cand candidates per active pixel from
  * its bounding ellipsoid, one likelihood batch over all of them, one wave per pixel doing the
  * replace / evidence / stop / refit step.  pix[n_pix]: cube pixel of each run.  n_cand: candidates
- * per pixel and round at least; the number is raised (up to 1024) so that a round evaluates about
- * batch_target candidates however few pixels are still running.  cap_iter: dead
+ * per pixel and round at least; the number is raised (up to 16384) so that a round proposes about
+ * batch_target candidates however few pixels are still running; only the proposals inside the
+ * unit cube (the prior's support) are compacted and sent to the likelihood.  cap_iter: dead
  * point slots per pixel (a run stops when they are full).  tol, efr, seed, maxiter as
  * run_multinest; upd = replacements between ellipsoid refits; log_zero replaces non-finite
  * likelihoods; check_every = rounds between two compactions of the active-pixel list.

@@ -49,8 +49,10 @@ struct NsDev {
     int    *use_cube;                   // [P] 1: the ellipsoid is larger than the unit cube, draw from the cube
     double  ln_vball;                   // ln volume of the unit D-ball
     double *deadT, *deadL, *deadlnw;    // [P][cap][D], [P][cap], [P][cap]
-    double *candU, *candT, *candL;      // [P*K][D], [P*K][D], [P*K]
-    int    *candpix, *valid;            // [P*K]
+    double *candU, *candT, *candL;      // proposals [rows][D]; compact: theta [rows][D], lnL [rows]
+    int    *candpix, *valid;            // [rows]: pixel of a compact row; validity of a proposal
+    int    *slot;                       // [rows] compact row of a valid proposal
+    int    *count;                      // number of compact rows filled in this round
     const int *actlist;                 // [n_act] active pixels of this round
 };
 
@@ -83,42 +85,46 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
     const int q = (int)(gid / Kr), k = (int)(gid - (long)q * Kr);
     const int p = S.actlist[q];
     const int D = S.D;
-    double *cu = S.candU + gid * D, *ct = S.candT + gid * D;
-    S.candpix[gid] = S.pixmap[p];
-    if (!S.active[p]) {                 // finished since the last compaction: harmless dummy row
-        for (int j = 0; j < D; ++j) { cu[j] = 0.5; ct[j] = 0.5; }
+    double *cu = S.candU + gid * D;
+    if (!S.active[p]) {                 // finished since the last compaction of the pixel list
         S.valid[gid] = 0;
         return;
     }
     const uint64_t a = (uint64_t)S.cand_base[p] + (uint64_t)k;
-    if (S.use_cube[p]) {                // early on the bounding ellipsoid is no better than the prior itself
-        for (int j = 0; j < D; ++j) { const double u = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)j); cu[j] = u; ct[j] = u; }
-        S.valid[gid] = 1;
-        return;
-    }
-    double z[NS_MAXD];
-    double n2 = 0.0;
-    for (int m = 0; m < D; m += 2) {    // Box-Muller pairs
-        const double u1 = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)m);
-        const double u2 = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)(m + 1));
-        const double r = sqrt(-2.0 * log(u1));
-        const double ang = 6.283185307179586 * u2;
-        z[m] = r * cos(ang);
-        n2 += z[m] * z[m];
-        if (m + 1 < D) { z[m + 1] = r * sin(ang); n2 += z[m + 1] * z[m + 1]; }
-    }
-    const double ur = ns_uniform(S.seed, (uint64_t)p, a, NS_B_RADIUS);
-    const double f = exp(log(ur) / D) / sqrt(n2);         // uniform in the unit ball
-    const double *c = S.centre + (long)p * D, *A = S.axes + (long)p * D * D;
     bool ok = true;
-    for (int j = 0; j < D; ++j) {
-        double v = c[j];
-        for (int i = 0; i <= j; ++i) v += A[j * D + i] * (z[i] * f);
-        ok = ok && (v >= 0.0) && (v < 1.0);
-        cu[j] = v;
+    if (S.use_cube[p]) {                // early on the bounding ellipsoid is no better than the prior itself
+        for (int j = 0; j < D; ++j) cu[j] = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)j);
+    } else {
+        double z[NS_MAXD];
+        double n2 = 0.0;
+        for (int m = 0; m < D; m += 2) {    // Box-Muller pairs
+            const double u1 = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)m);
+            const double u2 = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)(m + 1));
+            const double r = sqrt(-2.0 * log(u1));
+            const double ang = 6.283185307179586 * u2;
+            z[m] = r * cos(ang);
+            n2 += z[m] * z[m];
+            if (m + 1 < D) { z[m + 1] = r * sin(ang); n2 += z[m + 1] * z[m + 1]; }
+        }
+        const double ur = ns_uniform(S.seed, (uint64_t)p, a, NS_B_RADIUS);
+        const double f = exp(log(ur) / D) / sqrt(n2);         // uniform in the unit ball
+        const double *c = S.centre + (long)p * D, *A = S.axes + (long)p * D * D;
+        for (int j = 0; j < D; ++j) {
+            double v = c[j];
+            for (int i = 0; i <= j; ++i) v += A[j * D + i] * (z[i] * f);
+            ok = ok && (v >= 0.0) && (v < 1.0);               // outside the unit cube = outside the prior
+            cu[j] = v;
+        }
     }
-    for (int j = 0; j < D; ++j) ct[j] = ok ? cu[j] : 0.5;   // outside the prior: not a candidate
     S.valid[gid] = ok ? 1 : 0;
+    if (!ok) return;
+    // only candidates inside the prior go to the likelihood: compact rows (order is irrelevant,
+    // every proposal remembers its row)
+    const int row = atomicAdd(S.count, 1);
+    S.slot[gid] = row;
+    S.candpix[row] = S.pixmap[p];
+    double *ct = S.candT + (long)row * D;
+    for (int j = 0; j < D; ++j) ct[j] = cu[j];
 }
 
 // ---- wave helpers (one 64-lane wave per pixel; nothing here is hot) -------------------------
@@ -247,34 +253,41 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     int since = S.since_fit[p];
     bool done = false;
     // every candidate of the round is used: within a round the bound only goes stale by the
-    // factor exp(-replacements / N) in volume, far cheaper than throwing evaluated points away
-    for (int k = 0; k < K && !done; ++k) {
-        const long g = (long)q * K + k;
-        if (!S.valid[g]) continue;
-        evals += 1;
-        double Lk = S.candL[g];
-        if (!isfinite(Lk)) Lk = S.log_zero;
-        if (!(Lk > Lmin)) continue;
-        // the worst live point dies with prior mass X_it - X_(it+1)
-        const double lnw = -(double)it / N + S.ln_shrink;
-        lnZ = ns_logaddexp(lnZ, lnw + Lmin);
-        if (it < S.cap) {
-            double *dT = S.deadT + ((long)p * S.cap + it) * D;
-            const double *Tw = S.Tlive + ((long)p * N + w) * D;
-            for (int j = lane; j < D; j += 64) dT[j] = Tw[j];
-            if (lane == 0) { S.deadL[(long)p * S.cap + it] = Lmin; S.deadlnw[(long)p * S.cap + it] = lnw; }
+    // factor exp(-replacements / N) in volume, far cheaper than throwing evaluated points away.
+    // The proposals are walked 64 at a time; only the valid ones cost anything.
+    for (int k0 = 0; k0 < K && !done; k0 += 64) {
+        const int kk = k0 + lane;
+        unsigned long long mask = __ballot(kk < K && S.valid[(long)q * K + kk] != 0);
+        while (mask && !done) {
+            const int k = k0 + __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const long g = (long)q * K + k;
+            const long row = S.slot[g];
+            evals += 1;
+            double Lk = S.candL[row];
+            if (!isfinite(Lk)) Lk = S.log_zero;
+            if (!(Lk > Lmin)) continue;
+            // the worst live point dies with prior mass X_it - X_(it+1)
+            const double lnw = -(double)it / N + S.ln_shrink;
+            lnZ = ns_logaddexp(lnZ, lnw + Lmin);
+            if (it < S.cap) {
+                double *dT = S.deadT + ((long)p * S.cap + it) * D;
+                const double *Tw = S.Tlive + ((long)p * N + w) * D;
+                for (int j = lane; j < D; j += 64) dT[j] = Tw[j];
+                if (lane == 0) { S.deadL[(long)p * S.cap + it] = Lmin; S.deadlnw[(long)p * S.cap + it] = lnw; }
+            }
+            wave_lds_sync();
+            for (int j = lane; j < D; j += 64) {
+                S.Ulive[((long)p * N + w) * D + j] = S.candU[g * D + j];
+                S.Tlive[((long)p * N + w) * D + j] = S.candT[row * D + j];
+            }
+            if (lane == 0) { sL[w] = Lk; Ll[w] = Lk; }
+            wave_lds_sync();
+            it += 1; since += 1;
+            extremes(Lmin, w, Lmax);
+            const double remain = Lmax - (double)it / N;
+            done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= S.cap;
         }
-        wave_lds_sync();
-        for (int j = lane; j < D; j += 64) {
-            S.Ulive[((long)p * N + w) * D + j] = S.candU[g * D + j];
-            S.Tlive[((long)p * N + w) * D + j] = S.candT[g * D + j];
-        }
-        if (lane == 0) { sL[w] = Lk; Ll[w] = Lk; }
-        wave_lds_sync();
-        it += 1; since += 1;
-        extremes(Lmin, w, Lmax);
-        const double remain = Lmax - (double)it / N;
-        done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= S.cap;
     }
     if (lane == 0) {
         S.n_iter[p] = it; S.n_evals[p] = evals; S.lnZ[p] = lnZ; S.cand_base[p] += Kr;
@@ -289,7 +302,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
 }
 
 // ---- host side -----------------------------------------------------------------------------
-#define NS_KMAX 1024            // most candidates one pixel gets in a round
+#define NS_KMAX 16384           // most proposals one pixel gets in a round
 struct nfa_sampler {
     nfa_runner *r = nullptr;
     NsDev d = {};
@@ -308,7 +321,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
     if (!s) return NFA_OK;
     NsDev &d = s->d;
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
-                    d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid,
+                    d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
                     s->d_pixmap, s->d_actlist, s->d_livepix};
     for (void *p : ptrs) (void)hipFree(p);
     delete s;
@@ -350,7 +363,7 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P); NS_ALLOC(d.use_cube, int, P);
     NS_ALLOC(d.deadT, double, P * C * D); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
     NS_ALLOC(d.candU, double, P * K * D); NS_ALLOC(d.candT, double, P * K * D); NS_ALLOC(d.candL, double, P * K);
-    NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K);
+    NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K); NS_ALLOC(d.slot, int, P * K); NS_ALLOC(d.count, int, 1);
 #undef NS_ALLOC
     HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     d.pixmap = s->d_pixmap; d.actlist = s->d_actlist;
@@ -424,10 +437,16 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
         const int Kr = (int)std::min<long>(NS_KMAX, std::max<long>(K, s->b_target / n_act));
         for (int c = 0; c < s->check_every; ++c) {
             const long B = (long)n_act * Kr;
+            HIP_TRY(hipMemsetAsync(d.count, 0, sizeof(int), st));
             hipLaunchKernelGGL(ns_propose_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, d, n_act, Kr);
             HIP_TRY(hipGetLastError());
-            int rc = run_batch(r, d.candpix, d.candT, d.candL, nullptr, B, true, 0, nullptr);
-            if (rc) return rc;
+            int n_rows = 0;             // proposals inside the prior: the only ones worth a likelihood
+            HIP_TRY(hipMemcpyAsync(&n_rows, d.count, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (n_rows > 0) {
+                int rc = run_batch(r, d.candpix, d.candT, d.candL, nullptr, n_rows, true, 0, nullptr);
+                if (rc) return rc;
+            }
             hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_act), dim3(64), s->lds, st, d, n_act, Kr, 0);
             HIP_TRY(hipGetLastError());
             s->rounds += 1;

@@ -151,7 +151,7 @@ def _resolve_seed(seed):
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
-               check_every=8, batch_target=65536, progress=None):
+               check_every=8, batch_target=262144, progress=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -165,8 +165,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         volume), RNG seed (-1 = from the OS), iteration cap per pixel.
     n_cand : candidates per pixel and round (default ceil(2 / efr)), at least: every
         `check_every` rounds the number is raised so that the round's batch stays near
-        max(n_pix * n_cand, batch_target) however few pixels are still running (at most 1024 per
-        pixel).
+        max(n_pix * n_cand, batch_target) proposals however few pixels are still running (at most
+        16384 per pixel); only proposals inside the unit cube are evaluated.
         They are scanned in order and every one above the pixel's current threshold replaces its
         worst live point.
     upd_frac : the ellipsoids are refitted at the end of a round once this fraction of nlive
@@ -209,7 +209,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     Kr = K
     while active.any():
         if rnd % check_every == 0:                              # the device compacts its pixel list here
-            Kr = int(min(1024, max(K, b_target // int(active.sum()))))
+            Kr = int(min(16384, max(K, b_target // int(active.sum()))))
         idx = np.flatnonzero(active)
         n = idx.size
         cand = _candidates(seed, idx, cand_base[idx], Kr, centre[idx], axes[idx], use_cube[idx])
@@ -274,7 +274,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
 
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
-                      upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=65536,
+                      upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=262144,
                       progress=None, time_limit=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host

@@ -64,6 +64,8 @@ def main():
     print(f'GPU: {n_pix} pixels, ncomp={ncomp}, nlive={nlive}: {dt:.1f} s wall, {evals/1e6:.1f} M likelihood '
           f'evaluations ({evals/dt/1e6:.2f} M evals/s end to end), {n_pix/dt:.1f} pixels/s, '
           f'iterations per pixel {iters.min()}..{iters.max()}, detections (dlnZ > 11): {(dlnz > 11).sum()}')
+    if n_cpu < 1:
+        return
     # CPU oracle on a few pixels, same sampler and seed
     from oracle import nfo
     ps = nfo.PriorSet(ut.lower())
