@@ -226,6 +226,35 @@ def main():
         _ffi.check(lib.nfa_runner_get_profile(rh, prof, C.byref(calls)))
         _ffi.check(lib.nfa_runner_set_profiling(rh, 0))
 
+    # The same kernel with the GPU to itself: a second runner with ONE stream lane, so that launches
+    # do not overlap and a HIP-event interval is the kernel's execution time (what rocprofv3 reports
+    # for a launch).  Outside the timed region.
+    alone_us = None
+    if profile and rank == 0:
+        _ffi.set_option('streams', 1)
+        solo = na.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp)
+        _ffi.set_option('streams', args.streams if args.streams else 3)
+        sh = solo._run.handle
+        n_solo = min(40, n_total)
+        for k in range(5):
+            _ffi.check(lib.nfa_runner_loglike_batch_dev(sh, None, C.c_void_p(d_U.value + k * B * ndim * 8),
+                                                        C.c_void_p(d_lnL.value + k * B * 8), B))
+        _ffi.check(lib.nfa_runner_synchronize(sh))
+        # the warm-up overwrote the first U slices with theta: restore unit-cube inputs
+        for k in range(n_solo):
+            _ffi.check(lib.nfa_memcpy_h2d(C.c_void_p(d_U.value + k * B * ndim * 8),
+                                          U_host.ctypes.data_as(C.c_void_p), B * ndim * 8))
+        _ffi.check(lib.nfa_runner_set_profiling(sh, 1))
+        for k in range(n_solo):
+            _ffi.check(lib.nfa_runner_loglike_batch_dev(sh, None, C.c_void_p(d_U.value + k * B * ndim * 8),
+                                                        C.c_void_p(d_lnL.value + (n_total - 1) * B * 8), B))
+        _ffi.check(lib.nfa_runner_synchronize(sh))
+        sp = (C.c_double * 4)(0, 0, 0, 0)
+        sc = C.c_int64(0)
+        _ffi.check(lib.nfa_runner_get_profile(sh, sp, C.byref(sc)))
+        if sc.value > 0:
+            alone_us = (sp[1] / sc.value * 1e3, sp[0] / sc.value * 1e3)
+
     # results of the last step, for the end-of-run gather and a sanity check
     lnL = np.empty(B)
     _ffi.check(lib.nfa_memcpy_d2h(lnL.ctypes.data_as(C.c_void_p),
@@ -254,7 +283,7 @@ def main():
         roof = None
         if profile and calls.value > 0:
             n = calls.value
-            raw_s = prof[1] / n / 1e3             # mean launch duration (what rocprofv3 --stats reports)
+            raw_s = prof[1] / n / 1e3             # mean event interval (includes queueing behind other lanes)
             eff_s = prof[3] / n / 1e3             # time with >= 1 likelihood kernel running, per launch
             achieved = bytes_eval * B / eff_s / 1e9
             roof = {
@@ -265,12 +294,18 @@ def main():
                 'achieved_from_raw_mean': bytes_eval * B / raw_s / 1e9,
                 'algorithmic_bytes_per_eval': bytes_eval, 'evals_per_launch': B,
                 'setup_kernel_avg_us': prof[2] / n * 1e3, 'setup_kernel_avg_us_raw_mean': prof[0] / n * 1e3,
-                'note': 'algorithmic bytes (SURVEY 8d) per launch / likelihood-kernel time per launch. '
-                        'Consecutive steps run on different HIP streams and overlap, so the time per '
-                        'launch is the union of the launch intervals / launches (HIP events on the '
-                        'launch streams); the plain mean, which counts overlapped time twice, is kept in '
-                        '*_raw_mean and is what rocprofv3 --stats shows. The kernel is VALU bound, the '
-                        'pixel data stay in L2 (traffic << algorithmic bytes), see DESIGN.md',
+                'alone_launch_us': None if alone_us is None else alone_us[0],
+                'alone_setup_us': None if alone_us is None else alone_us[1],
+                'achieved_alone': None if alone_us is None else bytes_eval * B / (alone_us[0] * 1e-6) / 1e9,
+                'note': 'algorithmic bytes (SURVEY 8d) per launch / likelihood-kernel time per launch '
+                        '(lnl_kernel + lnl_sum_kernel). Consecutive steps run on different HIP streams and '
+                        'overlap, so over the timed region the time per launch is the union of the launch '
+                        'intervals / launches (HIP events on the launch streams); *_raw_mean is the plain '
+                        'mean of those intervals, which also contains the time a launch waits behind the '
+                        'other lanes. alone_launch_us is the same kernel on a one-lane runner after the '
+                        'timed region (no overlap: the execution time rocprofv3 shows for such a launch). '
+                        'The kernel is VALU bound, the pixel data stay in L2 (traffic << algorithmic '
+                        'bytes), see DESIGN.md',
             }
             tfile = ROOT / 'profiles' / 'pmc_traffic.json'
             if tfile.exists():
