@@ -34,11 +34,14 @@ class CubeFitter:
     }
 
     def __init__(self, stack, utrans, runner_cls, runner_kwargs=None, lnZ_thresh=11, ncomp_max=2,
-                 mn_kwargs=None, nlive_snr_fact=5, nlive_quantum=20):
+                 mn_kwargs=None, nlive_snr_fact=5, nlive_quantum=20, fit_backend=None):
         """Parameters as the reference (main.py:388-420).  `nlive_quantum`: the reference gives
         every pixel its own number of live points, nlive + int(nlive_snr_fact * snr); pixels are
         batched by that number rounded up to a multiple of `nlive_quantum` (1 = exactly the
-        reference's value, at the price of smaller batches)."""
+        reference's value, at the price of smaller batches).  `fit_backend`: None = the device
+        sampler; otherwise a callable(fitter, lon, lat, ncomp, nlive, kw) -> (results, null_lnZ,
+        n_chan_tot) that fits the given pixels some other way (the tests plug the numpy twin of
+        the sampler fed by the CPU oracle in here, so that the driver logic runs without a GPU)."""
         self.stack = stack
         self.utrans = utrans
         self.runner_cls = runner_cls
@@ -50,6 +53,7 @@ class CubeFitter:
             self.mn_kwargs.update(mn_kwargs)
         self.nlive_snr_fact = nlive_snr_fact
         self.nlive_quantum = max(1, int(nlive_quantum))
+        self.fit_backend = fit_backend
         self.model_id = _MODEL_ID[inspect.getmodule(runner_cls).NAME]
         self.n_model = inspect.getmodule(runner_cls).N
 
@@ -79,26 +83,32 @@ class CubeFitter:
         hdf.flush()
         hdf.close()
 
+    def _fit_on_device(self, lon, lat, ncomp, nlive, kw):
+        runner, rlon, rlat = self.stack.to_device(self.utrans, ncomp=ncomp, lon=lon, lat=lat,
+                                                  model=self.model_id, **self.runner_kwargs)
+        assert np.array_equal(rlon, lon) and np.array_equal(rlat, lat)
+        res = sampler.fit_pixels(runner, np.arange(lon.size), nlive=nlive, **kw)
+        return res, runner.null_lnZ.copy(), int(runner._ss.chan_tot)
+
     def _fit_group(self, hdf, lon, lat, nlive, kw):
         old_lnZ = None
         nbest = np.zeros(lon.size, dtype=np.int64)
         alive = np.arange(lon.size)                      # pixels still adding components
         ncomp = 1
         while ncomp <= self.ncomp_max and alive.size:
-            runner, rlon, rlat = self.stack.to_device(self.utrans, ncomp=ncomp, lon=lon[alive], lat=lat[alive],
-                                                      model=self.model_id, **self.runner_kwargs)
-            assert np.array_equal(rlon, lon[alive]) and np.array_equal(rlat, lat[alive])
-            if ncomp == 1:
-                old_lnZ = runner.null_lnZ.copy()
-                assert np.isfinite(old_lnZ).all()
             print(f'-- {alive.size} pixels, nlive = {nlive} -> N = {ncomp}')
-            res = sampler.fit_pixels(runner, np.arange(alive.size), nlive=nlive, **kw)
-            n_chan_tot = int(runner._ss.chan_tot)
+            if self.fit_backend is not None:
+                res, null_lnZ, n_chan_tot = self.fit_backend(self, lon[alive], lat[alive], ncomp, nlive, kw)
+            else:
+                res, null_lnZ, n_chan_tot = self._fit_on_device(lon[alive], lat[alive], ncomp, nlive, kw)
+            if ncomp == 1:
+                old_lnZ = np.array(null_lnZ, dtype=np.float64)
+                assert np.isfinite(old_lnZ).all()
             gain = np.empty(alive.size)
             for k, (p, r) in enumerate(zip(alive, res)):
                 group = hdf.require_group(f'/pix/{lon[p]}/{lat[p]}')
                 sub_group = group.create_group(f'{ncomp}')
-                info = _RunInfo(ncomp, float(runner.null_lnZ[k]), n_chan_tot, self.n_model * ncomp)
+                info = _RunInfo(ncomp, float(null_lnZ[k]), n_chan_tot, self.n_model * ncomp)
                 sampler.Dumper(sub_group).dump(info, r)
                 assert np.isfinite(info.run_lnZ)
                 gain[k] = info.run_lnZ - old_lnZ[p]
