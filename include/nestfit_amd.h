@@ -235,10 +235,12 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
 int nfa_sampler_destroy(nfa_sampler *s);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
-/* the same in two steps: begin = live points + first ellipsoids; advance = up to max_chunks groups
+/* (nfa_sampler_run uses enlarge = 1.5: safety factor on the volume of the ellipsoid that just
+ * encloses the live points, before MultiNest's floor X / efr is applied)
+ * the same in two steps: begin = live points + first ellipsoids; advance = up to max_chunks groups
  * of check_every rounds (0 = to the end); *n_active = pixels still running (progress, time limits) */
 int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
-                      double log_zero, int check_every);
+                      double log_zero, int check_every, double enlarge);
 int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active);
 int nfa_sampler_counts(nfa_sampler *s, int64_t *n_iter, int64_t *n_evals, int64_t *rounds);
 int nfa_sampler_dead(nfa_sampler *s, int64_t p, int64_t n, double *theta, double *lnL, double *lnw);

@@ -35,7 +35,7 @@ __host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t
 struct NsDev {
     int     P, N, D, K;                 // pixels, live points, dimensions, candidates per round (at least)
     long    cap;                        // dead-point slots per pixel
-    double  tol, ln_shrink, enl_pow, log_zero;
+    double  tol, ln_shrink, ln_efr, ln_enlarge, log_zero;
     long    maxiter;
     int     upd;
     uint64_t seed;
@@ -152,9 +152,10 @@ __device__ __forceinline__ double ns_logaddexp(double a, double b) {
 }
 
 // Bounding ellipsoid of the live points of pixel p (same arithmetic as _fit_ellipsoids in
-// nestfit_amd/sampler.py): centre = mean, A = chol(cov) * sqrt(max Mahalanobis^2) * enl^(1/D).
+// nestfit_amd/sampler.py): centre = mean, A = chol(cov) * sqrt(max Mahalanobis^2) * growth, the
+// growth bringing the volume up to X / efr where the bounding ellipsoid is smaller than that.
 // sA: D*D doubles of LDS, sc: D doubles.
-__device__ void ns_refit(const NsDev &S, int p, double *sA, double *sc, int lane) {
+__device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double *sc, int lane) {
     const int N = S.N, D = S.D;
     const double *U = S.Ulive + (long)p * N * D;
     for (int j = 0; j < D; ++j) {
@@ -203,12 +204,14 @@ __device__ void ns_refit(const NsDev &S, int p, double *sA, double *sc, int lane
         r2 = fmax(r2, s2);
     }
     r2 = ns_wave_max(r2);
-    const double scale = sqrt(r2) * S.enl_pow;
-    if (lane == 0) {                    // ln volume of the ellipsoid against ln 1 of the unit cube
-        double lnv = S.ln_vball + D * log(scale);
-        for (int a = 0; a < D; ++a) lnv += log(sA[a * D + a]);
-        S.use_cube[p] = lnv >= 0.0 ? 1 : 0;
-    }
+    // the covariance ellipsoid scaled to enclose every live point, then MultiNest's rule: enlarged
+    // until its volume is at least the expected prior volume over the target efficiency, X / efr
+    double lnv = S.ln_vball + 0.5 * D * log(r2) + S.ln_enlarge;   // safety factor on the enclosing volume
+    for (int a = 0; a < D; ++a) lnv += log(sA[a * D + a]);
+    const double ln_x = -(double)n_iter / N;
+    const double grow = fmax((ln_x - S.ln_efr) - lnv, 0.0);
+    const double scale = sqrt(r2) * exp((grow + S.ln_enlarge) / D);
+    if (lane == 0) S.use_cube[p] = (lnv + grow) >= 0.0 ? 1 : 0;   // larger than the unit cube: use the cube
     double *A = S.axes + (long)p * D * D, *c = S.centre + (long)p * D;
     for (int e = lane; e < D * D; e += 64) {
         const int a = e / D, b = e - a * D;
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     double *sL = smem;                              // live log-likelihoods of the pixel
     double *sA = sL + ((N + 1) & ~1);               // D*D
     double *sc = sA + D * D;                        // D
-    if (force_refit) { ns_refit(S, p, sA, sc, lane); return; }
+    if (force_refit) { ns_refit(S, p, 0, sA, sc, lane); return; }
     if (!S.active[p]) return;
     double *Ll = S.Llive + (long)p * N;
     for (int i = lane; i < N; i += 64) sL[i] = Ll[i];
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     }
     if (!done && since >= S.upd) {
         __threadfence();                            // the wave's own stores to Ulive, then its loads
-        ns_refit(S, p, sA, sc, lane);
+        ns_refit(S, p, it, sA, sc, lane);
         since = 0;
     }
     if (lane == 0) S.since_fit[p] = since;
@@ -378,16 +381,17 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
 // has stopped) and reports how many pixels are still running, so the caller can show progress
 // or give up; nfa_sampler_run = begin + advance to the end.
 int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
-                      double log_zero, int check_every) {
+                      double log_zero, int check_every, double enlarge) {
     if (!s) return fail(NFA_ERR_ARG, "null sampler");
-    if (!(tol > 0) || !(efr > 0 && efr <= 1) || maxiter < 0 || upd < 1 || check_every < 1)
+    if (!(tol > 0) || !(efr > 0 && efr <= 1) || maxiter < 0 || upd < 1 || check_every < 1 || !(enlarge >= 1))
         return fail(NFA_ERR_ARG, "bad sampler options");
     nfa_runner *r = s->r;
     NsDev &d = s->d;
     const int P = d.P, N = d.N, D = d.D;
+    d.ln_enlarge = log(enlarge);
     d.tol = tol; d.maxiter = (long)maxiter; d.upd = upd; d.seed = (uint64_t)seed; d.log_zero = log_zero;
     d.ln_shrink = log1p(-exp(-1.0 / N));
-    d.enl_pow = pow(1.0 / efr, 1.0 / D);
+    d.ln_efr = log(efr);
     d.ln_vball = 0.5 * D * log(M_PI) - lgamma(0.5 * D + 1.0);
     s->check_every = check_every;
     hipStream_t st = r->lanes[0];
@@ -465,7 +469,7 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
 
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every) {
-    int rc = nfa_sampler_begin(s, tol, efr, seed, maxiter, upd, log_zero, check_every);
+    int rc = nfa_sampler_begin(s, tol, efr, seed, maxiter, upd, log_zero, check_every, 1.5);
     if (rc) return rc;
     return nfa_sampler_advance(s, 0, nullptr);
 }

@@ -99,9 +99,11 @@ def _candidates(seed, pix, base, K, centre, axes, use_cube):
     return cand
 
 
-def _fit_ellipsoids(U, enlarge):
-    """Bounding ellipsoid of live points U[P, nlive, ndim]: centre, and a lower-triangular A with
-    {c + A z : |z| <= 1} containing every live point, its volume scaled by `enlarge` (ns_refit)."""
+def _fit_ellipsoids(U, efr, ln_x, enlarge=1.0):
+    """Bounding ellipsoid of live points U[P, nlive, ndim] (ns_refit): centre c and lower-triangular
+    A with {c + A z : |z| <= 1}: the covariance ellipsoid scaled until it encloses every live point,
+    its volume times the safety factor `enlarge`, and, MultiNest's rule (Feroz et al. 2009, sec. 5.1.1), enlarged until its volume is at least
+    the expected prior volume over the target efficiency, X / efr, with ln X = ln_x[P]."""
     P, nlive, ndim = U.shape
     c = U.sum(axis=1) / nlive
     d = U - c[:, None, :]
@@ -111,12 +113,14 @@ def _fit_ellipsoids(U, enlarge):
     L = np.linalg.cholesky(cov)
     y = np.linalg.solve(L, d.transpose(0, 2, 1))               # (P, ndim, nlive)
     r2 = np.max(np.sum(y * y, axis=1), axis=1)                 # largest Mahalanobis distance^2
-    scale = np.sqrt(r2) * enlarge ** (1.0 / ndim)
-    A = L * scale[:, None, None]
+    ln_vball = 0.5 * ndim * np.log(np.pi) - math.lgamma(0.5 * ndim + 1.0)
+    lnv = (ln_vball + 0.5 * ndim * np.log(r2) + np.log(np.diagonal(L, axis1=1, axis2=2)).sum(axis=1)
+           + math.log(enlarge))
+    grow = np.maximum((np.asarray(ln_x) - np.log(efr)) - lnv, 0.0)
+    scale = np.sqrt(r2) * np.exp((grow + math.log(enlarge)) / ndim)
+    lnv = lnv + grow
     # ln volume against ln 1 of the unit cube: a larger ellipsoid is no better than the prior itself
-    lnv = (0.5 * ndim * np.log(np.pi) - math.lgamma(0.5 * ndim + 1.0) + ndim * np.log(scale)
-           + np.log(np.diagonal(L, axis1=1, axis2=2)).sum(axis=1))
-    return c, A, lnv >= 0.0
+    return c, L * scale[:, None, None], lnv >= 0.0
 
 
 def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive):
@@ -151,7 +155,7 @@ def _resolve_seed(seed):
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
-               check_every=8, batch_target=262144, progress=None):
+               check_every=8, batch_target=262144, enlarge=1.5, progress=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -161,8 +165,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         Evaluates unit-cube rows against pixels; must overwrite U with the physical parameters
         (the convention of Runner.loglikelihood, core.pyx:558-561).
     nlive, tol, efr, seed, maxiter : as in ``run_multinest`` (core.pyx:727-744): live points,
-        evidence tolerance, target sampling efficiency (sets the ellipsoid enlargement 1/efr in
-        volume), RNG seed (-1 = from the OS), iteration cap per pixel.
+        evidence tolerance, target sampling efficiency (the bounding ellipsoid is enlarged until its
+        volume reaches X / efr), RNG seed (-1 = from the OS), iteration cap per pixel.
     n_cand : candidates per pixel and round (default ceil(2 / efr)), at least: every
         `check_every` rounds the number is raised so that the round's batch stays near
         max(n_pix * n_cand, batch_target) proposals however few pixels are still running (at most
@@ -172,6 +176,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     upd_frac : the ellipsoids are refitted at the end of a round once this fraction of nlive
         replacements has accumulated.
     cap_iter : dead-point slots per pixel (default: no other cap than maxiter).
+    enlarge : safety factor on the volume of the ellipsoid that just encloses the live points
+        (scripts/sampler_bias_check.py: 1.0 biases lnZ by +0.020, 1.25 by +0.011, 2.0 by nothing measurable; the error is 0.18).
 
     Returns a list of `NestedResult`, one per pixel.
     """
@@ -201,7 +207,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     active = np.full(P, maxiter > 0)
     since_fit = np.zeros(P, dtype=np.int64)
     upd = max(1, int(upd_frac * nlive))
-    centre, axes, use_cube = _fit_ellipsoids(Ulive, 1.0 / efr)
+    centre, axes, use_cube = _fit_ellipsoids(Ulive, efr, np.zeros(P), enlarge)
     dead_T, dead_L, dead_lnw, dead_pix = [], [], [], []
     rnd = 0
     b_target = max(P * K, int(batch_target))
@@ -253,7 +259,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             going[acc[done]] = False
         refit = idx[active[idx] & (since_fit[idx] >= upd)]
         if refit.size:
-            centre[refit], axes[refit], use_cube[refit] = _fit_ellipsoids(Ulive[refit], 1.0 / efr)
+            centre[refit], axes[refit], use_cube[refit] = _fit_ellipsoids(Ulive[refit], efr,
+                                                                          -n_iter[refit] / nlive, enlarge)
             since_fit[refit] = 0
         rnd += 1
         if progress is not None:
@@ -275,7 +282,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
                       upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=262144,
-                      progress=None, time_limit=None):
+                      enlarge=1.5, progress=None, time_limit=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
     work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive).  `progress`
@@ -296,7 +303,8 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
                                       int(nlive), K, int(batch_target), cap))
     try:
         _ffi.check(lib.nfa_sampler_begin(h, float(tol), float(efr), seed, int(maxiter),
-                                         max(1, int(upd_frac * nlive)), float(log_zero), int(check_every)))
+                                         max(1, int(upd_frac * nlive)), float(log_zero), int(check_every),
+                                         float(enlarge)))
         n_active = C.c_int64(P)
         t0 = time.perf_counter()
         chunks = 16
