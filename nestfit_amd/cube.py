@@ -78,6 +78,34 @@ class CubeRunner:
         return lnL
 
 
+    def predict_batch(self, pix, theta, want_spectra=True):
+        """Model spectra [B, n_chan_tot] and lnL[B] of physical parameter rows theta[B, ndim]
+        against pixels pix[B]: `runner.predict` for many pixels at once (the spectra-out mode of
+        the post-processing, nestfit/main.py:1106-1113, 1186)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        if theta.ndim != 2 or theta.shape[1] != self.ndim:
+            raise ValueError(f'Invalid shape for ncomp={self.ncomp}: {theta.shape}')
+        pix = np.ascontiguousarray(pix, dtype=np.int32)
+        if pix.shape != (theta.shape[0],):
+            raise ValueError('one pixel index per row is required')
+        B = theta.shape[0]
+        spec = np.empty((B, self.n_chan_tot)) if want_spectra else None
+        lnl = np.empty(B)
+        _ffi.check(_ffi.load().nfa_runner_predict_batch(
+            self._run.handle, pix.ctypes.data_as(_ffi._ip), _ffi.dptr(theta), B,
+            _ffi.dptr(spec) if want_spectra else None, _ffi.dptr(lnl)))
+        return spec, lnl
+
+    def peak_and_integrated(self, pix, theta):
+        """max_spec and sum_spec of every spectrum for parameter rows (core.pyx:532-539 as
+        `deblend_hf_intensity` uses them, main.py:1110-1113): two arrays [B, n_spec]."""
+        spec, _ = self.predict_batch(pix, theta)
+        off = self._ss.offsets
+        peak = np.stack([np.nanmax(spec[:, off[k]:off[k + 1]], axis=1) for k in range(self.n_spec)], axis=1)
+        tot = np.stack([np.nansum(spec[:, off[k]:off[k + 1]], axis=1) for k in range(self.n_spec)], axis=1)
+        return peak, tot
+
+
 def gather_pixel_records(records, group=None):
     """All-gather fixed-size per-pixel result records (float64 [n_local, width]) from
     every rank; returns the concatenation in rank order.  Ranks may own different
