@@ -42,6 +42,7 @@ struct Engine {
     int    n_cu = 256;
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
     int    wpb = 4;                  // waves per workgroup of the likelihood kernel
+    int    wpb_table = 8;            // the same in table mode (51 KB of product tables per workgroup)
     int    occ = 7;                  // fast mode: resident waves per SIMD, capped through LDS padding (0 = no cap)
     int    ablate = 0;
     int    streams = 3;              // stream lanes of new runners
@@ -177,6 +178,7 @@ int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "occ") && value >= 0 && value <= 8) { g_eng.occ = value; return NFA_OK; }
+    if (key && !strcmp(key, "wpb_table") && value >= 1 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }
     if (key && !strcmp(key, "ablate") && value >= 0 && value <= 15) { g_eng.ablate = value; return NFA_OK; }
     if (key && !strcmp(key, "streams") && value >= 1 && value <= NFA_MAX_LANES) { g_eng.streams = value; return NFA_OK; }
@@ -528,7 +530,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     // per component)
     G.wave_doubles = ((drec + 1) & ~1) + r->ncomp * (G.nhf_max * (int)(sizeof(LineRec) / sizeof(double)) + 64);
     // table mode shares 51 KB of product tables: fat workgroups; otherwise g_eng.wpb waves
-    const int waves = MODE == 0 ? 4 : std::max(1, std::min(g_eng.wpb, 16));
+    const int waves = MODE == 0 ? g_eng.wpb_table : std::max(1, std::min(g_eng.wpb, 16));
     const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
     size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * waves);
     // A 4096-row batch of two spectra is exactly one full machine of waves (8 per SIMD): the next
