@@ -308,17 +308,27 @@ struct __attribute__((aligned(16))) LineRec {
 // those lanes repeat that rounding in fp64, under a wave-uniform branch that is rarely taken.
 __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
     const float r3 = __builtin_fmaf(t, -1.0f / 3.0f, 1.0f);
-    const float pc = __builtin_fmaf(t * r3, -0.5f, 1.0f);
-    float p = 1.0f / 5040.0f;                                 // (1 - e^-t)/t = sum (-t)^k/(k+1)!
-    p = __builtin_fmaf(p, t, -1.0f / 720.0f);
-    p = __builtin_fmaf(p, t, 1.0f / 120.0f);
-    p = __builtin_fmaf(p, t, -1.0f / 24.0f);
-    p = __builtin_fmaf(p, t, 1.0f / 6.0f);
-    p = __builtin_fmaf(p, t, -0.5f);
-    p = __builtin_fmaf(p, t, 1.0f);
-    p = (t < 0.03125f) ? pc : p;
-    const float w_big = 1.0f - exp_neg_f32(t);
-    double w = (double)((t < 0.25f) ? t * p : w_big);
+    const float pc = __builtin_fmaf(t * r3, -0.5f, 1.0f);        // the reference's cubic (fastexp.c:264-270)
+    float wf = t * pc;
+    // Most rows lie in the line wings where every lane is below 2^-5 and the cubic is all there is;
+    // the other two ranges are evaluated only when some lane of the wave needs them.
+    if (__builtin_amdgcn_ballot_w64(!(t < 0.03125f)) != 0ull) {
+        asm volatile("" ::: "memory");
+        float p = 1.0f / 5040.0f;                             // (1 - e^-t)/t = sum (-t)^k/(k+1)!
+        p = __builtin_fmaf(p, t, -1.0f / 720.0f);
+        p = __builtin_fmaf(p, t, 1.0f / 120.0f);
+        p = __builtin_fmaf(p, t, -1.0f / 24.0f);
+        p = __builtin_fmaf(p, t, 1.0f / 6.0f);
+        p = __builtin_fmaf(p, t, -0.5f);
+        p = __builtin_fmaf(p, t, 1.0f);
+        wf = (t < 0.03125f) ? wf : t * p;
+        if (__builtin_amdgcn_ballot_w64(!(t < 0.25f)) != 0ull) {
+            asm volatile("" ::: "memory");
+            const float w_big = 1.0f - exp_neg_f32(t);
+            wf = (t < 0.25f) ? wf : w_big;
+        }
+    }
+    double w = (double)wf;
     const bool tiny = t < 1e-8f;
     if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) {
         asm volatile("" ::: "memory");            // keep the rare path a branch (no if-conversion)

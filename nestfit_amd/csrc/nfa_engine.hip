@@ -42,7 +42,7 @@ struct Engine {
     int    n_cu = 256;
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
     int    wpb = 4;                  // waves per workgroup of the likelihood kernel
-    int    wpb_table = 8;            // the same in table mode (51 KB of product tables per workgroup)
+    int    wpb_table = 0;            // the same in table mode; 0 = chosen per spectra set (launch_lnl_t)
     int    occ = 7;                  // fast mode: resident waves per SIMD, capped through LDS padding (0 = no cap)
     int    ablate = 0;
     int    streams = 3;              // stream lanes of new runners
@@ -178,7 +178,7 @@ int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "occ") && value >= 0 && value <= 8) { g_eng.occ = value; return NFA_OK; }
-    if (key && !strcmp(key, "wpb_table") && value >= 1 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
+    if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }
     if (key && !strcmp(key, "ablate") && value >= 0 && value <= 15) { g_eng.ablate = value; return NFA_OK; }
     if (key && !strcmp(key, "streams") && value >= 1 && value <= NFA_MAX_LANES) { g_eng.streams = value; return NFA_OK; }
@@ -529,17 +529,24 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     // LDS per wave: the item's record + the line table of one spectrum (32-B records + 64 windows
     // per component)
     G.wave_doubles = ((drec + 1) & ~1) + r->ncomp * (G.nhf_max * (int)(sizeof(LineRec) / sizeof(double)) + 64);
-    // table mode shares 51 KB of product tables: fat workgroups; otherwise g_eng.wpb waves
-    const int waves = MODE == 0 ? g_eng.wpb_table : std::max(1, std::min(g_eng.wpb, 16));
     const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
-    size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * waves);
-    // A 4096-row batch of two spectra is exactly one full machine of waves (8 per SIMD): the next
-    // batch on the neighbouring stream could not start a single wave until this one drains.  Capping
-    // the residency at 7 lets the batches interleave (measured +6 %).
-    if (MODE == 2 && g_eng.occ > 0) {            // blocks per CU = occ * 4 SIMDs / waves
-        const size_t per_block = (160 * 1024) / std::max(1, g_eng.occ * 4 / waves);
-        lds = std::max(lds, per_block - 256);
+    // waves per workgroup.  Table mode stages 51 KB of product tables per workgroup, so the
+    // workgroup is made as fat as keeps the most waves resident per CU (ties: more workgroups,
+    // so that one stages while another computes): 8 waves for NH3 (1,1)+(2,2), 16 for N2H+.
+    int waves = std::max(1, std::min(g_eng.wpb, 16));
+    if (MODE == 0) {
+        waves = g_eng.wpb_table;
+        if (waves <= 0) {
+            int best = -1, best_blocks = 0;
+            for (int w = 4; w <= 16; w += 2) {
+                const size_t need = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * w);
+                const int blocks = (int)((160 * 1024) / need);
+                const int resident = std::min(32, blocks * w);
+                if (resident > best || (resident == best && blocks > best_blocks)) { best = resident; best_blocks = blocks; waves = w; }
+            }
+        }
     }
+    const size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * waves);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "ncomp too large for the LDS line table");
     auto kern = lnl_kernel<MODE, WS, WIDE>;
     if (lds > 64 * 1024)
