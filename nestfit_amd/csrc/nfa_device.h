@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                 if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;
                 double tb;
                 if ((ablate & 1) || S.model == NFA_MODEL_GAUSSIAN) {      // gaussian.pyx:50: pred += peak * e
-                    if (live) pred += (double)tau;
+                    pred += (double)tau;                              // tau == 0 adds nothing
                     continue;
                 }
                 if (MODE == 2 && dk_kind != 0.0) {
@@ -511,7 +511,9 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                     if (MODE == 2) tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
                     else tb = (T0 * (y - tbg)) * (1.0 - nf_fastexp<MODE>((double)tau, sm));
                 }
-                if (live) pred += tb;
+                // lanes with tau == 0 (the reference skips them, hyperfine.pyx:104-105) get tb = x * 0:
+                // adding it changes nothing, so the sum needs no per-lane select
+                pred += tb;
             }
             if (WRITE_SPEC) { if (valid) spec_out[b * S.chan_tot + off + j] = pred; }
             const double dev = dj - pred;
