@@ -235,12 +235,18 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
 int nfa_sampler_destroy(nfa_sampler *s);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
-/* (nfa_sampler_run uses enlarge = 1.5: safety factor on the volume of the ellipsoid that just
+/* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the
+ * bounding ellipsoid only; 1 = a pixel whose rejection round accepted fewer than 1 in n_steps of
+ * the evaluated candidates switches to constrained random walks: 64 walkers start from random live
+ * points and take n_steps Metropolis steps inside {L > threshold} with ellipsoid-shaped proposals
+ * whose scale is tuned to an acceptance of one half (the `rwalk` idea of dynesty, Speagle 2020);
+ * 2 = walks from the first round.  nfa_sampler_run uses method 1, n_steps 25.
+ * (nfa_sampler_run uses enlarge = 1.5: safety factor on the volume of the ellipsoid that just
  * encloses the live points, before MultiNest's floor X / efr is applied)
  * the same in two steps: begin = live points + first ellipsoids; advance = up to max_chunks groups
  * of check_every rounds (0 = to the end); *n_active = pixels still running (progress, time limits) */
 int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
-                      double log_zero, int check_every, double enlarge);
+                      double log_zero, int check_every, double enlarge, int method, int n_steps);
 int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active);
 int nfa_sampler_counts(nfa_sampler *s, int64_t *n_iter, int64_t *n_evals, int64_t *rounds);
 int nfa_sampler_dead(nfa_sampler *s, int64_t p, int64_t n, double *theta, double *lnL, double *lnw);

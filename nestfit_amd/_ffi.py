@@ -84,7 +84,7 @@ SIGNATURES = {
     'nfa_sampler_run': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int,
                                   C.c_double, C.c_int]),
     'nfa_sampler_begin': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int,
-                                    C.c_double, C.c_int, C.c_double]),
+                                    C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]),
     'nfa_sampler_advance': (C.c_int, [C.c_void_p, C.c_int64, _lp]),
     'nfa_sampler_counts': (C.c_int, [C.c_void_p, _lp, _lp, _lp]),
     'nfa_sampler_dead': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp, _dp]),

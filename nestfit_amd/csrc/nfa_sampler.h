@@ -18,6 +18,8 @@
 #define NS_MAXD      60          // 6 parameters x MAXCOMP
 #define NS_TAG_LIVE  (1ull << 62)
 #define NS_B_RADIUS  255ull
+#define NS_B_START   250ull      // stream index of a walker's starting live point
+#define NS_W         64          // walkers per pixel: one per lane of the update wave
 
 __host__ __device__ inline uint64_t ns_mix(uint64_t x) {             // splitmix64 finaliser
     x += 0x9E3779B97F4A7C15ull;
@@ -54,6 +56,13 @@ struct NsDev {
     int    *slot;                       // [rows] compact row of a valid proposal
     int    *count;                      // number of compact rows filled in this round
     const int *actlist;                 // [n_act] active pixels of this round
+    // constrained random walks (pixels whose rejection sampling has become too inefficient)
+    int     method, n_steps;            // 0 rejection only, 1 automatic switch, 2 walks from the start
+    int    *walk, *wstep, *wW;          // [P] mode flag, step inside the current cycle, walkers in it
+    double *wscale, *wLthr;             // [P] proposal scale, threshold frozen at the cycle start
+    long   *wacc_sum, *wtot_sum;        // [P] accepted / evaluated steps of the current cycle
+    double *wU, *wT, *wL;               // walker states [P][NS_W][D], [P][NS_W][D], [P][NS_W]
+    int    *wnacc;                      // [P][NS_W] accepted steps of each walker in the cycle
 };
 
 // ---- live points -------------------------------------------------------------------------
@@ -92,7 +101,28 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
     }
     const uint64_t a = (uint64_t)S.cand_base[p] + (uint64_t)k;
     bool ok = true;
-    if (S.use_cube[p]) {                // early on the bounding ellipsoid is no better than the prior itself
+    const bool walking = S.walk[p] != 0;
+    double wscale = 1.0;
+    const double *origin = S.centre + (long)p * D;
+    if (walking) {
+        // Metropolis step of walker k inside {L > threshold}: proposal = current point + scale * (a
+        // uniform point of the bounding ellipsoid, centred); a cycle starts from a random live point
+        const int step = S.wstep[p];
+        const int W = step == 0 ? min(NS_W, Kr) : S.wW[p];
+        if (k >= W) { S.valid[gid] = 0; return; }
+        double *wu = S.wU + ((long)p * NS_W + k) * D;
+        if (step == 0) {
+            const int idx = min(S.N - 1, (int)(ns_uniform(S.seed, (uint64_t)p, a, NS_B_START) * S.N));
+            const double *lu = S.Ulive + ((long)p * S.N + idx) * D, *lt = S.Tlive + ((long)p * S.N + idx) * D;
+            double *wt = S.wT + ((long)p * NS_W + k) * D;
+            for (int j = 0; j < D; ++j) { wu[j] = lu[j]; wt[j] = lt[j]; }
+            S.wL[(long)p * NS_W + k] = S.Llive[(long)p * S.N + idx];
+            S.wnacc[(long)p * NS_W + k] = 0;
+        }
+        origin = wu;
+        wscale = S.wscale[p];
+    }
+    if (!walking && S.use_cube[p]) {    // early on the bounding ellipsoid is no better than the prior itself
         for (int j = 0; j < D; ++j) cu[j] = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)j);
     } else {
         double z[NS_MAXD];
@@ -107,8 +137,8 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
             if (m + 1 < D) { z[m + 1] = r * sin(ang); n2 += z[m + 1] * z[m + 1]; }
         }
         const double ur = ns_uniform(S.seed, (uint64_t)p, a, NS_B_RADIUS);
-        const double f = exp(log(ur) / D) / sqrt(n2);         // uniform in the unit ball
-        const double *c = S.centre + (long)p * D, *A = S.axes + (long)p * D * D;
+        const double f = wscale * exp(log(ur) / D) / sqrt(n2);      // uniform in the (scaled) unit ball
+        const double *c = origin, *A = S.axes + (long)p * D * D;
         for (int j = 0; j < D; ++j) {
             double v = c[j];
             for (int i = 0; i <= j; ++i) v += A[j * D + i] * (z[i] * f);
@@ -255,41 +285,97 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     double lnZ = S.lnZ[p];
     int since = S.since_fit[p];
     bool done = false;
-    // every candidate of the round is used: within a round the bound only goes stale by the
-    // factor exp(-replacements / N) in volume, far cheaper than throwing evaluated points away.
-    // The proposals are walked 64 at a time; only the valid ones cost anything.
-    for (int k0 = 0; k0 < K && !done; k0 += 64) {
-        const int kk = k0 + lane;
-        unsigned long long mask = __ballot(kk < K && S.valid[(long)q * K + kk] != 0);
-        while (mask && !done) {
-            const int k = k0 + __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const long g = (long)q * K + k;
-            const long row = S.slot[g];
-            evals += 1;
-            double Lk = S.candL[row];
-            if (!isfinite(Lk)) Lk = S.log_zero;
-            if (!(Lk > Lmin)) continue;
-            // the worst live point dies with prior mass X_it - X_(it+1)
-            const double lnw = -(double)it / N + S.ln_shrink;
-            lnZ = ns_logaddexp(lnZ, lnw + Lmin);
-            if (it < S.cap) {
-                double *dT = S.deadT + ((long)p * S.cap + it) * D;
-                const double *Tw = S.Tlive + ((long)p * N + w) * D;
-                for (int j = lane; j < D; j += 64) dT[j] = Tw[j];
-                if (lane == 0) { S.deadL[(long)p * S.cap + it] = Lmin; S.deadlnw[(long)p * S.cap + it] = lnw; }
+    // a candidate above the threshold replaces the worst live point, which dies with prior mass
+    // X_it - X_(it+1); returns nothing, updates the wave-uniform state above
+    auto replace = [&](const double *cU, const double *cT, double Lk) {
+        const double lnw = -(double)it / N + S.ln_shrink;
+        lnZ = ns_logaddexp(lnZ, lnw + Lmin);
+        if (it < S.cap) {
+            double *dT = S.deadT + ((long)p * S.cap + it) * D;
+            const double *Tw = S.Tlive + ((long)p * N + w) * D;
+            for (int j = lane; j < D; j += 64) dT[j] = Tw[j];
+            if (lane == 0) { S.deadL[(long)p * S.cap + it] = Lmin; S.deadlnw[(long)p * S.cap + it] = lnw; }
+        }
+        wave_lds_sync();
+        for (int j = lane; j < D; j += 64) {
+            S.Ulive[((long)p * N + w) * D + j] = cU[j];
+            S.Tlive[((long)p * N + w) * D + j] = cT[j];
+        }
+        if (lane == 0) { sL[w] = Lk; Ll[w] = Lk; }
+        wave_lds_sync();
+        it += 1; since += 1;
+        extremes(Lmin, w, Lmax);
+        const double remain = Lmax - (double)it / N;
+        done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= S.cap;
+    };
+    if (S.walk[p]) {
+        // ---- one Metropolis step of every walker (lane = walker), cycle end every n_steps rounds
+        const int step = S.wstep[p];
+        const int W = step == 0 ? min(NS_W, K) : S.wW[p];
+        const double Lthr = step == 0 ? Lmin : S.wLthr[p];
+        int tot = 0, acc = 0;
+        if (lane < W) {
+            const long g = (long)q * K + lane;
+            if (S.valid[g]) {
+                tot = 1;
+                const long row = S.slot[g];
+                double Lk = S.candL[row];
+                if (!isfinite(Lk)) Lk = S.log_zero;
+                if (Lk > Lthr) {
+                    acc = 1;
+                    double *wu = S.wU + ((long)p * NS_W + lane) * D, *wt = S.wT + ((long)p * NS_W + lane) * D;
+                    for (int j = 0; j < D; ++j) { wu[j] = S.candU[g * D + j]; wt[j] = S.candT[row * D + j]; }
+                    S.wL[(long)p * NS_W + lane] = Lk;
+                    S.wnacc[(long)p * NS_W + lane] += 1;
+                }
             }
-            wave_lds_sync();
-            for (int j = lane; j < D; j += 64) {
-                S.Ulive[((long)p * N + w) * D + j] = S.candU[g * D + j];
-                S.Tlive[((long)p * N + w) * D + j] = S.candT[row * D + j];
+        }
+        const long tot_w = (long)ns_wave_sum((double)tot), acc_w = (long)ns_wave_sum((double)acc);
+        evals += tot_w;
+        long acc_sum = S.wacc_sum[p] + acc_w, tot_sum = S.wtot_sum[p] + tot_w;
+        double scale = S.wscale[p];
+        int next_step = step + 1;
+        if (next_step >= S.n_steps) {
+            __threadfence();                        // walker states written by other lanes of this wave
+            for (int k = 0; k < W && !done; ++k) {
+                const int moved = __hip_atomic_load(&S.wnacc[(long)p * NS_W + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!moved) continue;               // never left its starting live point: not a new sample
+                const double Lk = __hip_atomic_load(&S.wL[(long)p * NS_W + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(Lk > Lmin)) continue;
+                replace(S.wU + ((long)p * NS_W + k) * D, S.wT + ((long)p * NS_W + k) * D, Lk);
             }
-            if (lane == 0) { sL[w] = Lk; Ll[w] = Lk; }
-            wave_lds_sync();
-            it += 1; since += 1;
-            extremes(Lmin, w, Lmax);
-            const double remain = Lmax - (double)it / N;
-            done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= S.cap;
+            // acceptance near one half (as dynesty's rwalk tunes it)
+            if (tot_sum > 0) scale = fmin(1.0, scale * exp(((double)acc_sum / (double)tot_sum - 0.5) / (0.5 * sqrt((double)D))));
+            acc_sum = 0; tot_sum = 0; next_step = 0;
+        }
+        if (lane == 0) {
+            if (step == 0) { S.wLthr[p] = Lthr; S.wW[p] = W; }
+            S.wstep[p] = next_step; S.wacc_sum[p] = acc_sum; S.wtot_sum[p] = tot_sum; S.wscale[p] = scale;
+        }
+    } else {
+        // ---- rejection sampling: every candidate of the round is used: within a round the bound only
+        // goes stale by the factor exp(-replacements / N) in volume, far cheaper than throwing evaluated
+        // points away.  The proposals are walked 64 at a time; only the valid ones cost anything.
+        long scanned = 0, accepted = 0;
+        for (int k0 = 0; k0 < K && !done; k0 += 64) {
+            const int kk = k0 + lane;
+            unsigned long long mask = __ballot(kk < K && S.valid[(long)q * K + kk] != 0);
+            while (mask && !done) {
+                const int k = k0 + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const long g = (long)q * K + k;
+                const long row = S.slot[g];
+                evals += 1; scanned += 1;
+                double Lk = S.candL[row];
+                if (!isfinite(Lk)) Lk = S.log_zero;
+                if (!(Lk > Lmin)) continue;
+                accepted += 1;
+                replace(S.candU + g * D, S.candT + row * D, Lk);
+            }
+        }
+        // too few acceptances for the work: from the next round on this pixel walks
+        if (lane == 0 && !done && (S.method == 2 || (S.method == 1 && scanned >= 64 && accepted * S.n_steps < scanned))) {
+            S.walk[p] = 1; S.wstep[p] = 0; S.wscale[p] = 1.0; S.wacc_sum[p] = 0; S.wtot_sum[p] = 0;
         }
     }
     if (lane == 0) {
@@ -325,6 +411,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
     NsDev &d = s->d;
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
                     d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
+                    d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc,
                     s->d_pixmap, s->d_actlist, s->d_livepix};
     for (void *p : ptrs) (void)hipFree(p);
     delete s;
@@ -367,6 +454,10 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.deadT, double, P * C * D); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
     NS_ALLOC(d.candU, double, P * K * D); NS_ALLOC(d.candT, double, P * K * D); NS_ALLOC(d.candL, double, P * K);
     NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K); NS_ALLOC(d.slot, int, P * K); NS_ALLOC(d.count, int, 1);
+    NS_ALLOC(d.walk, int, P); NS_ALLOC(d.wstep, int, P); NS_ALLOC(d.wW, int, P); NS_ALLOC(d.wscale, double, P);
+    NS_ALLOC(d.wLthr, double, P); NS_ALLOC(d.wacc_sum, long, P); NS_ALLOC(d.wtot_sum, long, P);
+    NS_ALLOC(d.wU, double, P * NS_W * D); NS_ALLOC(d.wT, double, P * NS_W * D); NS_ALLOC(d.wL, double, P * NS_W);
+    NS_ALLOC(d.wnacc, int, P * NS_W);
 #undef NS_ALLOC
     HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     d.pixmap = s->d_pixmap; d.actlist = s->d_actlist;
@@ -381,14 +472,16 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
 // has stopped) and reports how many pixels are still running, so the caller can show progress
 // or give up; nfa_sampler_run = begin + advance to the end.
 int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
-                      double log_zero, int check_every, double enlarge) {
+                      double log_zero, int check_every, double enlarge, int method, int n_steps) {
     if (!s) return fail(NFA_ERR_ARG, "null sampler");
-    if (!(tol > 0) || !(efr > 0 && efr <= 1) || maxiter < 0 || upd < 1 || check_every < 1 || !(enlarge >= 1))
+    if (!(tol > 0) || !(efr > 0 && efr <= 1) || maxiter < 0 || upd < 1 || check_every < 1 || !(enlarge >= 1) ||
+        method < 0 || method > 2 || n_steps < 1)
         return fail(NFA_ERR_ARG, "bad sampler options");
     nfa_runner *r = s->r;
     NsDev &d = s->d;
     const int P = d.P, N = d.N, D = d.D;
     d.ln_enlarge = log(enlarge);
+    d.method = method; d.n_steps = n_steps;
     d.tol = tol; d.maxiter = (long)maxiter; d.upd = upd; d.seed = (uint64_t)seed; d.log_zero = log_zero;
     d.ln_shrink = log1p(-exp(-1.0 / N));
     d.ln_efr = log(efr);
@@ -398,6 +491,10 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemsetAsync(d.n_iter, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.cand_base, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.since_fit, 0, sizeof(int) * P, st));
+    HIP_TRY(hipMemsetAsync(d.walk, 0, sizeof(int) * P, st));
+    HIP_TRY(hipMemsetAsync(d.wstep, 0, sizeof(int) * P, st));
+    HIP_TRY(hipMemsetAsync(d.wacc_sum, 0, sizeof(long) * P, st));
+    HIP_TRY(hipMemsetAsync(d.wtot_sum, 0, sizeof(long) * P, st));
     {   // live points
         const long tot = (long)P * N * D;
         hipLaunchKernelGGL(ns_init_live_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, s->d_livepix);
@@ -469,7 +566,7 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
 
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every) {
-    int rc = nfa_sampler_begin(s, tol, efr, seed, maxiter, upd, log_zero, check_every, 1.5);
+    int rc = nfa_sampler_begin(s, tol, efr, seed, maxiter, upd, log_zero, check_every, 1.5, 1, 25);
     if (rc) return rc;
     return nfa_sampler_advance(s, 0, nullptr);
 }

@@ -74,6 +74,27 @@ def _uniform(seed, p, a, b):
     return ((h >> _U64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
 
 
+_B_START = _U64(250)
+_NS_W = 64
+
+
+def _ball_points(seed, p, a, D):
+    """Uniform points of the unit D-ball for stream indices a[K] of pixel p (the Box-Muller and
+    radius draws of ns_propose_kernel)."""
+    a = np.asarray(a, dtype=_U64)
+    z = np.empty((a.size, D))
+    for m in range(0, D, 2):
+        u1 = _uniform(seed, p, a, _U64(m))
+        u2 = _uniform(seed, p, a, _U64(m + 1))
+        r = np.sqrt(-2.0 * np.log(u1))
+        ang = 6.283185307179586 * u2
+        z[:, m] = r * np.cos(ang)
+        if m + 1 < D:
+            z[:, m + 1] = r * np.sin(ang)
+    ur = _uniform(seed, p, a, _B_RADIUS)
+    return z * (np.exp(np.log(ur) / D) / np.sqrt((z * z).sum(axis=1)))[:, None]
+
+
 def _candidates(seed, pix, base, K, centre, axes, use_cube):
     """K candidates per pixel of `pix`, uniform in the bounding ellipsoids, or in the unit cube
     where `use_cube` says the ellipsoid is the larger of the two (ns_propose_kernel);
@@ -155,7 +176,7 @@ def _resolve_seed(seed):
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
-               check_every=8, batch_target=262144, enlarge=1.5, progress=None):
+               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=25, progress=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -176,6 +197,11 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     upd_frac : the ellipsoids are refitted at the end of a round once this fraction of nlive
         replacements has accumulated.
     cap_iter : dead-point slots per pixel (default: no other cap than maxiter).
+    method, n_steps : 'reject' = rejection sampling in the bounding ellipsoid only; 'auto' = a pixel
+        whose rejection round accepted fewer than 1 in `n_steps` of the evaluated candidates
+        switches to constrained random walks (64 walkers from random live points, `n_steps`
+        Metropolis steps inside {L > threshold}, ellipsoid-shaped proposals tuned to an acceptance
+        of one half: the `rwalk` idea of dynesty, Speagle 2020); 'walk' = walks from the start.
     enlarge : safety factor on the volume of the ellipsoid that just encloses the live points
         (scripts/sampler_bias_check.py: 1.0 biases lnZ by +0.020, 1.25 by +0.011, 2.0 by nothing measurable; the error is 0.18).
 
@@ -213,55 +239,105 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     b_target = max(P * K, int(batch_target))
     cand_base = np.zeros(P, dtype=np.int64)
     Kr = K
+    method = {'reject': 0, 'auto': 1, 'walk': 2}[method] if isinstance(method, str) else int(method)
+    n_steps = int(n_steps)
+    # constrained random walks (ns_update_kernel's walk branch): state per pixel and per walker
+    walk = np.zeros(P, dtype=bool)
+    wstep = np.zeros(P, dtype=np.int64)
+    wW = np.zeros(P, dtype=np.int64)
+    wscale = np.ones(P)
+    wLthr = np.zeros(P)
+    wacc_sum = np.zeros(P, dtype=np.int64)
+    wtot_sum = np.zeros(P, dtype=np.int64)
+    wU = np.zeros((P, _NS_W, ndim))
+    wT = np.zeros((P, _NS_W, ndim))
+    wL = np.zeros((P, _NS_W))
+    wnacc = np.zeros((P, _NS_W), dtype=np.int64)
+
+    def replace(p, cU, cT, Lk):
+        """The worst live point of pixel p dies, the candidate takes its slot; True when p is done."""
+        w = int(np.argmin(Llive[p]))
+        Lmin = Llive[p, w]
+        lnw = -n_iter[p] / nlive + ln_shrink
+        lnZ[p] = np.logaddexp(lnZ[p], lnw + Lmin)
+        if n_iter[p] < cap:
+            dead_T.append(Tlive[p, w][None].copy()); dead_L.append(np.array([Lmin]))
+            dead_lnw.append(np.array([lnw])); dead_pix.append(np.array([p]))
+        Ulive[p, w], Tlive[p, w], Llive[p, w] = cU, cT, Lk
+        n_iter[p] += 1
+        since_fit[p] += 1
+        remain = Llive[p].max() - n_iter[p] / nlive
+        return bool((np.logaddexp(lnZ[p], remain) - lnZ[p] < tol) or n_iter[p] >= maxiter or n_iter[p] >= cap)
+
     while active.any():
         if rnd % check_every == 0:                              # the device compacts its pixel list here
             Kr = int(min(16384, max(K, b_target // int(active.sum()))))
         idx = np.flatnonzero(active)
-        n = idx.size
-        cand = _candidates(seed, idx, cand_base[idx], Kr, centre[idx], axes[idx], use_cube[idx])
-        cand_base[idx] += Kr
-        valid = np.all((cand >= 0.0) & (cand < 1.0), axis=2)    # outside the unit cube = outside the prior
-        flat = np.flatnonzero(valid.ravel())
-        Lc = np.full(n * Kr, -np.inf)
-        Tc = cand.reshape(n * Kr, ndim).copy()
-        if flat.size:
-            Tsub = Tc[flat]
-            Lc[flat] = evaluate(np.repeat(idx, Kr).astype(np.int32)[flat], Tsub)
-            Tc[flat] = Tsub
-        Lc = Lc.reshape(n, Kr)
-        Tc = Tc.reshape(n, Kr, ndim)
-        going = np.ones(n, dtype=bool)                          # still scanning in this round
-        for k in range(Kr):                                     # the wave's sequential scan
-            if not going.any():
-                break
-            sel = going & valid[:, k]
-            n_evals[idx[sel]] += 1
-            worst = np.argmin(Llive[idx], axis=1)
-            Lmin = Llive[idx, worst]
-            acc = np.flatnonzero(sel & (Lc[:, k] > Lmin))
-            if not acc.size:
-                continue
-            p, w = idx[acc], worst[acc]
-            lnw = -n_iter[p] / nlive + ln_shrink
-            lnZ[p] = np.logaddexp(lnZ[p], lnw + Lmin[acc])
-            keep = n_iter[p] < cap
-            dead_T.append(Tlive[p, w][keep]); dead_L.append(Lmin[acc][keep])
-            dead_lnw.append(lnw[keep]); dead_pix.append(p[keep])
-            Ulive[p, w] = cand[acc, k]
-            Tlive[p, w] = Tc[acc, k]
-            Llive[p, w] = Lc[acc, k]
-            n_iter[p] += 1
-            since_fit[p] += 1
-            # termination (MultiNest's tol): the live points cannot add more than tol to lnZ
-            remain = Llive[p].max(axis=1) - n_iter[p] / nlive
-            done = (np.logaddexp(lnZ[p], remain) - lnZ[p] < tol) | (n_iter[p] >= maxiter) | (n_iter[p] >= cap)
-            active[p[done]] = False
-            going[acc[done]] = False
-        refit = idx[active[idx] & (since_fit[idx] >= upd)]
-        if refit.size:
-            centre[refit], axes[refit], use_cube[refit] = _fit_ellipsoids(Ulive[refit], efr,
-                                                                          -n_iter[refit] / nlive, enlarge)
-            since_fit[refit] = 0
+        for p in idx:                                           # one wave per pixel on the device
+            p = int(p)
+            done = False
+            if walk[p]:
+                # one Metropolis step of every walker inside {L > threshold frozen at the cycle start}
+                step = int(wstep[p])
+                W = min(_NS_W, Kr) if step == 0 else int(wW[p])
+                a = _U64(cand_base[p]) + np.arange(W, dtype=_U64)
+                if step == 0:
+                    start = np.minimum(nlive - 1, (_uniform(seed, p, a, _B_START) * nlive).astype(np.int64))
+                    wU[p, :W], wT[p, :W], wL[p, :W] = Ulive[p, start], Tlive[p, start], Llive[p, start]
+                    wnacc[p, :W] = 0
+                    wLthr[p] = Llive[p].min()
+                    wW[p] = W
+                z = _ball_points(seed, p, a, ndim) * wscale[p]
+                cand = wU[p, :W] + z @ axes[p].T
+                valid = np.all((cand >= 0.0) & (cand < 1.0), axis=1)
+                vi = np.flatnonzero(valid)
+                if vi.size:
+                    Tsub = cand[vi].copy()
+                    Lsub = evaluate(np.full(vi.size, p, dtype=np.int32), Tsub)
+                    n_evals[p] += vi.size
+                    ok = Lsub > wLthr[p]
+                    wU[p, vi[ok]], wT[p, vi[ok]], wL[p, vi[ok]] = cand[vi[ok]], Tsub[ok], Lsub[ok]
+                    wnacc[p, vi[ok]] += 1
+                    wacc_sum[p] += int(ok.sum())
+                    wtot_sum[p] += vi.size
+                wstep[p] = step + 1
+                if wstep[p] >= n_steps:                         # cycle end: the walkers are the candidates
+                    for k in range(W):
+                        if done:
+                            break
+                        if wnacc[p, k] == 0 or not (wL[p, k] > Llive[p].min()):
+                            continue
+                        done = replace(p, wU[p, k].copy(), wT[p, k].copy(), wL[p, k])
+                    if wtot_sum[p] > 0:                         # acceptance near one half
+                        wscale[p] = min(1.0, wscale[p] * math.exp((wacc_sum[p] / wtot_sum[p] - 0.5)
+                                                                  / (0.5 * math.sqrt(ndim))))
+                    wacc_sum[p] = wtot_sum[p] = wstep[p] = 0
+            else:
+                cand = _candidates(seed, [p], cand_base[p:p + 1], Kr, centre[p:p + 1], axes[p:p + 1],
+                                   use_cube[p:p + 1])[0]
+                valid = np.all((cand >= 0.0) & (cand < 1.0), axis=1)   # outside the unit cube = outside the prior
+                vi = np.flatnonzero(valid)
+                scanned = accepted = 0
+                if vi.size:
+                    Tsub = cand[vi].copy()
+                    Lsub = evaluate(np.full(vi.size, p, dtype=np.int32), Tsub)
+                    for j in range(vi.size):                    # the wave's sequential scan
+                        scanned += 1
+                        n_evals[p] += 1
+                        if Lsub[j] > Llive[p].min():
+                            accepted += 1
+                            done = replace(p, cand[vi[j]].copy(), Tsub[j].copy(), Lsub[j])
+                            if done:
+                                break
+                if not done and (method == 2 or (method == 1 and scanned >= 64 and accepted * n_steps < scanned)):
+                    walk[p], wstep[p], wscale[p], wacc_sum[p], wtot_sum[p] = True, 0, 1.0, 0, 0
+            cand_base[p] += Kr
+            if done:
+                active[p] = False
+            elif since_fit[p] >= upd:
+                c1, a1, u1 = _fit_ellipsoids(Ulive[p:p + 1], efr, -n_iter[p:p + 1] / nlive, enlarge)
+                centre[p], axes[p], use_cube[p] = c1[0], a1[0], u1[0]
+                since_fit[p] = 0
         rnd += 1
         if progress is not None:
             progress(int(active.sum()), int(n_iter.max()))
@@ -282,7 +358,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
                       upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=262144,
-                      enlarge=1.5, progress=None, time_limit=None):
+                      enlarge=1.5, method='auto', n_steps=25, progress=None, time_limit=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
     work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive).  `progress`
@@ -304,7 +380,9 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
     try:
         _ffi.check(lib.nfa_sampler_begin(h, float(tol), float(efr), seed, int(maxiter),
                                          max(1, int(upd_frac * nlive)), float(log_zero), int(check_every),
-                                         float(enlarge)))
+                                         float(enlarge),
+                                         {'reject': 0, 'auto': 1, 'walk': 2}[method] if isinstance(method, str)
+                                         else int(method), int(n_steps)))
         n_active = C.c_int64(P)
         t0 = time.perf_counter()
         chunks = 16

@@ -52,6 +52,33 @@ def test_two_modes_in_one_ellipsoid():
         assert w[x < 0.5].sum() == pytest.approx(0.5, abs=0.15)               # both modes populated
 
 
+def test_walk_mode_evidence_and_switch():
+    """Constrained random walks instead of rejection sampling: same evidence within the error, about
+    n_steps evaluations per iteration; 'auto' switches when rejection gets inefficient."""
+    ndim, sigma, P = 6, 0.04, 6
+    f = _gauss_problem(np.full(ndim, 0.5), sigma)
+    truth = ndim * np.log(sigma * np.sqrt(2 * np.pi))
+    res = sampler.run_nested(f, ndim, P, nlive=150, tol=0.1, efr=0.5, seed=21, method='walk', n_steps=20,
+                             batch_target=512)
+    lnZ = np.array([r.lnZ for r in res])
+    err = np.mean([r.lnZ_err for r in res])
+    assert abs(lnZ.mean() - truth) < 4 * err / np.sqrt(P) + 0.05, (lnZ - truth, err)
+    assert np.all(np.abs(lnZ - truth) < 4.5 * err)
+    per_iter = np.mean([r.n_evals / r.n_iter for r in res])
+    assert 15 < per_iter < 30
+    np.testing.assert_allclose(res[0].param_constr[1], sigma, rtol=0.25)
+    # two narrow modes in opposite corners: one ellipsoid around both accepts almost nothing, 'auto' walks
+    D, sig = 5, 0.01
+    f2 = _gauss_problem(np.array([[0.25] * D, [0.75] * D]), sig)
+    truth2 = np.log(2) + D * np.log(sig * np.sqrt(2 * np.pi))
+    auto = sampler.run_nested(f2, D, 1, nlive=100, tol=0.5, seed=4, method='auto', n_steps=20, batch_target=512)[0]
+    rej = sampler.run_nested(f2, D, 1, nlive=100, tol=0.5, seed=4, method='reject', batch_target=512)[0]
+    assert auto.n_evals < 0.7 * rej.n_evals
+    assert abs(auto.lnZ - truth2) < 4 * auto.lnZ_err and abs(rej.lnZ - truth2) < 4 * rej.lnZ_err
+    w, x = auto.posterior[:, -1], auto.posterior[:, 0]
+    assert 0.1 < w[x < 0.5].sum() < 0.9                                      # both modes kept
+
+
 def test_seed_reproducibility_and_independent_pixels():
     f = _gauss_problem(np.full(3, 0.4), 0.1)
     a = sampler.run_nested(f, 3, 3, nlive=60, seed=7)
@@ -181,6 +208,14 @@ def test_sampler_on_gpu_matches_the_same_sampler_on_the_oracle(engine, nfo):
                 assert 0 <= g.rounds - r.rounds < 8            # the device looks up every 8 rounds
                 assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
                 np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
+        # constrained random walks from the first round on: twin and device take the same steps
+        kww = dict(kw, method='walk', n_steps=7, maxiter=400)
+        ref_w = sampler.run_nested(cpu_loglike, cube.ndim, n_pix, **kww)
+        got_w = sampler.fit_pixels(cube, np.arange(n_pix), **kww)
+        for g, r in zip(got_w, ref_w):
+            assert g.n_iter == r.n_iter and g.n_evals == r.n_evals, (g.n_iter, r.n_iter, g.n_evals, r.n_evals)
+            assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
+            np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
         engine.set_exp_mode('fast')
         fast = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
         for g, r in zip(fast, ref):
