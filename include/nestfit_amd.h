@@ -236,11 +236,12 @@ int nfa_sampler_destroy(nfa_sampler *s);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
 /* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the
- * bounding ellipsoid only; 1 = a pixel whose rejection round accepted fewer than 1 in n_steps of
+ * bounding ellipsoid only; 1 = a pixel whose rejection round accepted fewer than 1 in 2 n_steps of
  * the evaluated candidates switches to constrained random walks: 64 walkers start from random live
  * points and take n_steps Metropolis steps inside {L > threshold} with ellipsoid-shaped proposals
  * whose scale is tuned to an acceptance of one half (the `rwalk` idea of dynesty, Speagle 2020);
- * 2 = walks from the first round.  nfa_sampler_run uses method 1, n_steps 25.
+ * 2 = walks from the first round.  nfa_sampler_run uses method 1, n_steps 8 * ndim (walks that are
+ * too short bias lnZ upwards: +0.11 with 25 steps in 6 dimensions, nothing measurable from ~50).
  * (nfa_sampler_run uses enlarge = 1.5: safety factor on the volume of the ellipsoid that just
  * encloses the live points, before MultiNest's floor X / efr is applied)
  * the same in two steps: begin = live points + first ellipsoids; advance = up to max_chunks groups

@@ -63,6 +63,7 @@ struct NsDev {
     long   *wacc_sum, *wtot_sum;        // [P] accepted / evaluated steps of the current cycle
     double *wU, *wT, *wL;               // walker states [P][NS_W][D], [P][NS_W][D], [P][NS_W]
     int    *wnacc;                      // [P][NS_W] accepted steps of each walker in the cycle
+    double *lnvol;                      // [P] ln volume of the bounding ellipsoid (last refit)
 };
 
 // ---- live points -------------------------------------------------------------------------
@@ -241,7 +242,7 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
     const double ln_x = -(double)n_iter / N;
     const double grow = fmax((ln_x - S.ln_efr) - lnv, 0.0);
     const double scale = sqrt(r2) * exp((grow + S.ln_enlarge) / D);
-    if (lane == 0) S.use_cube[p] = (lnv + grow) >= 0.0 ? 1 : 0;   // larger than the unit cube: use the cube
+    if (lane == 0) { S.use_cube[p] = (lnv + grow) >= 0.0 ? 1 : 0; S.lnvol[p] = lnv + grow; }   // >= cube: use the cube
     double *A = S.axes + (long)p * D * D, *c = S.centre + (long)p * D;
     for (int e = lane; e < D * D; e += 64) {
         const int a = e / D, b = e - a * D;
@@ -347,6 +348,9 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
             // acceptance near one half (as dynesty's rwalk tunes it)
             if (tot_sum > 0) scale = fmin(1.0, scale * exp(((double)acc_sum / (double)tot_sum - 0.5) / (0.5 * sqrt((double)D))));
             acc_sum = 0; tot_sum = 0; next_step = 0;
+            // back to rejection sampling once the bound promises clearly more than a walk delivers:
+            // expected acceptance X / min(V_ellipsoid, 1) > 4 / n_steps
+            if (lane == 0 && S.method == 1 && (-(double)it / N - fmin(S.lnvol[p], 0.0)) > log(4.0 / S.n_steps)) S.walk[p] = 0;
         }
         if (lane == 0) {
             if (step == 0) { S.wLthr[p] = Lthr; S.wW[p] = W; }
@@ -373,8 +377,9 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
                 replace(S.candU + g * D, S.candT + row * D, Lk);
             }
         }
-        // too few acceptances for the work: from the next round on this pixel walks
-        if (lane == 0 && !done && (S.method == 2 || (S.method == 1 && scanned >= 64 && accepted * S.n_steps < scanned))) {
+        // clearly (2x) fewer acceptances per evaluation than a walk delivers: from the next round on
+        // this pixel walks
+        if (lane == 0 && !done && (S.method == 2 || (S.method == 1 && scanned >= 64 && 2 * accepted * S.n_steps < scanned))) {
             S.walk[p] = 1; S.wstep[p] = 0; S.wscale[p] = 1.0; S.wacc_sum[p] = 0; S.wtot_sum[p] = 0;
         }
     }
@@ -411,7 +416,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
     NsDev &d = s->d;
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
                     d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
-                    d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc,
+                    d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol,
                     s->d_pixmap, s->d_actlist, s->d_livepix};
     for (void *p : ptrs) (void)hipFree(p);
     delete s;
@@ -457,7 +462,7 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.walk, int, P); NS_ALLOC(d.wstep, int, P); NS_ALLOC(d.wW, int, P); NS_ALLOC(d.wscale, double, P);
     NS_ALLOC(d.wLthr, double, P); NS_ALLOC(d.wacc_sum, long, P); NS_ALLOC(d.wtot_sum, long, P);
     NS_ALLOC(d.wU, double, P * NS_W * D); NS_ALLOC(d.wT, double, P * NS_W * D); NS_ALLOC(d.wL, double, P * NS_W);
-    NS_ALLOC(d.wnacc, int, P * NS_W);
+    NS_ALLOC(d.wnacc, int, P * NS_W); NS_ALLOC(d.lnvol, double, P);
 #undef NS_ALLOC
     HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     d.pixmap = s->d_pixmap; d.actlist = s->d_actlist;
@@ -566,7 +571,7 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
 
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every) {
-    int rc = nfa_sampler_begin(s, tol, efr, seed, maxiter, upd, log_zero, check_every, 1.5, 1, 25);
+    int rc = nfa_sampler_begin(s, tol, efr, seed, maxiter, upd, log_zero, check_every, 1.5, 1, 8 * s->d.D);
     if (rc) return rc;
     return nfa_sampler_advance(s, 0, nullptr);
 }
