@@ -254,7 +254,7 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
 
 // ---- one wave per pixel: accept / replace / evidence / stop / refit ------------------------
 // q indexes actlist (force_refit: q indexes pixels directly, no candidates: initial ellipsoids)
-__global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int Kr, int force_refit) {
+__global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int Kr, int force_refit, long round) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= n_act) return;
@@ -361,25 +361,40 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         // goes stale by the factor exp(-replacements / N) in volume, far cheaper than throwing evaluated
         // points away.  The proposals are walked 64 at a time; only the valid ones cost anything.
         long scanned = 0, accepted = 0;
-        for (int k0 = 0; k0 < K && !done; k0 += 64) {
-            const int kk = k0 + lane;
-            unsigned long long mask = __ballot(kk < K && S.valid[(long)q * K + kk] != 0);
-            while (mask && !done) {
-                const int k = k0 + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const long g = (long)q * K + k;
-                const long row = S.slot[g];
-                evals += 1; scanned += 1;
-                double Lk = S.candL[row];
-                if (!isfinite(Lk)) Lk = S.log_zero;
-                if (!(Lk > Lmin)) continue;
-                accepted += 1;
-                replace(S.candU + g * D, S.candT + row * D, Lk);
+        for (int kb = 0; kb < K && !done; kb += 512) {
+            // validity flags of 512 proposals at a time: eight independent loads per lane, so that a
+            // round of 16 k proposals costs 32 memory latencies, not 256
+            unsigned long long masks[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = kb + 64 * u + lane;
+                masks[u] = __ballot(kk < K && S.valid[(long)q * K + kk] != 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                unsigned long long mask = masks[u];
+                const int k0 = kb + 64 * u;
+                while (mask && !done) {
+                    const int k = k0 + __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const long g = (long)q * K + k;
+                    const long row = S.slot[g];
+                    evals += 1; scanned += 1;
+                    double Lk = S.candL[row];
+                    if (!isfinite(Lk)) Lk = S.log_zero;
+                    if (!(Lk > Lmin)) continue;
+                    accepted += 1;
+                    replace(S.candU + g * D, S.candT + row * D, Lk);
+                }
             }
         }
         // clearly (2x) fewer acceptances per evaluation than a walk delivers: from the next round on
         // this pixel walks
-        if (lane == 0 && !done && (S.method == 2 || (S.method == 1 && scanned >= 64 && 2 * accepted * S.n_steps < scanned))) {
+        // Walk cycles of all pixels are kept in phase (they start at rounds that are multiples of
+        // n_steps): the expensive cycle end then falls into the same launch for everybody instead of
+        // making every launch wait for somebody's.
+        if (lane == 0 && !done && (round + 1) % S.n_steps == 0 &&
+            (S.method == 2 || (S.method == 1 && scanned >= 64 && 2 * accepted * S.n_steps < scanned))) {
             S.walk[p] = 1; S.wstep[p] = 0; S.wscale[p] = 1.0; S.wacc_sum[p] = 0; S.wtot_sum[p] = 0;
         }
     }
@@ -519,7 +534,7 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     s->lds = sizeof(double) * ((size_t)((N + 1) & ~1) + (size_t)D * D + (size_t)D);
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));
-    hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), s->lds, st, d, P, 0, 1);   // first ellipsoids
+    hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), s->lds, st, d, P, 0, 1, 0L);   // first ellipsoids
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     s->rounds = 0;
@@ -553,7 +568,7 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                 int rc = run_batch(r, d.candpix, d.candT, d.candL, nullptr, n_rows, true, 0, nullptr);
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_act), dim3(64), s->lds, st, d, n_act, Kr, 0);
+            hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_act), dim3(64), s->lds, st, d, n_act, Kr, 0, s->rounds);
             HIP_TRY(hipGetLastError());
             s->rounds += 1;
         }

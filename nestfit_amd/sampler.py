@@ -335,7 +335,9 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                             done = replace(p, cand[vi[j]].copy(), Tsub[j].copy(), Lsub[j])
                             if done:
                                 break
-                if not done and (method == 2 or (method == 1 and scanned >= 64 and 2 * accepted * n_steps < scanned)):
+                # walk cycles of all pixels stay in phase: they start at rounds that are multiples of n_steps
+                if not done and (rnd + 1) % n_steps == 0 and (
+                        method == 2 or (method == 1 and scanned >= 64 and 2 * accepted * n_steps < scanned)):
                     walk[p], wstep[p], wscale[p], wacc_sum[p], wtot_sum[p] = True, 0, 1.0, 0, 0
             cand_base[p] += Kr
             if done:
