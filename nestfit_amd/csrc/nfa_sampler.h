@@ -158,22 +158,34 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
     for (int j = 0; j < D; ++j) ct[j] = cu[j];
 }
 
-// ---- wave helpers (one 64-lane wave per pixel; nothing here is hot) -------------------------
-__device__ __forceinline__ double ns_wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+// ---- wave helpers (one 64-lane wave per pixel) -------------------------------------------------
+// DPP butterflies inside the rows of 16 lanes, the four rows combined through readlane: a
+// replacement costs one arg-min over the live points, and there are ~15 k of them per pixel.
+__device__ __forceinline__ double ns_wave_sum(double v) { return wave_sum(v); }
+template <int CTRL>
+__device__ __forceinline__ void ns_max_step(double &v) { v = fmax(v, dpp_move<CTRL>(v)); }
 __device__ __forceinline__ double ns_wave_max(double v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+    ns_max_step<0xB1>(v); ns_max_step<0x4E>(v); ns_max_step<0x141>(v); ns_max_step<0x140>(v);
+    return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
 }
 // minimum with the lowest index among equals (numpy.argmin)
+__device__ __forceinline__ void ns_min_pick(double &v, int &ix, double ov, int oi) {
+    if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+}
+template <int CTRL>
+__device__ __forceinline__ void ns_argmin_step(double &v, int &ix) {
+    const double ov = dpp_move<CTRL>(v);
+    const int oi = __builtin_amdgcn_update_dpp(0, ix, CTRL, 0xf, 0xf, false);
+    ns_min_pick(v, ix, ov, oi);
+}
 __device__ __forceinline__ void ns_wave_argmin(double &v, int &ix) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(ix, o);
-        if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-    }
+    ns_argmin_step<0xB1>(v, ix); ns_argmin_step<0x4E>(v, ix); ns_argmin_step<0x141>(v, ix); ns_argmin_step<0x140>(v, ix);
+    double m = readlane_d(v, 0);
+    int mi = __builtin_amdgcn_readlane(ix, 0);
+    ns_min_pick(m, mi, readlane_d(v, 16), __builtin_amdgcn_readlane(ix, 16));
+    ns_min_pick(m, mi, readlane_d(v, 32), __builtin_amdgcn_readlane(ix, 32));
+    ns_min_pick(m, mi, readlane_d(v, 48), __builtin_amdgcn_readlane(ix, 48));
+    v = m; ix = mi;
 }
 __device__ __forceinline__ double ns_logaddexp(double a, double b) {
     if (a == -INFINITY) return b;
@@ -268,20 +280,24 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     double *Ll = S.Llive + (long)p * N;
     for (int i = lane; i < N; i += 64) sL[i] = Ll[i];
     wave_lds_sync();
-    auto extremes = [&](double &lmin, int &w, double &lmax) {
-        double mn = INFINITY, mx = -INFINITY;
+    auto worst_point = [&](double &lmin, int &w) {
+        double mn = INFINITY;
         int ix = 0x7fffffff;
         for (int i = lane; i < N; i += 64) {
             const double v = sL[i];
             if (v < mn) { mn = v; ix = i; }         // ascending i: first occurrence per lane
-            mx = fmax(mx, v);
         }
         ns_wave_argmin(mn, ix);
-        lmin = mn; w = ix; lmax = ns_wave_max(mx);
+        lmin = mn; w = ix;
     };
     double Lmin, Lmax;
     int w;
-    extremes(Lmin, w, Lmax);
+    worst_point(Lmin, w);
+    {
+        double mx = -INFINITY;
+        for (int i = lane; i < N; i += 64) mx = fmax(mx, sL[i]);
+        Lmax = ns_wave_max(mx);
+    }
     long it = S.n_iter[p], evals = S.n_evals[p];
     double lnZ = S.lnZ[p];
     int since = S.since_fit[p];
@@ -305,7 +321,8 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         if (lane == 0) { sL[w] = Lk; Ll[w] = Lk; }
         wave_lds_sync();
         it += 1; since += 1;
-        extremes(Lmin, w, Lmax);
+        Lmax = fmax(Lmax, Lk);                      // the point that left was the minimum
+        worst_point(Lmin, w);
         const double remain = Lmax - (double)it / N;
         done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= S.cap;
     };
@@ -364,32 +381,41 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         for (int kb = 0; kb < K && !done; kb += 512) {
             // validity flags of 512 proposals at a time: eight independent loads per lane, so that a
             // round of 16 k proposals costs 32 memory latencies, not 256
+            // (the rows and likelihoods of the valid ones are fetched lane-parallel as well: walking
+            // the candidates one by one through two dependent global loads each cost 3 us apiece)
             unsigned long long masks[8];
+            int rows[8];
+            double Ls[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int kk = kb + 64 * u + lane;
-                masks[u] = __ballot(kk < K && S.valid[(long)q * K + kk] != 0);
+                const bool v = kk < K && S.valid[(long)q * K + kk] != 0;
+                masks[u] = __ballot(v);
+                rows[u] = v ? S.slot[(long)q * K + kk] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool mine = (masks[u] >> lane) & 1ull;
+                const double L = mine ? S.candL[rows[u]] : 0.0;
+                Ls[u] = isfinite(L) ? L : S.log_zero;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 unsigned long long mask = masks[u];
                 const int k0 = kb + 64 * u;
                 while (mask && !done) {
-                    const int k = k0 + __builtin_ctzll(mask);
+                    const int src = __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    const long g = (long)q * K + k;
-                    const long row = S.slot[g];
+                    const long g = (long)q * K + k0 + src;
+                    const long row = __builtin_amdgcn_readlane(rows[u], src);
                     evals += 1; scanned += 1;
-                    double Lk = S.candL[row];
-                    if (!isfinite(Lk)) Lk = S.log_zero;
+                    const double Lk = readlane_d(Ls[u], src);
                     if (!(Lk > Lmin)) continue;
                     accepted += 1;
                     replace(S.candU + g * D, S.candT + row * D, Lk);
                 }
             }
         }
-        // clearly (2x) fewer acceptances per evaluation than a walk delivers: from the next round on
-        // this pixel walks
         // Walk cycles of all pixels are kept in phase (they start at rounds that are multiples of
         // n_steps): the expensive cycle end then falls into the same launch for everybody instead of
         // making every launch wait for somebody's.
