@@ -548,11 +548,15 @@ def run_multinest(runner, dumper, IS=False, mmodal=True, ceff=False, nlive=400, 
     if nClsPar > runner.n_params:
         raise ValueError('Number of clustering parameters must be less than total.')
 
-    def loglike(pix, U):
-        return runner.loglikelihood_batch(U)
+    if hasattr(runner, '_run'):          # engine runner: the whole run stays on the device
+        res = run_nested_device(runner, np.zeros(1, dtype=np.int32), nlive=nlive, tol=tol, efr=efr, seed=seed,
+                                maxiter=maxiter, log_zero=logZero)[0]
+    else:                                # any object with loglikelihood_batch(U): the numpy twin
+        def loglike(pix, U):
+            return runner.loglikelihood_batch(U)
 
-    res = run_nested(loglike, runner.ndim, 1, nlive=nlive, tol=tol, efr=efr, seed=seed,
-                     maxiter=maxiter, log_zero=logZero)[0]
+        res = run_nested(loglike, runner.ndim, 1, nlive=nlive, tol=tol, efr=efr, seed=seed,
+                         maxiter=maxiter, log_zero=logZero)[0]
     dumper.dump(runner, res)
     return res
 
