@@ -64,6 +64,7 @@ struct NsDev {
     double *wU, *wT, *wL;               // walker states [P][NS_W][D], [P][NS_W][D], [P][NS_W]
     int    *wnacc;                      // [P][NS_W] accepted steps of each walker in the cycle
     double *lnvol;                      // [P] ln volume of the bounding ellipsoid (last refit)
+    int     stage_live;                 // the refit stages the centred live points in LDS
 };
 
 // ---- live points -------------------------------------------------------------------------
@@ -198,7 +199,7 @@ __device__ __forceinline__ double ns_logaddexp(double a, double b) {
 // nestfit_amd/sampler.py): centre = mean, A = chol(cov) * sqrt(max Mahalanobis^2) * growth, the
 // growth bringing the volume up to X / efr where the bounding ellipsoid is smaller than that.
 // sA: D*D doubles of LDS, sc: D doubles.
-__device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double *sc, int lane) {
+__device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double *sc, double *sd, int lane) {
     const int N = S.N, D = S.D;
     const double *U = S.Ulive + (long)p * N * D;
     for (int j = 0; j < D; ++j) {
@@ -209,15 +210,35 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
     }
     wave_lds_sync();
     double tr = 0.0;
-    for (int a = 0; a < D; ++a)
-        for (int b = 0; b <= a; ++b) {
-            double s = 0.0;
-            for (int i = lane; i < N; i += 64) s += (U[(long)i * D + a] - sc[a]) * (U[(long)i * D + b] - sc[b]);
-            s = ns_wave_sum(s) / (N - 1);
-            if (lane == 0) sA[a * D + b] = s;
-            if (a == b) tr += s;
+    if (sd) {
+        // the centred live points fit in LDS (N * D doubles): staged once with coalesced loads, then
+        // lanes = entries of the covariance matrix, each walking all points in LDS -- the D(D+1)/2
+        // wave reductions over global memory of the fallback below cost ~200 us per refit for D = 12
+        for (int e = lane; e < N * D; e += 64) sd[e] = U[e] - sc[e % D];
+        wave_lds_sync();
+        const int n_ent = D * (D + 1) / 2;
+        for (int e = lane; e < n_ent; e += 64) {
+            int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);          // row of the lower triangle
+            while (a * (a + 1) / 2 > e) --a;
+            while ((a + 1) * (a + 2) / 2 <= e) ++a;
+            const int b = e - a * (a + 1) / 2;
+            double acc = 0.0;
+            for (int i = 0; i < N; ++i) acc += sd[i * D + a] * sd[i * D + b];
+            sA[a * D + b] = acc / (N - 1);
         }
-    wave_lds_sync();
+        wave_lds_sync();
+        for (int a = 0; a < D; ++a) tr += sA[a * D + a];
+    } else {
+        for (int a = 0; a < D; ++a)
+            for (int b = 0; b <= a; ++b) {
+                double acc = 0.0;
+                for (int i = lane; i < N; i += 64) acc += (U[(long)i * D + a] - sc[a]) * (U[(long)i * D + b] - sc[b]);
+                acc = ns_wave_sum(acc) / (N - 1);
+                if (lane == 0) sA[a * D + b] = acc;
+                if (a == b) tr += acc;
+            }
+        wave_lds_sync();
+    }
     if (lane == 0) {                    // Cholesky, lower triangle in place
         const double eps = 1e-12 * fmax(tr, 1e-30);
         for (int a = 0; a < D; ++a) sA[a * D + a] += eps;
@@ -239,7 +260,7 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         double y[NS_MAXD];
         double s2 = 0.0;
         for (int a = 0; a < D; ++a) {
-            double v = U[(long)i * D + a] - sc[a];
+            double v = sd ? sd[i * D + a] : U[(long)i * D + a] - sc[a];
             for (int k = 0; k < a; ++k) v -= sA[a * D + k] * y[k];
             y[a] = v / sA[a * D + a];
             s2 += y[a] * y[a];
@@ -275,7 +296,8 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     double *sL = smem;                              // live log-likelihoods of the pixel
     double *sA = sL + ((N + 1) & ~1);               // D*D
     double *sc = sA + D * D;                        // D
-    if (force_refit) { ns_refit(S, p, 0, sA, sc, lane); return; }
+    double *sd = S.stage_live ? sc + ((D + 1) & ~1) : nullptr;   // N*D centred live points (refit)
+    if (force_refit) { ns_refit(S, p, 0, sA, sc, sd, lane); return; }
     if (!S.active[p]) return;
     double *Ll = S.Llive + (long)p * N;
     for (int i = lane; i < N; i += 64) sL[i] = Ll[i];
@@ -430,7 +452,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     }
     if (!done && since >= S.upd) {
         __threadfence();                            // the wave's own stores to Ulive, then its loads
-        ns_refit(S, p, it, sA, sc, lane);
+        ns_refit(S, p, it, sA, sc, sd, lane);
         since = 0;
     }
     if (lane == 0) S.since_fit[p] = since;
@@ -557,7 +579,9 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemcpyAsync(d.n_evals, h_evals.data(), sizeof(long) * P, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d.lnZ, h_lnz.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d.active, s->h_active.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
-    s->lds = sizeof(double) * ((size_t)((N + 1) & ~1) + (size_t)D * D + (size_t)D);
+    s->lds = sizeof(double) * ((size_t)((N + 1) & ~1) + (size_t)D * D + (size_t)((D + 1) & ~1));
+    d.stage_live = (size_t)N * D * sizeof(double) <= 96 * 1024 ? 1 : 0;
+    if (d.stage_live) s->lds += sizeof(double) * (size_t)N * D;
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));
     hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), s->lds, st, d, P, 0, 1, 0L);   // first ellipsoids
