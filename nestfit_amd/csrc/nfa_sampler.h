@@ -202,19 +202,21 @@ __device__ __forceinline__ double ns_logaddexp(double a, double b) {
 __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double *sc, double *sd, int lane) {
     const int N = S.N, D = S.D;
     const double *U = S.Ulive + (long)p * N * D;
-    for (int j = 0; j < D; ++j) {
-        double s = 0.0;
-        for (int i = lane; i < N; i += 64) s += U[(long)i * D + j];
-        s = ns_wave_sum(s);
-        if (lane == 0) sc[j] = s / N;
-    }
-    wave_lds_sync();
     double tr = 0.0;
     if (sd) {
-        // the centred live points fit in LDS (N * D doubles): staged once with coalesced loads, then
-        // lanes = entries of the covariance matrix, each walking all points in LDS -- the D(D+1)/2
-        // wave reductions over global memory of the fallback below cost ~200 us per refit for D = 12
-        for (int e = lane; e < N * D; e += 64) sd[e] = U[e] - sc[e % D];
+        // the live points fit in LDS (N * D doubles): staged once with coalesced loads, then lanes =
+        // dimensions for the mean and lanes = entries of the covariance matrix, each walking all
+        // points in LDS -- the D(D+1)/2 wave reductions over global memory of the fallback below cost
+        // ~200 us per refit for D = 12
+        for (int e = lane; e < N * D; e += 64) sd[e] = U[e];
+        wave_lds_sync();
+        for (int j = lane; j < D; j += 64) {
+            double acc = 0.0;
+            for (int i = 0; i < N; ++i) acc += sd[i * D + j];
+            sc[j] = acc / N;
+        }
+        wave_lds_sync();
+        for (int e = lane; e < N * D; e += 64) sd[e] -= sc[e % D];
         wave_lds_sync();
         const int n_ent = D * (D + 1) / 2;
         for (int e = lane; e < n_ent; e += 64) {
@@ -229,6 +231,13 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         wave_lds_sync();
         for (int a = 0; a < D; ++a) tr += sA[a * D + a];
     } else {
+        for (int j = 0; j < D; ++j) {
+            double acc = 0.0;
+            for (int i = lane; i < N; i += 64) acc += U[(long)i * D + j];
+            acc = ns_wave_sum(acc);
+            if (lane == 0) sc[j] = acc / N;
+        }
+        wave_lds_sync();
         for (int a = 0; a < D; ++a)
             for (int b = 0; b <= a; ++b) {
                 double acc = 0.0;
@@ -348,7 +357,8 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         const double remain = Lmax - (double)it / N;
         done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= S.cap;
     };
-    if (S.walk[p]) {
+    const bool was_walking = S.walk[p] != 0;
+    if (was_walking) {
         // ---- one Metropolis step of every walker (lane = walker), cycle end every n_steps rounds
         const int step = S.wstep[p];
         const int W = step == 0 ? min(NS_W, K) : S.wW[p];
@@ -450,7 +460,10 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         S.n_iter[p] = it; S.n_evals[p] = evals; S.lnZ[p] = lnZ; S.cand_base[p] += Kr;
         if (done) S.active[p] = 0;
     }
-    if (!done && since >= S.upd) {
+    // A refit costs ~100 us and pixels are in lock-step: rejection-mode pixels refit only in every
+    // fourth round, so that three launches out of four do not wait for anybody's refit (walking
+    // pixels refit at their common cycle end).
+    if (!done && since >= S.upd && (was_walking || (round + 1) % 4 == 0)) {
         __threadfence();                            // the wave's own stores to Ulive, then its loads
         ns_refit(S, p, it, sA, sc, sd, lane);
         since = 0;

@@ -279,6 +279,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         for p in idx:                                           # one wave per pixel on the device
             p = int(p)
             done = False
+            was_walking = bool(walk[p])
             if walk[p]:
                 # one Metropolis step of every walker inside {L > threshold frozen at the cycle start}
                 step = int(wstep[p])
@@ -342,7 +343,9 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             cand_base[p] += Kr
             if done:
                 active[p] = False
-            elif since_fit[p] >= upd:
+            elif since_fit[p] >= upd and (was_walking or (rnd + 1) % 4 == 0):
+                # (rejection-mode pixels refit only in every fourth round: on the device a refit makes the
+                # whole launch wait, so they are taken together)
                 c1, a1, u1, v1 = _fit_ellipsoids(Ulive[p:p + 1], efr, -n_iter[p:p + 1] / nlive, enlarge)
                 centre[p], axes[p], use_cube[p], lnvol[p] = c1[0], a1[0], u1[0], v1[0]
                 since_fit[p] = 0
