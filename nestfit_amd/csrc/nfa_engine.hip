@@ -691,14 +691,29 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     rc = sync_all_lanes(r); if (rc) return rc;           // the staging buffers are shared
     rc = runner_reserve(r, B, false); if (rc) return rc;
-    hipStream_t st = r->lanes[0];
-    HIP_TRY(hipMemcpyAsync(r->d_U, U, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, st));
-    if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, st));
-    rc = run_batch(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, nullptr, B, true, 0, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(U, r->d_U, sizeof(double) * B * r->ndim, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(lnL, r->d_lnL, sizeof(double) * B, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // Large batches go through the stream lanes in chunks: the kernels of chunk c run while the
+    // host copies chunk c+1 in, and the results of chunk c come back while c+1 computes.  (Every
+    // per-item result is independent of the batch it travels in.)
+    const int n_chunks = (B >= 16384 && r->n_lanes > 1) ? (int)std::min<int64_t>(r->n_lanes, B / 4096) : 1;
+    const int64_t per = ((B + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+    const int ndim = r->ndim;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int64_t b0 = c * per, nb = std::min<int64_t>(per, B - b0);
+        if (nb <= 0) break;
+        hipStream_t st = r->lanes[c];
+        HIP_TRY(hipMemcpyAsync(r->d_U + b0 * ndim, U + b0 * ndim, sizeof(double) * nb * ndim, hipMemcpyHostToDevice, st));
+        if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix + b0, pix + b0, sizeof(int) * nb, hipMemcpyHostToDevice, st));
+        rc = run_batch(r, pix ? r->d_pix + b0 : nullptr, r->d_U + b0 * ndim, r->d_lnL + b0, nullptr, nb, true, c, nullptr);
+        if (rc) return rc;
+    }
+    for (int c = 0; c < n_chunks; ++c) {
+        const int64_t b0 = c * per, nb = std::min<int64_t>(per, B - b0);
+        if (nb <= 0) break;
+        hipStream_t st = r->lanes[c];
+        HIP_TRY(hipMemcpyAsync(U + b0 * ndim, r->d_U + b0 * ndim, sizeof(double) * nb * ndim, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(lnL + b0, r->d_lnL + b0, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+    }
+    for (int c = 0; c < n_chunks; ++c) HIP_TRY(hipStreamSynchronize(r->lanes[c]));
     return NFA_OK;
 }
 
