@@ -480,3 +480,31 @@ def test_cube_predict_batch_matches_per_pixel_predict(engine, nfo):
             assert tot[k, s_ix] == pytest.approx(sc.sum_spec, rel=1e-11)
     with pytest.raises(ValueError, match='Invalid shape'):
         cube.predict_batch(pix, theta[:, :6])
+
+
+def test_large_host_batch_is_pipelined_and_unchanged(engine, nfo):
+    """Host-pointer batches from 16384 rows travel through the stream lanes in chunks: the results
+    are bitwise those of small batches, the tail chunk included."""
+    engine.set_exp_mode('fast')
+    rng = np.random.default_rng(123)
+    ut = engine.get_irdc_priors(size=200, vsys=0.0)
+    args = []
+    for t in (1, 2):
+        x = freq_axis(t, 256)
+        args.append([x, rng.normal(0, 0.2, 256), 0.2, t])
+    run = engine.AmmoniaRunner.from_data(args, ut, ncomp=2)
+    B = 3 * 4096 + 5000 + 37
+    U = rng.uniform(size=(B, 12))
+    Ua = U.copy()
+    la = run.loglikelihood_batch(Ua)
+    lb = np.empty(B)
+    Ub = U.copy()
+    for a in range(0, B, 1000):
+        sub = Ub[a:a + 1000].copy()
+        lb[a:a + 1000] = run.loglikelihood_batch(sub)
+        Ub[a:a + 1000] = sub
+    assert np.array_equal(la, lb) and np.array_equal(Ua, Ub)
+    # one of them against the oracle
+    rc = nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(*a) for a in args], nfo.PriorSet(ut.lower()), ncomp=2)
+    u = U[B - 1].copy()
+    assert rc.loglikelihood(u) == pytest.approx(la[B - 1], rel=1e-6)
