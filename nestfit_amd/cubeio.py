@@ -146,36 +146,32 @@ class SimpleCube:
 
 
 class NoiseMap:
+    """Per-pixel RMS map, indexed (i_lon, i_lat) like the transposed cube data (reference:
+    nestfit/main.py:39-68)."""
+
     def __init__(self, data):
-        # NOTE The axes in the data cube are transposed, so these need to be as well
-        self.data = np.asarray(data).transpose()
+        self.data = np.asarray(data).T          # FITS image order (lat, lon) -> (lon, lat)
         self.shape = self.data.shape
 
     @classmethod
     def from_pbimg(cls, rms, pb_img):
-        pb_img = np.asarray(pb_img, dtype=np.float64)
-        shape = pb_img.shape
-        naxes = len(shape)
-        if naxes == 4:
-            pb_img = pb_img[0, 0]
-        elif naxes == 3:
-            pb_img = pb_img[0]
-        elif naxes == 2:
-            pass
-        else:
-            raise ValueError(f'Cannot parse shape : {shape}')
-        # A typical primary beam image will be masked with NaNs, so replace them in the noise map
-        # with Inf values.
+        """rms / primary-beam response; masked (NaN) beam pixels get an infinite noise."""
+        pb = np.asarray(pb_img, dtype=np.float64)
+        if pb.ndim not in (2, 3, 4):
+            raise ValueError(f'Cannot parse shape : {pb.shape}')
+        while pb.ndim > 2:                       # (stokes, chan, lat, lon) or (chan, lat, lon): first plane
+            pb = pb[0]
         with np.errstate(divide='ignore', invalid='ignore'):
-            img = rms / pb_img
-        img[~np.isfinite(img)] = np.inf
-        return cls(img)
+            img = rms / pb
+        return cls(np.where(np.isfinite(img), img, np.inf))
 
     def get_noise(self, i_lon, i_lat):
         return self.data[i_lon, i_lat]
 
 
 class NoiseMapUniform:
+    """One RMS for the whole map (reference: nestfit/main.py:66-72); `shape` is None."""
+
     def __init__(self, rms):
         self.rms = rms
         self.shape = None
@@ -184,23 +180,26 @@ class NoiseMapUniform:
         return self.rms
 
 
+_SIMPLE_HEADER_KEYS = ('SIMPLE', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'WCSAXES', 'CRPIX1', 'CRPIX2', 'CDELT1',
+                       'CDELT2', 'CUNIT1', 'CUNIT2', 'CTYPE1', 'CTYPE2', 'CRVAL1', 'CRVAL2', 'RADESYS', 'EQUINOX')
+_SKY_AXES = ('ra', 'dec', 'lon', 'lat')
+
+
 class DataCube:
-    """Reference: nestfit/main.py:77-172.  `cube` is a `SimpleCube` (or anything with the same
-    attributes)."""
+    """One transition's cube in the layout the fitter wants (reference: nestfit/main.py:77-172):
+    `data[i_lon, i_lat, chan]` in K with the frequency axis `xarr` ascending in Hz, `varr` the
+    matching (descending) radio velocities in km/s, `dv` the channel width in km/s.  `cube` is a
+    `SimpleCube` (or anything with the same attributes); `noise_map` a number or a NoiseMap."""
 
     def __init__(self, cube, noise_map, trans_id=None):
-        if isinstance(noise_map, (float, int)):
-            self.noise_map = NoiseMapUniform(noise_map)
-        else:
-            self.noise_map = noise_map
+        self.noise_map = NoiseMapUniform(noise_map) if isinstance(noise_map, (float, int)) else noise_map
         self.trans_id = trans_id
         self._header = dict(cube.header)
         self.dv = self.get_chan_width(cube)
         self.data, self.xarr = self.data_from_cube(cube)
         self.varr = self.velo_axis_from_cube(cube)
-        self.shape = self.data.shape
-        # NOTE data is transposed so (s, b, l) -> (l, b, s)
-        self.spatial_shape = (self.shape[0], self.shape[1])
+        self.shape = self.data.shape                       # (lon, lat, chan)
+        self.spatial_shape = self.shape[:2]
         self.nchan = self.shape[2]
         if self.noise_map.shape is not None:
             assert self.spatial_shape == self.noise_map.shape
@@ -211,61 +210,40 @@ class DataCube:
 
     @property
     def simple_header(self):
-        keys = (
-            'SIMPLE', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'WCSAXES', 'CRPIX1', 'CRPIX2', 'CDELT1',
-            'CDELT2', 'CUNIT1', 'CUNIT2', 'CTYPE1', 'CTYPE2', 'CRVAL1', 'CRVAL2', 'RADESYS', 'EQUINOX',
-        )
-        hdict = {}
-        for k in keys:
-            try:
-                hdict[k] = self._header[k]
-            except KeyError:
-                continue
-        hdict['NAXIS'] = 2
-        hdict['WCSAXES'] = 2
-        coord_sys = ('ra', 'dec', 'lon', 'lat')
-        # CTYPE's of form "RA---SIN"
-        assert hdict['CTYPE1'].split('-')[0].lower() in coord_sys
-        assert hdict['CTYPE2'].split('-')[0].lower() in coord_sys
+        """The celestial (2-D) part of the header, for map products."""
+        hdict = {k: self._header[k] for k in _SIMPLE_HEADER_KEYS if k in self._header}
+        hdict['NAXIS'] = hdict['WCSAXES'] = 2
+        for key in ('CTYPE1', 'CTYPE2'):                   # of the form "RA---SIN"
+            assert hdict[key].split('-')[0].lower() in _SKY_AXES
         return hdict
 
     def get_chan_width(self, cube):
-        axis = cube.spectral_axis_kms()
-        return abs(axis[1] - axis[0])
+        v = cube.spectral_axis_kms()
+        return abs(v[1] - v[0])
 
     def data_from_cube(self, cube):
-        # intensity units must be Kelvin (the reference converts with the beam; no beam maths here)
+        # the reference converts other brightness units with the beam; only K is taken here
         if cube.unit == '':
             print('-- Assuming cube intensity units of K')
         elif cube.unit != 'K':
             raise ValueError(f'cube intensity unit {cube.unit!r}: only K is supported')
-        axis = cube.spectral_axis_hz()
-        nu_chan = axis[1] - axis[0]
-        # ensure that the frequency axis is in ascending order
-        if nu_chan < 0:
+        if np.diff(cube.spectral_axis_hz()[:2])[0] < 0:    # the model wants ascending frequencies
             cube = cube[::-1]
-            axis = cube.spectral_axis_hz()
-        # data is transposed such that the frequency axis is contiguous (now the last or
-        # right-most in of the indices)
-        data = cube._data.transpose().copy()
-        return data, axis
+        # (chan, lat, lon) -> (lon, lat, chan): one pixel's spectrum is contiguous
+        return cube._data.transpose().copy(), cube.spectral_axis_hz()
 
     def velo_axis_from_cube(self, cube):
-        varr = cube.spectral_axis_kms()
-        # xarr is ascending in Hz, so the matching velocity axis must be descending
-        if varr[1] > varr[0]:
-            return varr[::-1].copy()
-        return varr.copy()
+        v = cube.spectral_axis_kms()
+        return (v[::-1] if v[1] > v[0] else v).copy()      # descending, element-wise partner of xarr
 
     def get_spec_data(self, i_lon, i_lat):
-        arr = self.data[i_lon, i_lat, :]  # axes reversed from typical cube
+        spec = self.data[i_lon, i_lat, :]
         noise = self.noise_map.get_noise(i_lon, i_lat)
-        has_nans = np.isnan(arr).any() or np.isnan(noise)
-        return self.xarr, arr, noise, self.trans_id, has_nans
+        return self.xarr, spec, noise, self.trans_id, bool(np.isnan(spec).any() or np.isnan(noise))
 
 
 class CubeStack:
-    """Reference: nestfit/main.py:175-223."""
+    """The cubes of all transitions of one field, same sky grid (reference: nestfit/main.py:175-223)."""
 
     def __init__(self, cubes):
         assert isinstance(cubes, Iterable)
@@ -273,48 +251,24 @@ class CubeStack:
         self.n_cubes = len(cubes)
 
     def __iter__(self):
-        for cube in self.cubes:
-            yield cube
+        return iter(self.cubes)
 
-    @property
-    def full_header(self):
-        return self.cubes[0].full_header
-
-    @property
-    def simple_header(self):
-        return self.cubes[0].simple_header
-
-    @property
-    def shape(self):
-        return self.cubes[0].shape
-
-    @property
-    def spatial_shape(self):
-        return self.cubes[0].spatial_shape
+    full_header = property(lambda self: self.cubes[0].full_header)
+    simple_header = property(lambda self: self.cubes[0].simple_header)
+    shape = property(lambda self: self.cubes[0].shape)
+    spatial_shape = property(lambda self: self.cubes[0].spatial_shape)
 
     def get_arrays(self, i_lon, i_lat):
-        arrays = []
-        for dcube in self.cubes:
-            xarr, arr, *_ = dcube.get_spec_data(i_lon, i_lat)
-            arrays.append(arr)
-        return arrays
+        return [dc.get_spec_data(i_lon, i_lat)[1] for dc in self.cubes]
 
     def get_spec_data(self, i_lon, i_lat):
-        all_spec_data = []
-        any_nans = False
-        for dcube in self.cubes:
-            *spec_data, has_nans = dcube.get_spec_data(i_lon, i_lat)
-            all_spec_data.append(spec_data)
-            any_nans |= has_nans
-        return all_spec_data, any_nans
+        """([[xarr, spectrum, noise, trans_id] per cube], any NaN in the pixel)."""
+        rows = [dc.get_spec_data(i_lon, i_lat) for dc in self.cubes]
+        return [list(r[:4]) for r in rows], any(r[4] for r in rows)
 
     def get_max_snr(self, i_lon, i_lat):
-        max_snr = 0.0
-        for dcube in self.cubes:
-            _, arr, noise, _, _ = dcube.get_spec_data(i_lon, i_lat)
-            spec_snr = np.max(arr) / noise
-            max_snr = spec_snr if spec_snr > max_snr else max_snr
-        return max_snr
+        snr = [np.max(spec) / noise for _, spec, noise, _, _ in (dc.get_spec_data(i_lon, i_lat) for dc in self.cubes)]
+        return max([0.0] + [v for v in snr if v > 0.0])
 
     # ---- what the GPU adds ----------------------------------------------------------------
     def good_pixels(self, lon=None, lat=None):

@@ -252,32 +252,35 @@ class HdfStore:
             print('Store HDF already closed.')
 
     def iter_pix_groups(self):
+        """Every /pix/<i_lon>/<i_lat> group of the (linked) table."""
         assert self.is_open
-        for lon_pix in self.hdf['/pix']:
-            for lat_pix in self.hdf[f'/pix/{lon_pix}']:
-                group = self.hdf[f'/pix/{lon_pix}/{lat_pix}']
-                if not isinstance(group, Group):
-                    continue
-                yield group
+        pix = self.hdf['/pix']
+        for lon_name in pix:
+            for lat_name in pix[lon_name]:
+                node = pix[lon_name][lat_name]
+                if isinstance(node, Group):
+                    yield node
 
     def find_first_valid_group(self):
+        """The one-component run of the first pixel that has one (main.py:297-304)."""
         assert self.is_open
-        model_name = '1'  # one model component
         for group in self.iter_pix_groups():
-            if model_name in group:
-                return group[model_name]
+            if '1' in group:
+                return group['1']
         raise ValueError('No valid pix groups found.')
 
     def link_files(self):
+        """Make every pixel group of every chunk file reachable from the table (the reference
+        inserts h5py.ExternalLink objects, main.py:306-316)."""
         assert self.is_open
         for chunk_path in self.chunk_paths:
             chunk = StoreFile(chunk_path, 'r')
             if '/pix' not in chunk:
                 continue
-            for lon_pix in chunk['/pix']:
-                for lat_pix in chunk[f'/pix/{lon_pix}']:
-                    group_name = f'/pix/{lon_pix}/{lat_pix}'
-                    self.hdf[group_name] = chunk[group_name]
+            for lon_name in chunk['/pix']:
+                for lat_name in chunk[f'/pix/{lon_name}']:
+                    name = f'/pix/{lon_name}/{lat_name}'
+                    self.hdf[name] = chunk[name]
         self.hdf.attrs['linked'] = True
         self.hdf.flush()
 
@@ -287,30 +290,28 @@ class HdfStore:
             del self.hdf['/pix']
 
     def insert_header(self, stack):
-        if self.is_open:
-            sh_g = self.hdf.create_group('simple_header')
-            for k, v in stack.simple_header.items():
-                sh_g.attrs[k] = v
-            fh_g = self.hdf.create_group('full_header')
-            for k, v in stack.full_header.items():
-                fh_g.attrs[k] = v
-            self.hdf.attrs['naxis1'] = stack.shape[0]
-            self.hdf.attrs['naxis2'] = stack.shape[1]
-        else:
+        """Cube headers as attributes of the groups simple_header / full_header, map size as
+        naxis1 / naxis2 (main.py:323-339)."""
+        if not self.is_open:
             warnings.warn('Could not insert header: the HDF5 file is closed.', category=RuntimeWarning)
+            return
+        for name, header in (('simple_header', stack.simple_header), ('full_header', stack.full_header)):
+            self.hdf.create_group(name).attrs.update(header)
+        self.hdf.attrs['naxis1'], self.hdf.attrs['naxis2'] = stack.shape[0], stack.shape[1]
 
     def read_header(self, full=True):
         assert self.is_open
         return dict(self.hdf['full_header' if full else 'simple_header'].attrs)
 
     def create_dataset(self, dset_name, data, group='', clobber=True):
+        """Dataset `group`/`dset_name`; an existing one is replaced (with a warning) when clobber."""
         assert len(dset_name) > 0
-        g = self.hdf.require_group(group)
+        parent = self.hdf.require_group(group)
         path = f'{group.rstrip("/")}/{dset_name}'
-        if path in self.hdf and clobber:
+        if clobber and path in self.hdf:
             warnings.warn(f'Deleting dataset "{path}"', RuntimeWarning)
             del self.hdf[path]
-        return g.create_dataset(dset_name, data=data)
+        return parent.create_dataset(dset_name, data=data)
 
     def insert_fitter_pars(self, fitter):
         assert self.is_open
