@@ -508,3 +508,52 @@ def test_large_host_batch_is_pipelined_and_unchanged(engine, nfo):
     rc = nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(*a) for a in args], nfo.PriorSet(ut.lower()), ncomp=2)
     u = U[B - 1].copy()
     assert rc.loglikelihood(u) == pytest.approx(la[B - 1], rel=1e-6)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_extreme_parameters(engine, nfo, mode):
+    """Far outside the prior ranges: tex from just above the CMB to 300 K (all branches of the
+    1/(e^x-1) evaluation: table cells, band straddling a cell edge or the table ends, exact function),
+    optical depths from 1e-9 to 1e4, line widths from a fifth of a channel to the whole band, lines
+    half or entirely off the band; every transition."""
+    engine.set_exp_mode(mode)
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for trans in range(1, 10):
+        n = 512
+        x = freq_axis(trans, n, 35.0)
+        sg = engine.AmmoniaSpectrum(x, np.zeros(n), 0.1, trans)
+        sc = nfo.AmmoniaSpectrum(x, np.zeros(n), 0.1, trans)
+        for k in range(60):
+            ncomp = 1 + k % 3
+            th = np.concatenate([
+                rng.uniform(-60, 60, ncomp),                        # voff: partly off the band
+                rng.choice([3.0, 8.0, 25.0, 80.0, 300.0], ncomp) * rng.uniform(0.9, 1.1, ncomp),   # trot
+                rng.choice([2.73, 2.75, 2.8, 3.5, 6.0, 8.7, 40.0, 300.0], ncomp) * rng.uniform(1.0, 1.05, ncomp),
+                rng.uniform(8.0, 19.0, ncomp),                      # log N
+                10 ** rng.uniform(-1.5, 1.2, ncomp),                # sigma 0.03 .. 16 km/s
+                rng.uniform(0.0, 1.0, ncomp)])
+            for cold, lte in ((False, False), (True, True)):
+                engine.amm_predict(sg, th, cold=cold, lte=lte)
+                nfo.amm_predict(sc, th, cold=cold, lte=lte)
+                pg, pc = sg.get_spec(), sc.get_spec()
+                assert np.array_equal(np.isnan(pg), np.isnan(pc))
+                ok = ~np.isnan(pc)
+                assert np.array_equal(pg[ok] == 0, pc[ok] == 0), (trans, k, cold, lte)
+                nz = ok & (pc != 0)
+                if nz.any():
+                    err = np.abs(pg[nz] - pc[nz])
+                    # absolute floor of the fast mode = a few steps of the reference's own rounding of
+                    # 1 - FastExp(tau) = 1 - (1 - tau + ...): |T0 (y - tbg)| 2^-53 per component
+                    T0 = 6.62607015e-27 * x[n // 2] / 1.380649e-16
+                    amp = 0.0
+                    for c in range(ncomp):
+                        trot = nfo.swift_convert(th[ncomp + c]) if cold else th[ncomp + c]
+                        tex = trot if lte else th[2 * ncomp + c]
+                        amp += abs(T0 * (1.0 / np.expm1(T0 / tex) - 1.0 / np.expm1(T0 / 2.72548)))
+                    atol = 0.0 if mode != 'fast' else max(TB_ATOL_K[mode], 4 * amp * 2.0 ** -53)
+                    assert (err <= TB_RTOL * np.abs(pc[nz]) + atol).all(), (trans, k, cold, lte, th)
+                    big = np.abs(pc[nz]) > 1e-6
+                    if big.any():
+                        worst = max(worst, float(np.max(err[big] / np.abs(pc[nz][big]))))
+    print(f'extreme {mode}: worst relative Tb error {worst:.2e}')
