@@ -50,7 +50,8 @@ int nfa_device_name(char *buf, int buflen);
 int nfa_set_exp_mode(int mode);
 int nfa_get_exp_mode(void);
 /* Engine tuning knobs for A/B measurements: "wpb" = waves per workgroup of the
- * likelihood kernel (1..16, default 4; "wpb_table" = the same in table mode, 0 = automatic); "occ" = resident waves per SIMD the fast-mode
+ * likelihood kernel (1..16, default 4; "wpb_table" = the same in table mode, 0 = automatic); "sampler_parts" = groups of pixels the device sampler
+ * pipelines over the stream lanes (1..4, default 3); "occ" = resident waves per SIMD the fast-mode
  * likelihood kernel is capped to (0 = no cap, default 7); "streams" = number of HIP
  * streams ("lanes", 1..8, default 3) that runners created afterwards spread consecutive
  * nfa_runner_loglike_batch_dev calls over; "ablate" (only in builds with -DNFA_ABLATE,

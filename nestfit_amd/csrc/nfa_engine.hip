@@ -46,6 +46,7 @@ struct Engine {
     int    occ = 7;                  // fast mode: resident waves per SIMD, capped through LDS padding (0 = no cap)
     int    ablate = 0;
     int    streams = 3;              // stream lanes of new runners
+    int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
     bool   have_t0 = false;
     double *d_tabs = nullptr;                      // SM_END_TABLE doubles
     double t0_xmin = 0, t0_xmax = 0, t0_inv_dx = 0;
@@ -178,6 +179,7 @@ int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "occ") && value >= 0 && value <= 8) { g_eng.occ = value; return NFA_OK; }
+    if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }
     if (key && !strcmp(key, "ablate") && value >= 0 && value <= 15) { g_eng.ablate = value; return NFA_OK; }

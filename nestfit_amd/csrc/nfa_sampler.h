@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
 
 // ---- host side -----------------------------------------------------------------------------
 #define NS_KMAX 16384           // most proposals one pixel gets in a round
+#define NS_PARTS 4              // at most this many groups of pixels, each on its own stream lane
 struct nfa_sampler {
     nfa_runner *r = nullptr;
     NsDev d = {};
@@ -483,6 +484,8 @@ struct nfa_sampler {
     int  n_act = 0, check_every = 8;
     size_t lds = 0;
     bool ran = false;
+    int *h_rows = nullptr;      // pinned: compact-row counts of the parts
+    hipEvent_t ev[NS_PARTS] = {};
 };
 
 extern "C" {
@@ -495,6 +498,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol,
                     s->d_pixmap, s->d_actlist, s->d_livepix};
     for (void *p : ptrs) (void)hipFree(p);
+    if (s->h_rows) { (void)hipHostFree(s->h_rows); for (int h = 0; h < NS_PARTS; ++h) (void)hipEventDestroy(s->ev[h]); }
     delete s;
     return NFA_OK;
 }
@@ -534,7 +538,7 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P); NS_ALLOC(d.use_cube, int, P);
     NS_ALLOC(d.deadT, double, P * C * D); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
     NS_ALLOC(d.candU, double, P * K * D); NS_ALLOC(d.candT, double, P * K * D); NS_ALLOC(d.candL, double, P * K);
-    NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K); NS_ALLOC(d.slot, int, P * K); NS_ALLOC(d.count, int, 1);
+    NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K); NS_ALLOC(d.slot, int, P * K); NS_ALLOC(d.count, int, NS_PARTS);
     NS_ALLOC(d.walk, int, P); NS_ALLOC(d.wstep, int, P); NS_ALLOC(d.wW, int, P); NS_ALLOC(d.wscale, double, P);
     NS_ALLOC(d.wLthr, double, P); NS_ALLOC(d.wacc_sum, long, P); NS_ALLOC(d.wtot_sum, long, P);
     NS_ALLOC(d.wU, double, P * NS_W * D); NS_ALLOC(d.wT, double, P * NS_W * D); NS_ALLOC(d.wL, double, P * NS_W);
@@ -613,36 +617,67 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
     if (!s || !s->ran) return fail(NFA_ERR_STATE, "nfa_sampler_begin has not been called");
     nfa_runner *r = s->r;
     NsDev &d = s->d;
-    const int P = d.P, K = d.K;
-    hipStream_t st = r->lanes[0];
+    const int P = d.P, K = d.K, D = d.D;
+    // The active pixels are split in groups that run on different stream lanes: proposing and
+    // updating one group (latency-bound, few waves) overlaps the likelihood batch of another.  A pixel's random stream and decisions do not depend on its company, so the
+    // split changes nothing in the results.
+    const int n_half = std::max(1, std::min(std::min(r->n_lanes, NS_PARTS), g_eng.sampler_parts));
+    if (!s->h_rows) {
+        HIP_TRY(hipHostMalloc((void **)&s->h_rows, sizeof(int) * NS_PARTS));
+        for (int h = 0; h < NS_PARTS; ++h) HIP_TRY(hipEventCreateWithFlags(&s->ev[h], hipEventDisableTiming));
+    }
     for (int64_t chunk = 0; s->n_act > 0 && (max_chunks <= 0 || chunk < max_chunks); ++chunk) {
         // candidates per pixel: the round's batch stays near b_target however few pixels are left
         const int n_act = s->n_act;
         const int Kr = (int)std::min<long>(NS_KMAX, std::max<long>(K, s->b_target / n_act));
-        for (int c = 0; c < s->check_every; ++c) {
-            const long B = (long)n_act * Kr;
-            HIP_TRY(hipMemsetAsync(d.count, 0, sizeof(int), st));
-            hipLaunchKernelGGL(ns_propose_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, d, n_act, Kr);
-            HIP_TRY(hipGetLastError());
-            int n_rows = 0;             // proposals inside the prior: the only ones worth a likelihood
-            HIP_TRY(hipMemcpyAsync(&n_rows, d.count, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (n_rows > 0) {
-                int rc = run_batch(r, d.candpix, d.candT, d.candL, nullptr, n_rows, true, 0, nullptr);
-                if (rc) return rc;
+        int n_pix_h[NS_PARTS];
+        NsDev dh[NS_PARTS];
+        {   // every part works on its own slices of the proposal / compact-row buffers
+            long first = 0;
+            for (int h = 0; h < NS_PARTS; ++h) {
+                n_pix_h[h] = h < n_half ? (n_act * (h + 1)) / n_half - (n_act * h) / n_half : 0;
+                dh[h] = d;
+                const long off = first * Kr;
+                dh[h].candU += off * D; dh[h].candT += off * D; dh[h].candL += off;
+                dh[h].candpix += off; dh[h].valid += off; dh[h].slot += off;
+                dh[h].count += h; dh[h].actlist += first;
+                first += n_pix_h[h];
             }
-            hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_act), dim3(64), s->lds, st, d, n_act, Kr, 0, s->rounds);
-            HIP_TRY(hipGetLastError());
+        }
+        for (int c = 0; c < s->check_every; ++c) {
+            for (int h = 0; h < NS_PARTS; ++h) {
+                if (n_pix_h[h] == 0) continue;
+                hipStream_t st = r->lanes[h];
+                const long B = (long)n_pix_h[h] * Kr;
+                HIP_TRY(hipMemsetAsync(dh[h].count, 0, sizeof(int), st));
+                hipLaunchKernelGGL(ns_propose_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr);
+                HIP_TRY(hipGetLastError());
+                // proposals inside the prior: the only ones worth a likelihood
+                HIP_TRY(hipMemcpyAsync(&s->h_rows[h], dh[h].count, sizeof(int), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipEventRecord(s->ev[h], st));
+            }
+            for (int h = 0; h < NS_PARTS; ++h) {
+                if (n_pix_h[h] == 0) continue;
+                hipStream_t st = r->lanes[h];
+                HIP_TRY(hipEventSynchronize(s->ev[h]));
+                const int n_rows = s->h_rows[h];
+                if (n_rows > 0) {
+                    int rc = run_batch(r, dh[h].candpix, dh[h].candT, dh[h].candL, nullptr, n_rows, true, h, nullptr);
+                    if (rc) return rc;
+                }
+                hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_pix_h[h]), dim3(64), s->lds, st, dh[h], n_pix_h[h], Kr, 0,
+                                   s->rounds);
+                HIP_TRY(hipGetLastError());
+            }
             s->rounds += 1;
         }
-        HIP_TRY(hipMemcpyAsync(s->h_active.data(), d.active, sizeof(int) * P, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        for (int h = 0; h < n_half; ++h) HIP_TRY(hipStreamSynchronize(r->lanes[h]));
+        HIP_TRY(hipMemcpy(s->h_active.data(), d.active, sizeof(int) * P, hipMemcpyDeviceToHost));
         s->n_act = 0;
         for (int p = 0; p < P; ++p) if (s->h_active[p]) s->h_act[s->n_act++] = p;
-        if (s->n_act)
-            HIP_TRY(hipMemcpyAsync(s->d_actlist, s->h_act.data(), sizeof(int) * s->n_act, hipMemcpyHostToDevice, st));
+        if (s->n_act) HIP_TRY(hipMemcpy(s->d_actlist, s->h_act.data(), sizeof(int) * s->n_act, hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    for (int h = 0; h < n_half; ++h) HIP_TRY(hipStreamSynchronize(r->lanes[h]));
     if (n_active_out) *n_active_out = s->n_act;
     return NFA_OK;
 }
