@@ -224,7 +224,9 @@ int  nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int3
  * per pixel and round at least; the number is raised (up to 16384) so that a round proposes about
  * batch_target candidates however few pixels are still running; only the proposals inside the
  * unit cube (the prior's support) are compacted and sent to the likelihood.  cap_iter: dead
- * point slots per pixel (a run stops when they are full).  tol, efr, seed, maxiter as
+ * point slots per pixel (a run stops when they are full).  free_mask[ndim] (NULL = all ones): unit-cube
+ * slots the likelihood depends on; the others (constant or duplicated parameters) are not sampled --
+ * integrating a uniform dummy dimension out exactly -- and stay at u = 0.5.  tol, efr, seed, maxiter as
  * run_multinest; upd = replacements between ellipsoid refits; log_zero replaces non-finite
  * likelihoods; check_every = rounds between two compactions of the active-pixel list.
  * Outputs are the raw material of what mn_dump stores (core.pyx:627-687): dead points with
@@ -232,7 +234,7 @@ int  nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int3
  * assembles posteriors / lnZ from them and holds the bit-compatible host twin of the algorithm. */
 typedef struct nfa_sampler nfa_sampler;
 int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int64_t n_pix, int nlive,
-                       int n_cand, int64_t batch_target, int64_t cap_iter);
+                       int n_cand, int64_t batch_target, int64_t cap_iter, const int32_t *free_mask);
 int nfa_sampler_destroy(nfa_sampler *s);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);

@@ -79,7 +79,7 @@ SIGNATURES = {
     'nfa_broker_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'nfa_test_broker_storm': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp]),
     'nfa_sampler_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, _ip, C.c_int64, C.c_int, C.c_int,
-                                     C.c_int64, C.c_int64]),
+                                     C.c_int64, C.c_int64, _ip]),
     'nfa_sampler_destroy': (C.c_int, [C.c_void_p]),
     'nfa_sampler_run': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int,
                                   C.c_double, C.c_int]),

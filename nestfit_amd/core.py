@@ -213,6 +213,23 @@ class PriorTransformer:
         descs = [p._desc(add_dist) for p in self.priors]
         return dict(priors=descs, dists=dists, n_param=self.n_param)
 
+    def free_mask(self, ncomp):
+        """1 for every unit-cube slot (parameter-major, n_param * ncomp of them) the transformed
+        parameters depend on, 0 for the dummies: the slot of a ConstantPrior, the second slot of a
+        DuplicatePrior, the width slot of a placement prior whose width prior is constant.  A
+        sampler may leave the dummies alone -- a uniform dimension the likelihood ignores integrates
+        to one -- which is what the device sampler does."""
+        mask = np.ones((self.n_param, ncomp), dtype=np.int32)
+        for d in self.lower()['priors']:
+            if d['kind'] == KIND_CONSTANT:
+                mask[d['p_ix']] = 0
+            elif d['kind'] == KIND_DUPLICATE:
+                mask[d['p_ix2']] = 0
+            elif d['kind'] in (KIND_CENSEP, KIND_RESOLVED_CENSEP, KIND_RESOLVED_PLACEMENT) \
+                    and d['sub_kind'] == KIND_CONSTANT:
+                mask[d['p_ix2']] = 0
+        return np.ascontiguousarray(mask.reshape(-1))
+
     def _device_handle(self):
         if self._handle is not None:
             return self._handle

@@ -35,14 +35,16 @@ __host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t
 }
 
 struct NsDev {
-    int     P, N, D, K;                 // pixels, live points, dimensions, candidates per round (at least)
+    int     P, N, D, K;                 // pixels, live points, SAMPLED dimensions, candidates per round (at least)
+    int     DT;                         // length of a theta row (all unit-cube slots of the runner)
+    const int *fmap;                    // [D] slot of every sampled dimension; the others stay at u = 0.5
     long    cap;                        // dead-point slots per pixel
     double  tol, ln_shrink, ln_efr, ln_enlarge, log_zero;
     long    maxiter;
     int     upd;
     uint64_t seed;
     const int *pixmap;                  // sampler pixel -> cube pixel
-    double *Ulive, *Tlive, *Llive;      // [P][N][D], [P][N][D], [P][N]
+    double *Ulive, *Tlive, *Llive;      // [P][N][D], [P][N][DT], [P][N]
     double *centre, *axes;              // [P][D], [P][D][D] (lower triangular, scaled)
     long   *n_iter, *n_evals;           // [P]
     long   *cand_base;                  // [P] candidates drawn so far (index into the pixel's random stream)
@@ -50,8 +52,8 @@ struct NsDev {
     int    *active, *since_fit;         // [P]
     int    *use_cube;                   // [P] 1: the ellipsoid is larger than the unit cube, draw from the cube
     double  ln_vball;                   // ln volume of the unit D-ball
-    double *deadT, *deadL, *deadlnw;    // [P][cap][D], [P][cap], [P][cap]
-    double *candU, *candT, *candL;      // proposals [rows][D]; compact: theta [rows][D], lnL [rows]
+    double *deadT, *deadL, *deadlnw;    // [P][cap][DT], [P][cap], [P][cap]
+    double *candU, *candT, *candL;      // proposals [rows][D]; compact: theta [rows][DT], lnL [rows]
     int    *candpix, *valid;            // [rows]: pixel of a compact row; validity of a proposal
     int    *slot;                       // [rows] compact row of a valid proposal
     int    *count;                      // number of compact rows filled in this round
@@ -61,7 +63,7 @@ struct NsDev {
     int    *walk, *wstep, *wW;          // [P] mode flag, step inside the current cycle, walkers in it
     double *wscale, *wLthr;             // [P] proposal scale, threshold frozen at the cycle start
     long   *wacc_sum, *wtot_sum;        // [P] accepted / evaluated steps of the current cycle
-    double *wU, *wT, *wL;               // walker states [P][NS_W][D], [P][NS_W][D], [P][NS_W]
+    double *wU, *wT, *wL;               // walker states [P][NS_W][D], [P][NS_W][DT], [P][NS_W]
     int    *wnacc;                      // [P][NS_W] accepted steps of each walker in the cycle
     double *lnvol;                      // [P] ln volume of the bounding ellipsoid (last refit)
     int     stage_live;                 // the refit stages the centred live points in LDS
@@ -69,17 +71,18 @@ struct NsDev {
 
 // ---- live points -------------------------------------------------------------------------
 __global__ void ns_init_live_kernel(NsDev S, int *__restrict__ livepix) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long tot = (long)S.P * S.N * S.D;
-    if (gid >= tot) return;
-    const long pi = gid / S.D;
-    const int j = (int)(gid - pi * S.D);
+    const long pi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= (long)S.P * S.N) return;
     const long p = pi / S.N;
     const long i = pi - p * S.N;
-    const double u = ns_uniform(S.seed, (uint64_t)p, NS_TAG_LIVE + (uint64_t)i, (uint64_t)j);
-    S.Ulive[gid] = u;
-    S.Tlive[gid] = u;
-    if (j == 0) livepix[pi] = S.pixmap[p];
+    double *u = S.Ulive + pi * S.D, *t = S.Tlive + pi * S.DT;
+    for (int j = 0; j < S.DT; ++j) t[j] = 0.5;          // slots the likelihood does not depend on
+    for (int j = 0; j < S.D; ++j) {
+        const double v = ns_uniform(S.seed, (uint64_t)p, NS_TAG_LIVE + (uint64_t)i, (uint64_t)j);
+        u[j] = v;
+        t[S.fmap[j]] = v;
+    }
+    livepix[pi] = S.pixmap[p];
 }
 
 __global__ void ns_sanitize_kernel(double *__restrict__ L, long n, double log_zero) {
@@ -115,9 +118,10 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
         double *wu = S.wU + ((long)p * NS_W + k) * D;
         if (step == 0) {
             const int idx = min(S.N - 1, (int)(ns_uniform(S.seed, (uint64_t)p, a, NS_B_START) * S.N));
-            const double *lu = S.Ulive + ((long)p * S.N + idx) * D, *lt = S.Tlive + ((long)p * S.N + idx) * D;
-            double *wt = S.wT + ((long)p * NS_W + k) * D;
-            for (int j = 0; j < D; ++j) { wu[j] = lu[j]; wt[j] = lt[j]; }
+            const double *lu = S.Ulive + ((long)p * S.N + idx) * D, *lt = S.Tlive + ((long)p * S.N + idx) * S.DT;
+            double *wt = S.wT + ((long)p * NS_W + k) * S.DT;
+            for (int j = 0; j < D; ++j) wu[j] = lu[j];
+            for (int j = 0; j < S.DT; ++j) wt[j] = lt[j];
             S.wL[(long)p * NS_W + k] = S.Llive[(long)p * S.N + idx];
             S.wnacc[(long)p * NS_W + k] = 0;
         }
@@ -155,8 +159,9 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
     const int row = atomicAdd(S.count, 1);
     S.slot[gid] = row;
     S.candpix[row] = S.pixmap[p];
-    double *ct = S.candT + (long)row * D;
-    for (int j = 0; j < D; ++j) ct[j] = cu[j];
+    double *ct = S.candT + (long)row * S.DT;
+    for (int j = 0; j < S.DT; ++j) ct[j] = 0.5;
+    for (int j = 0; j < D; ++j) ct[S.fmap[j]] = cu[j];
 }
 
 // ---- wave helpers (one 64-lane wave per pixel) -------------------------------------------------
@@ -339,16 +344,14 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         const double lnw = -(double)it / N + S.ln_shrink;
         lnZ = ns_logaddexp(lnZ, lnw + Lmin);
         if (it < S.cap) {
-            double *dT = S.deadT + ((long)p * S.cap + it) * D;
-            const double *Tw = S.Tlive + ((long)p * N + w) * D;
-            for (int j = lane; j < D; j += 64) dT[j] = Tw[j];
+            double *dT = S.deadT + ((long)p * S.cap + it) * S.DT;
+            const double *Tw = S.Tlive + ((long)p * N + w) * S.DT;
+            for (int j = lane; j < S.DT; j += 64) dT[j] = Tw[j];
             if (lane == 0) { S.deadL[(long)p * S.cap + it] = Lmin; S.deadlnw[(long)p * S.cap + it] = lnw; }
         }
         wave_lds_sync();
-        for (int j = lane; j < D; j += 64) {
-            S.Ulive[((long)p * N + w) * D + j] = cU[j];
-            S.Tlive[((long)p * N + w) * D + j] = cT[j];
-        }
+        for (int j = lane; j < D; j += 64) S.Ulive[((long)p * N + w) * D + j] = cU[j];
+        for (int j = lane; j < S.DT; j += 64) S.Tlive[((long)p * N + w) * S.DT + j] = cT[j];
         if (lane == 0) { sL[w] = Lk; Ll[w] = Lk; }
         wave_lds_sync();
         it += 1; since += 1;
@@ -373,8 +376,9 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
                 if (!isfinite(Lk)) Lk = S.log_zero;
                 if (Lk > Lthr) {
                     acc = 1;
-                    double *wu = S.wU + ((long)p * NS_W + lane) * D, *wt = S.wT + ((long)p * NS_W + lane) * D;
-                    for (int j = 0; j < D; ++j) { wu[j] = S.candU[g * D + j]; wt[j] = S.candT[row * D + j]; }
+                    double *wu = S.wU + ((long)p * NS_W + lane) * D, *wt = S.wT + ((long)p * NS_W + lane) * S.DT;
+                    for (int j = 0; j < D; ++j) wu[j] = S.candU[g * D + j];
+                    for (int j = 0; j < S.DT; ++j) wt[j] = S.candT[row * S.DT + j];
                     S.wL[(long)p * NS_W + lane] = Lk;
                     S.wnacc[(long)p * NS_W + lane] += 1;
                 }
@@ -392,7 +396,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
                 if (!moved) continue;               // never left its starting live point: not a new sample
                 const double Lk = __hip_atomic_load(&S.wL[(long)p * NS_W + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!(Lk > Lmin)) continue;
-                replace(S.wU + ((long)p * NS_W + k) * D, S.wT + ((long)p * NS_W + k) * D, Lk);
+                replace(S.wU + ((long)p * NS_W + k) * D, S.wT + ((long)p * NS_W + k) * S.DT, Lk);
             }
             // acceptance near one half (as dynesty's rwalk tunes it)
             if (tot_sum > 0) scale = fmin(1.0, scale * exp(((double)acc_sum / (double)tot_sum - 0.5) / (0.5 * sqrt((double)D))));
@@ -444,7 +448,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
                     const double Lk = readlane_d(Ls[u], src);
                     if (!(Lk > Lmin)) continue;
                     accepted += 1;
-                    replace(S.candU + g * D, S.candT + row * D, Lk);
+                    replace(S.candU + g * D, S.candT + row * S.DT, Lk);
                 }
             }
         }
@@ -478,7 +482,7 @@ struct nfa_sampler {
     nfa_runner *r = nullptr;
     NsDev d = {};
     long b_target = 0;          // candidates per round the sampler aims for (all pixels together)
-    int *d_pixmap = nullptr, *d_actlist = nullptr, *d_livepix = nullptr;
+    int *d_pixmap = nullptr, *d_actlist = nullptr, *d_livepix = nullptr, *d_fmap = nullptr;
     std::vector<int> h_active, h_act;
     long rounds = 0;
     int  n_act = 0, check_every = 8;
@@ -496,7 +500,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
                     d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol,
-                    s->d_pixmap, s->d_actlist, s->d_livepix};
+                    s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap};
     for (void *p : ptrs) (void)hipFree(p);
     if (s->h_rows) { (void)hipHostFree(s->h_rows); for (int h = 0; h < NS_PARTS; ++h) (void)hipEventDestroy(s->ev[h]); }
     delete s;
@@ -508,7 +512,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
 // n_pix = 1 makes sense then).  cap_iter = dead-point slots per pixel (a run stops there).
 // batch_target = candidates per round over all pixels the sampler aims for.
 int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int64_t n_pix, int nlive,
-                       int n_cand, int64_t batch_target, int64_t cap_iter) {
+                       int n_cand, int64_t batch_target, int64_t cap_iter, const int32_t *free_mask) {
     if (!out || !r) return fail(NFA_ERR_ARG, "null argument");
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     if (n_pix < 1 || n_pix > (1 << 24)) return fail(NFA_ERR_ARG, "n_pix out of range");
@@ -521,8 +525,13 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     nfa_sampler *s = new nfa_sampler();
     s->r = r;
     NsDev &d = s->d;
-    d.P = (int)n_pix; d.N = nlive; d.D = r->ndim; d.K = n_cand; d.cap = (long)cap_iter;
-    const size_t P = (size_t)n_pix, N = (size_t)nlive, D = (size_t)r->ndim, C = (size_t)cap_iter;
+    // sampled dimensions: the unit-cube slots the likelihood depends on (free_mask[ndim], NULL = all);
+    // a constant or duplicated parameter's slot is integrated out exactly by not sampling it
+    std::vector<int> fm;
+    for (int j = 0; j < r->ndim; ++j) if (!free_mask || free_mask[j]) fm.push_back(j);
+    if (fm.empty()) { delete s; return fail(NFA_ERR_ARG, "no free dimension to sample"); }
+    d.P = (int)n_pix; d.N = nlive; d.D = (int)fm.size(); d.DT = r->ndim; d.K = n_cand; d.cap = (long)cap_iter;
+    const size_t P = (size_t)n_pix, N = (size_t)nlive, D = fm.size(), DT = (size_t)r->ndim, C = (size_t)cap_iter;
     s->b_target = std::max<long>((long)n_pix * n_cand, (long)batch_target);
     // rows of the candidate buffers: n_act * Kr <= max(b_target, n_act * K) <= b_target
     const size_t K = ((size_t)s->b_target + P - 1) / P;       // so that P * K >= b_target
@@ -532,20 +541,22 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     if (hipMalloc((void **)&(ptr), sizeof(type) * (count)) != hipSuccess) { \
         nfa_sampler_destroy(s); return fail(NFA_ERR_DEVICE, "out of device memory for the sampler state"); }
     NS_ALLOC(s->d_pixmap, int, P); NS_ALLOC(s->d_actlist, int, P); NS_ALLOC(s->d_livepix, int, P * N);
-    NS_ALLOC(d.Ulive, double, P * N * D); NS_ALLOC(d.Tlive, double, P * N * D); NS_ALLOC(d.Llive, double, P * N);
+    NS_ALLOC(s->d_fmap, int, D);
+    NS_ALLOC(d.Ulive, double, P * N * D); NS_ALLOC(d.Tlive, double, P * N * DT); NS_ALLOC(d.Llive, double, P * N);
     NS_ALLOC(d.centre, double, P * D); NS_ALLOC(d.axes, double, P * D * D);
     NS_ALLOC(d.n_iter, long, P); NS_ALLOC(d.n_evals, long, P); NS_ALLOC(d.cand_base, long, P); NS_ALLOC(d.lnZ, double, P);
     NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P); NS_ALLOC(d.use_cube, int, P);
-    NS_ALLOC(d.deadT, double, P * C * D); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
-    NS_ALLOC(d.candU, double, P * K * D); NS_ALLOC(d.candT, double, P * K * D); NS_ALLOC(d.candL, double, P * K);
+    NS_ALLOC(d.deadT, double, P * C * DT); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
+    NS_ALLOC(d.candU, double, P * K * D); NS_ALLOC(d.candT, double, P * K * DT); NS_ALLOC(d.candL, double, P * K);
     NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K); NS_ALLOC(d.slot, int, P * K); NS_ALLOC(d.count, int, NS_PARTS);
     NS_ALLOC(d.walk, int, P); NS_ALLOC(d.wstep, int, P); NS_ALLOC(d.wW, int, P); NS_ALLOC(d.wscale, double, P);
     NS_ALLOC(d.wLthr, double, P); NS_ALLOC(d.wacc_sum, long, P); NS_ALLOC(d.wtot_sum, long, P);
-    NS_ALLOC(d.wU, double, P * NS_W * D); NS_ALLOC(d.wT, double, P * NS_W * D); NS_ALLOC(d.wL, double, P * NS_W);
+    NS_ALLOC(d.wU, double, P * NS_W * D); NS_ALLOC(d.wT, double, P * NS_W * DT); NS_ALLOC(d.wL, double, P * NS_W);
     NS_ALLOC(d.wnacc, int, P * NS_W); NS_ALLOC(d.lnvol, double, P);
 #undef NS_ALLOC
     HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
-    d.pixmap = s->d_pixmap; d.actlist = s->d_actlist;
+    HIP_TRY(hipMemcpy(s->d_fmap, fm.data(), sizeof(int) * D, hipMemcpyHostToDevice));
+    d.pixmap = s->d_pixmap; d.actlist = s->d_actlist; d.fmap = s->d_fmap;
     *out = s;
     return NFA_OK;
 }
@@ -581,7 +592,7 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemsetAsync(d.wacc_sum, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.wtot_sum, 0, sizeof(long) * P, st));
     {   // live points
-        const long tot = (long)P * N * D;
+        const long tot = (long)P * N;
         hipLaunchKernelGGL(ns_init_live_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, s->d_livepix);
         HIP_TRY(hipGetLastError());
         int rc = run_batch(r, s->d_livepix, d.Tlive, d.Llive, nullptr, (int64_t)P * N, true, 0, nullptr);
@@ -638,7 +649,7 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                 n_pix_h[h] = h < n_half ? (n_act * (h + 1)) / n_half - (n_act * h) / n_half : 0;
                 dh[h] = d;
                 const long off = first * Kr;
-                dh[h].candU += off * D; dh[h].candT += off * D; dh[h].candL += off;
+                dh[h].candU += off * D; dh[h].candT += off * d.DT; dh[h].candL += off;
                 dh[h].candpix += off; dh[h].valid += off; dh[h].slot += off;
                 dh[h].count += h; dh[h].actlist += first;
                 first += n_pix_h[h];
@@ -704,7 +715,7 @@ int nfa_sampler_dead(nfa_sampler *s, int64_t p, int64_t n, double *theta, double
     if (!s || !s->ran || p < 0 || p >= s->d.P || n < 0 || n > s->d.cap) return fail(NFA_ERR_ARG, "bad argument");
     if (n == 0) return NFA_OK;
     const NsDev &d = s->d;
-    HIP_TRY(hipMemcpy(theta, d.deadT + (size_t)p * d.cap * d.D, sizeof(double) * n * d.D, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(theta, d.deadT + (size_t)p * d.cap * d.DT, sizeof(double) * n * d.DT, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(lnL, d.deadL + (size_t)p * d.cap, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(lnw, d.deadlnw + (size_t)p * d.cap, sizeof(double) * n, hipMemcpyDeviceToHost));
     return NFA_OK;
@@ -714,7 +725,7 @@ int nfa_sampler_dead(nfa_sampler *s, int64_t p, int64_t n, double *theta, double
 int nfa_sampler_live(nfa_sampler *s, double *theta, double *lnL) {
     if (!s || !s->ran || !theta || !lnL) return fail(NFA_ERR_ARG, "sampler has not run");
     const NsDev &d = s->d;
-    HIP_TRY(hipMemcpy(theta, d.Tlive, sizeof(double) * (size_t)d.P * d.N * d.D, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(theta, d.Tlive, sizeof(double) * (size_t)d.P * d.N * d.DT, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(lnL, d.Llive, sizeof(double) * (size_t)d.P * d.N, hipMemcpyDeviceToHost));
     return NFA_OK;
 }

@@ -176,7 +176,8 @@ def _resolve_seed(seed):
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
-               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, progress=None):
+               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None,
+               progress=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -205,6 +206,9 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         n_steps defaults to 8 * ndim: scripts/sampler_bias_check.py measures the lnZ bias of walks
         that are too short (6 dimensions: +0.11 with 25 steps, +0.025 with 50, +0.006 with 100;
         the error per run is 0.18).
+    free_mask : ndim flags, 0 for unit-cube slots the likelihood does not depend on (constant or
+        duplicated parameters: `PriorTransformer.free_mask`).  They are not sampled -- a uniform dummy
+        dimension integrates to one -- and stay at u = 0.5: fewer dimensions for the same evidence.
     enlarge : safety factor on the volume of the ellipsoid that just encloses the live points
         (scripts/sampler_bias_check.py: 1.0 biases lnZ by +0.020, 1.25 by +0.011, 2.0 by nothing measurable; the error is 0.18).
 
@@ -223,10 +227,20 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             out[a:a + chunk] = loglike(pix[a:a + chunk], U[a:a + chunk])
         return np.where(np.isfinite(out), out, log_zero)
 
+    fmap = np.arange(ndim) if free_mask is None else np.flatnonzero(np.asarray(free_mask))
+    assert fmap.size > 0 and fmap.max() < ndim
+    nd = int(fmap.size)                                         # sampled dimensions
+
+    def expand(U):
+        """Rows of the full unit cube from rows of the sampled dimensions."""
+        T = np.full(U.shape[:-1] + (ndim,), 0.5)
+        T[..., fmap] = U
+        return T
+
     # live points: unit-cube positions, physical parameters, log-likelihoods
     Ulive = _uniform(seed, all_pix[:, None, None], _TAG_LIVE + np.arange(nlive, dtype=_U64)[None, :, None],
-                     np.arange(ndim, dtype=_U64)[None, None, :])
-    Tlive = Ulive.reshape(-1, ndim).copy()
+                     np.arange(nd, dtype=_U64)[None, None, :])
+    Tlive = expand(Ulive).reshape(-1, ndim)
     Llive = evaluate(np.repeat(all_pix, nlive), Tlive).reshape(P, nlive)
     Tlive = Tlive.reshape(P, nlive, ndim)
     n_evals = np.full(P, nlive, dtype=np.int64)
@@ -243,7 +257,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     cand_base = np.zeros(P, dtype=np.int64)
     Kr = K
     method = {'reject': 0, 'auto': 1, 'walk': 2}[method] if isinstance(method, str) else int(method)
-    n_steps = int(n_steps) if n_steps else 8 * ndim
+    n_steps = int(n_steps) if n_steps else 8 * nd
     # constrained random walks (ns_update_kernel's walk branch): state per pixel and per walker
     walk = np.zeros(P, dtype=bool)
     wstep = np.zeros(P, dtype=np.int64)
@@ -252,7 +266,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     wLthr = np.zeros(P)
     wacc_sum = np.zeros(P, dtype=np.int64)
     wtot_sum = np.zeros(P, dtype=np.int64)
-    wU = np.zeros((P, _NS_W, ndim))
+    wU = np.zeros((P, _NS_W, nd))
     wT = np.zeros((P, _NS_W, ndim))
     wL = np.zeros((P, _NS_W))
     wnacc = np.zeros((P, _NS_W), dtype=np.int64)
@@ -291,12 +305,12 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                     wnacc[p, :W] = 0
                     wLthr[p] = Llive[p].min()
                     wW[p] = W
-                z = _ball_points(seed, p, a, ndim) * wscale[p]
+                z = _ball_points(seed, p, a, nd) * wscale[p]
                 cand = wU[p, :W] + z @ axes[p].T
                 valid = np.all((cand >= 0.0) & (cand < 1.0), axis=1)
                 vi = np.flatnonzero(valid)
                 if vi.size:
-                    Tsub = cand[vi].copy()
+                    Tsub = expand(cand[vi])
                     Lsub = evaluate(np.full(vi.size, p, dtype=np.int32), Tsub)
                     n_evals[p] += vi.size
                     ok = Lsub > wLthr[p]
@@ -314,7 +328,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                         done = replace(p, wU[p, k].copy(), wT[p, k].copy(), wL[p, k])
                     if wtot_sum[p] > 0:                         # acceptance near one half
                         wscale[p] = min(1.0, wscale[p] * math.exp((wacc_sum[p] / wtot_sum[p] - 0.5)
-                                                                  / (0.5 * math.sqrt(ndim))))
+                                                                  / (0.5 * math.sqrt(nd))))
                     wacc_sum[p] = wtot_sum[p] = wstep[p] = 0
                     # back to rejection once the bound promises clearly more than a walk delivers
                     if method == 1 and (-n_iter[p] / nlive - min(lnvol[p], 0.0)) > math.log(4.0 / n_steps):
@@ -326,7 +340,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                 vi = np.flatnonzero(valid)
                 scanned = accepted = 0
                 if vi.size:
-                    Tsub = cand[vi].copy()
+                    Tsub = expand(cand[vi])
                     Lsub = evaluate(np.full(vi.size, p, dtype=np.int32), Tsub)
                     for j in range(vi.size):                    # the wave's sequential scan
                         scanned += 1
@@ -369,7 +383,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
                       upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=262144,
-                      enlarge=1.5, method='auto', n_steps=None, progress=None, time_limit=None):
+                      enlarge=1.5, method='auto', n_steps=None, free_mask=None, progress=None, time_limit=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
     work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive).  `progress`
@@ -385,15 +399,19 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
     seed = _resolve_seed(seed)
     K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
     cap = int(cap_iter) if cap_iter else int(max(1, min(maxiter, 60 * nlive)))
+    fm = None if free_mask is None else np.ascontiguousarray(free_mask, dtype=np.int32)
+    assert fm is None or fm.shape == (ndim,)
+    nd = ndim if fm is None else int(np.count_nonzero(fm))
     h = C.c_void_p()
     _ffi.check(lib.nfa_sampler_create(C.byref(h), runner._run.handle, pix.ctypes.data_as(_ffi._ip), P,
-                                      int(nlive), K, int(batch_target), cap))
+                                      int(nlive), K, int(batch_target), cap,
+                                      None if fm is None else fm.ctypes.data_as(_ffi._ip)))
     try:
         _ffi.check(lib.nfa_sampler_begin(h, float(tol), float(efr), seed, int(maxiter),
                                          max(1, int(upd_frac * nlive)), float(log_zero), int(check_every),
                                          float(enlarge),
                                          {'reject': 0, 'auto': 1, 'walk': 2}[method] if isinstance(method, str)
-                                         else int(method), int(n_steps) if n_steps else 8 * ndim))
+                                         else int(method), int(n_steps) if n_steps else 8 * nd))
         n_active = C.c_int64(P)
         t0 = time.perf_counter()
         chunks = 16
@@ -551,15 +569,17 @@ def run_multinest(runner, dumper, IS=False, mmodal=True, ceff=False, nlive=400, 
     if nClsPar > runner.n_params:
         raise ValueError('Number of clustering parameters must be less than total.')
 
+    utrans = getattr(runner, 'utrans', None)
+    free_mask = utrans.free_mask(runner.ncomp) if hasattr(utrans, 'free_mask') else None
     if hasattr(runner, '_run'):          # engine runner: the whole run stays on the device
         res = run_nested_device(runner, np.zeros(1, dtype=np.int32), nlive=nlive, tol=tol, efr=efr, seed=seed,
-                                maxiter=maxiter, log_zero=logZero)[0]
+                                maxiter=maxiter, log_zero=logZero, free_mask=free_mask)[0]
     else:                                # any object with loglikelihood_batch(U): the numpy twin
         def loglike(pix, U):
             return runner.loglikelihood_batch(U)
 
         res = run_nested(loglike, runner.ndim, 1, nlive=nlive, tol=tol, efr=efr, seed=seed,
-                         maxiter=maxiter, log_zero=logZero)[0]
+                         maxiter=maxiter, log_zero=logZero, free_mask=free_mask)[0]
     dumper.dump(runner, res)
     return res
 
@@ -570,6 +590,8 @@ def fit_pixels(cube_runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=i
     device=True keeps the sampler state on the GPU (`run_nested_device`); device=False runs the
     host twin and sends only the likelihood batches to the GPU."""
     pix = np.ascontiguousarray(pix, dtype=np.int32)
+    if 'free_mask' not in kwargs and getattr(cube_runner, 'utrans', None) is not None:
+        kwargs['free_mask'] = cube_runner.utrans.free_mask(cube_runner.ncomp)   # dummies are not sampled
     if device:
         return run_nested_device(cube_runner, pix, nlive=nlive, tol=tol, efr=efr, seed=seed,
                                  maxiter=maxiter, **kwargs)

@@ -79,6 +79,31 @@ def test_walk_mode_evidence_and_switch():
     assert 0.02 < w[x < 0.5].sum() < 0.98                                    # both modes kept (100 live points: noisy)
 
 
+def test_dummy_dimensions_are_integrated_out():
+    """free_mask: slots the likelihood ignores are not sampled; the evidence is the one of the
+    reduced problem, the full-length rows carry u = 0.5 there."""
+    sigma = 0.05
+    def like5(pix, U):                                   # depends on slots 0, 2, 3 only
+        assert (U[:, 1] == 0.5).all() and (U[:, 4] == 0.5).all()
+        return -0.5 * ((U[:, [0, 2, 3]] - 0.5) ** 2).sum(axis=1) / sigma ** 2
+    res = sampler.run_nested(like5, 5, 6, nlive=150, tol=0.1, efr=0.5, seed=9, free_mask=[1, 0, 1, 1, 0])
+    truth = 3 * np.log(sigma * np.sqrt(2 * np.pi))
+    lnZ = np.array([r.lnZ for r in res])
+    err = np.mean([r.lnZ_err for r in res])
+    assert abs(lnZ.mean() - truth) < 4 * err / np.sqrt(6) + 0.03
+    assert res[0].posterior.shape[1] == 7 and (res[0].posterior[:, 1] == 0.5).all()
+    full = sampler.run_nested(lambda pix, U: -0.5 * ((U[:, [0, 2, 3]] - 0.5) ** 2).sum(axis=1) / sigma ** 2,
+                              5, 6, nlive=150, tol=0.1, efr=0.5, seed=9)
+    assert np.mean([r.n_evals for r in res]) < np.mean([r.n_evals for r in full])     # cheaper, same answer
+    assert abs(np.mean([r.lnZ for r in full]) - truth) < 4 * err / np.sqrt(6) + 0.03
+
+
+def test_free_mask_of_the_reference_prior_sets():
+    import nestfit_amd as na
+    assert na.get_irdc_priors().free_mask(2).tolist() == [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0]      # orth constant
+    assert na.get_synth_priors().free_mask(1).tolist() == [1, 1, 0, 1, 1, 0]                        # tex duplicated
+
+
 def test_seed_reproducibility_and_independent_pixels():
     f = _gauss_problem(np.full(3, 0.4), 0.1)
     a = sampler.run_nested(f, 3, 3, nlive=60, seed=7)
@@ -196,8 +221,12 @@ def test_sampler_on_gpu_matches_the_same_sampler_on_the_oracle(engine, nfo):
             U[m] = sub
         return out
 
-    kw = dict(nlive=60, tol=0.5, efr=0.3, seed=33)
+    # the constant-prior slot (orth) is not sampled: 5 of the 6 dimensions
+    mask = cube.utrans.free_mask(1)
+    assert mask.tolist() == [1, 1, 1, 1, 1, 0]
+    kw = dict(nlive=60, tol=0.5, efr=0.3, seed=33, free_mask=mask)
     ref = sampler.run_nested(cpu_loglike, cube.ndim, n_pix, **kw)
+    assert all((r.posterior[:, 5] == 0).all() for r in ref)       # theta of the constant slot
     try:
         engine.set_exp_mode('table')
         # host twin (numpy rounds, GPU likelihood) and device-resident sampler, same seed
