@@ -19,6 +19,7 @@
 #define NS_TAG_LIVE  (1ull << 62)
 #define NS_B_RADIUS  255ull
 #define NS_B_START   250ull      // stream index of a walker's starting live point
+#define NS_WALK_TARGET 0.5     // acceptance the walk scale is tuned to
 #define NS_W         64          // walkers per pixel: one per lane of the update wave
 
 __host__ __device__ inline uint64_t ns_mix(uint64_t x) {             // splitmix64 finaliser
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
                 replace(S.wU + ((long)p * NS_W + k) * D, S.wT + ((long)p * NS_W + k) * S.DT, Lk);
             }
             // acceptance near one half (as dynesty's rwalk tunes it)
-            if (tot_sum > 0) scale = fmin(1.0, scale * exp(((double)acc_sum / (double)tot_sum - 0.5) / (0.5 * sqrt((double)D))));
+            if (tot_sum > 0) scale = fmin(1.0, scale * exp(((double)acc_sum / (double)tot_sum - NS_WALK_TARGET) / (0.5 * sqrt((double)D))));
             acc_sum = 0; tot_sum = 0; next_step = 0;
             // back to rejection sampling once the bound promises clearly more than a walk delivers:
             // expected acceptance X / min(V_ellipsoid, 1) > 4 / n_steps

@@ -76,6 +76,7 @@ def _uniform(seed, p, a, b):
 
 _B_START = _U64(250)
 _NS_W = 64
+_WALK_TARGET = 0.5              # acceptance the walk scale is tuned to (NS_WALK_TARGET on the device)
 
 
 def _ball_points(seed, p, a, D):
@@ -327,7 +328,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                             continue
                         done = replace(p, wU[p, k].copy(), wT[p, k].copy(), wL[p, k])
                     if wtot_sum[p] > 0:                         # acceptance near one half
-                        wscale[p] = min(1.0, wscale[p] * math.exp((wacc_sum[p] / wtot_sum[p] - 0.5)
+                        wscale[p] = min(1.0, wscale[p] * math.exp((wacc_sum[p] / wtot_sum[p] - _WALK_TARGET)
                                                                   / (0.5 * math.sqrt(nd))))
                     wacc_sum[p] = wtot_sum[p] = wstep[p] = 0
                     # back to rejection once the bound promises clearly more than a walk delivers
