@@ -134,6 +134,8 @@ def main():
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('NFA_BENCH_SAME_GPU'):      # rehearsal of the N > 1 path on a one-GPU box (gloo barrier)
+        local_rank = 0
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
@@ -163,7 +165,10 @@ def main():
     if use_dist:                              # one rank per GPU over RCCL
         import torch.distributed as dist
         with stdout_to_stderr():
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            if os.environ.get('NFA_BENCH_SAME_GPU'):
+                dist.init_process_group('gloo')
+            else:
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
             dist.barrier()                    # creates the communicator (and prints the banner)
             torch.cuda.synchronize()
 
@@ -266,12 +271,13 @@ def main():
     summary = [(rank, float(lnL.max()), int(args.steps * B))]
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tdev = 'cpu' if os.environ.get('NFA_BENCH_SAME_GPU') else 'cuda'
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = float(t.item())
         # end-of-run gather of fixed-size per-pixel records
         rec = torch.tensor([float(rank), float(lnL.max()), float(args.steps * B)],
-                           dtype=torch.float64, device='cuda')
+                           dtype=torch.float64, device=tdev)
         out = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(out, rec)
         summary = [(int(o[0].item()), float(o[1].item()), int(o[2].item())) for o in out]
