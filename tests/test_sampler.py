@@ -294,3 +294,25 @@ def test_device_sampler_limits_and_errors(engine, nfo):
         sampler.run_nested_device(cube, pix, nlive=cube.ndim + 2 + 9000, seed=1)
     with pytest.raises(engine.EngineError, match='pixel index'):
         sampler.run_nested_device(cube, np.array([7]), nlive=40, seed=1)
+
+
+@pytest.mark.gpu
+def test_device_refit_paths_large_nlive(engine, nfo):
+    """The ellipsoid refit stages the live points in LDS when they fit (nlive * ndim * 8 <= 96 KB) and
+    falls back to wave reductions over global memory otherwise: both against the numpy twin."""
+    cube, cpu_runners, truths, _, _ = _cube(engine, nfo, 1, seed=3)
+    mask = cube.utrans.free_mask(1)
+
+    def cpu_loglike(pix, U):
+        return cpu_runners[0].loglikelihood_batch(U)
+    try:
+        engine.set_exp_mode('table')
+        for nlive in (1500, 2600):                    # 5 sampled dimensions: 60 KB staged / 104 KB not
+            kw = dict(nlive=nlive, seed=12, maxiter=nlive // 2, free_mask=mask, batch_target=4096)
+            ref = sampler.run_nested(cpu_loglike, cube.ndim, 1, **kw)[0]
+            got = sampler.fit_pixels(cube, np.zeros(1, dtype=np.int32), **kw)[0]
+            assert got.n_iter == ref.n_iter == nlive // 2 and got.n_evals == ref.n_evals
+            assert got.lnZ == pytest.approx(ref.lnZ, rel=1e-10)
+            np.testing.assert_allclose(got.posterior, ref.posterior, rtol=1e-8, atol=1e-12)
+    finally:
+        engine.set_exp_mode('fast')
