@@ -316,3 +316,45 @@ def test_device_refit_paths_large_nlive(engine, nfo):
             np.testing.assert_allclose(got.posterior, ref.posterior, rtol=1e-8, atol=1e-12)
     finally:
         engine.set_exp_mode('fast')
+
+
+@pytest.mark.gpu
+def test_sampler_on_sibling_models(engine, nfo):
+    """The device sampler is model-agnostic: N2H+ (4 parameters) and Gaussian (3) cubes."""
+    from scipy import stats
+    from nestfit_amd.cube import CubeRunner
+    CKMS = 299792.458
+
+    def priors(ranges, size=200):
+        x = np.linspace(0, 1, size)
+        return engine.PriorTransformer([
+            engine.Prior(engine.Distribution(lo + x * (hi - lo), stats.uniform(lo, hi - lo).pdf(lo + x * (hi - lo))), k)
+            for k, (lo, hi) in enumerate(ranges)])
+    rng = np.random.default_rng(4)
+    n, n_pix, noise = 256, 3, 0.1
+    # N2H+ 1-0
+    nu0 = 93173.7637e6
+    x = nu0 * (1.0 - np.linspace(15, -15, n) / CKMS)
+    truth = np.array([0.5, 7.0, 0.3, 0.4])
+    sc = nfo.DiazenyliumSpectrum(x, np.zeros(n), noise, 1)
+    nfo.nnhp_predict(sc, truth)
+    data = sc.get_spec()[None, :] + rng.normal(0, noise, (n_pix, n))
+    ut = priors([(-4, 4), (2.8, 20), (-1.5, 1.0), (0.1, 1.5)])
+    cube = CubeRunner([x], [1], data, np.full((n_pix, 1), noise), ut, ncomp=1, model=1)
+    res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=80, seed=6)
+    for p, r in enumerate(res):
+        assert r.lnZ - cube.null_lnZ[p] > 11 and r.posterior.shape[1] == 6
+        mean, sig = r.param_constr[0], r.param_constr[1]
+        assert abs(mean[0] - truth[0]) < 5 * sig[0] + 0.02 and abs(mean[3] - truth[3]) < 5 * sig[3] + 0.02
+    # Gaussian line
+    nu0 = 110.201354e9
+    x = nu0 * (1.0 - np.linspace(20, -20, n) / CKMS)
+    sg = nfo.Spectrum(x, np.zeros(n), noise, rest_freq=nu0)
+    nfo.gauss_predict(sg, np.array([-2.0, 1.2, 1.5]))
+    data = sg.get_spec()[None, :] + rng.normal(0, noise, (n_pix, n))
+    utg = priors([(-15, 15), (0.2, 3.0), (0.0, 5.0)])
+    cube = CubeRunner([x], [1], data, np.full((n_pix, 1), noise), utg, ncomp=1, model=2, rest_freqs=[nu0])
+    res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=80, seed=7)
+    for p, r in enumerate(res):
+        assert r.lnZ - cube.null_lnZ[p] > 11
+        np.testing.assert_allclose(r.param_constr[0], [-2.0, 1.2, 1.5], atol=0.15)
