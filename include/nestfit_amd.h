@@ -241,10 +241,11 @@ int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_
 /* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the
  * bounding ellipsoid only; 1 = a pixel whose rejection round accepted fewer than 1 in 2 n_steps of
  * the evaluated candidates switches to constrained random walks: 64 walkers start from random live
- * points and take n_steps Metropolis steps inside {L > threshold} with ellipsoid-shaped proposals
- * whose scale is tuned to an acceptance of one half (the `rwalk` idea of dynesty, Speagle 2020);
- * 2 = walks from the first round.  nfa_sampler_run uses method 1, n_steps 8 * ndim (walks that are
- * too short bias lnZ upwards: +0.11 with 25 steps in 6 dimensions, nothing measurable from ~50).
+ * points and take n_steps Metropolis steps inside {L > threshold}; a step is a scaled difference of
+ * two random live points (differential evolution, ter Braak 2006), the scale tuned to an acceptance
+ * of one half;
+ * 2 = walks from the first round.  nfa_sampler_run uses method 1, n_steps 10 x sampled dimensions
+ * (walks that are too short bias lnZ upwards: +0.13 with 40 steps in 10 dimensions, +0.014 with 120).
  * (nfa_sampler_run uses enlarge = 1.5: safety factor on the volume of the ellipsoid that just
  * encloses the live points, before MultiNest's floor X / efr is applied)
  * the same in two steps: begin = live points + first ellipsoids; advance = up to max_chunks groups

@@ -111,8 +111,7 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
     double wscale = 1.0;
     const double *origin = S.centre + (long)p * D;
     if (walking) {
-        // Metropolis step of walker k inside {L > threshold}: proposal = current point + scale * (a
-        // uniform point of the bounding ellipsoid, centred); a cycle starts from a random live point
+        // Metropolis step of walker k inside {L > threshold}; a cycle starts from a random live point
         const int step = S.wstep[p];
         const int W = step == 0 ? min(NS_W, Kr) : S.wW[p];
         if (k >= W) { S.valid[gid] = 0; return; }
@@ -129,7 +128,23 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
         origin = wu;
         wscale = S.wscale[p];
     }
-    if (!walking && S.use_cube[p]) {    // early on the bounding ellipsoid is no better than the prior itself
+    if (walking) {
+        // differential-evolution move (ter Braak 2006): the step is a scaled difference of two random
+        // live points, so its shape follows the constraint region whatever that looks like (measured
+        // against ellipsoid-shaped steps and an alternation of both on 576 two-component pixels: half
+        // the lnZ bias at equal length, scripts/sampler_bias_check.py)
+        const int N = S.N;
+        int ia = min(N - 1, (int)(ns_uniform(S.seed, (uint64_t)p, a, 251ull) * N));
+        int ib = min(N - 2, (int)(ns_uniform(S.seed, (uint64_t)p, a, 252ull) * (N - 1)));
+        if (ib >= ia) ib += 1;
+        const double gam = wscale * 2.38 / sqrt(2.0 * D);
+        const double *ua = S.Ulive + ((long)p * N + ia) * D, *ub = S.Ulive + ((long)p * N + ib) * D;
+        for (int j = 0; j < D; ++j) {
+            const double v = origin[j] + gam * (ua[j] - ub[j]);
+            ok = ok && (v >= 0.0) && (v < 1.0);
+            cu[j] = v;
+        }
+    } else if (!walking && S.use_cube[p]) {    // early on the bounding ellipsoid is no better than the prior itself
         for (int j = 0; j < D; ++j) cu[j] = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)j);
     } else {
         double z[NS_MAXD];
@@ -144,8 +159,8 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
             if (m + 1 < D) { z[m + 1] = r * sin(ang); n2 += z[m + 1] * z[m + 1]; }
         }
         const double ur = ns_uniform(S.seed, (uint64_t)p, a, NS_B_RADIUS);
-        const double f = wscale * exp(log(ur) / D) / sqrt(n2);      // uniform in the (scaled) unit ball
-        const double *c = origin, *A = S.axes + (long)p * D * D;
+        const double f = exp(log(ur) / D) / sqrt(n2);               // uniform in the unit ball
+        const double *c = S.centre + (long)p * D, *A = S.axes + (long)p * D * D;
         for (int j = 0; j < D; ++j) {
             double v = c[j];
             for (int i = 0; i <= j; ++i) v += A[j * D + i] * (z[i] * f);
@@ -696,7 +711,7 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
 
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every) {
-    int rc = nfa_sampler_begin(s, tol, efr, seed, maxiter, upd, log_zero, check_every, 1.5, 1, 8 * s->d.D);
+    int rc = nfa_sampler_begin(s, tol, efr, seed, maxiter, upd, log_zero, check_every, 1.5, 1, 10 * s->d.D);
     if (rc) return rc;
     return nfa_sampler_advance(s, 0, nullptr);
 }

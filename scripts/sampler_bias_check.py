@@ -39,7 +39,8 @@ out = {}
 runs = [('auto', 0.3, 1.5, 25), ('auto', 0.3, 1.5, 50), ('walk', 0.3, 1.5, 25), ('walk', 0.3, 1.5, 50), ('walk', 0.3, 1.5, 100),
         ('reject', 0.3, 1.5, 0), ('reject', 0.02, 1.5, 0)]
 if len(sys.argv) > 1 and sys.argv[1] == 'short':
-    runs = [('auto', 0.3, 1.5, 8 * 6 * ncomp), ('auto', 0.3, 1.5, 16 * 6 * ncomp), ('reject', 0.3, 1.5, 0)]
+    nd = 5 * ncomp                                   # sampled dimensions with get_irdc_priors
+    runs = [('auto', 0.3, 1.5, 10 * nd), ('walk', 0.3, 1.5, 10 * nd), ('walk', 0.3, 1.5, 4 * nd), ('reject', 0.3, 1.5, 0)]
 for method, efr, enl, steps in runs:
     t0 = time.perf_counter()
     res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=400, tol=0.5, efr=efr, seed=11, enlarge=enl, method=method,
