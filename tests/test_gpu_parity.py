@@ -557,3 +557,36 @@ def test_extreme_parameters(engine, nfo, mode):
                     if big.any():
                         worst = max(worst, float(np.max(err[big] / np.abs(pc[nz][big]))))
     print(f'extreme {mode}: worst relative Tb error {worst:.2e}')
+
+
+def test_handles_release_their_device_memory(engine, nfo):
+    """Spectra sets, priors, runners, brokers and samplers created and destroyed many times leave the
+    free device memory where it was."""
+    import gc
+    from nestfit_amd import sampler
+    from nestfit_amd.broker import LikelihoodBroker
+    from nestfit_amd.cube import CubeRunner
+    hip = C.CDLL('libamdhip64.so')
+    free, total = C.c_size_t(), C.c_size_t()
+
+    def free_bytes():
+        gc.collect()
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+    rng = np.random.default_rng(0)
+    axes = [freq_axis(1, 512), freq_axis(2, 512)]
+
+    def cycle():
+        ut = engine.get_irdc_priors(size=200, vsys=0.0)
+        cube = CubeRunner(axes, (1, 2), rng.normal(0, 0.2, (8, 1024)), np.full((8, 2), 0.2), ut, ncomp=2)
+        cube.loglikelihood_batch(np.arange(8, dtype=np.int32), rng.uniform(size=(8, 12)))
+        b = LikelihoodBroker(cube, max_batch=4, max_wait_us=10)
+        b.loglikelihood(rng.uniform(size=12), pix=3)
+        b.close()
+        sampler.fit_pixels(cube, np.arange(2), nlive=30, maxiter=20, seed=1)
+    cycle()                                           # first use: caches, code objects
+    before = free_bytes()
+    for _ in range(25):
+        cycle()
+    after = free_bytes()
+    assert abs(before - after) < 64 << 20, (before, after)     # allocator granularity, not a leak per cycle
