@@ -42,3 +42,27 @@ def test_product_fails_loudly_without_gpu():
 def test_product_never_imports_the_oracle():
     for f in list((ROOT / 'nestfit_amd').rglob('*.py')) + list((ROOT / 'nestfit_amd').rglob('*.hip')):
         assert 'oracle' not in f.read_text().replace('test oracle', '').replace('CPU oracle', ''), f
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/nestfit_amd.h compiles as C99 (no C++ or torch types at the boundary) and a C program
+    that references every declared entry point links against the built library."""
+    import re
+    import subprocess
+    from nestfit_amd import _ffi
+    from nestfit_amd.build import OUT, build
+    build()
+    header = (ROOT / 'include' / 'nestfit_amd.h').read_text()
+    names = sorted(set(re.findall(r'\b(nfa_[a-z0-9_]+)\s*\(', header)) & set(_ffi.SIGNATURES))
+    assert len(names) == len(_ffi.SIGNATURES)
+    src = tmp_path / 'use_abi.c'
+    table = ',\n'.join(f'    (fn_t){n}' for n in names)
+    src.write_text('#include "nestfit_amd.h"\n#include <stdio.h>\ntypedef void (*fn_t)(void);\n'
+                   'static fn_t table[] = {\n' + table + '\n};\n'
+                   'int main(void) {\n    printf("%u\\n", (unsigned)(sizeof table / sizeof table[0]));\n'
+                   '    return table[0] == 0;\n}\n')
+    exe = tmp_path / 'use_abi'
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic', f'-I{ROOT / "include"}', str(src), '-o', str(exe),
+           f'-L{OUT.parent}', '-lnestfit_amd', f'-Wl,-rpath,{OUT.parent}', '-Wl,--allow-shlib-undefined']
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
