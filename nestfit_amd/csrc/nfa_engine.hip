@@ -134,6 +134,12 @@ struct nfa_runner {
     double *d_U = nullptr, *d_lnL = nullptr, *d_spec = nullptr;
     int    *d_pix = nullptr;
     int64_t cap_B = 0, cap_spec = 0;
+    // single-point calls (MultiNest's LogLike): the whole H2D -> 5 kernels -> D2H sequence as one
+    // captured graph, replayed per call (built on the third single-point call in a given mode)
+    hipGraphExec_t g1 = nullptr;
+    int     g1_mode = -1;
+    double *h_pin = nullptr;         // pinned staging: ndim + 1 doubles
+    uint64_t n_single = 0;
     // optional per-kernel timing (HIP events on the runner's stream)
     bool profiling = false;
     std::vector<hipEvent_t> ev;      // triples: before priors, before lnl, after lnl
@@ -433,6 +439,8 @@ int nfa_runner_destroy(nfa_runner *r) {
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamSynchronize(r->lanes[k]);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
     for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_Q[k]); (void)hipFree(r->d_part[k]); }
+    if (r->g1) (void)hipGraphExecDestroy(r->g1);
+    if (r->h_pin) (void)hipHostFree(r->h_pin);
     for (hipEvent_t x : r->ev) (void)hipEventDestroy(x);
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamDestroy(r->lanes[k]);
     delete r;
@@ -443,6 +451,7 @@ int nfa_runner_ndim(const nfa_runner *r) { return r ? r->ndim : 0; }
 
 static int runner_reserve(nfa_runner *r, int64_t B, bool spec) {
     if (B > r->cap_B) {
+        if (r->g1) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
         (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix);
         r->d_U = nullptr; r->d_lnL = nullptr; r->d_pix = nullptr; r->cap_B = 0;
         const int64_t cap = std::max<int64_t>(B, 64);
@@ -475,6 +484,7 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     const int drec = drec_size(r->ncomp, S.n_spec);
     hipStream_t st = r->lanes[slot];
     if (B > r->cap_D[slot]) {                // grown outside any timed loop
+        if (slot == 0 && r->g1) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
         HIP_TRY(hipStreamSynchronize(st));
         (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_Q[slot]); (void)hipFree(r->d_part[slot]);
         r->d_D[slot] = nullptr; r->d_Q[slot] = nullptr; r->d_part[slot] = nullptr; r->cap_D[slot] = 0;
@@ -686,6 +696,43 @@ int nfa_runner_synchronize(nfa_runner *r) {
     return sync_all_lanes(r);
 }
 
+}  // extern "C"
+
+// One point through a captured graph; returns 1 when the call was served, 0 when the plain path
+// has to do it (first calls, table mode whose launch sets a function attribute, profiling on).
+static int single_point_graph(nfa_runner *r, double *U, double *lnL) {
+    if (r->profiling || g_eng.exp_mode == 0 || r->cap_B < 1 || r->cap_D[0] < 1 || r->n_single < 2) return 0;
+    const int ndim = r->ndim;
+    hipStream_t st = r->lanes[0];
+    if (!r->h_pin && hipHostMalloc((void **)&r->h_pin, sizeof(double) * (ndim + 1)) != hipSuccess) return 0;
+    if (r->g1 && r->g1_mode != g_eng.exp_mode) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
+    if (!r->g1) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return 0;
+        bool ok = hipMemcpyAsync(r->d_U, r->h_pin, sizeof(double) * ndim, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && run_batch(r, nullptr, r->d_U, r->d_lnL, nullptr, 1, true, 0, nullptr) == NFA_OK;
+        ok = ok && hipMemcpyAsync(r->h_pin, r->d_U, sizeof(double) * ndim, hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(r->h_pin + ndim, r->d_lnL, sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess;
+        const bool ended = hipStreamEndCapture(st, &graph) == hipSuccess && graph;
+        if (!ok || !ended || hipGraphInstantiate(&r->g1, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            r->g1 = nullptr;
+            (void)hipGetLastError();
+            r->n_single = 0;                         // do not try again right away
+            return 0;
+        }
+        (void)hipGraphDestroy(graph);
+        r->g1_mode = g_eng.exp_mode;
+    }
+    memcpy(r->h_pin, U, sizeof(double) * ndim);
+    if (hipGraphLaunch(r->g1, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
+    memcpy(U, r->h_pin, sizeof(double) * ndim);
+    *lnL = r->h_pin[ndim];
+    return 1;
+}
+
+extern "C" {
+
 int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, double *lnL, int64_t B) {
     if (!r || !U || !lnL) return fail(NFA_ERR_ARG, "null argument");
     if (B <= 0) return NFA_OK;
@@ -693,6 +740,10 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     rc = sync_all_lanes(r); if (rc) return rc;           // the staging buffers are shared
     rc = runner_reserve(r, B, false); if (rc) return rc;
+    if (B == 1 && !pix) {                                // MultiNest-style single points: one graph launch
+        r->n_single += 1;
+        if (single_point_graph(r, U, lnL)) return NFA_OK;
+    }
     // Large batches go through the stream lanes in chunks: the kernels of chunk c run while the
     // host copies chunk c+1 in, and the results of chunk c come back while c+1 computes.  (Every
     // per-item result is independent of the batch it travels in.)

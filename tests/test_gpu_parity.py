@@ -590,3 +590,37 @@ def test_handles_release_their_device_memory(engine, nfo):
         cycle()
     after = free_bytes()
     assert abs(before - after) < 64 << 20, (before, after)     # allocator granularity, not a leak per cycle
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_single_point_calls_replay_a_graph_and_match_batches(engine, nfo, mode):
+    """From the third single-point call on (MultiNest's LogLike pattern) the engine replays one
+    captured graph instead of enqueueing copies and kernels one by one (table mode keeps the plain
+    path): results bitwise those of a batch call, also after a batch call in between, after a mode
+    change and for a second runner."""
+    engine.set_exp_mode(mode)
+    rng = np.random.default_rng(31)
+    ut = engine.get_irdc_priors(size=200, vsys=0.0)
+    args = [[freq_axis(t, 300), rng.normal(0, 0.2, 300), 0.2, t] for t in (1, 2)]
+    runs = [engine.AmmoniaRunner.from_data(args, ut, ncomp=2), engine.AmmoniaRunner.from_data(args, ut, ncomp=1)]
+    for run in runs:
+        U = rng.uniform(size=(12, run.ndim))
+        Ub = U.copy()
+        want = run.loglikelihood_batch(Ub)
+        for k in range(12):
+            if k == 7:
+                run.loglikelihood_batch(rng.uniform(size=(5000, run.ndim)))      # grows the buffers
+            u = U[k].copy()
+            assert run.loglikelihood(u) == want[k]
+            assert np.array_equal(u, Ub[k])
+    other = 'poly' if mode != 'poly' else 'fast'
+    engine.set_exp_mode(other)
+    u = U[3].copy()
+    l_other = runs[1].loglikelihood(u)
+    engine.set_exp_mode(mode)
+    u = U[3].copy()
+    assert runs[1].loglikelihood(u) == want[3]
+    assert l_other == pytest.approx(want[3], rel=1e-6)
+    rc = nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(*a) for a in args], nfo.PriorSet(ut.lower()), ncomp=1)
+    u = U[3].copy()
+    assert rc.loglikelihood(u) == pytest.approx(want[3], rel=LNL_RTOL[mode])
