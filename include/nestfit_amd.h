@@ -49,14 +49,17 @@ int nfa_device_name(char *buf, int buflen);
  *       <= 1e-6 relative on brightness temperature (the metric's tolerance). */
 int nfa_set_exp_mode(int mode);
 int nfa_get_exp_mode(void);
-/* Engine tuning knobs for A/B measurements: "wpb" = waves per workgroup of the
- * likelihood kernel (1..16, default 4; "wpb_table" = the same in table mode, 0 = automatic); "sampler_parts" = groups of pixels the device sampler
- * pipelines over the stream lanes (1..4, default 3); "occ" = resident waves per SIMD the fast-mode
- * likelihood kernel is capped to (0 = no cap, default 7); "streams" = number of HIP
- * streams ("lanes", 1..8, default 3) that runners created afterwards spread consecutive
- * nfa_runner_loglike_batch_dev calls over; "ablate" (only in builds with -DNFA_ABLATE,
- * timing experiments, results invalid) = bit mask: 1 skip the Tb pass, 2 skip the
- * hyperfine-line loop, 4 skip the rows, 8 skip the line set-up. */
+/* Engine tuning knobs for A/B measurements (key, value):
+ *   "wpb"           waves per workgroup of the likelihood kernel (1..16, default 4);
+ *   "wpb_table"     the same in table mode (0 = chosen per spectra set, the default);
+ *   "occ"           resident waves per SIMD the fast-mode likelihood kernel is capped to
+ *                   (0 = no cap, default 7);
+ *   "streams"       number of HIP streams ("lanes", 1..8, default 3) that runners created
+ *                   afterwards spread consecutive nfa_runner_loglike_batch_dev calls over;
+ *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
+ *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid): bit
+ *                   mask, 1 skip the Tb pass, 2 skip the hyperfine-line loop, 4 skip the rows,
+ *                   8 skip the line set-up. */
 int nfa_set_option(const char *key, int value);
 
 /* 1/(e^x-1) interpolation table.  The reference builds T0_X, T0_Y with numpy at
