@@ -131,6 +131,7 @@ struct nfa_runner {
     int64_t     cap_D[NFA_MAX_LANES] = {};
     hipStream_t stream = nullptr;            // lane 0: also the stream of the host-pointer entry points
     uint64_t    n_calls = 0;
+    unsigned    lane_busy = 0;               // lanes with work enqueued and not yet synchronised
     double *d_U = nullptr, *d_lnL = nullptr, *d_spec = nullptr;
     int    *d_pix = nullptr;
     int64_t cap_B = 0, cap_spec = 0;
@@ -619,12 +620,17 @@ static int run_batch(nfa_runner *r, const int *d_pix, double *d_U, double *d_lnL
     if (rc) return rc;
     if (e) HIP_TRY(hipEventRecord(e[2], st));
     r->n_calls++;
+    r->lane_busy |= 1u << slot;
     if (lane_out) *lane_out = slot;
     return NFA_OK;
 }
 
 static int sync_all_lanes(nfa_runner *r) {
-    for (int k = 0; k < r->n_lanes; ++k) HIP_TRY(hipStreamSynchronize(r->lanes[k]));
+    // only lanes that had work enqueued since their last synchronisation (a synchronise call on an
+    // idle stream still costs a couple of microseconds, and single-point callers pay it per point)
+    for (int k = 0; k < r->n_lanes; ++k)
+        if (r->lane_busy & (1u << k)) HIP_TRY(hipStreamSynchronize(r->lanes[k]));
+    r->lane_busy = 0;
     return NFA_OK;
 }
 
@@ -726,6 +732,7 @@ static int single_point_graph(nfa_runner *r, double *U, double *lnL) {
     }
     memcpy(r->h_pin, U, sizeof(double) * ndim);
     if (hipGraphLaunch(r->g1, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
+    r->lane_busy &= ~1u;
     memcpy(U, r->h_pin, sizeof(double) * ndim);
     *lnL = r->h_pin[ndim];
     return 1;
@@ -767,6 +774,7 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
         HIP_TRY(hipMemcpyAsync(lnL + b0, r->d_lnL + b0, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
     }
     for (int c = 0; c < n_chunks; ++c) HIP_TRY(hipStreamSynchronize(r->lanes[c]));
+    r->lane_busy &= ~((1u << n_chunks) - 1u);
     return NFA_OK;
 }
 
@@ -789,6 +797,7 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
     if (lnL_out)
         HIP_TRY(hipMemcpyAsync(lnL_out, r->d_lnL, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    r->lane_busy &= ~1u;
     return NFA_OK;
 }
 
