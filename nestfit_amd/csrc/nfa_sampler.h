@@ -5,14 +5,22 @@
 // available, laid out for the GPU: every pixel is an independent nested-sampling run, all runs
 // advance in lock-step rounds and their whole state (live points, bounding ellipsoids, evidence
 // accumulators, dead points) stays in HBM.  One round =
-//     ns_propose_kernel   K candidates per active pixel, uniform in the pixel's bounding ellipsoid
-//                         (counter-based RNG, so the host twin in nestfit_amd/sampler.py draws
-//                         the very same candidates)
-//     set-up + lnl kernels the engine's likelihood batch over all candidates of all pixels
-//     ns_update_kernel    one wave per pixel: scan the K candidates in order, every one above the
+//     ns_propose_kernel   Kr proposals per active pixel from a counter-based random stream (the host
+//                         twin in nestfit_amd/sampler.py draws the very same numbers): uniform in the
+//                         pixel's bounding ellipsoid (or in the unit cube while that is the smaller
+//                         bound), or -- for pixels that have switched to constrained random walks --
+//                         one differential-evolution Metropolis step of each of its 64 walkers.
+//                         Proposals inside the prior's support are compacted into the rows the
+//                         likelihood will see.
+//     set-up + lnl kernels the engine's likelihood batch over the compacted rows of all pixels
+//     ns_update_kernel    one wave per pixel: scan the candidates in order, every one above the
 //                         pixel's current threshold replaces the worst live point (Skilling's
-//                         bookkeeping: dead point, ln w, running lnZ), stop test, ellipsoid refit
-// The host only counts rounds and, every few rounds, compacts the list of still-active pixels.
+//                         bookkeeping: dead point, ln w, running lnZ), stop test, ellipsoid refit;
+//                         walkers accept / reject their step, and at the end of a cycle their end
+//                         points are the candidates
+// The host counts rounds, reads back how many rows a round has, compacts the list of still-active
+// pixels every few rounds and keeps three groups of pixels in flight on three stream lanes.
+// Only the unit-cube slots the likelihood depends on are sampled (free_mask).
 #pragma once
 
 #define NS_MAXD      60          // 6 parameters x MAXCOMP
