@@ -4,10 +4,12 @@
 The reference drives one serial MultiNest instance per pixel
 (``run_multinest``, nestfit/core/core.pyx:727-823; pixel loop nestfit/main.py:452-469), one
 likelihood per callback.  Here every pixel of a cube is a nested-sampling run of its own, but all
-runs advance in lock-step: each iteration proposes ``k`` candidates per active pixel from the
+runs advance in lock-step: each round proposes candidates per active pixel -- uniform in the
 bounding ellipsoid of its live points (the idea of MultiNest's ellipsoidal rejection sampling,
-Feroz et al. 2009, without the mode clustering), all candidates of all pixels go to the device in
-ONE likelihood batch, and every pixel whose batch contains a point above its current threshold
+Feroz et al. 2009, without the mode clustering), or, where that has become hopeless, one
+differential-evolution Metropolis step of each of 64 walkers inside the likelihood constraint --
+all candidates of all pixels go to the device in ONE likelihood batch, and every pixel scans its
+candidates in order: each one above the pixel's current threshold
 replaces its worst live point (Skilling 2006 bookkeeping).  The outputs follow what the
 reference's ``mn_dump`` stores (core.pyx:627-687): posterior rows ``[theta..., -2 lnL, weight]``,
 ``param_constr`` rows 2, 3 = best-fit and MAP, global lnZ and its error, max log-likelihood.
