@@ -6,7 +6,8 @@ pixel (nestfit/main.py:437-441, 456).
 
 Supported FITS subset (enough for the reference's own test cubes, nestfit/test/data/*.fits, and
 for what CASA / spectral_cube write): primary HDU image, BITPIX 8/16/32/64/-32/-64 with
-BSCALE/BZERO, 3 axes (or 4 with a degenerate Stokes axis), brightness unit K, spectral axis
+BSCALE/BZERO, 3 axes (or 4 with a degenerate Stokes axis), brightness unit K or Jy/beam (with
+BMAJ/BMIN), spectral axis
 VRAD / VELO (radio convention) in m/s or km/s, or FREQ in Hz..GHz, with RESTFRQ / RESTFREQ.
 """
 from collections.abc import Iterable
@@ -145,6 +146,18 @@ class SimpleCube:
         return CKMS * (1.0 - self._freq / float(self.rest_freq))
 
 
+def jy_per_beam_to_kelvin(freq_hz, header):
+    """K per (Jy/beam) at each frequency for the elliptical Gaussian beam BMAJ x BMIN (degrees, FWHM)
+    of the header: T = S c^2 / (2 k nu^2 Omega), Omega = pi BMAJ BMIN / (4 ln 2)."""
+    try:
+        bmaj, bmin = float(header['BMAJ']), float(header['BMIN'])
+    except KeyError:
+        raise ValueError('a Jy/beam cube needs BMAJ and BMIN in its header') from None
+    omega = np.pi * np.radians(bmaj) * np.radians(bmin) / (4.0 * np.log(2.0))       # sr
+    c, kb = 299792458.0, 1.380649e-23
+    return 1e-26 * c ** 2 / (2.0 * kb * np.asarray(freq_hz, dtype=np.float64) ** 2 * omega)
+
+
 class NoiseMap:
     """Per-pixel RMS map, indexed (i_lon, i_lat) like the transposed cube data (reference:
     nestfit/main.py:39-68)."""
@@ -222,15 +235,21 @@ class DataCube:
         return abs(v[1] - v[0])
 
     def data_from_cube(self, cube):
-        # the reference converts other brightness units with the beam; only K is taken here
+        # brightness in K (main.py:127-132).  Jy/beam is converted like spectral_cube's `to('K')`:
+        # Rayleigh-Jeans brightness temperature of the header's Gaussian beam, channel by channel
+        factor = None
         if cube.unit == '':
             print('-- Assuming cube intensity units of K')
+        elif cube.unit.replace(' ', '').lower() in ('jy/beam', 'jybeam-1', 'beam-1jy'):
+            factor = jy_per_beam_to_kelvin(cube.spectral_axis_hz(), cube.header)
         elif cube.unit != 'K':
-            raise ValueError(f'cube intensity unit {cube.unit!r}: only K is supported')
-        if np.diff(cube.spectral_axis_hz()[:2])[0] < 0:    # the model wants ascending frequencies
-            cube = cube[::-1]
+            raise ValueError(f'cube intensity unit {cube.unit!r}: only K and Jy/beam are supported')
+        data = cube._data if factor is None else cube._data * factor[:, None, None]
+        axis = cube.spectral_axis_hz()
+        if axis[1] - axis[0] < 0:                          # the model wants ascending frequencies
+            data, axis = data[::-1], axis[::-1]
         # (chan, lat, lon) -> (lon, lat, chan): one pixel's spectrum is contiguous
-        return cube._data.transpose().copy(), cube.spectral_axis_hz()
+        return data.transpose().copy(), axis.copy()
 
     def velo_axis_from_cube(self, cube):
         v = cube.spectral_axis_kms()

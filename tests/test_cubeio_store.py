@@ -137,8 +137,14 @@ def test_fits_reader_other_encodings(tmp_path):
     np.testing.assert_allclose(dc.xarr, [23.699e9, 23.7e9])           # flipped to ascending
     assert dc.data.shape == (4, 3, 2) and dc.data[1, 2, 0] == data[0, 1, 2, 1]
     with pytest.raises(ValueError, match='only K'):
-        h2 = dict(hdr, BUNIT='Jy/beam')
-        DataCube(SimpleCube(h2, data), 0.1)
+        DataCube(SimpleCube(dict(hdr, BUNIT='mJy/pixel'), data), 0.1)
+    with pytest.raises(ValueError, match='BMAJ'):
+        DataCube(SimpleCube(dict(hdr, BUNIT='Jy/beam'), data), 0.1)
+    # Jy/beam -> K: 1.222e6 S / (nu_GHz^2 theta_maj theta_min [arcsec^2]) per channel
+    hj = dict(hdr, BUNIT='Jy/beam', BMAJ=3.95 / 3600, BMIN=2.87 / 3600)
+    dj = DataCube(SimpleCube(hj, data), 0.1)
+    k = 1.222e6 / (np.array([23.699, 23.7]) ** 2 * 3.95 * 2.87)
+    np.testing.assert_allclose(dj.data / dc.data, np.broadcast_to(k, dc.data.shape), rtol=5e-4)
 
 
 def test_noise_map_from_pbimg_and_nan_pixels():
