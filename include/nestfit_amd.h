@@ -57,6 +57,8 @@ int nfa_get_exp_mode(void);
  *   "streams"       number of HIP streams ("lanes", 1..8, default 3) that runners created
  *                   afterwards spread consecutive nfa_runner_loglike_batch_dev calls over;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
+ *   "graph"         1 / 0: replay single-point calls as one captured hipGraph or not (default: on,
+ *                   off when the rocprofiler tool library is attached: capture crashed under it);
  *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid): bit
  *                   mask, 1 skip the Tb pass, 2 skip the hyperfine-line loop, 4 skip the rows,
  *                   8 skip the line set-up. */

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -47,6 +48,7 @@ struct Engine {
     int    ablate = 0;
     int    streams = 3;              // stream lanes of new runners
     int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
+    int    graph = -1;               // single-point graph replay: -1 = decide at first use, 0 off, 1 on
     bool   have_t0 = false;
     double *d_tabs = nullptr;                      // SM_END_TABLE doubles
     double t0_xmin = 0, t0_xmax = 0, t0_inv_dx = 0;
@@ -186,6 +188,7 @@ int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "occ") && value >= 0 && value <= 8) { g_eng.occ = value; return NFA_OK; }
+    if (key && !strcmp(key, "graph") && (value == 0 || value == 1)) { g_eng.graph = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }
@@ -707,7 +710,13 @@ int nfa_runner_synchronize(nfa_runner *r) {
 // One point through a captured graph; returns 1 when the call was served, 0 when the plain path
 // has to do it (first calls, table mode whose launch sets a function attribute, profiling on).
 static int single_point_graph(nfa_runner *r, double *U, double *lnL) {
-    if (r->profiling || g_eng.exp_mode == 0 || r->cap_B < 1 || r->cap_D[0] < 1 || r->n_single < 2) return 0;
+    if (g_eng.graph < 0) {
+        // Stream capture under the rocprofiler-sdk tool library (rocprofv3) has crashed the process
+        // here: with a profiler attached single points take the plain path unless asked otherwise.
+        const char *tool = getenv("ROCP_TOOL_LIBRARIES"), *pre = getenv("LD_PRELOAD");
+        g_eng.graph = ((tool && *tool) || (pre && strstr(pre, "rocprofiler"))) ? 0 : 1;
+    }
+    if (!g_eng.graph || r->profiling || g_eng.exp_mode == 0 || r->cap_B < 1 || r->cap_D[0] < 1 || r->n_single < 2) return 0;
     const int ndim = r->ndim;
     hipStream_t st = r->lanes[0];
     if (!r->h_pin && hipHostMalloc((void **)&r->h_pin, sizeof(double) * (ndim + 1)) != hipSuccess) return 0;
