@@ -713,8 +713,14 @@ static int single_point_graph(nfa_runner *r, double *U, double *lnL) {
     if (g_eng.graph < 0) {
         // Stream capture under the rocprofiler-sdk tool library (rocprofv3) has crashed the process
         // here: with a profiler attached single points take the plain path unless asked otherwise.
-        const char *tool = getenv("ROCP_TOOL_LIBRARIES"), *pre = getenv("LD_PRELOAD");
-        g_eng.graph = ((tool && *tool) || (pre && strstr(pre, "rocprofiler"))) ? 0 : 1;
+        bool profiled = false;
+        for (const char *name : {"ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB", "HSA_TOOLS_LIB"}) {
+            const char *v = getenv(name);
+            profiled = profiled || (v && *v);
+        }
+        const char *pre = getenv("LD_PRELOAD");
+        profiled = profiled || (pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer")));
+        g_eng.graph = profiled ? 0 : 1;
     }
     if (!g_eng.graph || r->profiling || g_eng.exp_mode == 0 || r->cap_B < 1 || r->cap_D[0] < 1 || r->n_single < 2) return 0;
     const int ndim = r->ndim;
