@@ -168,7 +168,6 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='rows per step (default: workload B)')
     ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'fast'),
                     choices=['table', 'poly', 'fast'])
-    ap.add_argument('--occ', type=int, default=0, help='engine A/B knob: cap waves per SIMD (0 = no cap)')
     ap.add_argument('--wpb', type=int, default=0, help='engine A/B knob: waves per workgroup (0 = default)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
     ap.add_argument('--ablate', type=int, default=0, help='timing experiment: 1 skip Tb, 2 skip lines, 3 both (INVALID results)')
@@ -201,8 +200,6 @@ def main():
     na.set_exp_mode(args.exp_mode)
     if args.wpb:
         _ffi.set_option('wpb', args.wpb)
-    if args.occ:
-        _ffi.set_option('occ', args.occ)
     if args.ablate:
         _ffi.set_option('ablate', args.ablate)
     if args.streams:

@@ -38,7 +38,8 @@ int nfa_set_device(int device);              /* one process per GPU: call first 
 int nfa_device_synchronize(void);
 int nfa_device_name(char *buf, int buflen);
 
-/* Numerical mode of the FastExp replacement (per process; default 2):
+/* Numerical mode of the FastExp replacement (process default, 2 unless set; a runner can pin
+ * its own with nfa_runner_set_exp_mode):
  *   0 = "table": the reference's three-table product held in LDS
  *       (nestfit/core/fastexp.c:234-283), bit-identical table indices;
  *   1 = "poly" : exp(-(double)(float)x) by fp64 range reduction + polynomial,
@@ -50,18 +51,18 @@ int nfa_device_name(char *buf, int buflen);
 int nfa_set_exp_mode(int mode);
 int nfa_get_exp_mode(void);
 /* Engine tuning knobs for A/B measurements (key, value):
- *   "wpb"           waves per workgroup of the likelihood kernel (1..16, default 4);
- *   "wpb_table"     the same in table mode (0 = chosen per spectra set, the default);
- *   "occ"           resident waves per SIMD the fast-mode likelihood kernel is capped to
- *                   (0 = no cap, default 7);
+ *   "wpb"           waves per workgroup of the likelihood kernel (1..16, default 4), and
+ *   "wpb_table"     the same in table mode (0 = chosen per spectra set, the default): both are
+ *                   taken over by runners created afterwards;
  *   "streams"       number of HIP streams ("lanes", 1..8, default 3) that runners created
  *                   afterwards spread consecutive nfa_runner_loglike_batch_dev calls over;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
  *   "graph"         1 / 0: replay single-point calls as one captured hipGraph or not (default: on,
  *                   off when the rocprofiler tool library is attached: capture crashed under it);
- *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid): bit
- *                   mask, 1 skip the Tb pass, 2 skip the hyperfine-line loop, 4 skip the rows,
- *                   8 skip the line set-up. */
+ *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid; the
+ *                   shipped library rejects the key): bit mask, 1 skip the Tb pass, 2 skip the
+ *                   hyperfine-line loop, 4 skip the rows, 8 skip the line set-up.
+ * Unknown keys and values out of range return NFA_ERR_ARG. */
 int nfa_set_option(const char *key, int value);
 
 /* 1/(e^x-1) interpolation table.  The reference builds T0_X, T0_Y with numpy at
@@ -157,6 +158,11 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors,
                       int ncomp, int cold, int lte);
 int nfa_runner_destroy(nfa_runner *r);
 int nfa_runner_ndim(const nfa_runner *r);
+/* Numerical mode of this runner: -1 (default) = whatever nfa_set_exp_mode says when a batch is
+ * launched; 0..2 = pinned, so that runners of different modes can work side by side (threads of a
+ * broker, a table-mode checker next to a fast-mode sampler). */
+int nfa_runner_set_exp_mode(nfa_runner *r, int mode);
+int nfa_runner_get_exp_mode(const nfa_runner *r);
 
 /* AmmoniaRunner.c_loglikelihood (ammonia.pyx:423-432) for B unit-cube rows of
  * pixel `pix[b]` (pix == NULL: pixel 0).  U[B][ndim] host memory, overwritten

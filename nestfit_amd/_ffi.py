@@ -63,6 +63,8 @@ SIGNATURES = {
                                     C.c_int, C.c_int]),
     'nfa_runner_destroy': (C.c_int, [C.c_void_p]),
     'nfa_runner_ndim': (C.c_int, [C.c_void_p]),
+    'nfa_runner_set_exp_mode': (C.c_int, [C.c_void_p, C.c_int]),
+    'nfa_runner_get_exp_mode': (C.c_int, [C.c_void_p]),
     'nfa_runner_loglike_batch': (C.c_int, [C.c_void_p, _ip, _dp, _dp, C.c_int64]),
     'nfa_runner_predict_batch': (C.c_int, [C.c_void_p, _ip, _dp, C.c_int64, _dp, _dp]),
     'nfa_runner_loglike_batch_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -15,9 +15,10 @@
 //   * inside a wave lanes are frequency channels: a row is 64 consecutive
 //     channels (coalesced 512-B loads of x, data, T0, tbg); the optical depth of
 //     the row lives in one register per lane;
-//   * the (component, hyperfine line) constants of the wave's spectrum are formed
-//     with lanes = lines, kept in the wave's LDS slice and broadcast-read in the
-//     row loop; a ballot over the line windows selects the lines that touch a row;
+//   * the (component, hyperfine line) constants are formed by the set-up stage with
+//     lanes = lines (lines_kernel) and reach the row loop through scalar loads: line
+//     constants are SGPR operands, the line's window is the EXEC mask; a ballot over
+//     the line windows selects the lines that touch a row;
 //   * chi^2 is reduced with DPP lane permutes; the per-spectrum terms of an item are
 //     added in spectrum order by lnl_sum_kernel (bitwise reproducible).
 // No MFMA: the path is elementwise fp64/fp32 plus reductions.
@@ -57,6 +58,7 @@ __constant__ int    c_nhf[NFA_T_ALL];
 __constant__ double c_nu[NFA_T_ALL];
 __constant__ double c_ea[NFA_N_LEVELS];
 __constant__ double c_voff[NFA_T_ALL][NFA_MAX_HF_N];
+__constant__ double c_hfreq[NFA_T_ALL][NFA_MAX_HF_N];       // (1 - voff / CKMS) * nu of every line
 __constant__ double c_tauw[NFA_T_ALL][NFA_MAX_HF_N];
 
 struct SpecDev {
@@ -67,6 +69,10 @@ struct SpecDev {
     double  nu_min[MAXSPEC], nu_chan[MAXSPEC];
     int64_t chan_tot;
     const double *xarr, *t0, *tbg, *data, *noise;
+    const double *t0tbg;                 // T0 * tbg per channel (fast mode: g = B0x x^2 + A0x x - T0 tbg)
+    const double *rowsq;                 // [n_pix][rows_tot]: sum of data^2 over each row of 64 channels
+    int     row_off[MAXSPEC];            // first row of spectrum s inside a pixel's rowsq slice
+    int64_t rows_tot;                    // sum over the spectra of ceil(size / 64)
     double  t0_xmin, t0_xmax, t0_inv_dx;
 };
 
@@ -81,16 +87,21 @@ struct SpecDev {
 //   kind 2  two adjacent cells:  second cell from T0 >= split       (m = q = 0)
 //   kind 3  outside the table:   Taylor of 1/expm1 about the band centre m (split = inf)
 //   kind 0  anything else:       per-channel evaluation of hyperfine.pyx:23-45
-#define DREC_CS 10
+// For kind 1 the record also holds the cell written in the frequency x of the channel
+// (T0 = kappa x, kappa = h/k): A0X = A0 kappa, B0X = B0 kappa^2, so that
+//      T0 (y - tbg) = B0X x^2 + A0X x - T0 tbg          (two fused multiply-adds per channel)
+#define DREC_CS 12
 #define DK_TMAIN 0
 #define DK_KIND  1
-#define DK_A0 2
-#define DK_B0 3
-#define DK_A1 4
-#define DK_B1 5
-#define DK_SPLIT 6
-#define DK_M 7
-#define DK_Q 8
+#define DK_A0X 2
+#define DK_B0X 3
+#define DK_A0 4
+#define DK_B0 5
+#define DK_A1 6
+#define DK_B1 7
+#define DK_SPLIT 8
+#define DK_M 9
+#define DK_Q 10
 __host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncomp + ncomp * nspec * DREC_CS; }
 
 struct LnlGeom {
@@ -259,7 +270,9 @@ struct LineConst { double nucen, idenom; int lo, hi; };
 __device__ __forceinline__ LineConst nf_line(int t, int i, double v_over_c, double s_over_c, double nu0,
                                              double nu_min, double nu_chan, int N) {
     LineConst r;
-    const double hf_freq   = (1.0 - c_voff[t][i] / NFA_CKMS) * nu0;
+    // hf_freq = (1 - voff_i / CKMS) nu0 (hyperfine.pyx:71) is a constant of the line: the host forms it
+    // with the same two IEEE operations at start-up (c_hfreq); the Gaussian model's line has voff = 0
+    const double hf_freq   = t == NFA_T_GAUSS ? nu0 : c_hfreq[t][i];
     const double hf_width  = s_over_c * hf_freq;             // (sigm / CKMS) * hf_freq
     const double hf_offset = v_over_c * hf_freq;             // (voff / CKMS) * hf_freq
     // the Gaussian model forms its centre as rest_freq * (1 - voff / CKMS) (gaussian.pyx:33)
@@ -291,13 +304,34 @@ __device__ __forceinline__ const double *stage_exp_tables(double *smem, const do
 }
 
 // ---------------------------------------------------------------------------
-//  lnl_kernel
+//  line records (hyperfine.pyx:68-91) of one (item, spectrum) unit, in the wave's LDS slice
 // ---------------------------------------------------------------------------
 struct __attribute__((aligned(16))) LineRec {
     double nucen, idenom;                        // first 16-B read
     union { double htau; float htau_f; };        // second 16-B read: weight and window
     int lo, len;                                 // window [lo, lo+len)
 };
+typedef const __attribute__((address_space(4))) double *k_dbl_p;     // constant address space: a
+                                                                     // uniform index gives an s_load
+
+// exp(-x), x = float in [0, 32): 2^yh * (1 + r) with yh = fl(-x log2 e) and r = -x - yh ln 2
+// carried in two fused steps (|r| < 4e-6, so e^r = 1 + r to 1e-11); <= 2e-7 relative.
+__device__ __forceinline__ float exp_neg_core_f32(float x) {
+    const float yh = x * -1.44269502162933349609375f;
+    float r = __builtin_fmaf(yh, -0.693147182464599609375f, -x);        // -x - yh ln2_hi (exact product)
+    r = __builtin_fmaf(yh, 1.904654299957e-09f, r);                     //    - yh ln2_lo
+    const float e0 = __builtin_amdgcn_exp2f(yh);
+    return __builtin_fmaf(e0, r, e0);
+}
+
+// lane masks straight from one compare (a ballot of a combined bool costs a select and a second compare)
+#define NF_ICMP_SGT 38
+#define NF_ICMP_SLT 40
+#define NF_FCMP_OLT 4
+#define NF_FCMP_UGE 11
+#define NF_FCMP_UNE 14
+__device__ __forceinline__ unsigned long long lanes_lt(int a, int b) { return __builtin_amdgcn_sicmp(a, b, NF_ICMP_SLT); }
+__device__ __forceinline__ unsigned long long lanes_gt(int a, int b) { return __builtin_amdgcn_sicmp(a, b, NF_ICMP_SGT); }
 
 // 1 - FastExp(tau) of the reference for fp32 tau (MODE 2):
 //   tau < 2^-5   the reference's cubic  tau (1 - tau/2 (1 - tau/3))   (fastexp.c:264-270)
@@ -307,12 +341,12 @@ struct __attribute__((aligned(16))) LineRec {
 // even returns exactly 0 below 1.1e-16, which decides the zero pattern of faint channels):
 // those lanes repeat that rounding in fp64, under a wave-uniform branch that is rarely taken.
 __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
-    const float r3 = __builtin_fmaf(t, -1.0f / 3.0f, 1.0f);
-    const float pc = __builtin_fmaf(t * r3, -0.5f, 1.0f);        // the reference's cubic (fastexp.c:264-270)
+    float pc = __builtin_fmaf(t, 1.0f / 6.0f, -0.5f);            // 1 - t/2 + t^2/6: the reference's cubic / t
+    pc = __builtin_fmaf(t, pc, 1.0f);
     float wf = t * pc;
     // Most rows lie in the line wings where every lane is below 2^-5 and the cubic is all there is;
     // the other two ranges are evaluated only when some lane of the wave needs them.
-    if (__builtin_amdgcn_ballot_w64(!(t < 0.03125f)) != 0ull) {
+    if (__builtin_amdgcn_fcmpf(t, 0.03125f, NF_FCMP_UGE) != 0ull) {
         asm volatile("" ::: "memory");
         float p = 1.0f / 5040.0f;                             // (1 - e^-t)/t = sum (-t)^k/(k+1)!
         p = __builtin_fmaf(p, t, -1.0f / 720.0f);
@@ -322,7 +356,7 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
         p = __builtin_fmaf(p, t, -0.5f);
         p = __builtin_fmaf(p, t, 1.0f);
         wf = (t < 0.03125f) ? wf : t * p;
-        if (__builtin_amdgcn_ballot_w64(!(t < 0.25f)) != 0ull) {
+        if (__builtin_amdgcn_fcmpf(t, 0.25f, NF_FCMP_UGE) != 0ull) {
             asm volatile("" ::: "memory");
             const float w_big = 1.0f - exp_neg_f32(t);
             wf = (t < 0.25f) ? wf : w_big;
@@ -330,7 +364,7 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
     }
     double w = (double)wf;
     const bool tiny = t < 1e-8f;
-    if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) {
+    if (__builtin_amdgcn_fcmpf(t, 1e-8f, NF_FCMP_OLT) != 0ull) {
         asm volatile("" ::: "memory");            // keep the rare path a branch (no if-conversion)
         const double r1 = 1.0 - (double)(t * pc);
         w = tiny ? 1.0 - r1 : w;
@@ -340,27 +374,63 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
 
 // ---------------------------------------------------------------------------
 //  lnl_kernel: one wavefront per (item, spectrum) unit, no coupling between waves.
-//  Every wave loads the item's record, forms the line constants of its spectrum in
-//  its own LDS slice, walks the rows and writes the spectrum's log-likelihood term;
-//  lnl_sum_kernel adds the terms of an item in spectrum order (ammonia.pyx:429-432).
-//  (A workgroup-per-item version with the partial sums meeting at a barrier lost
-//  ~20 % of the SIMD time to waves waiting for their slower siblings.)
+//  Lanes = channels of a row of 64; the optical depth of the row lives in one register per
+//  lane.  The wave forms the line constants of its spectrum with lanes = (component, line)
+//  into its LDS slice (32-byte records); in the row loop a ballot over the windows selects
+//  the lines touching the row, their records are broadcast-read (two ds_read_b128) and the
+//  window of the line is applied as the EXEC mask: lanes outside it are idle instead of
+//  multiplied by zero.  Per line x row: thirteen vector instructions -- the LDS address, two
+//  for the window test, three fp64 operations for the float-narrowed FastExp argument
+//  (math.pxd:17), the conversion, five fp32 operations for exp, one multiply-add -- and eight
+//  scalar ones (the scalar unit is shared by the four SIMDs of a CU: a scalar instruction
+//  costs the wave as much as an fp64 one, scripts/ubench_lineloop.hip).
+//  Rows without any line window (about 40 % at the metric shape) cost two compares per
+//  component: their chi^2 term is the precomputed sum of data^2 of the row (SpecDev.rowsq).
+//  NCOMP > 0: the number of components is a compile-time constant, the component loop is
+//  unrolled, line windows and the constants of the Tb pass live in registers; NCOMP == 0 is
+//  the general form (any ncomp up to MAXCOMP, windows re-read from LDS, constants through
+//  scalar loads).  lnl_sum_kernel adds the terms of an item in spectrum order
+//  (ammonia.pyx:429-432).
 // ---------------------------------------------------------------------------
+// the fast mode's line x row step as one instruction block: window test -> EXEC, float-narrowed
+// Gaussian argument, exp, tau += htau * e; EXEC is all ones on entry (every branch around it is
+// wave-uniform) and on exit
+__device__ __forceinline__ void line_step_fast(float &tau, int j, double xj, double nucen, double idenom,
+                                               float htau, int lo, int len) {
+    double d;
+    float t0, t1, t2;
+    asm volatile("v_sub_u32 %[t0], %[j], %[lo]\n\t"
+                 "v_cmpx_lt_u32 %[t0], %[len]\n\t"
+                 "v_add_f64 %[d], %[xj], -%[nucen]\n\t"
+                 "v_mul_f64 %[d], %[d], %[d]\n\t"
+                 "v_mul_f64 %[d], %[d], %[idenom]\n\t"
+                 "v_cvt_f32_f64 %[t0], %[d]\n\t"                       // math.pxd:17 narrowing
+                 "v_mul_f32 %[t1], 0xbfb8aa3b, %[t0]\n\t"               // yh = -x log2(e)
+                 "v_exp_f32 %[t2], %[t1]\n\t"
+                 "v_fma_f32 %[t0], %[t1], %[kln2], -%[t0]\n\t"          // r = -x - yh ln2_hi
+                 "v_fmac_f32 %[t0], 0x3102e308, %[t1]\n\t"              //       - yh ln2_lo
+                 "v_fmac_f32 %[t2], %[t2], %[t0]\n\t"                   // e = 2^yh (1 + r)
+                 "v_fmac_f32 %[tau], %[htau], %[t2]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [tau] "+v"(tau), [d] "=&v"(d), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                 : [j] "v"(j), [lo] "v"(lo), [len] "v"(len), [xj] "v"(xj), [nucen] "v"(nucen),
+                   [idenom] "v"(idenom), [htau] "v"(htau), [kln2] "s"(-0.693147182464599609375f)
+                 : "vcc");
+}
+
 // WIDE (fast mode only): the spectra set holds a transition with more than 26 lines (N2H+)
-template <int MODE, bool WRITE_SPEC, bool WIDE>
-__global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restrict__ pix,
-                                                  const double *__restrict__ D,
-                                                  double *__restrict__ part,
-                                                  double *__restrict__ spec_out, long B, LnlGeom G,
-                                                  const double *__restrict__ g_tabs) {
+template <int MODE, bool WRITE_SPEC, bool WIDE, int NCOMP>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))
+lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D, double *__restrict__ part,
+           double *__restrict__ spec_out, long B, LnlGeom G, const double *__restrict__ g_tabs) {
     typedef typename std::conditional<MODE == 2, float, double>::type tau_t;
+    constexpr int NC = NCOMP > 0 ? NCOMP : 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int n_shared = 0;
     const double *sm = smem;
     if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);   // fast: no tables
     const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
 
-    // wave-uniform values live in SGPRs: SpecDev fields come through scalar loads
 #ifdef NFA_ABLATE
     const int ablate = G.ablate;      // timing experiments (build with -DNFA_ABLATE)
 #else
@@ -368,11 +438,9 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
 #endif
     const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ncomp = S.ncomp, nspec = S.n_spec;
+    const int ncomp = NCOMP > 0 ? NCOMP : S.ncomp, nspec = S.n_spec;
     const int drec = drec_size(ncomp, nspec);
-    double *w_d = smem + n_shared + (size_t)wave * G.wave_doubles;
-    LineRec *w_line = (LineRec *)(w_d + ((drec + 1) & ~1));
-    int2 *w_win = (int2 *)(w_line + ncomp * G.nhf_max);       // 64 windows per component (padded)
+    LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)wave * G.wave_doubles);
 
     const long units = B * nspec;
     // one unit per wave; the grid covers them all.  Waves of a workgroup land on the SIMDs of a CU
@@ -380,20 +448,22 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
     // only ever see the spectrum with the most hyperfine lines.
     const int rot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 0x9E3779B1u) >> 28));
     const long unit = (long)blockIdx.x * waves + (wave + rot) % waves;
-    if (unit < units) {
-        const long b = unit / nspec;
-        const int s = (int)(unit - b * nspec);
-        const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
-        const int nhf = c_nhf[t];
-        const double nu0 = S.rest[s];
-        const double *xs = S.xarr + off, *t0s = S.t0 + off, *tbgs = S.tbg + off;
-        const long p_ix = pix ? (long)pix[b] : 0;
-        for (int k = lane; k < drec; k += 64) w_d[k] = D[b * drec + k];
-        wave_lds_sync();
-        // --- line constants + windows, lanes = (component, line) pairs (hyperfine.pyx:68-91)
-        for (int p = lane; p < ncomp * nhf && !(ablate & 8); p += 64) {
-            const int c = p / nhf, i = p - c * nhf;
-            const LineConst lc = nf_line(t, i, w_d[c * 4 + 2], w_d[c * 4 + 1], nu0, S.nu_min[s],
+    if (unit >= units) return;
+    const long b = unit / nspec;
+    const int s = (int)(unit - b * nspec);
+    const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
+    const int nhf = __builtin_amdgcn_readfirstlane(c_nhf[t]);
+    const long p_ix = pix ? (long)__builtin_amdgcn_readfirstlane(pix[b]) : 0;
+    const double nu0 = S.rest[s];
+    const double *xs = S.xarr + off;
+    const k_dbl_p Dk = (k_dbl_p)(D + b * drec);                    // the item's record: scalar loads
+    // --- line constants + windows, lanes = (component, line) pairs (hyperfine.pyx:68-91)
+    for (int p = lane; p < ncomp * G.nhf_max && !(ablate & 8); p += 64) {
+        const int c = p / G.nhf_max, i = p - c * G.nhf_max;
+        LineRec rec;
+        rec.nucen = 0.0; rec.idenom = 0.0; rec.htau = 0.0; rec.lo = 0; rec.len = 0;   // slots beyond the last line
+        if (i < nhf) {
+            const LineConst lc = nf_line(t, i, D[b * drec + c * 4 + 2], D[b * drec + c * 4 + 1], nu0, S.nu_min[s],
                                          S.nu_chan[s], N);
             int lo = lc.lo;
             const int hi = lc.hi;
@@ -405,126 +475,178 @@ __global__ void __launch_bounds__(1024) lnl_kernel(SpecDev S, const int *__restr
                 const float a = (float)(nu * nu * lc.idenom);
                 if (!(a < 32.0f)) lo += 1;
             }
-            LineRec rec;
             rec.nucen = lc.nucen;
             rec.idenom = lc.idenom;
-            const double htau = w_d[4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
+            const double htau = D[b * drec + 4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
             // fast mode keeps the weight as a float in the low word (no union store: that goes through scratch)
             rec.htau = MODE == 2 ? __longlong_as_double((long long)__float_as_uint((float)htau)) : htau;
             rec.lo = lo;
             rec.len = hi > lo ? hi - lo : 0;
-            w_line[c * G.nhf_max + i] = rec;
-            w_win[c * 64 + i] = make_int2(lo, hi > lo ? hi : lo);
         }
-        for (int q = lane; q < ncomp * 64; q += 64)
-            if ((q & 63) >= nhf) w_win[q] = make_int2(0, 0);      // lanes beyond the last line
-        wave_lds_sync();
-        // --- rows of 64 channels: tau profile, Tb, chi^2 (hyperfine.pyx:93-113, core.pyx:522-530)
-        const double *ds = S.data + p_ix * S.chan_tot + off;
-        double acc = 0.0;
-        for (int r0 = 0; r0 < N && !(ablate & 4); r0 += 64) {
-            const int j = r0 + lane;
+        w_line[p] = rec;
+    }
+    wave_lds_sync();
+    // windows [lo, hi) of the lines of each component, lane = line (an empty window is [0, 0):
+    // it fails `hi > r0` for every row), and the component's constants of the Tb pass
+    int wlo[NC], whi[NC];
+    double ck_kind[NC], ck_a0x[NC], ck_b0x[NC];
+    bool need_t0 = MODE != 2;      // T0 and tbg per channel: exact modes always; fast mode only where
+                                   // y(T0) is not the single table cell (kind != 1)
+    if (NCOMP > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const LineRec *q = w_line + c * G.nhf_max + (lane < G.nhf_max ? lane : 0);
+            const int lo = q->lo, len = q->len;
+            wlo[c] = lane < G.nhf_max ? lo : 0;
+            whi[c] = lane < G.nhf_max ? lo + len : 0;
+            if (ablate & 8) { wlo[c] = 0; whi[c] = 0; }
+            const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
+            ck_kind[c] = Dk[dko + DK_KIND]; ck_a0x[c] = Dk[dko + DK_A0X]; ck_b0x[c] = Dk[dko + DK_B0X];
+            if (MODE == 2 && S.model != NFA_MODEL_GAUSSIAN) need_t0 = need_t0 || ck_kind[c] != 1.0;
+        }
+    } else if (MODE == 2 && S.model != NFA_MODEL_GAUSSIAN) {
+        for (int c = 0; c < ncomp; ++c) need_t0 = need_t0 || Dk[4 * ncomp + (c * nspec + s) * DREC_CS + DK_KIND] != 1.0;
+    }
+    // --- rows of 64 channels: tau profile, Tb, chi^2 (hyperfine.pyx:93-113, core.pyx:522-530)
+    const double *t0s = S.t0 + off, *tbgs = S.tbg + off, *p3s = S.t0tbg + off;
+    const double *ds = S.data + p_ix * S.chan_tot + off;
+    const double *rsq = S.rowsq + p_ix * S.rows_tot + S.row_off[s];
+    double acc = 0.0;
+    unsigned long long empt = 0ull;                              // signal-free rows of this block of 64 rows
+    int row = 0;
+    for (int r0 = 0; r0 < N && !(ablate & 4); r0 += 64, ++row) {
+        const int j = r0 + lane;
+        // lines of each component that touch this row
+        unsigned long long hitm[NC];
+        bool any = false;
+        if (NCOMP > 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                hitm[c] = lanes_lt(wlo[c], r0 + 64) & lanes_gt(whi[c], r0);
+                any = any || hitm[c] != 0ull;
+            }
+        } else {
+            for (int c = 0; c < ncomp && !any; ++c) {
+                const LineRec *q = w_line + c * G.nhf_max + (lane < G.nhf_max ? lane : 0);
+                const int lo = q->lo, hi = lo + q->len;
+                any = __builtin_amdgcn_ballot_w64((lane < G.nhf_max) & (lo < r0 + 64) & (hi > r0) & (hi > lo)) != 0ull;
+            }
+        }
+        if (any || WRITE_SPEC) {
             const bool valid = j < N;
-            const int jj = valid ? j : N - 1;
-            const double xj = xs[jj], dj = ds[jj], T0 = t0s[jj], tbg = tbgs[jj];
+            const unsigned jo = (unsigned)(valid ? j : N - 1) * 8u;           // byte offset of the lane's channel
+            const double xj = *(const double *)((const char *)xs + jo);
+            const double dj = *(const double *)((const char *)ds + jo);
+            double p3 = 0.0, x2 = 0.0, T0 = 0.0, tbg = 0.0;
+            if (MODE == 2) { p3 = *(const double *)((const char *)p3s + jo); x2 = xj * xj; }
+            if (need_t0) { T0 = *(const double *)((const char *)t0s + jo); tbg = *(const double *)((const char *)tbgs + jo); }
             double pred = 0.0;
-            for (int c = 0; c < ncomp; ++c) {
-                const LineRec *lines = w_line + c * G.nhf_max;
-                const double *dk = w_d + 4 * ncomp + (c * nspec + s) * DREC_CS;
-                const double dk_kind = dk[DK_KIND], dk_a0 = dk[DK_A0], dk_b0 = dk[DK_B0];
-                const int2 win = w_win[c * 64 + lane];
-                const bool hit = (win.x < r0 + 64) & (win.y > r0) & (win.y > win.x);
-                unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                if (mask == 0ull) continue;
+            // one component: the lines in `mask` add their optical depths, then the Tb pass
+            auto component = [&](int c, unsigned long long mask, double kind, double a0x, double b0x) {
+                const LineRec *lrec = w_line + c * G.nhf_max;
                 tau_t tau = 0;
+                double td = 0.0;                                      // WIDE: fp64 running sum
+                auto line = [&](int i) {
+                    const char *q = (const char *)lrec + (i << 5);
+                    const double2 ab = *(const double2 *)q;           // nucen, idenom
+                    const int4 hw = *(const int4 *)(q + 16);          // htau (8 bytes), lo, len
+                    if constexpr (MODE == 2 && !WIDE) {
+                        line_step_fast(tau, j, xj, ab.x, ab.y, __int_as_float(hw.x), hw.z, hw.w);
+                    } else if ((unsigned)(j - hw.z) < (unsigned)hw.w) {           // the window is the EXEC mask
+                        asm volatile("" ::: "memory");                // keep it a branch (no if-conversion)
+                        const double nu = xj - ab.x;
+                        const double tau_exp = nu * nu * ab.y;
+                        if constexpr (MODE == 2) {
+                            const float e = exp_neg_core_f32((float)tau_exp);          // math.pxd:17 narrowing
+                            td = __builtin_fma((double)__int_as_float(hw.x), (double)e, td);
+                        } else {
+                            const double e = nf_fastexp<MODE>(tau_exp, sm);
+                            tau = __builtin_fma(__hiloint2double(hw.y, hw.x), e, (double)tau);
+                        }
+                    }
+                };
                 if (ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); }
-                else if (MODE == 2 && WIDE) {
-                    // N2H+ 2-1 / 3-2 stack up to 45 overlapping lines: a float running sum could
-                    // drift past the 1e-6 bar, so the sum (only the sum) is kept in fp64
-                    double td = 0.0;
-                    while (mask) {
-                        const int i = __builtin_ctzll(mask);
-                        mask &= mask - 1;
-                        const LineRec rec = lines[i];
-                        const double nu = xj - rec.nucen;
-                        const float x = (float)(nu * nu * rec.idenom);
-                        const float NEG_L2E_HI = -1.44269502162933349609375f;
-                        const float NEG_L2E_LO = -1.925963033500011e-08f;
-                        const float yh = x * NEG_L2E_HI;
-                        float yl = __builtin_fmaf(x, NEG_L2E_HI, -yh);
-                        yl = __builtin_fmaf(x, NEG_L2E_LO, yl);
-                        float e = __builtin_amdgcn_exp2f(yh);
-                        e = __builtin_fmaf(e * 0.693147180559945f, yl, e);
-                        const bool inwin = (unsigned)(j - rec.lo) < (unsigned)rec.len;
-                        const float h = inwin ? rec.htau_f : 0.0f;
-                        td = __builtin_fma((double)h, (double)e, td);
-                    }
-                    tau = (tau_t)td;
+                else if (nhf <= 32) {                                 // every NH3 transition: 32-bit mask arithmetic
+                    unsigned m = (unsigned)mask;
+                    do { const int i = __builtin_ctz(m); m &= m - 1; line(i); } while (m);
                 } else {
-                while (mask) {
-                    const int i = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const LineRec rec = lines[i];                     // two 16-byte broadcast reads
-                    const double nu = xj - rec.nucen;
-                    const double tau_exp = nu * nu * rec.idenom;
-                    const bool inwin = (unsigned)(j - rec.lo) < (unsigned)rec.len;
-                    if (MODE == 2) {
-                        const float x = (float)tau_exp;               // math.pxd:17 narrowing
-                        const float NEG_L2E_HI = -1.44269502162933349609375f;
-                        const float NEG_L2E_LO = -1.925963033500011e-08f;
-                        const float yh = x * NEG_L2E_HI;
-                        float yl = __builtin_fmaf(x, NEG_L2E_HI, -yh);
-                        yl = __builtin_fmaf(x, NEG_L2E_LO, yl);
-                        float e = __builtin_amdgcn_exp2f(yh);
-                        e = __builtin_fmaf(e * 0.693147180559945f, yl, e);
-                        // predicate the weight, not the arithmetic: straight-line code
-                        const float h = inwin ? rec.htau_f : 0.0f;
-                        tau = __builtin_fmaf(h, e, (float)tau);
-                    } else {
-                        const double e = nf_fastexp<MODE>(tau_exp, sm);
-                        tau = inwin ? __builtin_fma(rec.htau, e, (double)tau) : tau;
-                    }
+                    do { const int i = __builtin_ctzll(mask); mask &= mask - 1; line(i); } while (mask);
                 }
-                }
-                const bool live = valid && !(tau == 0);               // hyperfine.pyx:104-105
-                if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;
-                double tb;
+                if (MODE == 2 && WIDE) tau = (tau_t)td;
+                // hyperfine.pyx:104-105: channels with tau == 0 are skipped (lanes beyond the last channel
+                // are in no window: tau == 0 there too)
+                const unsigned long long livem = MODE == 2 ? __builtin_amdgcn_fcmpf((float)tau, 0.0f, NF_FCMP_UNE)
+                                                           : __builtin_amdgcn_fcmp((double)tau, 0.0, NF_FCMP_UNE);
+                if (livem == 0ull) return;
                 if ((ablate & 1) || S.model == NFA_MODEL_GAUSSIAN) {      // gaussian.pyx:50: pred += peak * e
                     pred += (double)tau;                              // tau == 0 adds nothing
-                    continue;
+                    return;
                 }
-                if (MODE == 2 && dk_kind != 0.0) {
-                    double y;
-                    if (dk_kind == 1.0) {                             // one table cell over the band (usual)
-                        y = __builtin_fma(dk_b0, T0, dk_a0);
+                const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
+                if (MODE == 2) {
+                    // lanes with tau == 0 (the reference skips them, hyperfine.pyx:104-105) get g * 0:
+                    // adding it changes nothing, so the sum needs no per-lane select
+                    double g;                                         // T0 (y(T0) - tbg)
+                    if (kind == 1.0) {                                // one table cell over the band (usual):
+                        // y = A0 + B0 T0 and T0 = kappa x:  g = B0x x^2 + A0x x - T0 tbg
+                        g = __builtin_fma(b0x, x2, __builtin_fma(a0x, xj, -p3));
+                    } else if (kind != 0.0) {
+                        const bool up = !(T0 < Dk[dko + DK_SPLIT]);
+                        const double dT = T0 - Dk[dko + DK_M];
+                        const double ya = up ? Dk[dko + DK_A1] : Dk[dko + DK_A0];
+                        const double yb = up ? Dk[dko + DK_B1] : Dk[dko + DK_B0];
+                        const double y = __builtin_fma(__builtin_fma(Dk[dko + DK_Q], dT, yb), dT, ya);
+                        g = T0 * (y - tbg);
                     } else {
-                        const bool up = !(T0 < dk[DK_SPLIT]);
-                        const double dT = T0 - dk[DK_M];
-                        const double ya = up ? dk[DK_A1] : dk_a0;
-                        const double yb = up ? dk[DK_B1] : dk_b0;
-                        y = __builtin_fma(__builtin_fma(dk[DK_Q], dT, yb), dT, ya);
+                        const double y = nf_iemtex(T0 / Dk[c * 4], g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
+                        g = T0 * (y - tbg);
                     }
-                    tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
+                    pred = __builtin_fma(g, one_minus_fastexp_f32((float)tau), pred);
                 } else {
-                    const double y = nf_iemtex(T0 / w_d[c * 4], g_t0x, g_t0y, S.t0_xmin, S.t0_xmax,
-                                               S.t0_inv_dx);
-                    if (MODE == 2) tb = (T0 * (y - tbg)) * one_minus_fastexp_f32((float)tau);
-                    else tb = (T0 * (y - tbg)) * (1.0 - nf_fastexp<MODE>((double)tau, sm));
+                    const double y = nf_iemtex(T0 / Dk[c * 4], g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
+                    // the reference's order: pred[i] += T0 * (y - tbg) * (1 - FastExp(tau)), only where tau != 0
+                    const double tb = (T0 * (y - tbg)) * (1.0 - nf_fastexp<MODE>((double)tau, sm));
+                    pred += !(tau == 0) ? tb : 0.0;
                 }
-                // lanes with tau == 0 (the reference skips them, hyperfine.pyx:104-105) get tb = x * 0:
-                // adding it changes nothing, so the sum needs no per-lane select
-                pred += tb;
+            };
+            if (NCOMP > 0) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (hitm[c] != 0ull) component(c, hitm[c], ck_kind[c], ck_a0x[c], ck_b0x[c]);
+            } else {
+                for (int c = 0; c < ncomp; ++c) {
+                    const LineRec *q = w_line + c * G.nhf_max + (lane < G.nhf_max ? lane : 0);
+                    const int lo = q->lo, hi = lo + q->len;
+                    const unsigned long long mask =
+                        __builtin_amdgcn_ballot_w64((lane < G.nhf_max) & (lo < r0 + 64) & (hi > r0) & (hi > lo));
+                    if (mask == 0ull) continue;
+                    const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
+                    component(c, mask, Dk[dko + DK_KIND], Dk[dko + DK_A0X], Dk[dko + DK_B0X]);
+                }
             }
             if (WRITE_SPEC) { if (valid) spec_out[b * S.chan_tot + off + j] = pred; }
-            const double dev = dj - pred;
-            if (valid) acc = __builtin_fma(dev, dev, acc);
+            if (any) {
+                const double dev = dj - pred;
+                if (r0 + 64 <= N) acc = __builtin_fma(dev, dev, acc);      // full row: no lane select
+                else if (valid) acc = __builtin_fma(dev, dev, acc);
+            }
         }
-        acc = wave_sum(acc);
-        if (lane == 0 && part) {
-            const double noise = S.noise[p_ix * nspec + s];
-            part[unit] = -acc / (2 * (noise * noise));                // core.pyx:530
+        if (!any) empt |= 1ull << (row & 63);
+        if ((row & 63) == 63 || r0 + 64 >= N) {
+            // chi^2 of the signal-free rows of this block: their precomputed sums of data^2
+            if (empt) {
+                const int rr = (row & ~63) + lane;
+                const bool mine = (empt >> lane) & 1ull;
+                const double q = rsq[mine ? rr : 0];
+                acc += mine ? q : 0.0;
+            }
+            empt = 0ull;
         }
-        wave_lds_sync();
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && part) {
+        const double noise = S.noise[p_ix * nspec + s];
+        part[unit] = -acc / (2 * (noise * noise));                // core.pyx:530
     }
 }
 
@@ -543,12 +665,31 @@ __global__ void lnl_sum_kernel(const double *__restrict__ part, double *__restri
 //  set-up kernels
 // ---------------------------------------------------------------------------
 __global__ void prep_kernel(const double *__restrict__ x, double *__restrict__ t0,
-                            double *__restrict__ tbg, long n) {
+                            double *__restrict__ tbg, double *__restrict__ t0tbg, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double T0 = NFA_H * x[i] / NFA_KB;                  // hyperfine.pyx:106
     t0[i] = T0;
-    tbg[i] = 1.0 / expm1(T0 / NFA_TCMB);                      // ammonia.pyx:274-277
+    const double bg = 1.0 / expm1(T0 / NFA_TCMB);             // ammonia.pyx:274-277
+    tbg[i] = bg;
+    t0tbg[i] = T0 * bg;
+}
+
+// rowsq[pix][row_off[s] + r] = sum over the channels of row r of spectrum s of data^2: the chi^2
+// term of a row without any line window (pred == 0 there, core.pyx:522-530).  One wave per row.
+__global__ void rowsq_kernel(SpecDev S, long pix0, long n_pix, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long w = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= n_pix * S.rows_tot) return;
+    const long p = pix0 + w / S.rows_tot;
+    const int rr = (int)(w % S.rows_tot);
+    int s = 0;
+    while (s + 1 < S.n_spec && rr >= S.row_off[s + 1]) ++s;
+    const int j = (rr - S.row_off[s]) * 64 + lane;
+    double v = 0.0;
+    if (j < S.size[s]) { const double d = S.data[p * S.chan_tot + S.off[s] + j]; v = d * d; }
+    v = wave_sum(v);
+    if (lane == 0) out[p * S.rows_tot + rr] = v;
 }
 
 // null_lnZ[pix][spec] = -sum(data^2)/(2 noise^2): Spectrum.c_loglikelihood with

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -44,7 +45,6 @@ struct Engine {
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
     int    wpb = 4;                  // waves per workgroup of the likelihood kernel
     int    wpb_table = 0;            // the same in table mode; 0 = chosen per spectra set (launch_lnl_t)
-    int    occ = 7;                  // fast mode: resident waves per SIMD, capped through LDS padding (0 = no cap)
     int    ablate = 0;
     int    streams = 3;              // stream lanes of new runners
     int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
@@ -55,7 +55,22 @@ struct Engine {
 };
 static Engine g_eng;
 
+static int engine_init_once();
+// HIP's current device is per host thread (default 0): every public entry point that allocates or
+// launches binds the calling thread to the engine's device first (broker threads, sampler threads
+// of a host application, MultiNest's own thread).
 static int engine_init() {
+    if (!g_eng.init) { int rc = engine_init_once(); if (rc) return rc; }
+    static thread_local int bound = -1;
+    if (bound != g_eng.device) {
+        HIP_TRY(hipSetDevice(g_eng.device));
+        bound = g_eng.device;
+    }
+    return NFA_OK;
+}
+static int engine_init_once() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (g_eng.init) return NFA_OK;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -79,6 +94,14 @@ static int engine_init() {
             memcpy(h_voff[g], nfa_n2hp_voff[t], sizeof(h_voff[g])); memcpy(h_tauw[g], nfa_n2hp_tau_wts[t], sizeof(h_tauw[g]));
         }
         h_nhf[NFA_T_GAUSS] = 1; h_nu[NFA_T_GAUSS] = 0.0; h_tauw[NFA_T_GAUSS][0] = 1.0;
+        static double h_hfreq[NFA_T_ALL][NFA_MAX_HF_N];
+        for (int t = 0; t < NFA_T_ALL; ++t)
+            for (int i = 0; i < NFA_MAX_HF_N; ++i) {
+                volatile double q = h_voff[t][i] / NFA_CKMS;      // hyperfine.pyx:71, one rounding per operation
+                volatile double f = 1.0 - q;
+                h_hfreq[t][i] = f * h_nu[t];
+            }
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hfreq), h_hfreq, sizeof(h_hfreq)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_nhf), h_nhf, sizeof(h_nhf)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_nu), h_nu, sizeof(h_nu)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_ea), nfa_ea, sizeof(nfa_ea)));
@@ -108,6 +131,7 @@ struct nfa_specset {
     int64_t n_pix = 0;
     int     nhf_max = 0;
     double *d_xarr = nullptr, *d_t0 = nullptr, *d_tbg = nullptr, *d_data = nullptr, *d_noise = nullptr;
+    double *d_t0tbg = nullptr, *d_rowsq = nullptr;
 };
 
 struct nfa_priors {
@@ -121,6 +145,10 @@ struct nfa_runner {
     nfa_specset *ss = nullptr;
     nfa_priors  *pr = nullptr;
     int ncomp = 1, cold = 0, lte = 0, ndim = 6;
+    // numerical mode: -1 = the process default at call time (nfa_set_exp_mode), 0..2 = pinned to
+    // this runner (nfa_runner_set_exp_mode): runners of different modes may then work side by side
+    int exp_mode = -1;
+    int wpb = 4, wpb_table = 0;      // launch geometry, taken from the process options at creation
     // Stream lanes: consecutive batches go to different HIP streams (round robin), so the
     // tail of one batch (few workgroups left, SIMDs draining) overlaps the start of the
     // next; inside a lane the set-up kernel and the likelihood kernel run in order and own
@@ -187,14 +215,15 @@ int nfa_set_exp_mode(int mode) {
 int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
-    if (key && !strcmp(key, "occ") && value >= 0 && value <= 8) { g_eng.occ = value; return NFA_OK; }
     if (key && !strcmp(key, "graph") && (value == 0 || value == 1)) { g_eng.graph = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }
+#ifdef NFA_ABLATE
     if (key && !strcmp(key, "ablate") && value >= 0 && value <= 15) { g_eng.ablate = value; return NFA_OK; }
+#endif
     if (key && !strcmp(key, "streams") && value >= 1 && value <= NFA_MAX_LANES) { g_eng.streams = value; return NFA_OK; }
-    return fail(NFA_ERR_ARG, "unknown option");
+    return fail(NFA_ERR_ARG, "unknown option, or value out of range");
 }
 
 int nfa_set_iemtex_table(const double *t0_x, const double *t0_y, int64_t n) {
@@ -217,6 +246,82 @@ int nfa_specset_create(nfa_specset **out, int n_spec, const int64_t *sizes,
                                     data, noise);
 }
 
+// sums of data^2 per row of 64 channels (chi^2 of the rows without a line window) of pixels
+// [pix0, pix0 + n)
+static int launch_rowsq(nfa_specset *ss, int64_t pix0, int64_t n) {
+    const int64_t waves = n * ss->dev.rows_tot;
+    hipLaunchKernelGGL(rowsq_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, 0, ss->dev,
+                       (long)pix0, (long)n, ss->d_rowsq);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return NFA_OK;
+}
+
+static int specset_fill(nfa_specset *ss, int model, int n_spec, const int64_t *sizes, const int32_t *trans_ids,
+                        const double *rest_freqs, const double *const *xarr, int64_t n_pix, const double *data,
+                        const double *noise) {
+    SpecDev &d = ss->dev;
+    d.n_spec = n_spec;
+    d.model = model;
+    d.npar = model == NFA_MODEL_DIAZENYLIUM ? NFA_N2HP_PARAMS : model == NFA_MODEL_GAUSSIAN ? NFA_GAUSS_PARAMS
+                                                                                          : NFA_N_PARAMS;
+    int64_t tot = 0, rows = 0;
+    for (int s = 0; s < n_spec; ++s) {
+        if (sizes[s] < 2 || sizes[s] > (1 << 24)) return fail(NFA_ERR_ARG, "spectrum size out of range");
+        int tglob;                                                      // index into the device tables
+        if (model == NFA_MODEL_AMMONIA) {
+            if (trans_ids[s] < 1 || trans_ids[s] > NFA_N_LEVELS)        // ammonia.pyx:268
+                return fail(NFA_ERR_ARG, "trans_id must be in 1..9");
+            tglob = trans_ids[s] - 1;
+            d.rest[s] = nfa_nu[tglob];
+            ss->nhf_max = std::max(ss->nhf_max, nfa_nhf[tglob]);
+        } else if (model == NFA_MODEL_DIAZENYLIUM) {
+            if (trans_ids[s] < 1 || trans_ids[s] > NFA_N2HP_LEVELS)     // diazenylium.pyx:128
+                return fail(NFA_ERR_ARG, "trans_id must be in 1..3");
+            tglob = NFA_T_N2HP + trans_ids[s] - 1;
+            d.rest[s] = nfa_n2hp_nu[trans_ids[s] - 1];
+            ss->nhf_max = std::max(ss->nhf_max, nfa_n2hp_nhf[trans_ids[s] - 1]);
+        } else {
+            tglob = NFA_T_GAUSS;
+            d.rest[s] = rest_freqs ? rest_freqs[s] : 0.0;               // core.pyx:510
+            ss->nhf_max = std::max(ss->nhf_max, 1);
+        }
+        const double nu_chan = xarr[s][1] - xarr[s][0];
+        if (!(nu_chan > 0)) return fail(NFA_ERR_ARG, "frequency axis must be ascending");   // core.pyx:503-504
+        d.size[s] = (int)sizes[s];
+        d.trans[s] = tglob + 1;
+        d.off[s] = (int)tot;
+        d.row_off[s] = (int)rows;
+        d.nu_min[s] = xarr[s][0];
+        d.nu_chan[s] = nu_chan;
+        tot += sizes[s];
+        rows += (sizes[s] + 63) / 64;
+    }
+    for (int64_t i = 0; i < n_pix * n_spec; ++i)
+        if (!(noise[i] > 0)) return fail(NFA_ERR_ARG, "noise must be > 0");                 // core.pyx:502
+    d.chan_tot = tot;
+    d.rows_tot = rows;
+    ss->n_pix = n_pix;
+    std::vector<double> xcat(tot);
+    for (int s = 0; s < n_spec; ++s) memcpy(xcat.data() + d.off[s], xarr[s], sizeof(double) * sizes[s]);
+    HIP_TRY(hipMalloc(&ss->d_xarr, sizeof(double) * tot));
+    HIP_TRY(hipMalloc(&ss->d_t0, sizeof(double) * tot));
+    HIP_TRY(hipMalloc(&ss->d_tbg, sizeof(double) * tot));
+    HIP_TRY(hipMalloc(&ss->d_t0tbg, sizeof(double) * tot));
+    HIP_TRY(hipMalloc(&ss->d_data, sizeof(double) * tot * n_pix));
+    HIP_TRY(hipMalloc(&ss->d_noise, sizeof(double) * n_spec * n_pix));
+    HIP_TRY(hipMalloc(&ss->d_rowsq, sizeof(double) * rows * n_pix));
+    HIP_TRY(hipMemcpy(ss->d_xarr, xcat.data(), sizeof(double) * tot, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ss->d_data, data, sizeof(double) * tot * n_pix, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ss->d_noise, noise, sizeof(double) * n_spec * n_pix, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0,
+                       ss->d_xarr, ss->d_t0, ss->d_tbg, ss->d_t0tbg, (long)tot);
+    HIP_TRY(hipGetLastError());
+    d.xarr = ss->d_xarr; d.t0 = ss->d_t0; d.tbg = ss->d_tbg; d.data = ss->d_data; d.noise = ss->d_noise;
+    d.t0tbg = ss->d_t0tbg; d.rowsq = ss->d_rowsq;
+    return launch_rowsq(ss, 0, n_pix);
+}
+
 int nfa_specset_create_model(nfa_specset **out, int model, int n_spec, const int64_t *sizes,
                              const int32_t *trans_ids, const double *rest_freqs,
                              const double *const *xarr, int64_t n_pix, const double *data,
@@ -230,64 +335,8 @@ int nfa_specset_create_model(nfa_specset **out, int model, int n_spec, const int
     if (n_pix < 1) return fail(NFA_ERR_ARG, "n_pix must be >= 1");
     int rc = engine_init(); if (rc) return rc;
     nfa_specset *ss = new nfa_specset();
-    SpecDev &d = ss->dev;
-    d.n_spec = n_spec;
-    d.model = model;
-    d.npar = model == NFA_MODEL_DIAZENYLIUM ? NFA_N2HP_PARAMS : model == NFA_MODEL_GAUSSIAN ? NFA_GAUSS_PARAMS
-                                                                                          : NFA_N_PARAMS;
-    int64_t tot = 0;
-    for (int s = 0; s < n_spec; ++s) {
-        if (sizes[s] < 2 || sizes[s] > (1 << 24)) { delete ss; return fail(NFA_ERR_ARG, "spectrum size out of range"); }
-        int tglob;                                                      // index into the device tables
-        if (model == NFA_MODEL_AMMONIA) {
-            if (trans_ids[s] < 1 || trans_ids[s] > NFA_N_LEVELS) {      // ammonia.pyx:268
-                delete ss; return fail(NFA_ERR_ARG, "trans_id must be in 1..9");
-            }
-            tglob = trans_ids[s] - 1;
-            d.rest[s] = nfa_nu[tglob];
-            ss->nhf_max = std::max(ss->nhf_max, nfa_nhf[tglob]);
-        } else if (model == NFA_MODEL_DIAZENYLIUM) {
-            if (trans_ids[s] < 1 || trans_ids[s] > NFA_N2HP_LEVELS) {   // diazenylium.pyx:128
-                delete ss; return fail(NFA_ERR_ARG, "trans_id must be in 1..3");
-            }
-            tglob = NFA_T_N2HP + trans_ids[s] - 1;
-            d.rest[s] = nfa_n2hp_nu[trans_ids[s] - 1];
-            ss->nhf_max = std::max(ss->nhf_max, nfa_n2hp_nhf[trans_ids[s] - 1]);
-        } else {
-            tglob = NFA_T_GAUSS;
-            d.rest[s] = rest_freqs ? rest_freqs[s] : 0.0;               // core.pyx:510
-            ss->nhf_max = std::max(ss->nhf_max, 1);
-        }
-        const double nu_chan = xarr[s][1] - xarr[s][0];
-        if (!(nu_chan > 0)) {                                           // core.pyx:503-504
-            delete ss; return fail(NFA_ERR_ARG, "frequency axis must be ascending");
-        }
-        d.size[s] = (int)sizes[s];
-        d.trans[s] = tglob + 1;
-        d.off[s] = (int)tot;
-        d.nu_min[s] = xarr[s][0];
-        d.nu_chan[s] = nu_chan;
-        tot += sizes[s];
-    }
-    for (int64_t i = 0; i < n_pix * n_spec; ++i)
-        if (!(noise[i] > 0)) { delete ss; return fail(NFA_ERR_ARG, "noise must be > 0"); }   // core.pyx:502
-    d.chan_tot = tot;
-    ss->n_pix = n_pix;
-    std::vector<double> xcat(tot);
-    for (int s = 0; s < n_spec; ++s) memcpy(xcat.data() + d.off[s], xarr[s], sizeof(double) * sizes[s]);
-    HIP_TRY(hipMalloc(&ss->d_xarr, sizeof(double) * tot));
-    HIP_TRY(hipMalloc(&ss->d_t0, sizeof(double) * tot));
-    HIP_TRY(hipMalloc(&ss->d_tbg, sizeof(double) * tot));
-    HIP_TRY(hipMalloc(&ss->d_data, sizeof(double) * tot * n_pix));
-    HIP_TRY(hipMalloc(&ss->d_noise, sizeof(double) * n_spec * n_pix));
-    HIP_TRY(hipMemcpy(ss->d_xarr, xcat.data(), sizeof(double) * tot, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ss->d_data, data, sizeof(double) * tot * n_pix, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ss->d_noise, noise, sizeof(double) * n_spec * n_pix, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0,
-                       ss->d_xarr, ss->d_t0, ss->d_tbg, (long)tot);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    d.xarr = ss->d_xarr; d.t0 = ss->d_t0; d.tbg = ss->d_tbg; d.data = ss->d_data; d.noise = ss->d_noise;
+    rc = specset_fill(ss, model, n_spec, sizes, trans_ids, rest_freqs, xarr, n_pix, data, noise);
+    if (rc) { nfa_specset_destroy(ss); return rc; }          // frees whatever was allocated
     *out = ss;
     return NFA_OK;
 }
@@ -295,15 +344,17 @@ int nfa_specset_create_model(nfa_specset **out, int model, int n_spec, const int
 int nfa_specset_destroy(nfa_specset *ss) {
     if (!ss) return NFA_OK;
     (void)hipFree(ss->d_xarr); (void)hipFree(ss->d_t0); (void)hipFree(ss->d_tbg); (void)hipFree(ss->d_data); (void)hipFree(ss->d_noise);
+    (void)hipFree(ss->d_t0tbg); (void)hipFree(ss->d_rowsq);
     delete ss;
     return NFA_OK;
 }
 
 int nfa_specset_set_data(nfa_specset *ss, int64_t pix, const double *data) {
     if (!ss || !data || pix < 0 || pix >= ss->n_pix) return fail(NFA_ERR_ARG, "bad pixel index");
+    int rc = engine_init(); if (rc) return rc;
     HIP_TRY(hipMemcpy(ss->d_data + pix * ss->dev.chan_tot, data, sizeof(double) * ss->dev.chan_tot,
                       hipMemcpyHostToDevice));
-    return NFA_OK;
+    return launch_rowsq(ss, pix, 1);
 }
 
 int nfa_specset_null_lnz(const nfa_specset *ss, double *out) {
@@ -328,35 +379,33 @@ int nfa_specset_tbg(const nfa_specset *ss, double *out) {
 int64_t nfa_specset_chan_tot(const nfa_specset *ss) { return ss ? ss->dev.chan_tot : 0; }
 
 // ---- priors ----------------------------------------------------------------
-int nfa_priors_create(nfa_priors **out, const nfa_prior_desc *priors, int n_prior,
-                      const nfa_dist_desc *dists, int n_dist, int n_param) {
-    if (!out || !priors || n_prior < 1 || n_prior > MAXPRIOR || n_dist < 0 || n_dist > MAXDIST)
-        return fail(NFA_ERR_ARG, "prior program out of range (<=16 priors, <=16 distributions)");
-    int rc = engine_init(); if (rc) return rc;
-    nfa_priors *p = new nfa_priors();
+static int priors_fill(nfa_priors *p, const nfa_prior_desc *priors, int n_prior, const nfa_dist_desc *dists,
+                       int n_dist, int n_param) {
     PriorProg &g = p->prog;
     g.n_prior = n_prior; g.n_dist = n_dist; g.n_param = n_param; g.max_size = 2;
     for (int k = 0; k < n_prior; ++k) {
         g.pr[k] = priors[k];
         const int dd[3] = {priors[k].dist0, priors[k].dist1, priors[k].dist2};
         for (int q = 0; q < 3; ++q)
-            if (dd[q] >= n_dist) { delete p; return fail(NFA_ERR_ARG, "distribution index out of range"); }
-        if (priors[k].p_ix < 0) { delete p; return fail(NFA_ERR_ARG, "p_ix must be >= 0"); }   // core.pyx:186
+            if (dd[q] >= n_dist) return fail(NFA_ERR_ARG, "distribution index out of range");
+        if (priors[k].p_ix < 0) return fail(NFA_ERR_ARG, "p_ix must be >= 0");   // core.pyx:186
     }
+    auto upload = [&](const double *src, int64_t n, const double **dst) -> int {
+        double *dp = nullptr;
+        HIP_TRY(hipMalloc(&dp, sizeof(double) * n));
+        p->d_arrays.push_back(dp);                 // owned from here on: nfa_priors_destroy frees it
+        HIP_TRY(hipMemcpy(dp, src, sizeof(double) * n, hipMemcpyHostToDevice));
+        *dst = dp;
+        return NFA_OK;
+    };
     for (int k = 0; k < n_dist; ++k) {
         const nfa_dist_desc &s = dists[k];
-        if (s.size < 2 || s.size > 65536) { delete p; return fail(NFA_ERR_ARG, "distribution size out of range"); }
+        if (s.size < 2 || s.size > 65536) return fail(NFA_ERR_ARG, "distribution size out of range");
         DistDev &d = g.ds[k];
         d.size = (int)s.size; d.du = s.du; d.dx = s.dx; d.xmin = s.xmin; d.xmax = s.xmax;
         const double *src[4] = {s.xax, s.pdf, s.cdf, s.ppf};
         const double **dst[4] = {&d.xax, &d.pdf, &d.cdf, &d.ppf};
-        for (int q = 0; q < 4; ++q) {
-            double *dp = nullptr;
-            HIP_TRY(hipMalloc(&dp, sizeof(double) * s.size));
-            HIP_TRY(hipMemcpy(dp, src[q], sizeof(double) * s.size, hipMemcpyHostToDevice));
-            p->d_arrays.push_back(dp);
-            *dst[q] = dp;
-        }
+        for (int q = 0; q < 4; ++q) { int rc = upload(src[q], s.size, dst[q]); if (rc) return rc; }
         // prefix moments of the trapezoid terms (long double accumulation, one rounding each)
         std::vector<double> m0(s.size), m1(s.size), m2(s.size);
         long double a0 = 0, a1 = 0, a2 = 0;
@@ -369,17 +418,22 @@ int nfa_priors_create(nfa_priors **out, const nfa_prior_desc *priors, int n_prio
         }
         const double *msrc[3] = {m0.data(), m1.data(), m2.data()};
         const double **mdst[3] = {&d.m0, &d.m1, &d.m2};
-        for (int q = 0; q < 3; ++q) {
-            double *dp = nullptr;
-            HIP_TRY(hipMalloc(&dp, sizeof(double) * s.size));
-            HIP_TRY(hipMemcpy(dp, msrc[q], sizeof(double) * s.size, hipMemcpyHostToDevice));
-            p->d_arrays.push_back(dp);
-            *mdst[q] = dp;
-        }
+        for (int q = 0; q < 3; ++q) { int rc = upload(msrc[q], s.size, mdst[q]); if (rc) return rc; }
         g.max_size = std::max(g.max_size, (int)s.size);
     }
     HIP_TRY(hipMalloc(&p->d_prog, sizeof(PriorProg)));
     HIP_TRY(hipMemcpy(p->d_prog, &p->prog, sizeof(PriorProg), hipMemcpyHostToDevice));
+    return NFA_OK;
+}
+
+int nfa_priors_create(nfa_priors **out, const nfa_prior_desc *priors, int n_prior,
+                      const nfa_dist_desc *dists, int n_dist, int n_param) {
+    if (!out || !priors || n_prior < 1 || n_prior > MAXPRIOR || n_dist < 0 || n_dist > MAXDIST)
+        return fail(NFA_ERR_ARG, "prior program out of range (<=16 priors, <=16 distributions)");
+    int rc = engine_init(); if (rc) return rc;
+    nfa_priors *p = new nfa_priors();
+    rc = priors_fill(p, priors, n_prior, dists, n_dist, n_param);
+    if (rc) { nfa_priors_destroy(p); return rc; }            // frees whatever was uploaded
     *out = p;
     return NFA_OK;
 }
@@ -432,6 +486,7 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors, int
     r->ss = ss; r->pr = priors; r->ncomp = ncomp; r->cold = cold ? 1 : 0; r->lte = lte ? 1 : 0;
     r->ndim = ss->dev.npar * ncomp;
     r->n_lanes = std::max(1, std::min(g_eng.streams, NFA_MAX_LANES));
+    r->wpb = g_eng.wpb; r->wpb_table = g_eng.wpb_table;
     for (int k = 0; k < r->n_lanes; ++k) HIP_TRY(hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking));
     r->stream = r->lanes[0];
     *out = r;
@@ -452,6 +507,14 @@ int nfa_runner_destroy(nfa_runner *r) {
 }
 
 int nfa_runner_ndim(const nfa_runner *r) { return r ? r->ndim : 0; }
+
+int nfa_runner_set_exp_mode(nfa_runner *r, int mode) {
+    if (!r) return fail(NFA_ERR_ARG, "null runner");
+    if (mode < -1 || mode > 2) return fail(NFA_ERR_ARG, "exp mode must be -1 (process default), 0 (table), 1 (poly) or 2 (fast)");
+    r->exp_mode = mode;
+    return NFA_OK;
+}
+int nfa_runner_get_exp_mode(const nfa_runner *r) { return !r ? -1 : r->exp_mode >= 0 ? r->exp_mode : g_eng.exp_mode; }
 
 static int runner_reserve(nfa_runner *r, int64_t B, bool spec) {
     if (B > r->cap_B) {
@@ -483,7 +546,7 @@ static SpecDev runner_specdev(const nfa_runner *r) {
 
 // Set-up stage of a batch on stream lane `slot`: [unit cube -> theta in place] ->
 // partition sums -> derived records r->d_D[slot]   (kernels: nfa_setup.h)
-static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot) {
+static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot, int mode) {
     const SpecDev S = runner_specdev(r);
     const int drec = drec_size(r->ncomp, S.n_spec);
     hipStream_t st = r->lanes[slot];
@@ -512,7 +575,7 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     {   // partition sums: lane = (item, component, quarter of the J levels)
         const int64_t lanes = B * r->ncomp * 4;
         const unsigned blocks = (unsigned)((lanes + 255) / 256);
-        if (g_eng.exp_mode == 0) {
+        if (mode == 0) {
             const size_t lds = sizeof(double) * (SM_END_TABLE - SM_EXP2);
             HIP_TRY(hipFuncSetAttribute((const void *)qsum_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(qsum_kernel<0>, dim3(blocks), dim3(256), lds, st, (const double *)d_U, r->d_Q[slot],
@@ -534,24 +597,22 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
 }
 
 
-template <int MODE, bool WS, bool WIDE>
+template <int MODE, bool WS, bool WIDE, int NCOMP>
 static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL,
                         double *d_spec, int64_t B) {
     const SpecDev S = runner_specdev(r);
     LnlGeom G;
     G.ablate = g_eng.ablate;
     G.nhf_max = r->ss->nhf_max;
-    const int drec = drec_size(r->ncomp, S.n_spec);
-    // LDS per wave: the item's record + the line table of one spectrum (32-B records + 64 windows
-    // per component)
-    G.wave_doubles = ((drec + 1) & ~1) + r->ncomp * (G.nhf_max * (int)(sizeof(LineRec) / sizeof(double)) + 64);
+    // LDS per wave: the line table of one spectrum (32-byte records, nhf_max per component)
+    G.wave_doubles = r->ncomp * G.nhf_max * (int)(sizeof(LineRec) / sizeof(double));
     const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
     // waves per workgroup.  Table mode stages 51 KB of product tables per workgroup, so the
     // workgroup is made as fat as keeps the most waves resident per CU (ties: more workgroups,
-    // so that one stages while another computes): 8 waves for NH3 (1,1)+(2,2), 16 for N2H+.
-    int waves = std::max(1, std::min(g_eng.wpb, 16));
+    // so that one stages while another computes).
+    int waves = std::max(1, std::min(r->wpb, 16));
     if (MODE == 0) {
-        waves = g_eng.wpb_table;
+        waves = r->wpb_table;
         if (waves <= 0) {
             int best = -1, best_blocks = 0;
             for (int w = 4; w <= 16; w += 2) {
@@ -564,7 +625,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     }
     const size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * waves);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "ncomp too large for the LDS line table");
-    auto kern = lnl_kernel<MODE, WS, WIDE>;
+    auto kern = lnl_kernel<MODE, WS, WIDE, NCOMP>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t units = B * S.n_spec;
@@ -583,20 +644,32 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     return NFA_OK;
 }
 
-static int launch_lnl(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, double *d_spec, int64_t B) {
-    switch (g_eng.exp_mode) {
+// component count: 1..3 are compiled with the component loop unrolled, anything else takes the general form
+template <int MODE, bool WS, bool WIDE>
+static int launch_lnl_n(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, double *d_spec, int64_t B) {
+    switch (r->ncomp) {
+    case 1: return launch_lnl_t<MODE, WS, WIDE, 1>(r, d_pix, slot, d_lnL, d_spec, B);
+    case 2: return launch_lnl_t<MODE, WS, WIDE, 2>(r, d_pix, slot, d_lnL, d_spec, B);
+    case 3: return launch_lnl_t<MODE, WS, WIDE, 3>(r, d_pix, slot, d_lnL, d_spec, B);
+    default: return launch_lnl_t<MODE, WS, WIDE, 0>(r, d_pix, slot, d_lnL, d_spec, B);
+    }
+}
+
+static int launch_lnl(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, double *d_spec, int64_t B,
+                      int mode) {
+    switch (mode) {
     case 0:
-        return d_spec ? launch_lnl_t<0, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
-                      : launch_lnl_t<0, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
+        return d_spec ? launch_lnl_n<0, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
+                      : launch_lnl_n<0, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
     case 1:
-        return d_spec ? launch_lnl_t<1, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
-                      : launch_lnl_t<1, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
+        return d_spec ? launch_lnl_n<1, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
+                      : launch_lnl_n<1, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
     default:
         if (r->ss->nhf_max > 26)        // more lines than any NH3 transition: fp64 running sum of tau
-            return d_spec ? launch_lnl_t<2, true, true>(r, d_pix, slot, d_lnL, d_spec, B)
-                          : launch_lnl_t<2, false, true>(r, d_pix, slot, d_lnL, d_spec, B);
-        return d_spec ? launch_lnl_t<2, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
-                      : launch_lnl_t<2, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
+            return d_spec ? launch_lnl_n<2, true, true>(r, d_pix, slot, d_lnL, d_spec, B)
+                          : launch_lnl_n<2, false, true>(r, d_pix, slot, d_lnL, d_spec, B);
+        return d_spec ? launch_lnl_n<2, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
+                      : launch_lnl_n<2, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
     }
 }
 
@@ -604,6 +677,7 @@ static int launch_lnl(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, 
 // receives the lane (stream) the batch was enqueued on.
 static int run_batch(nfa_runner *r, const int *d_pix, double *d_U, double *d_lnL, double *d_spec,
                      int64_t B, bool has_prior, int force_lane, int *lane_out) {
+    int rc0 = engine_init(); if (rc0) return rc0;            // binds the calling thread to the device
     if (!g_eng.have_t0) return fail(NFA_ERR_STATE, "nfa_set_iemtex_table has not been called");
     const int slot = force_lane >= 0 ? force_lane : (int)(r->n_calls % (uint64_t)r->n_lanes);
     hipStream_t st = r->lanes[slot];
@@ -616,10 +690,11 @@ static int run_batch(nfa_runner *r, const int *d_pix, double *d_U, double *d_lnL
         r->ev_used += 3;
         HIP_TRY(hipEventRecord(e[0], st));
     }
-    int rc = launch_setup(r, d_U, B, has_prior, slot);
+    const int mode = r->exp_mode >= 0 ? r->exp_mode : g_eng.exp_mode;      // read once per batch
+    int rc = launch_setup(r, d_U, B, has_prior, slot, mode);
     if (rc) return rc;
     if (e) HIP_TRY(hipEventRecord(e[1], st));
-    rc = launch_lnl(r, d_pix, slot, d_lnL, d_spec, B);
+    rc = launch_lnl(r, d_pix, slot, d_lnL, d_spec, B, mode);
     if (rc) return rc;
     if (e) HIP_TRY(hipEventRecord(e[2], st));
     r->n_calls++;
@@ -722,11 +797,12 @@ static int single_point_graph(nfa_runner *r, double *U, double *lnL) {
         profiled = profiled || (pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer")));
         g_eng.graph = profiled ? 0 : 1;
     }
-    if (!g_eng.graph || r->profiling || g_eng.exp_mode == 0 || r->cap_B < 1 || r->cap_D[0] < 1 || r->n_single < 2) return 0;
+    const int mode = r->exp_mode >= 0 ? r->exp_mode : g_eng.exp_mode;
+    if (!g_eng.graph || r->profiling || mode == 0 || r->cap_B < 1 || r->cap_D[0] < 1 || r->n_single < 2) return 0;
     const int ndim = r->ndim;
     hipStream_t st = r->lanes[0];
     if (!r->h_pin && hipHostMalloc((void **)&r->h_pin, sizeof(double) * (ndim + 1)) != hipSuccess) return 0;
-    if (r->g1 && r->g1_mode != g_eng.exp_mode) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
+    if (r->g1 && r->g1_mode != mode) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
     if (!r->g1) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return 0;
@@ -743,7 +819,7 @@ static int single_point_graph(nfa_runner *r, double *U, double *lnL) {
             return 0;
         }
         (void)hipGraphDestroy(graph);
-        r->g1_mode = g_eng.exp_mode;
+        r->g1_mode = mode;
     }
     memcpy(r->h_pin, U, sizeof(double) * ndim);
     if (hipGraphLaunch(r->g1, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;

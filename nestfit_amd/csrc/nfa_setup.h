@@ -311,7 +311,9 @@ __device__ __forceinline__ void write_y_model(double *dk, const SpecDev &S, int 
         kind = 3.0;
     }
     dk[DK_KIND] = kind; dk[DK_A0] = A0; dk[DK_B0] = B0; dk[DK_A1] = A1; dk[DK_B1] = B1;
-    dk[DK_SPLIT] = split; dk[DK_M] = m; dk[DK_Q] = q; dk[9] = 0.0;
+    dk[DK_SPLIT] = split; dk[DK_M] = m; dk[DK_Q] = q;
+    const double kappa = NFA_H / NFA_KB;                       // T0 = kappa x (hyperfine.pyx:106)
+    dk[DK_A0X] = A0 * kappa; dk[DK_B0X] = B0 * (kappa * kappa); dk[11] = 0.0;
 }
 
 // ---------------------------------------------------------------------------
@@ -399,3 +401,4 @@ __global__ void __launch_bounds__(256) derive_simple_kernel(SpecDev S, const dou
         write_y_model(dk, S, s, tex, g_tabs);
     }
 }
+
