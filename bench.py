@@ -169,6 +169,7 @@ def main():
     ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'fast'),
                     choices=['table', 'poly', 'fast'])
     ap.add_argument('--wpb', type=int, default=0, help='engine A/B knob: waves per workgroup (0 = default)')
+    ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
     ap.add_argument('--ablate', type=int, default=0, help='timing experiment: 1 skip Tb, 2 skip lines, 3 both (INVALID results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -200,6 +201,8 @@ def main():
     na.set_exp_mode(args.exp_mode)
     if args.wpb:
         _ffi.set_option('wpb', args.wpb)
+    if args.lnl_cap >= 0:
+        _ffi.set_option('lnl_cap', args.lnl_cap)
     if args.ablate:
         _ffi.set_option('ablate', args.ablate)
     if args.streams:

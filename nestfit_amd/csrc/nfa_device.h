@@ -76,7 +76,7 @@ struct SpecDev {
     double  t0_xmin, t0_xmax, t0_inv_dx;
 };
 
-// derived-parameter record of one item (doubles), written by derive_kernel (nfa_setup.h):
+// derived-parameter record of one item (doubles), written by setup_kernel (nfa_setup.h):
 //   [c*4 + 0] tex  [c*4 + 1] sigm/CKMS  [c*4 + 2] voff/CKMS  [c*4 + 3] 1/tex
 //   [4*ncomp + (c*nspec + s)*DREC_CS + 0] main-line optical depth of (component, spectrum)
 //                                    + 1 kind, + 2.. the y(T0) = 1/(e^(T0/tex)-1) model:
@@ -107,6 +107,7 @@ __host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncom
 struct LnlGeom {
     int nhf_max;       // lines per component slot in the LDS line table
     int wave_doubles;  // LDS doubles per wave
+    unsigned inv_nspec; // floor(2^32 / nspec) + 1: unit / nspec = mulhi(unit, inv_nspec) for unit < 2^28; 0: nspec == 1
     int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 4 skip rows, 8 skip line set-up
 };
 
@@ -335,7 +336,7 @@ __device__ __forceinline__ unsigned long long lanes_gt(int a, int b) { return __
 
 // 1 - FastExp(tau) of the reference for fp32 tau (MODE 2):
 //   tau < 2^-5   the reference's cubic  tau (1 - tau/2 (1 - tau/3))   (fastexp.c:264-270)
-//   tau < 0.25   tau * P6(tau), truncation < 2e-9
+//   tau < 0.25   tau * P4(tau), a degree-4 fit of (1 - e^-tau)/tau on [2^-5, 1/4]
 //   otherwise    1 - exp(-tau) (6e-8 e/(1-e) <= 2.2e-7; exactly 1 from 32 and for NaN)
 // Below 1e-8 the reference's own evaluation 1 - (1 - q) is quantised in steps of 2^-53 (it
 // even returns exactly 0 below 1.1e-16, which decides the zero pattern of faint channels):
@@ -348,12 +349,12 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
     // the other two ranges are evaluated only when some lane of the wave needs them.
     if (__builtin_amdgcn_fcmpf(t, 0.03125f, NF_FCMP_UGE) != 0ull) {
         asm volatile("" ::: "memory");
-        float p = 1.0f / 5040.0f;                             // (1 - e^-t)/t = sum (-t)^k/(k+1)!
-        p = __builtin_fmaf(p, t, -1.0f / 720.0f);
-        p = __builtin_fmaf(p, t, 1.0f / 120.0f);
-        p = __builtin_fmaf(p, t, -1.0f / 24.0f);
-        p = __builtin_fmaf(p, t, 1.0f / 6.0f);
-        p = __builtin_fmaf(p, t, -0.5f);
+        // (1 - e^-t)/t on [2^-5, 1/4]: degree-4 interpolant at the Chebyshev nodes of the interval
+        // (1.2e-7 relative in fp32 arithmetic, the rounding floor; the degree-6 Taylor sum was no better)
+        float p = 0.00741590978577733f;
+        p = __builtin_fmaf(p, t, -0.04143298789858818f);
+        p = __builtin_fmaf(p, t, 0.16663944721221924f);
+        p = __builtin_fmaf(p, t, -0.4999985992908478f);
         p = __builtin_fmaf(p, t, 1.0f);
         wf = (t < 0.03125f) ? wf : t * p;
         if (__builtin_amdgcn_fcmpf(t, 0.25f, NF_FCMP_UGE) != 0ull) {
@@ -442,15 +443,17 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
     const int drec = drec_size(ncomp, nspec);
     LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)wave * G.wave_doubles);
 
-    const long units = B * nspec;
-    // one unit per wave; the grid covers them all.  Waves of a workgroup land on the SIMDs of a CU
-    // in order, so the unit -> wave assignment is rotated per workgroup: otherwise one SIMD would
-    // only ever see the spectrum with the most hyperfine lines.
-    const int rot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 0x9E3779B1u) >> 28));
-    const long unit = (long)blockIdx.x * waves + (wave + rot) % waves;
+    // one unit per wave; the grid covers them all (the host keeps B * nspec below 2^28).  Waves of a
+    // workgroup land on the SIMDs of a CU in order, so the unit -> wave assignment is rotated per
+    // workgroup: otherwise one SIMD would only ever see the spectrum with the most hyperfine lines.
+    const unsigned units = (unsigned)B * (unsigned)nspec;
+    const unsigned rot = __builtin_amdgcn_readfirstlane((blockIdx.x * 0x9E3779B1u) >> 28);
+    const unsigned wsel = (unsigned)wave + rot;
+    const unsigned unit = blockIdx.x * (unsigned)waves + (waves == 4 ? (wsel & 3u) : wsel % (unsigned)waves);
     if (unit >= units) return;
-    const long b = unit / nspec;
-    const int s = (int)(unit - b * nspec);
+    const unsigned bu = G.inv_nspec ? __umulhi(unit, G.inv_nspec) : unit;      // unit / nspec without a division
+    const long b = (long)bu;
+    const int s = (int)(unit - bu * (unsigned)nspec);
     const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
     const int nhf = __builtin_amdgcn_readfirstlane(c_nhf[t]);
     const long p_ix = pix ? (long)__builtin_amdgcn_readfirstlane(pix[b]) : 0;
@@ -513,8 +516,18 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
     const double *rsq = S.rowsq + p_ix * S.rows_tot + S.row_off[s];
     double acc = 0.0;
     unsigned long long empt = 0ull;                              // signal-free rows of this block of 64 rows
-    int row = 0;
-    for (int r0 = 0; r0 < N && !(ablate & 4); r0 += 64, ++row) {
+    // chi^2 of the signal-free rows of a block of 64 rows: their precomputed sums of data^2
+    auto flush_empty = [&](int block_row0) {
+        if (empt) {
+            const bool mine = (empt >> lane) & 1ull;
+            const double q = rsq[mine ? block_row0 + lane : 0];
+            acc += mine ? q : 0.0;
+        }
+        empt = 0ull;
+    };
+    const int n_rows = (ablate & 4) ? 0 : (N + 63) >> 6;
+    for (int row = 0; row < n_rows; ++row) {
+        const int r0 = row << 6;
         const int j = r0 + lane;
         // lines of each component that touch this row
         unsigned long long hitm[NC];
@@ -537,7 +550,7 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
             const unsigned jo = (unsigned)(valid ? j : N - 1) * 8u;           // byte offset of the lane's channel
             const double xj = *(const double *)((const char *)xs + jo);
             const double dj = *(const double *)((const char *)ds + jo);
-            double p3 = 0.0, x2 = 0.0, T0 = 0.0, tbg = 0.0;
+            double p3, x2, T0, tbg;                    // read only where the branches below have set them
             if (MODE == 2) { p3 = *(const double *)((const char *)p3s + jo); x2 = xj * xj; }
             if (need_t0) { T0 = *(const double *)((const char *)t0s + jo); tbg = *(const double *)((const char *)tbgs + jo); }
             double pred = 0.0;
@@ -632,17 +645,9 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
             }
         }
         if (!any) empt |= 1ull << (row & 63);
-        if ((row & 63) == 63 || r0 + 64 >= N) {
-            // chi^2 of the signal-free rows of this block: their precomputed sums of data^2
-            if (empt) {
-                const int rr = (row & ~63) + lane;
-                const bool mine = (empt >> lane) & 1ull;
-                const double q = rsq[mine ? rr : 0];
-                acc += mine ? q : 0.0;
-            }
-            empt = 0ull;
-        }
+        if ((row & 63) == 63) flush_empty(row & ~63);
     }
+    flush_empty((n_rows - 1) & ~63);
     acc = wave_sum(acc);
     if (lane == 0 && part) {
         const double noise = S.noise[p_ix * nspec + s];
@@ -652,6 +657,7 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
 
 // lnL[b] = sum over the spectra of the item, in order (ammonia.pyx:425-432)
 __global__ void lnl_sum_kernel(const double *__restrict__ part, double *__restrict__ lnL, long B, int nspec) {
+    __builtin_amdgcn_s_setprio(3);
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double tot = 0.0;

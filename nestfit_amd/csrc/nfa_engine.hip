@@ -45,6 +45,10 @@ struct Engine {
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
     int    wpb = 4;                  // waves per workgroup of the likelihood kernel
     int    wpb_table = 0;            // the same in table mode; 0 = chosen per spectra set (launch_lnl_t)
+    int    lnl_cap = 7;              // fast / poly mode: workgroups of the likelihood kernel resident per CU at most
+                                     // (LDS padding; 0 = no cap).  One slot per CU is left to the set-up kernels of
+                                     // the NEXT batch: without it they starve behind the 8192 waves of a launch and
+                                     // consecutive likelihood launches run back to back instead of overlapping.
     int    ablate = 0;
     int    streams = 3;              // stream lanes of new runners
     int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
@@ -148,7 +152,7 @@ struct nfa_runner {
     // numerical mode: -1 = the process default at call time (nfa_set_exp_mode), 0..2 = pinned to
     // this runner (nfa_runner_set_exp_mode): runners of different modes may then work side by side
     int exp_mode = -1;
-    int wpb = 4, wpb_table = 0;      // launch geometry, taken from the process options at creation
+    int wpb = 4, wpb_table = 0, lnl_cap = 7;   // launch geometry, taken from the process options at creation
     // Stream lanes: consecutive batches go to different HIP streams (round robin), so the
     // tail of one batch (few workgroups left, SIMDs draining) overlaps the start of the
     // next; inside a lane the set-up kernel and the likelihood kernel run in order and own
@@ -156,7 +160,6 @@ struct nfa_runner {
     int         n_lanes = 1;
     hipStream_t lanes[NFA_MAX_LANES] = {};
     double     *d_D[NFA_MAX_LANES] = {};
-    double     *d_Q[NFA_MAX_LANES] = {};     // partition sums, QREC doubles per (item, component)
     double     *d_part[NFA_MAX_LANES] = {};  // per (item, spectrum) log-likelihood terms
     int64_t     cap_D[NFA_MAX_LANES] = {};
     hipStream_t stream = nullptr;            // lane 0: also the stream of the host-pointer entry points
@@ -215,12 +218,13 @@ int nfa_set_exp_mode(int mode) {
 int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
+    if (key && !strcmp(key, "lnl_cap") && value >= 0 && value <= 8) { g_eng.lnl_cap = value; return NFA_OK; }
     if (key && !strcmp(key, "graph") && (value == 0 || value == 1)) { g_eng.graph = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }
 #ifdef NFA_ABLATE
-    if (key && !strcmp(key, "ablate") && value >= 0 && value <= 15) { g_eng.ablate = value; return NFA_OK; }
+    if (key && !strcmp(key, "ablate") && value >= 0 && value <= 127) { g_eng.ablate = value; return NFA_OK; }
 #endif
     if (key && !strcmp(key, "streams") && value >= 1 && value <= NFA_MAX_LANES) { g_eng.streams = value; return NFA_OK; }
     return fail(NFA_ERR_ARG, "unknown option, or value out of range");
@@ -421,6 +425,27 @@ static int priors_fill(nfa_priors *p, const nfa_prior_desc *priors, int n_prior,
         for (int q = 0; q < 3; ++q) { int rc = upload(msrc[q], s.size, mdst[q]); if (rc) return rc; }
         g.max_size = std::max(g.max_size, (int)s.size);
     }
+    // tables the set-up kernel keeps in LDS: ppf of every distribution a prior interpolates, and the
+    // abscissa + prefix moments (+ pdf, for more than three components) of a placement prior's distribution
+    {
+        bool need[MAXDIST][6] = {};
+        for (int k = 0; k < n_prior; ++k) {
+            const nfa_prior_desc &q = priors[k];
+            const bool composite = q.kind == NFA_PRIOR_RESOLVED_CENSEP || q.kind == NFA_PRIOR_RESOLVED_PLACEMENT;
+            if (q.kind != NFA_PRIOR_CONSTANT && q.dist0 >= 0) need[q.dist0][ST_PPF] = true;
+            if ((q.kind == NFA_PRIOR_SPACED || q.kind == NFA_PRIOR_CENSEP || q.kind == NFA_PRIOR_RESOLVED_CENSEP) && q.dist1 >= 0)
+                need[q.dist1][ST_PPF] = true;
+            if (composite && q.sub_kind != NFA_PRIOR_CONSTANT && q.dist2 >= 0) need[q.dist2][ST_PPF] = true;
+            if (q.kind == NFA_PRIOR_RESOLVED_PLACEMENT && q.dist0 >= 0)
+                for (int f : {ST_XAX, ST_PDF, ST_M0, ST_M1, ST_M2}) need[q.dist0][f] = true;
+        }
+        int n = 0, off = 0;
+        for (int d = 0; d < n_dist; ++d)
+            for (int f = 0; f < 6; ++f)
+                if (need[d][f] && n < MAXSTAGE) { g.stage[n++] = StageItem{d, f, g.ds[d].size, off}; off += g.ds[d].size; }
+        g.n_stage = n; g.stage_doubles = off;
+        if (off * sizeof(double) > 72 * 1024) { g.n_stage = 0; g.stage_doubles = 0; }     // too big: stay in global memory
+    }
     HIP_TRY(hipMalloc(&p->d_prog, sizeof(PriorProg)));
     HIP_TRY(hipMemcpy(p->d_prog, &p->prog, sizeof(PriorProg), hipMemcpyHostToDevice));
     return NFA_OK;
@@ -486,7 +511,7 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors, int
     r->ss = ss; r->pr = priors; r->ncomp = ncomp; r->cold = cold ? 1 : 0; r->lte = lte ? 1 : 0;
     r->ndim = ss->dev.npar * ncomp;
     r->n_lanes = std::max(1, std::min(g_eng.streams, NFA_MAX_LANES));
-    r->wpb = g_eng.wpb; r->wpb_table = g_eng.wpb_table;
+    r->wpb = g_eng.wpb; r->wpb_table = g_eng.wpb_table; r->lnl_cap = g_eng.lnl_cap;
     for (int k = 0; k < r->n_lanes; ++k) HIP_TRY(hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking));
     r->stream = r->lanes[0];
     *out = r;
@@ -497,7 +522,7 @@ int nfa_runner_destroy(nfa_runner *r) {
     if (!r) return NFA_OK;
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamSynchronize(r->lanes[k]);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
-    for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_Q[k]); (void)hipFree(r->d_part[k]); }
+    for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_part[k]); }
     if (r->g1) (void)hipGraphExecDestroy(r->g1);
     if (r->h_pin) (void)hipHostFree(r->h_pin);
     for (hipEvent_t x : r->ev) (void)hipEventDestroy(x);
@@ -544,8 +569,8 @@ static SpecDev runner_specdev(const nfa_runner *r) {
     return S;
 }
 
-// Set-up stage of a batch on stream lane `slot`: [unit cube -> theta in place] ->
-// partition sums -> derived records r->d_D[slot]   (kernels: nfa_setup.h)
+// Set-up stage of a batch on stream lane `slot`: [unit cube -> theta in place] -> partition sums ->
+// derived records r->d_D[slot], one launch (setup_kernel, nfa_setup.h)
 static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot, int mode) {
     const SpecDev S = runner_specdev(r);
     const int drec = drec_size(r->ncomp, S.n_spec);
@@ -553,49 +578,30 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     if (B > r->cap_D[slot]) {                // grown outside any timed loop
         if (slot == 0 && r->g1) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
         HIP_TRY(hipStreamSynchronize(st));
-        (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_Q[slot]); (void)hipFree(r->d_part[slot]);
-        r->d_D[slot] = nullptr; r->d_Q[slot] = nullptr; r->d_part[slot] = nullptr; r->cap_D[slot] = 0;
+        (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_part[slot]);
+        r->d_D[slot] = nullptr; r->d_part[slot] = nullptr; r->cap_D[slot] = 0;
         const int64_t cap = std::max<int64_t>(B, 4096);
         HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec));
-        HIP_TRY(hipMalloc(&r->d_Q[slot], sizeof(double) * cap * r->ncomp * QREC));
         HIP_TRY(hipMalloc(&r->d_part[slot], sizeof(double) * cap * S.n_spec));
         r->cap_D[slot] = cap;
     }
-    if (has_prior) {
-        int rc = launch_priors(r->pr, d_U, B, r->ncomp, st);
-        if (rc) return rc;
-    }
-    if (S.model != NFA_MODEL_AMMONIA) {     // sibling models: theta goes to c_hf_predict as it is
-        const int64_t lanes = B * r->ncomp * S.n_spec;
-        hipLaunchKernelGGL(derive_simple_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, S,
-                           (const double *)d_U, r->d_D[slot], (long)B, (const double *)g_eng.d_tabs);
-        HIP_TRY(hipGetLastError());
-        return NFA_OK;
-    }
-    {   // partition sums: lane = (item, component, quarter of the J levels)
-        const int64_t lanes = B * r->ncomp * 4;
-        const unsigned blocks = (unsigned)((lanes + 255) / 256);
-        if (mode == 0) {
-            const size_t lds = sizeof(double) * (SM_END_TABLE - SM_EXP2);
-            HIP_TRY(hipFuncSetAttribute((const void *)qsum_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(qsum_kernel<0>, dim3(blocks), dim3(256), lds, st, (const double *)d_U, r->d_Q[slot],
-                               (long)B, r->ncomp, r->cold, (const double *)g_eng.d_tabs);
-        } else {
-            hipLaunchKernelGGL(qsum_kernel<1>, dim3(blocks), dim3(256), sizeof(double) * 32, st, (const double *)d_U,
-                               r->d_Q[slot], (long)B, r->ncomp, r->cold, (const double *)g_eng.d_tabs);
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    {   // derived records: lane = (item, component, spectrum)
-        const int64_t lanes = B * r->ncomp * S.n_spec;
-        hipLaunchKernelGGL(derive_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, S,
-                           (const double *)d_U, (const double *)r->d_Q[slot], r->d_D[slot], (long)B,
-                           (const double *)g_eng.d_tabs);
-        HIP_TRY(hipGetLastError());
-    }
+    if (has_prior && !r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
+    const PriorProg *prog = has_prior ? (const PriorProg *)r->pr->d_prog : nullptr;
+    const unsigned blocks = (unsigned)((B + SETUP_TI - 1) / SETUP_TI);
+    // theta + partition records + the program and its tables
+    const size_t work = (size_t)64 * r->ndim + (size_t)SETUP_TI * r->ncomp * QREC + sizeof(PriorProg) / sizeof(double) + 1
+                        + (has_prior ? (size_t)r->pr->prog.stage_doubles : 0);
+    const bool tables = mode == 0 && S.model == NFA_MODEL_AMMONIA;
+    const size_t lds = sizeof(double) * ((tables ? (SM_END_TABLE - SM_EXP2) : 32) + work);
+    if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "too many parameters for the set-up kernel");
+    auto kern = tables ? setup_kernel<0> : setup_kernel<1>;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(SETUP_THREADS), lds, st, prog, S, d_U, r->d_D[slot], (long)B,
+                       has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate);
+    HIP_TRY(hipGetLastError());
     return NFA_OK;
 }
-
 
 template <int MODE, bool WS, bool WIDE, int NCOMP>
 static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL,
@@ -604,6 +610,8 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     LnlGeom G;
     G.ablate = g_eng.ablate;
     G.nhf_max = r->ss->nhf_max;
+    G.inv_nspec = S.n_spec == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)S.n_spec) + 1u;
+    if (B * S.n_spec >= (1LL << 28)) return fail(NFA_ERR_ARG, "batch too large for one launch");
     // LDS per wave: the line table of one spectrum (32-byte records, nhf_max per component)
     G.wave_doubles = r->ncomp * G.nhf_max * (int)(sizeof(LineRec) / sizeof(double));
     const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
@@ -623,8 +631,10 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
             }
         }
     }
-    const size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * waves);
+    size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * waves);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "ncomp too large for the LDS line table");
+    if (MODE != 0 && r->lnl_cap > 0 && waves * r->lnl_cap < 32)      // residency cap: see Engine::lnl_cap
+        lds = std::max(lds, (size_t)((160 * 1024) / r->lnl_cap) & ~(size_t)15);
     auto kern = lnl_kernel<MODE, WS, WIDE, NCOMP>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

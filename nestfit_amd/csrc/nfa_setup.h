@@ -1,21 +1,19 @@
 // nfa_setup.h -- set-up stage of a likelihood batch: everything of
 // AmmoniaRunner.c_loglikelihood that does not depend on the channel.
 //
-//   prior_items_kernel   unit cube -> theta      core/core.pyx:459-476 (all Prior kinds)
-//   qsum_kernel          partition sums          models/ammonia.pyx:289-315
-//   derive_kernel        tau_main, y(T0) model   models/ammonia.pyx:337-361
+//   prior_transform_lane   unit cube -> theta      core/core.pyx:459-476 (all Prior kinds)
+//   qsum_lane              partition sums          models/ammonia.pyx:289-315
+//   derive_lane            tau_main, y(T0) model   models/ammonia.pyx:337-361
 //
-// This stage is scalar work per item (table look-ups, libm).  One wave per item
-// spends 64 lanes on one or two useful ones and ties the work to the latency of
-// dependent loads, so the mapping here is one LANE per unit of scalar work:
-//   * priors:         lane = item; the prior program is interpreted per lane, theta
-//                     lives in LDS transposed ([slot][lane], conflict free);
-//   * partition sums: lane = (item, component, quarter of the 51 J levels), the four
-//                     partial sums meet through two DPP quad permutes;
+// This stage is scalar work per item (table look-ups, libm).  The mapping is one LANE per unit
+// of scalar work, all three phases in one wave per 16 items (setup_kernel, one launch per batch):
+//   * priors:         lane = item; the prior program is interpreted per lane, theta lives in
+//                     LDS transposed ([slot][lane], conflict free);
+//   * partition sums: lane = (item, component, quarter of the 51 J levels), the four partial
+//                     sums meet through two DPP quad permutes;
 //   * derive:         lane = (item, component, spectrum).
-// The three kernels exchange Trot/Tex and the partition sums through small global
-// scratch arrays of the runner; their cost is ~0.5 M wave-instructions per 4096
-// items (the one-wave-per-item version needed 10 M).
+// theta and the partition sums pass from phase to phase through the wave's LDS.
+// (prior_items_kernel = the first phase alone, for PriorTransformer.transform.)
 #pragma once
 
 // ---------------------------------------------------------------------------
@@ -32,10 +30,17 @@ struct DistDev {
 };
 #define MAXPRIOR 16
 #define MAXDIST  16
+// tables the set-up kernel copies into LDS before it interprets the program (a look-up is then
+// an LDS access instead of a dependent trip to L2: the prior phase is a chain of ~35 of them)
+#define MAXSTAGE (MAXDIST * 5)
+enum { ST_XAX = 0, ST_PDF, ST_PPF, ST_M0, ST_M1, ST_M2 };
+struct StageItem { int dist, field, n, off; };     // ds[dist].<field>: n doubles at LDS offset off (doubles)
 struct PriorProg {
     int n_prior, n_dist, n_param, max_size;
     nfa_prior_desc pr[MAXPRIOR];
     DistDev        ds[MAXDIST];
+    int            n_stage, stage_doubles;          // 0: the tables stay in global memory
+    StageItem      stage[MAXSTAGE];
 };
 
 __device__ __forceinline__ double d_ppf_interp(const DistDev &d, double u) {   // core.pyx:47-63
@@ -223,6 +228,7 @@ __device__ void prior_transform_lane(const PriorProg &pp, double *u, int n) {
 __global__ void __launch_bounds__(64) prior_items_kernel(const PriorProg *__restrict__ ppp,
                                                          double *__restrict__ U, long B, int n) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    __builtin_amdgcn_s_setprio(3);     // few waves, long dependent chains: do not queue behind the likelihood waves
     const PriorProg &pp = *ppp;
     const int lane = threadIdx.x;
     const int ndim = pp.n_param * n;
@@ -236,28 +242,16 @@ __global__ void __launch_bounds__(64) prior_items_kernel(const PriorProg *__rest
 #undef TH
 
 // ---------------------------------------------------------------------------
-//  partition sums (ammonia.pyx:289-315): lane = (item, component, quarter)
-//  Q[(b*ncomp + c)*12 + {0: qpara, 1: qorth, 2: trot', 3..11: (2J+1) FastExp(E_J/kT), J = 1..9}]
+//  partition sums (ammonia.pyx:289-315): lane = (item, component, quarter of the 51 J levels)
+//  qrec[{0: qpara, 1: qorth, 2: trot', 3..11: (2J+1) FastExp(E_J/kT), J = 1..9}] per (item, component)
 // ---------------------------------------------------------------------------
 #define QREC 12
 template <int MODE>
-__global__ void __launch_bounds__(256) qsum_kernel(const double *__restrict__ theta, double *__restrict__ Q,
-                                                   long B, int ncomp, int cold,
-                                                   const double *__restrict__ g_tabs) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    int n_shared;
-    const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long pair = gid >> 2;
-    const int chunk = (int)(gid & 3);
-    const bool on = pair < B * ncomp;
-    const long b = on ? pair / ncomp : 0;
-    const int c = on ? (int)(pair - b * ncomp) : 0;
-    const int ndim = NFA_N_PARAMS * ncomp;
-    double trot = theta[b * ndim + ncomp + c];
+__device__ __forceinline__ void qsum_lane(bool on, double trot_in, int cold, int chunk, double *qrec,
+                                          const double *sm) {
+    double trot = trot_in;
     if (cold) trot = nf_swift(trot);                          // ammonia.pyx:344-345
     double qp = 0.0, qo = 0.0;
-    double *qrec = Q + pair * QREC;
     for (int k = 0; k < 13; ++k) {
         const int j = chunk * 13 + k;
         const bool lev_on = on && j < NFA_NPART;
@@ -317,30 +311,22 @@ __device__ __forceinline__ void write_y_model(double *dk, const SpecDev &S, int 
 }
 
 // ---------------------------------------------------------------------------
-//  derive_kernel: lane = (item, component, spectrum); ammonia.pyx:337-361
+//  derive: lane = (item, component, spectrum); ammonia.pyx:337-361.  TH(k) = parameter slot k of the
+//  lane's item (parameter-major, ammonia.pyx:338-343), qrec = its partition record.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) derive_kernel(SpecDev S, const double *__restrict__ theta,
-                                                     const double *__restrict__ Q, double *__restrict__ D,
-                                                     long B, const double *__restrict__ g_tabs) {
-    const int ncomp = S.ncomp, nspec = S.n_spec, ndim = NFA_N_PARAMS * ncomp;
-    const int drec = drec_size(ncomp, nspec);
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per_item = ncomp * nspec;
-    if (gid >= B * per_item) return;
-    const long b = gid / per_item;
-    const int k = (int)(gid - b * per_item);
-    const int c = k / nspec, s = k - c * nspec;
-    const double *th = theta + b * ndim;
-    const double *qrec = Q + (b * ncomp + c) * QREC;
+#define TH(k) th[(k) * 64]
+__device__ __forceinline__ void derive_lane(const SpecDev &S, const double *th, const double *qrec, double *Db,
+                                            int c, int s, const double *__restrict__ g_tabs) {
+    const int ncomp = S.ncomp, nspec = S.n_spec;
     const int t = S.trans[s] - 1;
     const double nu0 = c_nu[t];
     const bool para = ((t + 1) % 3) != 0;
     const double trot = qrec[2];
-    double tex = th[2 * ncomp + c];
+    double tex = TH(2 * ncomp + c);
     if (S.lte) tex = trot;                                    // ammonia.pyx:346
-    const double ntot = th[3 * ncomp + c];
-    const double sigm = th[4 * ncomp + c];
-    const double orth = th[5 * ncomp + c];
+    const double ntot = TH(3 * ncomp + c);
+    const double sigm = TH(4 * ncomp + c);
+    const double orth = TH(5 * ncomp + c);
     const double zlev = qrec[2 + (t + 1)];
     const double qtot = para ? qrec[0] : qrec[1];
     const double species_frac = para ? 1.0 - orth : orth;
@@ -350,42 +336,29 @@ __global__ void __launch_bounds__(256) derive_kernel(SpecDev S, const double *__
     const double fracterm = (NFA_CCMS * NFA_CCMS) * c_ea[t] / (8 * M_PI * (nu0 * nu0));
     const double widthterm = NFA_CKMS / (sigm * nu0 * sqrt(2 * M_PI));
     const double tau_main = pop_rotstate * fracterm * expterm * widthterm;
-    double *Db = D + b * drec;
     if (s == 0) {
         double *d = Db + c * 4;
         d[0] = tex;
         d[1] = sigm / NFA_CKMS;                               // hyperfine.pyx:72
-        d[2] = th[c] / NFA_CKMS;                              // hyperfine.pyx:73
+        d[2] = TH(c) / NFA_CKMS;                              // hyperfine.pyx:73
         d[3] = 1.0 / tex;
     }
-    double *dk = Db + 4 * ncomp + k * DREC_CS;
+    double *dk = Db + 4 * ncomp + (c * nspec + s) * DREC_CS;
     dk[DK_TMAIN] = pow(10.0, log10(tau_main));                // ammonia.pyx:361, hyperfine.pyx:63
     write_y_model(dk, S, s, tex, g_tabs);
 }
 
-// ---------------------------------------------------------------------------
-//  derive_simple_kernel: the sibling models hand c_hf_predict its arguments directly.
+//  The sibling models hand c_hf_predict its arguments directly.
 //  N2H+ (diazenylium.pyx:138-154): voff, tex, ltau, sigm -> tau_main = 10**ltau (hyperfine.pyx:63)
 //  Gaussian (gaussian.pyx:17-35): voff, sigm, peak -> one line of weight `peak`, no Tb pass
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) derive_simple_kernel(SpecDev S, const double *__restrict__ theta,
-                                                            double *__restrict__ D, long B,
-                                                            const double *__restrict__ g_tabs) {
-    const int ncomp = S.ncomp, nspec = S.n_spec, ndim = S.npar * ncomp;
-    const int drec = drec_size(ncomp, nspec);
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per_item = ncomp * nspec;
-    if (gid >= B * per_item) return;
-    const long b = gid / per_item;
-    const int k = (int)(gid - b * per_item);
-    const int c = k / nspec, s = k - c * nspec;
-    const double *th = theta + b * ndim;
+__device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const double *th, double *Db, int c, int s,
+                                                   const double *__restrict__ g_tabs) {
+    const int ncomp = S.ncomp, nspec = S.n_spec;
     const bool gauss = S.model == NFA_MODEL_GAUSSIAN;
-    const double voff = th[c];
-    const double tex  = gauss ? 1.0 : th[ncomp + c];
-    const double sigm = gauss ? th[ncomp + c] : th[3 * ncomp + c];
-    const double amp  = gauss ? th[2 * ncomp + c] : pow(10.0, th[2 * ncomp + c]);
-    double *Db = D + b * drec;
+    const double voff = TH(c);
+    const double tex  = gauss ? 1.0 : TH(ncomp + c);
+    const double sigm = gauss ? TH(ncomp + c) : TH(3 * ncomp + c);
+    const double amp  = gauss ? TH(2 * ncomp + c) : pow(10.0, TH(2 * ncomp + c));
     if (s == 0) {
         double *d = Db + c * 4;
         d[0] = tex;
@@ -393,7 +366,7 @@ __global__ void __launch_bounds__(256) derive_simple_kernel(SpecDev S, const dou
         d[2] = voff / NFA_CKMS;
         d[3] = 1.0 / tex;
     }
-    double *dk = Db + 4 * ncomp + k * DREC_CS;
+    double *dk = Db + 4 * ncomp + (c * nspec + s) * DREC_CS;
     dk[DK_TMAIN] = amp;
     if (gauss) {
         for (int q = 1; q < DREC_CS; ++q) dk[q] = 0.0;
@@ -402,3 +375,102 @@ __global__ void __launch_bounds__(256) derive_simple_kernel(SpecDev S, const dou
     }
 }
 
+// ---------------------------------------------------------------------------
+//  setup_kernel: the whole set-up stage of SETUP_TI = 64 items in one workgroup of four waves,
+//  one launch per batch:
+//      all threads                          prior tables -> LDS (StageItem list of the program)
+//      wave 0, lanes = items                unit cube -> theta (written back to U in place)
+//      lanes = (item, component, quarter)   partition sums -> LDS
+//      lanes = (item, component, spectrum)  derived record D of the item
+//  theta and the partition records stay in LDS between the phases (the three-kernel version of
+//  this stage paid three launch gaps and two round trips through global memory per batch, and
+//  its prior phase was a chain of ~35 dependent trips to L2: the latency of the stage, not its
+//  work, set the pace of a 4096-row batch).  The waves raise their priority: there are few of
+//  them, each a long dependent chain, beside thousands of likelihood waves of the neighbouring
+//  stream lanes.
+//  LDS: [exp tables][theta: ndim x 64][Q: 64 x ncomp x QREC][PriorProg copy][staged prior tables]
+// ---------------------------------------------------------------------------
+#define SETUP_TI 64
+#define SETUP_THREADS 256
+template <int MODE>
+__global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
+                                                              double *__restrict__ U, double *__restrict__ D,
+                                                              long B, int has_prior,
+                                                              const double *__restrict__ g_tabs, int ablate_in) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __builtin_amdgcn_s_setprio(3);
+#ifdef NFA_ABLATE
+    const int ablate = ablate_in;      // timing experiments: 16 skip the priors, 32 the partition sums, 64 the derive phase
+#else
+    const int ablate = 0;
+#endif
+    int n_shared;
+    const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
+    const int tid = threadIdx.x;
+    const int ncomp = S.ncomp, nspec = S.n_spec, ndim = S.npar * ncomp;
+    const int drec = drec_size(ncomp, nspec);
+    double *th_all = smem + n_shared;                          // theta of item `it`: th_all[k * 64 + it]
+    double *q_all = th_all + 64 * ndim;
+    PriorProg *lp = (PriorProg *)(q_all + SETUP_TI * ncomp * QREC);
+    double *tab = (double *)(lp + 1);
+    const long b0 = (long)blockIdx.x * SETUP_TI;
+    const int n_it = (int)(B - b0 < SETUP_TI ? B - b0 : SETUP_TI);
+    const bool do_prior = has_prior && !(ablate & 16);
+    // ---- phase 0: the program and its tables -> LDS; theta of the items -> LDS
+    if (do_prior) {
+        const int nw = (int)(sizeof(PriorProg) / sizeof(int));
+        for (int k = tid; k < nw; k += SETUP_THREADS) ((int *)lp)[k] = ((const int *)ppp)[k];
+        for (int q = 0; q < ppp->n_stage; ++q) {
+            const StageItem it = ppp->stage[q];
+            const DistDev &d = ppp->ds[it.dist];
+            const double *src = it.field == ST_XAX ? d.xax : it.field == ST_PDF ? d.pdf : it.field == ST_PPF ? d.ppf
+                              : it.field == ST_M0 ? d.m0 : it.field == ST_M1 ? d.m1 : d.m2;
+            for (int k = tid; k < it.n; k += SETUP_THREADS) tab[it.off + k] = src[k];
+        }
+    }
+    for (int q = tid; q < n_it * ndim; q += SETUP_THREADS) {   // coalesced; LDS holds it transposed
+        const int it = q / ndim, k = q - it * ndim;
+        th_all[k * 64 + it] = U[b0 * ndim + q];
+    }
+    __syncthreads();
+    if (do_prior && tid < ppp->n_stage) {                      // the LDS copy of the program points at the LDS tables
+        const StageItem it = lp->stage[tid];
+        DistDev &d = lp->ds[it.dist];
+        const double *p = tab + it.off;
+        if (it.field == ST_XAX) d.xax = p; else if (it.field == ST_PDF) d.pdf = p; else if (it.field == ST_PPF) d.ppf = p;
+        else if (it.field == ST_M0) d.m0 = p; else if (it.field == ST_M1) d.m1 = p; else d.m2 = p;
+    }
+    __syncthreads();
+    // ---- phase 1: wave 0, lanes = items (core.pyx:459-476)
+    if (do_prior && tid < n_it) prior_transform_lane(*lp, th_all + tid, ncomp);
+    __syncthreads();
+    if (do_prior)
+        for (int q = tid; q < n_it * ndim; q += SETUP_THREADS) {
+            const int it = q / ndim, k = q - it * ndim;
+            U[b0 * ndim + q] = th_all[k * 64 + it];
+        }
+    const bool ammonia = S.model == NFA_MODEL_AMMONIA;
+    // ---- phase 2: lanes = (item, component, quarter)
+    if (ammonia && !(ablate & 32)) {
+        const int n_task = SETUP_TI * ncomp * 4;               // padded: whole quads are on or off
+        for (int q0 = 0; q0 < n_task; q0 += SETUP_THREADS) {
+            const int q = q0 + tid;
+            const int pair = q >> 2, chunk = q & 3;
+            const int it = pair / ncomp, c = pair - it * ncomp;
+            const bool on = q < n_task && it < n_it;
+            const double trot = on ? th_all[(ncomp + c) * 64 + it] : 1.0;
+            qsum_lane<MODE>(on, trot, S.cold, chunk, q_all + (on ? pair : 0) * QREC, sm);
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: lanes = (item, component, spectrum)
+    const int per_item = ncomp * nspec;
+    for (int q = tid; q < n_it * per_item && !(ablate & 64); q += SETUP_THREADS) {
+        const int it = q / per_item, k = q - it * per_item;
+        const int c = k / nspec, s = k - c * nspec;
+        double *Db = D + (b0 + it) * drec;
+        if (ammonia) derive_lane(S, th_all + it, q_all + (it * ncomp + c) * QREC, Db, c, s, g_tabs);
+        else derive_simple_lane(S, th_all + it, Db, c, s, g_tabs);
+    }
+}
+#undef TH
