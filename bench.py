@@ -286,7 +286,7 @@ def main():
     if profile and rank == 0:
         _ffi.set_option('streams', 1)
         solo = na.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp)
-        _ffi.set_option('streams', args.streams if args.streams else 3)
+        _ffi.set_option('streams', args.streams if args.streams else 4)
         sh = solo._run.handle
         n_solo = min(40, n_total)
         for k in range(5):
@@ -383,7 +383,7 @@ def main():
                 'workload': f'{args.workload}: B={B} live-point draws per step per GPU, '
                             f'NH3 {"+".join(f"({t},{t})" for t in trans)}, {n_chan} ch, '
                             f'{ncomp} comp, get_irdc_priors(size=500)',
-                'exp_mode': args.exp_mode, 'stream_lanes': args.streams or 3, 'pixels_per_gpu': 1, 'sharding': 'pixel stripes, no collective',
+                'exp_mode': args.exp_mode, 'stream_lanes': args.streams or 4, 'pixels_per_gpu': 1, 'sharding': 'pixel stripes, no collective',
                 'device': name.value.decode(),
             },
             'roofline': roof, 'cpu_baseline': cpu,

@@ -55,9 +55,8 @@ int nfa_get_exp_mode(void);
  *   "wpb_table"     the same in table mode (0 = chosen per spectra set, the default): both are
  *                   taken over by runners created afterwards;
  *   "lnl_cap"       workgroups of the likelihood kernel resident per CU at most (fast and poly mode,
- *                   0 = no cap, default 7 of the 8 that fit): the free slot lets the set-up kernels of
- *                   the next batch run beside a launch that would otherwise own every wave slot;
- *   "streams"       number of HIP streams ("lanes", 1..8, default 3) that runners created
+ *                   0 = no cap, the default; 1..8): A/B knob, see DESIGN.md;
+ *   "streams"       number of HIP streams ("lanes", 1..8, default 4) that runners created
  *                   afterwards spread consecutive nfa_runner_loglike_batch_dev calls over;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
  *   "graph"         1 / 0: replay single-point calls as one captured hipGraph or not (default: on,

@@ -45,12 +45,12 @@ struct Engine {
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
     int    wpb = 4;                  // waves per workgroup of the likelihood kernel
     int    wpb_table = 0;            // the same in table mode; 0 = chosen per spectra set (launch_lnl_t)
-    int    lnl_cap = 7;              // fast / poly mode: workgroups of the likelihood kernel resident per CU at most
-                                     // (LDS padding; 0 = no cap).  One slot per CU is left to the set-up kernels of
-                                     // the NEXT batch: without it they starve behind the 8192 waves of a launch and
-                                     // consecutive likelihood launches run back to back instead of overlapping.
+    int    lnl_cap = 0;              // fast / poly mode: workgroups of the likelihood kernel resident per CU at most
+                                     // (LDS padding; 0 = no cap).  A/B knob: leaving one slot per CU to the set-up
+                                     // kernels of the next batch paid off (+7 %) until those kernels got a raised wave
+                                     // priority of their own; with it the cap only costs occupancy (-6 %).
     int    ablate = 0;
-    int    streams = 3;              // stream lanes of new runners
+    int    streams = 4;              // stream lanes of new runners
     int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
     int    graph = -1;               // single-point graph replay: -1 = decide at first use, 0 off, 1 on
     bool   have_t0 = false;
@@ -58,6 +58,12 @@ struct Engine {
     double t0_xmin = 0, t0_xmax = 0, t0_inv_dx = 0;
 };
 static Engine g_eng;
+
+// The HIP runtime multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4);
+// streams that share a queue run in order with each other.  A runner's stream lanes only overlap when
+// every lane has a queue of its own, so ask for 8 -- before the runtime reads the variable, i.e. when this
+// library is loaded, and only if the user has not set it.
+__attribute__((constructor)) static void nfa_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 static int engine_init_once();
 // HIP's current device is per host thread (default 0): every public entry point that allocates or
@@ -152,7 +158,7 @@ struct nfa_runner {
     // numerical mode: -1 = the process default at call time (nfa_set_exp_mode), 0..2 = pinned to
     // this runner (nfa_runner_set_exp_mode): runners of different modes may then work side by side
     int exp_mode = -1;
-    int wpb = 4, wpb_table = 0, lnl_cap = 7;   // launch geometry, taken from the process options at creation
+    int wpb = 4, wpb_table = 0, lnl_cap = 0;   // launch geometry, taken from the process options at creation
     // Stream lanes: consecutive batches go to different HIP streams (round robin), so the
     // tail of one batch (few workgroups left, SIMDs draining) overlaps the start of the
     // next; inside a lane the set-up kernel and the likelihood kernel run in order and own
