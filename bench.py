@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: log-likelihood evaluations per second at the
-metric shape of BASELINE.json (config C2: B = 4096 live-point draws per pixel,
-NH3 (1,1)+(2,2), 1024 channels each, 2 velocity components, get_irdc_priors).
+"""Benchmark of the hot path: log-likelihood evaluations per second at the metric shape of
+BASELINE.json (config C2: B = 4096 live-point draws against one pixel, NH3 (1,1)+(2,2), 1024
+channels each, 2 velocity components, get_irdc_priors).
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (prior transform -> model spectra -> chi^2)
-over one batch of B unit-cube rows for this rank's pixel.  Every input of the
-timed region (unit-cube rows for all steps, spectra, prior tables) is resident
-in HBM before the clock starts.  For N > 1 the driver launches one rank per GPU
-(torch.distributed.run); pixels are striped over ranks like the reference's
-get_multiproc_indices (nestfit/main.py:565-571), per-GPU work is fixed (weak
-scaling) and there is no data-path collective: the only communication is the
-barrier / max-time reduction around the timed region and the end-of-run gather
-of per-pixel summaries.
+A "step" is one pass of the hot path (prior transform -> model spectra -> chi^2) over one batch of
+B unit-cube rows against one map pixel.  The pixels are those of BASELINE config C3 (a synthetic
+128 x 128 cube of 2-component NH3 (1,1)+(2,2) spectra): rank r of N owns the longitude stripe
+i_lon % N == r exactly like the reference's get_multiproc_indices (nestfit/main.py:565-571), holds
+it in HBM and walks it, one pixel per step.  Per-GPU work is fixed (weak scaling); there is no
+data-path collective: the ranks only meet in the barrier / max-time reduction around a timed block
+and in the end-of-run gather of per-pixel records (RCCL through the engine's C ABI, no torch).
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+Every input of a timed block (the unit-cube rows of all its steps, the stripe, the prior tables) is
+resident in HBM before the clock starts.  A block is exactly K steps between barrier + device
+synchronisation on both sides; its time is the maximum over ranks.  `--blocks` R blocks are timed;
+`value` is the median block (whole-job evaluations / block time), `spread` holds min / max.
+The three numerical modes are timed in the same run (`modes`); `value` is the fast mode, whose
+arithmetic `dtype` states.  `roofline`: algorithmic bytes per launch / the average duration of
+lnl_kernel, measured live with HIP events on a one-lane runner (launches do not overlap there, so
+the interval is what `rocprofv3 --kernel-trace --stats -- python bench.py --streams 1` reports for
+the kernel: profiles/r02/); the pipelined rate of the timed blocks is given beside it.
+
+Rank 0 prints ONE JSON line (DESIGN.md "Measurement" explains every field).
 """
 import argparse
-import contextlib
 import ctypes as C
 import json
 import multiprocessing as mp
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,12 +42,17 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MODES = ('table', 'poly', 'fast')
+DTYPES = {'table': 'f64 (reference FastExp: float-narrowed argument, f64 table product)',
+          'poly': 'f64 (exp(-(double)(float)x) by an f64 polynomial)',
+          'fast': 'f64 indices and FastExp arguments, f32 exp and optical depth (mode fast, <= 1e-6 on Tb)'}
 WORKLOADS = {
     # name: (trans ids, channels, vhalf, ncomp, truth key, B)
     'C2': ((1, 2), 1024, 30.0, 2, 'TRUTH_2COMP', 4096),
     'C4': ((1, 2, 3), 2048, 40.0, 3, 'TRUTH_3COMP', 4096),
     'C1': ((1,), 256, 30.0, 1, 'TRUTH_1COMP', 4096),
 }
+PROFILE_DIR = ROOT / 'profiles' / 'r02'
 
 
 def algorithmic_bytes(trans, n_chan, ncomp):
@@ -48,17 +61,46 @@ def algorithmic_bytes(trans, n_chan, ncomp):
     return len(trans) * n_chan * 8 + 2 * ndim * 8 + 8
 
 
-def make_pixel(na, trans, n_chan, vhalf, truth, noise, seed):
-    """Synthetic pixel: engine model spectrum of `truth` + default_rng(seed) normal noise."""
+def stripe_truths(workload, side, lon, lat):
+    """Per-pixel truth parameters of the pixels (lon, lat) of the synthetic cube.  C2: ParamSampler
+    ranges (reference: nestfit/synth_spectra.py:165-192), seeded per pixel by its global index so that
+    a pixel is the same whatever the number of ranks; pixel (0, 0) carries get_test_spectra(kind=0)'s
+    truth; the other workloads repeat their one truth."""
+    from nestfit_amd import synth
+    trans, n_chan, vhalf, ncomp, truth_key, B = WORKLOADS[workload]
+    if workload != 'C2':
+        return np.tile(getattr(synth, truth_key), (lon.size, 1))
+    out = np.empty((lon.size, 6 * ncomp))
+    for k, (i, j) in enumerate(zip(lon, lat)):
+        out[k] = synth.param_sampler_draw(np.random.default_rng(11 + int(i) * side + int(j)))
+    if lon.size and (lon[0], lat[0]) == (0, 0):
+        out[0] = synth.TRUTH_2COMP
+    return out
+
+
+def make_stripe(na, workload, side, rank, world, noise):
+    """This rank's stripe of the cube as one device-resident spectra set: engine model spectra of the
+    per-pixel truths + noise seeded by the pixel's global index."""
+    from nestfit_amd.cube import CubeRunner, shard_pixels
     from nestfit_amd.synth import freq_axis
-    rng = np.random.default_rng(seed)
+    trans, n_chan, vhalf, ncomp, truth_key, B = WORKLOADS[workload]
+    lon, lat = shard_pixels((side, side), rank, world)
     axes = [freq_axis(t, n_chan, vhalf) for t in trans]
-    spec_data = []
-    for t, x in zip(trans, axes):
-        s = na.AmmoniaSpectrum(x, np.zeros(n_chan), noise, t)
-        na.amm_predict(s, truth)
-        spec_data.append([x, s.get_spec() + rng.normal(0, noise, n_chan), noise, t])
-    return spec_data
+    ut = na.get_irdc_priors(size=500, vsys=0.0)
+    truths = stripe_truths(workload, side, lon, lat)
+    n_pix = lon.size
+    n_tot = len(trans) * n_chan
+    probe = CubeRunner(axes, trans, np.zeros((1, n_tot)), np.full((1, len(trans)), noise), ut, ncomp=ncomp)
+    data = np.empty((n_pix, n_tot))
+    for a in range(0, n_pix, 2048):
+        b = min(n_pix, a + 2048)
+        data[a:b], _ = probe.predict_batch(np.zeros(b - a, dtype=np.int32), truths[a:b])
+    del probe
+    for k in range(n_pix):
+        data[k] += np.random.default_rng(5 + int(lon[k]) * side + int(lat[k])).normal(0, noise, n_tot)
+    runner = CubeRunner(axes, trans, data, np.full((n_pix, len(trans)), noise), ut, ncomp=ncomp)
+    spec0 = [[axes[s], data[0, s * n_chan:(s + 1) * n_chan].copy(), noise, trans[s]] for s in range(len(trans))]
+    return runner, ut, lon, lat, spec0
 
 
 def _cpu_worker(args):
@@ -75,9 +117,9 @@ def _cpu_worker(args):
 
 
 def cpu_baseline(spec_data, program, ncomp, U, budget_s=12.0):
-    """Times the CPU oracle (same algorithm, reference compile flags) on a bounded
-    sample of the same workload: 1 core, then all cores (one process per core,
-    like the reference's fit_cube(nproc))."""
+    """Times the CPU oracle (same algorithm, reference compile flags) on a bounded sample of the
+    same workload: 1 core, then all cores (one process per core, like the reference's
+    fit_cube(nproc))."""
     from oracle import nfo
     nfo.build(native=True)
     sample = U[:1024].copy()
@@ -93,25 +135,10 @@ def cpu_baseline(spec_data, program, ncomp, U, budget_s=12.0):
     all_cores = cores * reps * sample.shape[0] / wall
     return {
         'value': all_cores, 'unit': 'evals/s', 'cores': cores, 'kind': 'port',
-        'sample': f'{reps} x 1024 rows of the same U per core, {cores} processes '
+        'sample': f'{reps} x 1024 rows of the same U per core against pixel (0, 0), {cores} processes '
                   f'(oracle/nf_oracle.c, -O3 -march=native -ffast-math)',
         'one_core': one_core,
     }
-
-
-@contextlib.contextmanager
-def stdout_to_stderr():
-    """RCCL prints a version banner on stdout when the first communicator is created; the
-    contract is ONE JSON line on stdout, so native stdout goes to stderr meanwhile."""
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        yield
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved, 1)
-        os.close(saved)
 
 
 def bench_c5(args):
@@ -152,10 +179,22 @@ def bench_c5(args):
     print(json.dumps({
         'metric': 'pixels/sec, nested sampling (400 live points) of a 32x32 NH3(1,1)+(2,2) cube, 1 component',
         'value': out[1]['pixels_per_s'], 'unit': 'pixels/s', 'n_gpus': 1, 'higher_is_better': True,
-        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': DTYPES[args.exp_mode], 'data': 'synthetic',
         'config': {'workload': 'C5: 32x32 pixels x 2 spectra x 512 channels, built-in device sampler '
                                '(libmultinest is not available), tol 0.5, efr 0.3', 'exp_mode': args.exp_mode},
         'one_component': out[1], 'two_components': out[2]}))
+
+
+def relaunch_one_rank_per_gpu(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as child processes (this
+    process has not touched the GPU yet and never will) and pass their output through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
@@ -163,230 +202,219 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--blocks', type=int, default=21, help='timed blocks of --steps steps (value = the median block)')
     ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS) + ['C5'],
                     help='C2 (default) is the headline metric; C5 = nested sampling of a 32x32 cube (not a "step" bench)')
+    ap.add_argument('--side', type=int, default=128, help='pixels per side of the synthetic cube (C3: 128)')
     ap.add_argument('--batch', type=int, default=0, help='rows per step (default: workload B)')
-    ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'fast'),
-                    choices=['table', 'poly', 'fast'])
+    ap.add_argument('--pixels-per-step', default='1', choices=['1', 'B'],
+                    help="1: the B rows of a step share one pixel (C2, the metric); B: every row has its own pixel "
+                         "(one evaluation per pixel: the shape whose data really stream from HBM)")
+    ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'fast'), choices=list(MODES),
+                    help='the mode `value` is quoted in (all three are timed)')
+    ap.add_argument('--modes', default='all', choices=['all', 'one'], help='time all three numerical modes or only --exp-mode')
     ap.add_argument('--wpb', type=int, default=0, help='engine A/B knob: waves per workgroup (0 = default)')
     ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
-    ap.add_argument('--ablate', type=int, default=0, help='timing experiment: 1 skip Tb, 2 skip lines, 3 both (INVALID results)')
+    ap.add_argument('--ablate', type=int, default=0, help='timing experiment with the -DNFA_ABLATE build (INVALID results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-profile-events', action='store_true',
-                    help='do not record per-kernel HIP events inside the timed region')
     args = ap.parse_args()
 
     if args.workload == 'C5':
         return bench_c5(args)
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        relaunch_one_rank_per_gpu(args)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if os.environ.get('NFA_BENCH_SAME_GPU'):      # rehearsal of the N > 1 path on a one-GPU box (gloo barrier)
-        local_rank = 0
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU '
+                         f'(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)')
+    same_gpu = bool(os.environ.get('NFA_BENCH_SAME_GPU'))     # rehearsal of the N > 1 path on a one-GPU box
 
-    use_dist = world > 1 or os.environ.get('NFA_BENCH_FORCE_DIST') == '1'
-    if use_dist:
-        # torch ships its own HIP runtime (same soname as /opt/rocm's): it has to be the one
-        # that is loaded first, otherwise torch finds "no HIP GPUs" after the engine's init
-        import torch
-        torch.cuda.set_device(local_rank)
-        torch.cuda.init()
     import nestfit_amd as na
-    from nestfit_amd import _ffi, synth
-    na.set_device(local_rank)                 # one process per GPU, before any other call
-    na.set_exp_mode(args.exp_mode)
-    if args.wpb:
-        _ffi.set_option('wpb', args.wpb)
+    from nestfit_amd import _ffi, comm as nfcomm
+    na.set_device(0 if same_gpu else local_rank)      # one process per GPU, before any other call
+    for key, val in (('wpb', args.wpb), ('streams', args.streams), ('ablate', args.ablate)):
+        if val:
+            _ffi.set_option(key, val)
     if args.lnl_cap >= 0:
         _ffi.set_option('lnl_cap', args.lnl_cap)
-    if args.ablate:
-        _ffi.set_option('ablate', args.ablate)
-    if args.streams:
-        _ffi.set_option('streams', args.streams)
     lib = _ffi.engine()
-
-    dist = None
-    if use_dist:                              # one rank per GPU over RCCL
-        import torch.distributed as dist
-        with stdout_to_stderr():
-            if os.environ.get('NFA_BENCH_SAME_GPU'):
-                dist.init_process_group('gloo')
-            else:
-                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-            dist.barrier()                    # creates the communicator (and prints the banner)
-            torch.cuda.synchronize()
+    if world == 1:
+        comm = nfcomm.SoloComm()
+    elif same_gpu:
+        comm = nfcomm.TcpComm.from_env()
+    else:
+        comm = nfcomm.RcclComm.from_env()             # RCCL over xGMI, through the C ABI
 
     trans, n_chan, vhalf, ncomp, truth_key, B = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
-    truth = getattr(synth, truth_key)
     ndim = 6 * ncomp
     noise = 0.2
-    # pixel striping: rank r owns pixels i_lon with i_lon % world == r (main.py:565-571);
-    # here one pixel per rank, seeded by its global index
-    spec_data = make_pixel(na, trans, n_chan, vhalf, truth, noise, seed=5 + rank)
-    ut = na.get_irdc_priors(size=500, vsys=0.0)
-    runner = na.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp)
-    rh = runner._run.handle
+    n_steps = args.warmup + args.steps
+    per_row = args.pixels_per_step == 'B'
+    if per_row and args.side * args.side // world < B:
+        raise SystemExit('--pixels-per-step B needs a stripe of at least B pixels')
+    na.set_exp_mode('fast')                            # the synthetic data are made in one mode, whatever is timed
+    cube, ut, lon, lat, spec0 = make_stripe(na, args.workload, args.side, rank, world, noise)
+    n_pix = cube.n_pix
+    rh = cube._run.handle
 
-    # inputs of all steps resident in HBM before the clock starts
-    n_total = args.warmup + args.steps
+    # inputs of all steps of a block resident in HBM before the clock starts
     U_host = np.random.default_rng(7 + rank).uniform(size=(B, ndim))
-    d_U = C.c_void_p()
-    d_lnL = C.c_void_p()
-    _ffi.check(lib.nfa_malloc(C.byref(d_U), n_total * B * ndim * 8))
-    _ffi.check(lib.nfa_malloc(C.byref(d_lnL), n_total * B * 8))     # one result vector per step
-    for k in range(n_total):
-        _ffi.check(lib.nfa_memcpy_h2d(C.c_void_p(d_U.value + k * B * ndim * 8),
-                                      U_host.ctypes.data_as(C.c_void_p), B * ndim * 8))
+    U_all = np.ascontiguousarray(np.broadcast_to(U_host, (n_steps, B, ndim)))
+    if per_row:
+        pix_all = ((np.arange(n_steps)[:, None] * 977 + np.arange(B)[None, :]) % n_pix).astype(np.int32)
+    else:
+        pix_all = np.repeat((np.arange(n_steps) % n_pix).astype(np.int32)[:, None], B, axis=1)
+    pix_all = np.ascontiguousarray(pix_all)
+    d_U, d_lnL, d_pix = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _ffi.check(lib.nfa_malloc(C.byref(d_U), U_all.nbytes))
+    _ffi.check(lib.nfa_malloc(C.byref(d_lnL), n_steps * B * 8))        # one result vector per step
+    _ffi.check(lib.nfa_malloc(C.byref(d_pix), pix_all.nbytes))
+    _ffi.check(lib.nfa_memcpy_h2d(d_pix, pix_all.ctypes.data_as(C.c_void_p), pix_all.nbytes))
 
-    def step(k):
+    def reset_inputs():       # a pass overwrites U with theta in place: fresh unit-cube rows for the next block
+        _ffi.check(lib.nfa_memcpy_h2d(d_U, U_all.ctypes.data_as(C.c_void_p), U_all.nbytes))
+
+    def step(handle, k):
         # consecutive steps may overlap on the device (stream lanes): no buffer is shared
-        _ffi.check(lib.nfa_runner_loglike_batch_dev(rh, None, C.c_void_p(d_U.value + k * B * ndim * 8),
+        _ffi.check(lib.nfa_runner_loglike_batch_dev(handle, C.c_void_p(d_pix.value + k * B * 4),
+                                                    C.c_void_p(d_U.value + k * B * ndim * 8),
                                                     C.c_void_p(d_lnL.value + k * B * 8), B))
 
-    def sync():
-        _ffi.check(lib.nfa_runner_synchronize(rh))
+    def sync(handle):
+        _ffi.check(lib.nfa_runner_synchronize(handle))
         _ffi.check(lib.nfa_device_synchronize())
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
-    sync()
-    profile = not args.no_profile_events
-    if profile:
-        _ffi.check(lib.nfa_runner_set_profiling(rh, 1))
-    if dist is not None:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, n_total):
-        step(k)
-    sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    def timed_blocks(handle, n_blocks):
+        """[seconds of each block]: exactly --steps steps between barrier + synchronise, max over ranks."""
+        out = []
+        for _ in range(n_blocks):
+            reset_inputs()
+            for k in range(args.warmup):
+                step(handle, k)
+            sync(handle)
+            comm.barrier()
+            t0 = time.perf_counter()
+            for k in range(args.warmup, n_steps):
+                step(handle, k)
+            sync(handle)
+            comm.barrier()
+            out.append(time.perf_counter() - t0)
+        return comm.allreduce(np.array(out), 'max')
 
-    prof = (C.c_double * 4)(0, 0, 0, 0)
-    calls = C.c_int64(0)
-    if profile:
-        _ffi.check(lib.nfa_runner_get_profile(rh, prof, C.byref(calls)))
-        _ffi.check(lib.nfa_runner_set_profiling(rh, 0))
-
-    # The same kernel with the GPU to itself: a second runner with ONE stream lane, so that launches
-    # do not overlap and a HIP-event interval is the kernel's execution time (what rocprofv3 reports
-    # for a launch).  Outside the timed region.
-    alone_us = None
-    if profile and rank == 0:
+    def one_lane_kernel_times():
+        """(lnl_kernel us, set-up kernel us, launches) on a one-lane runner: launches do not overlap, a
+        HIP-event interval is the execution time (what rocprofv3 shows for such a launch)."""
+        from nestfit_amd._model import _RunnerHandle
         _ffi.set_option('streams', 1)
-        solo = na.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp)
+        solo = _RunnerHandle(cube._ss, ut, ncomp, False, False)
         _ffi.set_option('streams', args.streams if args.streams else 4)
-        sh = solo._run.handle
-        n_solo = min(40, n_total)
-        for k in range(5):
-            _ffi.check(lib.nfa_runner_loglike_batch_dev(sh, None, C.c_void_p(d_U.value + k * B * ndim * 8),
-                                                        C.c_void_p(d_lnL.value + k * B * 8), B))
-        _ffi.check(lib.nfa_runner_synchronize(sh))
-        # the warm-up overwrote the first U slices with theta: restore unit-cube inputs
-        for k in range(n_solo):
-            _ffi.check(lib.nfa_memcpy_h2d(C.c_void_p(d_U.value + k * B * ndim * 8),
-                                          U_host.ctypes.data_as(C.c_void_p), B * ndim * 8))
-        _ffi.check(lib.nfa_runner_set_profiling(sh, 1))
-        for k in range(n_solo):
-            _ffi.check(lib.nfa_runner_loglike_batch_dev(sh, None, C.c_void_p(d_U.value + k * B * ndim * 8),
-                                                        C.c_void_p(d_lnL.value + (n_total - 1) * B * 8), B))
-        _ffi.check(lib.nfa_runner_synchronize(sh))
+        n = min(60, n_steps)
+        reset_inputs()
+        for k in range(min(5, n)):
+            step(solo.handle, k)
+        sync(solo.handle)
+        reset_inputs()
+        _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 1))
+        for k in range(n):
+            step(solo.handle, k)
+        sync(solo.handle)
         sp = (C.c_double * 4)(0, 0, 0, 0)
         sc = C.c_int64(0)
-        _ffi.check(lib.nfa_runner_get_profile(sh, sp, C.byref(sc)))
-        if sc.value > 0:
-            alone_us = (sp[1] / sc.value * 1e3, sp[0] / sc.value * 1e3)
+        _ffi.check(lib.nfa_runner_get_profile(solo.handle, sp, C.byref(sc)))
+        _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 0))
+        return sp[1] / sc.value * 1e3, sp[0] / sc.value * 1e3, int(sc.value)
+
+    modes = list(MODES) if args.modes == 'all' else [args.exp_mode]
+    per_mode = {}
+    evals_per_block = args.steps * B * world
+    bytes_eval = algorithmic_bytes(trans, n_chan, ncomp)
+    for mode in modes:
+        na.set_exp_mode(mode)
+        n_blocks = args.blocks if mode == args.exp_mode else max(3, args.blocks // 3)
+        t = timed_blocks(rh, n_blocks)
+        med = float(np.median(t))
+        entry = {'value': evals_per_block / med, 'ms_per_step': med / args.steps * 1e3, 'blocks': int(n_blocks),
+                 'min': evals_per_block / float(t.max()), 'max': evals_per_block / float(t.min()), 'dtype': DTYPES[mode]}
+        if rank == 0 and world == 1 and not per_row:
+            lnl_us, setup_us, n_l = one_lane_kernel_times()
+            entry.update({'lnl_kernel_us': lnl_us, 'setup_kernel_us': setup_us, 'one_lane_launches': n_l,
+                          'roofline_frac': bytes_eval * B / (lnl_us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        per_mode[mode] = entry
 
     # results of the last step, for the end-of-run gather and a sanity check
     lnL = np.empty(B)
     _ffi.check(lib.nfa_memcpy_d2h(lnL.ctypes.data_as(C.c_void_p),
-                                  C.c_void_p(d_lnL.value + (n_total - 1) * B * 8), B * 8))
+                                  C.c_void_p(d_lnL.value + (n_steps - 1) * B * 8), B * 8))
     if not np.isfinite(lnL).all():
         raise SystemExit('non-finite log-likelihood in the benchmark batch')
-
-    t_max = elapsed
-    summary = [(rank, float(lnL.max()), int(args.steps * B))]
-    if dist is not None:
-        import torch
-        tdev = 'cpu' if os.environ.get('NFA_BENCH_SAME_GPU') else 'cuda'
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
-        # end-of-run gather of fixed-size per-pixel records
-        rec = torch.tensor([float(rank), float(lnL.max()), float(args.steps * B)],
-                           dtype=torch.float64, device=tdev)
-        out = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(out, rec)
-        summary = [(int(o[0].item()), float(o[1].item()), int(o[2].item())) for o in out]
+    # end-of-run gather of fixed-size per-pixel records (SURVEY.md 8e): here (i_lon, i_lat, rank, best lnL
+    # of the last pixel walked, evaluations made per block by this rank)
+    k_last = (n_steps - 1) % n_pix
+    rec = np.array([[lon[k_last], lat[k_last], rank, float(lnL.max()), float(args.steps * B)]])
+    allrec = nfcomm.gather_pixel_records(rec, comm)
+    assert allrec.shape == (world, 5) and (allrec[:, 0] % world == allrec[:, 2]).all()
 
     if rank == 0:
-        total_evals = sum(s[2] for s in summary)
-        value = total_evals / t_max
-        bytes_eval = algorithmic_bytes(trans, n_chan, ncomp)
-        roof = None
-        if profile and calls.value > 0:
-            n = calls.value
-            raw_s = prof[1] / n / 1e3             # mean event interval (includes queueing behind other lanes)
-            eff_s = prof[3] / n / 1e3             # time with >= 1 likelihood kernel running, per launch
-            achieved = bytes_eval * B / eff_s / 1e9
-            roof = {
-                'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                'kernel': 'lnl_kernel', 'avg_launch_us': eff_s * 1e6,
-                'avg_launch_us_raw_mean': raw_s * 1e6,
-                'achieved_from_raw_mean': bytes_eval * B / raw_s / 1e9,
-                'algorithmic_bytes_per_eval': bytes_eval, 'evals_per_launch': B,
-                'setup_kernel_avg_us': prof[2] / n * 1e3, 'setup_kernel_avg_us_raw_mean': prof[0] / n * 1e3,
-                'alone_launch_us': None if alone_us is None else alone_us[0],
-                'alone_setup_us': None if alone_us is None else alone_us[1],
-                'achieved_alone': None if alone_us is None else bytes_eval * B / (alone_us[0] * 1e-6) / 1e9,
-                'note': 'algorithmic bytes (SURVEY 8d) per launch / likelihood-kernel time per launch '
-                        '(lnl_kernel + lnl_sum_kernel). Consecutive steps run on different HIP streams and '
-                        'overlap, so over the timed region the time per launch is the union of the launch '
-                        'intervals / launches (HIP events on the launch streams); *_raw_mean is the plain '
-                        'mean of those intervals, which also contains the time a launch waits behind the '
-                        'other lanes. alone_launch_us is the same kernel on a one-lane runner after the '
-                        'timed region (no overlap: the execution time rocprofv3 shows for such a launch). '
-                        'The kernel is VALU bound, the pixel data stay in L2 (traffic << algorithmic '
-                        'bytes), see DESIGN.md',
-            }
-            tfile = ROOT / 'profiles' / 'pmc_traffic.json'
-            if tfile.exists():
+        head = per_mode[args.exp_mode]
+        value = head['value']
+        step_s = head['ms_per_step'] * 1e-3
+        roof = {'bound': 'valu', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
+                'kernel': 'lnl_kernel', 'algorithmic_bytes_per_eval': bytes_eval, 'evals_per_launch': B}
+        if 'lnl_kernel_us' in head:
+            ach = bytes_eval * B / (head['lnl_kernel_us'] * 1e-6) / 1e9
+            roof.update({'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'avg_launch_us': head['lnl_kernel_us'],
+                         'setup_kernel_us': head['setup_kernel_us'],
+                         'rocprof': 'profiles/r02/onelane_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- '
+                                    'python bench.py --streams 1 --modes one --no-cpu-baseline)'})
+        pipe = bytes_eval * B * world / step_s / 1e9
+        roof['pipeline'] = {'us_per_step': step_s * 1e6, 'achieved': pipe, 'frac': pipe / (HBM_PEAK_GBS * world),
+                            'note': 'the same bytes / the time per step of the timed blocks (stream lanes overlap the '
+                                    'launches): the rate the job sustains, a hard bound on the kernel'}
+        for name, key in (('pmc_lnl_fast.json', 'valu'), ('pmc_traffic.json', 'traffic_detail')):
+            f = PROFILE_DIR / name
+            if f.exists():
                 try:
-                    roof['traffic'] = json.loads(tfile.read_text()).get(args.workload, {}).get(
-                        args.exp_mode)
+                    roof[key] = json.loads(f.read_text())
                 except Exception:
                     pass
+        if isinstance(roof.get('traffic_detail'), dict):
+            roof['traffic'] = roof['traffic_detail'].get('bytes_per_launch')
+        roof['note'] = ('achieved / frac: algorithmic bytes (SURVEY 8d) per launch / lnl_kernel time per launch, HIP events on a '
+                        'one-lane runner after the timed blocks; `rocprof` names the committed summary of the one-lane command '
+                        'whose average agrees. The kernel is VALU bound: `valu` = busy fraction of the vector ALUs from '
+                        'SQ_ACTIVE_INST_VALU and instructions per evaluation (separate --pmc passes); with --pixels-per-step 1 '
+                        'the pixel stays in L2 (traffic << algorithmic bytes), see DESIGN.md')
         cpu = None
-        if args.gpus == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(spec_data, ut.lower(), ncomp, U_host)
+        if args.gpus == 1 and not args.no_cpu_baseline and not per_row:
+            cpu = cpu_baseline(spec0, ut.lower(), ncomp, U_host)
         name = C.create_string_buffer(128)
         lib.nfa_device_name(name, 128)
+        metric = 'loglikelihood evals/sec, 1024-ch 2-comp NH3(1,1)+(2,2); HBM GB/s vs peak'
+        if per_row:
+            metric += ' [one evaluation per pixel]'
         line = {
-            'metric': 'loglikelihood evals/sec, 1024-ch 2-comp NH3(1,1)+(2,2); HBM GB/s vs peak',
-            'value': value, 'unit': 'evals/s', 'n_gpus': args.gpus, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': t_max / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-            'data': 'synthetic',
+            'metric': metric, 'value': value, 'unit': 'evals/s', 'n_gpus': args.gpus, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': DTYPES[args.exp_mode], 'data': 'synthetic',
             'config': {
-                'workload': f'{args.workload}: B={B} live-point draws per step per GPU, '
-                            f'NH3 {"+".join(f"({t},{t})" for t in trans)}, {n_chan} ch, '
-                            f'{ncomp} comp, get_irdc_priors(size=500)',
-                'exp_mode': args.exp_mode, 'stream_lanes': args.streams or 4, 'pixels_per_gpu': 1, 'sharding': 'pixel stripes, no collective',
+                'workload': f'{args.workload}: B={B} live-point draws per step per GPU against one pixel, '
+                            f'NH3 {"+".join(f"({t},{t})" for t in trans)}, {n_chan} ch, {ncomp} comp, '
+                            f'get_irdc_priors(size=500); pixels = rank stripe (i_lon % {world}) of the C3 cube '
+                            f'{args.side}x{args.side}, one pixel per '
+                            + ('ROW (one evaluation per pixel)' if per_row else 'step'),
+                'exp_mode': args.exp_mode, 'stream_lanes': args.streams or 4, 'pixels_per_gpu': int(n_pix),
+                'sharding': 'pixel stripes i_lon % world (nestfit/main.py:565-571), no data-path collective; '
+                            'barrier / max-time / record gather over RCCL (nfa_comm_*)',
                 'device': name.value.decode(),
             },
-            'roofline': roof, 'cpu_baseline': cpu,
+            'spread': {'blocks': head['blocks'], 'statistic': 'median block', 'min': head['min'], 'max': head['max']},
+            'modes': per_mode, 'roofline': roof, 'cpu_baseline': cpu,
         }
         if cpu:
             line['speedup_vs_cpu_all_cores'] = value / cpu['value']
@@ -394,8 +422,9 @@ def main():
 
     lib.nfa_free(d_U)
     lib.nfa_free(d_lnL)
-    if dist is not None:
-        dist.destroy_process_group()
+    lib.nfa_free(d_pix)
+    comm.barrier()
+    comm.close()
 
 
 if __name__ == '__main__':

@@ -190,7 +190,8 @@ int nfa_runner_synchronize(nfa_runner *r);
 /* Per-kernel timing of nfa_runner_loglike_batch_dev with HIP events recorded on
  * the stream each kernel is launched on, over the calls made since profiling was
  * switched on.  out[0], out[1]: summed milliseconds of the set-up kernel and of the
- * likelihood kernel; out[2], out[3]: milliseconds during which at least one set-up /
+ * likelihood kernel (lnl_kernel alone: the interval rocprofv3 reports for it when the
+ * runner has one stream lane); out[2], out[3]: milliseconds during which at least one set-up /
  * likelihood kernel was running (union of the launch intervals: with several stream
  * lanes launches overlap and the plain sum counts that time more than once). */
 int nfa_runner_set_profiling(nfa_runner *r, int on);
@@ -269,6 +270,24 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active);
 int nfa_sampler_counts(nfa_sampler *s, int64_t *n_iter, int64_t *n_evals, int64_t *rounds);
 int nfa_sampler_dead(nfa_sampler *s, int64_t p, int64_t n, double *theta, double *lnL, double *lnw);
 int nfa_sampler_live(nfa_sampler *s, double *theta, double *lnL);
+
+/* ---- the exchange step of a sharded cube fit ---------------------
+ * The reference stripes pixels over processes, (lon_ix[i::nproc], lat_ix[i::nproc])
+ * (nestfit/main.py:565-571), and exchanges nothing while sampling; its processes meet through chunk
+ * files (main.py:516-523, docs/store_spec.rst:12-32).  One process per GPU here; these entry points
+ * are the end-of-run exchange: RCCL over xGMI (librccl.so, opened at run time).  Rank 0 calls
+ * nfa_comm_unique_id and the host carries the 128 bytes to the other ranks; every rank then calls
+ * nfa_comm_create (after nfa_set_device).  All buffers are host memory; calls are blocking.
+ * op: 0 sum, 2 max, 3 min. */
+typedef struct nfa_comm nfa_comm;
+int nfa_comm_unique_id(unsigned char *id128);
+int nfa_comm_create(nfa_comm **out, const unsigned char *id128, int rank, int world);
+int nfa_comm_destroy(nfa_comm *c);
+int nfa_comm_rank(const nfa_comm *c);
+int nfa_comm_world(const nfa_comm *c);
+int nfa_comm_allgather(nfa_comm *c, const double *send, int64_t count, double *recv /* [world][count] */);
+int nfa_comm_allreduce(nfa_comm *c, double *values, int64_t count, int op);
+int nfa_comm_barrier(nfa_comm *c);
 
 /* ---- device memory + events (for harnesses that keep inputs in HBM) ------- */
 int nfa_malloc(void **dptr, int64_t bytes);

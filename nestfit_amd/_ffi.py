@@ -91,6 +91,14 @@ SIGNATURES = {
     'nfa_sampler_counts': (C.c_int, [C.c_void_p, _lp, _lp, _lp]),
     'nfa_sampler_dead': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp, _dp]),
     'nfa_sampler_live': (C.c_int, [C.c_void_p, _dp, _dp]),
+    'nfa_comm_unique_id': (C.c_int, [C.POINTER(C.c_ubyte)]),
+    'nfa_comm_create': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
+    'nfa_comm_destroy': (C.c_int, [C.c_void_p]),
+    'nfa_comm_rank': (C.c_int, [C.c_void_p]),
+    'nfa_comm_world': (C.c_int, [C.c_void_p]),
+    'nfa_comm_allgather': (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp]),
+    'nfa_comm_allreduce': (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int]),
+    'nfa_comm_barrier': (C.c_int, [C.c_void_p]),
     'nfa_malloc': (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     'nfa_free': (C.c_int, [C.c_void_p]),
     'nfa_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

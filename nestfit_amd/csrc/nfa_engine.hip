@@ -182,8 +182,9 @@ struct nfa_runner {
     uint64_t n_single = 0;
     // optional per-kernel timing (HIP events on the runner's stream)
     bool profiling = false;
-    std::vector<hipEvent_t> ev;      // triples: before priors, before lnl, after lnl
+    std::vector<hipEvent_t> ev;      // triples: before the set-up kernel, before lnl_kernel, after lnl_kernel
     size_t ev_used = 0;
+    hipEvent_t ev_after_lnl = nullptr;   // recorded by the next likelihood launch right behind lnl_kernel (profiling)
 };
 
 extern "C" {
@@ -652,6 +653,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
                        (const double *)r->d_D[slot], d_lnL ? r->d_part[slot] : nullptr, d_spec, (long)B, G,
                        (const double *)g_eng.d_tabs);
     HIP_TRY(hipGetLastError());
+    if (r->ev_after_lnl) { HIP_TRY(hipEventRecord(r->ev_after_lnl, st)); r->ev_after_lnl = nullptr; }
     if (d_lnL) {
         hipLaunchKernelGGL(lnl_sum_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st,
                            (const double *)r->d_part[slot], d_lnL, (long)B, S.n_spec);
@@ -709,10 +711,9 @@ static int run_batch(nfa_runner *r, const int *d_pix, double *d_U, double *d_lnL
     const int mode = r->exp_mode >= 0 ? r->exp_mode : g_eng.exp_mode;      // read once per batch
     int rc = launch_setup(r, d_U, B, has_prior, slot, mode);
     if (rc) return rc;
-    if (e) HIP_TRY(hipEventRecord(e[1], st));
+    if (e) { HIP_TRY(hipEventRecord(e[1], st)); r->ev_after_lnl = e[2]; }
     rc = launch_lnl(r, d_pix, slot, d_lnL, d_spec, B, mode);
     if (rc) return rc;
-    if (e) HIP_TRY(hipEventRecord(e[2], st));
     r->n_calls++;
     r->lane_busy |= 1u << slot;
     if (lane_out) *lane_out = slot;
@@ -783,7 +784,7 @@ int nfa_runner_get_profile(nfa_runner *r, double *out, int64_t *calls) {
         iv_lnl.emplace_back(t1, t2);
     }
     out[0] = a;                          // sum of set-up kernel durations
-    out[1] = b;                          // sum of likelihood kernel durations
+    out[1] = b;                          // sum of lnl_kernel durations (lnl_sum_kernel not included)
     out[2] = union_length(iv_setup);     // time during which >= 1 set-up kernel was running
     out[3] = union_length(iv_lnl);       // time during which >= 1 likelihood kernel was running
     *calls = (int64_t)n;
@@ -1036,3 +1037,4 @@ int nfa_test_windows(nfa_runner *r, int spec, double voff, double sigm, int32_t 
 
 #include "nfa_broker.h"
 #include "nfa_sampler.h"
+#include "nfa_comm.h"

@@ -7,12 +7,7 @@ writes its own chunk file and nothing is exchanged while sampling
 (nestfit/main.py:423-474, docs/store_spec.rst:12-32).  Here rank r owns the same
 stripe, uploads its pixels once and evaluates batches of (pixel, unit-cube row)
 items.  The only collective is the end-of-run gather of fixed-size per-pixel
-records (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
-
-Loader note: torch bundles its own HIP runtime under the same soname as /opt/rocm's.  A
-process that uses both the engine and torch's GPU side (the "nccl" gather) must
-``import torch; torch.cuda.init()`` BEFORE the first engine call, so that one runtime
-serves both (bench.py does this); the other order leaves torch with "no HIP GPUs".
+records (`nestfit_amd.comm`: RCCL over xGMI through the engine's C ABI).
 """
 import ctypes as C
 
@@ -104,28 +99,3 @@ class CubeRunner:
         peak = np.stack([np.nanmax(spec[:, off[k]:off[k + 1]], axis=1) for k in range(self.n_spec)], axis=1)
         tot = np.stack([np.nansum(spec[:, off[k]:off[k + 1]], axis=1) for k in range(self.n_spec)], axis=1)
         return peak, tot
-
-
-def gather_pixel_records(records, group=None):
-    """All-gather fixed-size per-pixel result records (float64 [n_local, width]) from
-    every rank; returns the concatenation in rank order.  Ranks may own different
-    numbers of pixels (stripes of a cube whose width is not a multiple of world)."""
-    import torch
-    import torch.distributed as dist
-    records = np.ascontiguousarray(records, dtype=np.float64)
-    assert records.ndim == 2
-    world = dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
-    n_local = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    width = records.shape[1]
-    n_max = max(counts)
-    padded = torch.zeros((n_max, width), dtype=torch.float64, device=dev)
-    if records.shape[0]:
-        padded[:records.shape[0]] = torch.from_numpy(records).to(dev)
-    out = [torch.zeros_like(padded) for _ in range(world)]
-    dist.all_gather(out, padded, group=group)
-    return np.concatenate([o[:n].cpu().numpy() for o, n in zip(out, counts)], axis=0)

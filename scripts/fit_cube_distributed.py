@@ -22,13 +22,14 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     store_name = sys.argv[1] if len(sys.argv) > 1 else '/tmp/nestfit_amd_dist'
     same_gpu = len(sys.argv) > 2 and sys.argv[2] == 'same_gpu'
-    import torch.distributed as dist                      # gloo: only a barrier is needed
-    dist.init_process_group('gloo')
     import nestfit_amd as na
+    from nestfit_amd.comm import RcclComm, TcpComm
     from nestfit_amd.cubeio import CubeStack, DataCube, SimpleCube
     from nestfit_amd.fitter import CubeFitter
     from nestfit_amd.store import HdfStore
     na.set_device(0 if same_gpu else local)
+    # only a barrier is needed: RCCL between the ranks' GPUs, plain sockets when they share one
+    comm = TcpComm.from_env() if same_gpu else RcclComm.from_env()
     stack = CubeStack([
         DataCube(SimpleCube.read(ROOT / 'tests' / 'golden' / f'ammonia_{t}{t}_cutout.fits')[:-1], 0.35, trans_id=t)
         for t in (1, 2)])
@@ -39,14 +40,14 @@ def main():
     fitter.fit_cube(store_name, nproc=world, rank=rank)
     dt = time.perf_counter() - t0
     print(f'rank {rank}/{world}: stripe fitted in {dt:.1f} s', flush=True)
-    dist.barrier()
+    comm.barrier()
     if rank == 0:
         with HdfStore(store_name) as store:
             store.link_files()
             n = len(list(store.iter_pix_groups()))
         print(f'linked {world} chunk files: {n} pixels in {store_name}.store', flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 if __name__ == '__main__':

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: pixel striping identical to the reference's
 get_multiproc_indices (nestfit/main.py:565-571) and the end-of-run gather of
-per-pixel records over torch.distributed (gloo, world_size 2 and 3)."""
+per-pixel records (nestfit_amd.comm.gather_pixel_records) over a gloo-backed stand-in
+for the RCCL communicator (world_size 2 and 3)."""
 import os
 import socket
 
@@ -33,14 +34,20 @@ def _free_port():
 
 
 def _worker(rank, world, port, shape, out_dir):
+    import sys
     import torch.distributed as dist
-    from nestfit_amd.cube import gather_pixel_records, shard_pixels
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from comm_gloo import GlooComm
+    from nestfit_amd.comm import gather_pixel_records
+    from nestfit_amd.cube import shard_pixels
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    comm = GlooComm()
     lon, lat = shard_pixels(shape, rank, world)
     # a record per pixel: (lon, lat, rank, stand-in for lnZ) -- fixed width, variable count
     rec = np.stack([lon, lat, np.full(lon.size, rank), 1000.0 * lon + lat], axis=1).astype(float)
-    allrec = gather_pixel_records(rec)
-    dist.barrier()
+    allrec = gather_pixel_records(rec, comm)
+    assert comm.allreduce(np.array([float(rank)]), 'max')[0] == world - 1
+    comm.barrier()
     np.save(os.path.join(out_dir, f'r{rank}.npy'), allrec)
     dist.destroy_process_group()
 
@@ -59,3 +66,54 @@ def test_gather_of_pixel_records_gloo(tmp_path, world):
     assert len({(int(a), int(b)) for a, b in g[:, :2]}) == 35  # all pixels, once
     assert (g[:, 0] % world == g[:, 2]).all()                  # owner = i_lon mod world
     assert np.array_equal(g[:, 3], 1000.0 * g[:, 0] + g[:, 1])
+
+
+def test_solo_comm_and_id_exchange():
+    """world = 1 is the identity; the unique-id hand-off (rank 0 serves, the others fetch) over loopback."""
+    import threading
+    from nestfit_amd.comm import SoloComm, _exchange_id, gather_pixel_records
+    rec = np.arange(12.0).reshape(4, 3)
+    assert np.array_equal(gather_pixel_records(rec, SoloComm()), rec)
+    port = _free_port()
+    got = {}
+
+    def client(rank):
+        got[rank] = _exchange_id(rank, 3, None, '127.0.0.1', port, timeout=30)
+
+    threads = [threading.Thread(target=client, args=(r,)) for r in (1, 2)]
+    for t in threads:
+        t.start()
+    uid = _exchange_id(0, 3, lambda: bytes(range(128)), '127.0.0.1', port, timeout=30)
+    for t in threads:
+        t.join()
+    assert uid == bytes(range(128)) and got[1] == uid and got[2] == uid
+
+
+def _tcp_worker(rank, world, port, q):
+    from nestfit_amd.comm import TcpComm, gather_pixel_records
+    from nestfit_amd.cube import shard_pixels
+    comm = TcpComm(rank, world, '127.0.0.1', port, timeout=60)
+    lon, lat = shard_pixels((7, 5), rank, world)
+    rec = np.stack([lon, lat, np.full(lon.size, rank)], axis=1).astype(float)
+    allrec = gather_pixel_records(rec, comm)
+    tmax = comm.allreduce(np.array([1.0 + rank, 10.0 - rank]), 'max')
+    comm.barrier()
+    comm.close()
+    q.put((rank, allrec, tmax))
+
+
+def test_tcp_comm_world_3():
+    """The socket communicator used when ranks share a GPU: the same gather, same results on every rank."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_tcp_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(3)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, allrec, tmax in got:
+        assert np.array_equal(allrec, got[0][1]) and allrec.shape == (35, 3)
+        assert (allrec[:, 0] % 3 == allrec[:, 2]).all()
+        assert tmax.tolist() == [3.0, 10.0]
