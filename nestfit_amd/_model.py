@@ -70,6 +70,15 @@ class _RunnerHandle:
                                          int(bool(lte))))
         self.handle = h
 
+    def set_exp_mode(self, mode):
+        """Pin the numerical mode of this runner ('table' / 'poly' / 'fast' or 0 / 1 / 2); None or -1
+        = follow the process default (`nestfit_amd.set_exp_mode`) again."""
+        mode = -1 if mode is None else {'table': 0, 'poly': 1, 'fast': 2}.get(mode, mode)
+        _ffi.check(_ffi.load().nfa_runner_set_exp_mode(self.handle, int(mode)))
+
+    def get_exp_mode(self):
+        return _ffi.load().nfa_runner_get_exp_mode(self.handle)
+
     def __del__(self):
         if getattr(self, 'handle', None) is not None:
             try:
@@ -160,6 +169,11 @@ class EngineRunner(Runner):
         self._ss = _SpecSet([s.xarr for s in spectra], [s.trans_id for s in spectra], data, noise,
                             model=self.MODEL, rest_freqs=rest_freqs)
         self._run = _RunnerHandle(self._ss, utrans, self.ncomp, cold, lte)
+
+    def set_exp_mode(self, mode):
+        """Numerical mode of this runner alone (None: the process default again): runners of different
+        modes can then be used side by side, also from different threads."""
+        self._run.set_exp_mode(mode)
 
     def loglikelihood(self, utheta):
         """lnL of one unit-cube point; `utheta` is overwritten with the physical

@@ -58,6 +58,10 @@ class CubeRunner:
         self.n_chan_tot = self._ss.chan_tot
         self.null_lnZ = self._ss.null_lnZ().sum(axis=1)      # per pixel
 
+    def set_exp_mode(self, mode):
+        """Numerical mode of this runner alone (None: the process default again)."""
+        self._run.set_exp_mode(mode)
+
     def loglikelihood_batch(self, pix, U):
         """lnL[B] of unit-cube rows U[B, ndim] against pixels pix[B]; U is overwritten
         with the physical parameters (like Runner.loglikelihood, core.pyx:558-561)."""

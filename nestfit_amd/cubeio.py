@@ -146,6 +146,22 @@ class SimpleCube:
         return CKMS * (1.0 - self._freq / float(self.rest_freq))
 
 
+def read_spectrum(path):
+    """A one-dimensional FITS spectrum (NAXIS = 1, FREQ axis: what the CASA spectral profiler writes,
+    e.g. the reference's nestfit/test/data/test_spectrum_11.fits) as the model wants it:
+    (frequency axis in Hz ascending, intensities, header)."""
+    header, data = read_fits(str(path))
+    data = np.asarray(data, dtype=np.float64).ravel()
+    if int(header.get('NAXIS', 0)) != 1 or not str(header.get('CTYPE1', '')).upper().startswith('FREQ'):
+        raise ValueError('expected a one-dimensional spectrum on a frequency axis')
+    scale = {'hz': 1.0, 'khz': 1e3, 'mhz': 1e6, 'ghz': 1e9, '': 1.0}[str(header.get('CUNIT1', '')).strip().lower()]
+    freq = (float(header['CRVAL1']) + (np.arange(data.size) + 1.0 - float(header.get('CRPIX1', 1.0)))
+            * float(header['CDELT1'])) * scale
+    if freq[1] < freq[0]:
+        freq, data = freq[::-1], data[::-1]
+    return freq.copy(), data.copy(), header
+
+
 def jy_per_beam_to_kelvin(freq_hz, header):
     """K per (Jy/beam) at each frequency for the elliptical Gaussian beam BMAJ x BMIN (degrees, FWHM)
     of the header: T = S c^2 / (2 k nu^2 Omega), Omega = pi BMAJ BMIN / (4 ln 2)."""

@@ -147,6 +147,15 @@ def lib(native=False):
     return _LIBS[name]
 
 
+def oldconst_lib():
+    """The checker built with the reference's other constant set (__NEW_CONST = False,
+    nestfit/models/ammonia.pyx:20-22): only for the reference's own partition-function known answers."""
+    name = 'libnf_oracle_oldconst.so'
+    if name not in _LIBS:
+        _LIBS[name] = _load(name)
+    return _LIBS[name]
+
+
 def ref_fastexp_lib(fast_math=False):
     """The reference's own fastexp.c compiled as-is (oracle/_ref); None if absent."""
     path = HERE / '_ref' / ('libfastexp_ref_fm.so' if fast_math else 'libfastexp_ref.so')

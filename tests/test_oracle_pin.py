@@ -157,3 +157,35 @@ def test_edge_cases_of_the_model(nfo):
         nfo.AmmoniaSpectrum(x, np.zeros(n), 0.0, 1)
     with pytest.raises(AssertionError):
         nfo.AmmoniaSpectrum(x, np.zeros(n), 0.1, 10)
+
+
+def test_partition_function_reference_known_answers_old_constants(nfo):
+    """The reference's own partition-function test (nestfit/models/ammonia.pyx:496-514): its three
+    numbers come from pyspeckit with the Poynter & Kakar rotation constants and only hold when the
+    module is compiled with __NEW_CONST = False.  The restatement built the same way
+    (-DNFA_OLD_CONST) meets them to the reference's own precision (decimal=7); with the shipped
+    constants it must NOT (that is why the reference skips its test)."""
+    old = nfo.oldconst_lib()
+    np.testing.assert_almost_equal(old.nfo_partition_level(1, 10.0), 0.29279893434489096, decimal=7)
+    np.testing.assert_almost_equal(old.nfo_partition_level(2, 10.0), 0.007933862262432792, decimal=7)
+    np.testing.assert_almost_equal(old.nfo_partition_func(1, 10.0), 0.30073281405688107, decimal=7)
+    new = nfo.lib()
+    assert abs(new.nfo_partition_level(1, 10.0) - 0.29279893434489096) > 1e-5
+    assert abs(new.nfo_partition_func(1, 10.0) - 0.30073281405688107) > 1e-5
+
+
+def test_reference_spectrum_fixture_reads_as_model_axis():
+    """nestfit/test/data/test_spectrum_11.fits (kept under tests/golden/): a 380-channel VLA NH3 (1,1)
+    profile on a descending FREQ axis.  `cubeio.read_spectrum` hands it over ascending, on the grid
+    of the reference's 20 x 20 x 380 test cube (same CDELT / RESTFRQ as test/data/ammonia_11_cutout.fits)."""
+    from pathlib import Path
+    from nestfit_amd.cubeio import SimpleCube, read_spectrum
+    gold = Path(__file__).parent / 'golden'
+    x, d, hdr = read_spectrum(gold / 'test_spectrum_11.fits')
+    assert x.shape == d.shape == (380,) and np.all(np.diff(x) > 0) and np.isfinite(d).all()
+    assert float(hdr['RESTFRQ']) == 23.6944955e9
+    assert np.diff(x) == pytest.approx(1.249826974487e4, rel=1e-9)
+    assert x[-1] == pytest.approx(2.368986555182e10, rel=1e-12)          # CRVAL1 at CRPIX1 = 1, now the last channel
+    cube = SimpleCube.read(gold / 'ammonia_11_cutout.fits')
+    assert abs(np.diff(cube.spectral_axis_hz())).mean() == pytest.approx(1.249826974487e4, rel=2e-4)
+    assert 0.02 < d.max() < 0.05 and abs(np.median(d)) < 0.005           # a line profile (Jy/beam) on a flat baseline
