@@ -174,64 +174,88 @@ def jy_per_beam_to_kelvin(freq_hz, header):
     return 1e-26 * c ** 2 / (2.0 * kb * np.asarray(freq_hz, dtype=np.float64) ** 2 * omega)
 
 
-class NoiseMap:
-    """Per-pixel RMS map, indexed (i_lon, i_lat) like the transposed cube data (reference:
-    nestfit/main.py:39-68)."""
+class _Noise:
+    """RMS per map pixel.  `get_noise(i_lon, i_lat)` is the reference's accessor (main.py:39-72);
+    `values_at` is its array form (what the device upload and the pixel screening use)."""
+    shape = None
+
+    def get_noise(self, i_lon, i_lat):
+        return float(self.values_at(np.asarray(i_lon), np.asarray(i_lat)))
+
+    def values_at(self, lon, lat):
+        raise NotImplementedError
+
+
+class NoiseMap(_Noise):
+    """A noise image, given in FITS order (lat, lon) and indexed (i_lon, i_lat) like the transposed cube."""
 
     def __init__(self, data):
-        self.data = np.asarray(data).T          # FITS image order (lat, lon) -> (lon, lat)
+        self.data = np.asarray(data).T
         self.shape = self.data.shape
 
     @classmethod
     def from_pbimg(cls, rms, pb_img):
-        """rms / primary-beam response; masked (NaN) beam pixels get an infinite noise."""
+        """A flat `rms` divided by the primary-beam response `pb_img` (2-D, or 3-D / 4-D whose leading axes
+        are channel / Stokes: the first plane is taken).  Where the response is masked or zero the noise is
+        infinite."""
         pb = np.asarray(pb_img, dtype=np.float64)
-        if pb.ndim not in (2, 3, 4):
+        if not 2 <= pb.ndim <= 4:
             raise ValueError(f'Cannot parse shape : {pb.shape}')
-        while pb.ndim > 2:                       # (stokes, chan, lat, lon) or (chan, lat, lon): first plane
-            pb = pb[0]
+        plane = pb.reshape((-1,) + pb.shape[-2:])[0]
         with np.errstate(divide='ignore', invalid='ignore'):
-            img = rms / pb
-        return cls(np.where(np.isfinite(img), img, np.inf))
+            noise = rms / plane
+        noise[~np.isfinite(noise)] = np.inf
+        return cls(noise)
 
     def get_noise(self, i_lon, i_lat):
         return self.data[i_lon, i_lat]
 
+    def values_at(self, lon, lat):
+        return np.asarray(self.data[lon, lat], dtype=np.float64)
 
-class NoiseMapUniform:
-    """One RMS for the whole map (reference: nestfit/main.py:66-72); `shape` is None."""
+
+class NoiseMapUniform(_Noise):
+    """One RMS for every pixel (`shape` stays None: there is no image to compare with the cube's)."""
 
     def __init__(self, rms):
         self.rms = rms
-        self.shape = None
 
     def get_noise(self, i_lon, i_lat):
         return self.rms
 
+    def values_at(self, lon, lat):
+        return np.full(np.shape(lon), self.rms, dtype=np.float64)
 
-_SIMPLE_HEADER_KEYS = ('SIMPLE', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'WCSAXES', 'CRPIX1', 'CRPIX2', 'CDELT1',
-                       'CDELT2', 'CUNIT1', 'CUNIT2', 'CTYPE1', 'CTYPE2', 'CRVAL1', 'CRVAL2', 'RADESYS', 'EQUINOX')
+
+# celestial keywords a two-dimensional map product inherits from the cube
+_MAP_KEYWORDS = ('SIMPLE', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'WCSAXES') + tuple(
+    f'{stem}{axis}' for stem in ('CRPIX', 'CDELT', 'CUNIT', 'CTYPE', 'CRVAL') for axis in (1, 2)) + ('RADESYS', 'EQUINOX')
 _SKY_AXES = ('ra', 'dec', 'lon', 'lat')
+_JY_PER_BEAM = ('jy/beam', 'jybeam-1', 'beam-1jy')
 
 
 class DataCube:
-    """One transition's cube in the layout the fitter wants (reference: nestfit/main.py:77-172):
-    `data[i_lon, i_lat, chan]` in K with the frequency axis `xarr` ascending in Hz, `varr` the
-    matching (descending) radio velocities in km/s, `dv` the channel width in km/s.  `cube` is a
-    `SimpleCube` (or anything with the same attributes); `noise_map` a number or a NoiseMap."""
+    """One transition's cube in the layout the fitter wants (the reference's DataCube, main.py:77-172):
+    `data[i_lon, i_lat, chan]` in K with the frequency axis `xarr` ascending in Hz, `varr` the matching
+    (descending) radio velocities in km/s, `dv` the channel width in km/s.  `cube` is a `SimpleCube` (or
+    anything with its attributes); `noise_map` a number or a noise-map object."""
 
     def __init__(self, cube, noise_map, trans_id=None):
-        self.noise_map = NoiseMapUniform(noise_map) if isinstance(noise_map, (float, int)) else noise_map
         self.trans_id = trans_id
+        self.noise_map = noise_map if hasattr(noise_map, 'get_noise') else NoiseMapUniform(noise_map)
         self._header = dict(cube.header)
+        kelvin, freq, velo = self._ingest(cube)
+        self.data, self.xarr, self.varr = kelvin, freq, velo
         self.dv = self.get_chan_width(cube)
-        self.data, self.xarr = self.data_from_cube(cube)
-        self.varr = self.velo_axis_from_cube(cube)
-        self.shape = self.data.shape                       # (lon, lat, chan)
-        self.spatial_shape = self.shape[:2]
-        self.nchan = self.shape[2]
-        if self.noise_map.shape is not None:
-            assert self.spatial_shape == self.noise_map.shape
+        self.shape = kelvin.shape                          # (lon, lat, chan)
+        self.spatial_shape, self.nchan = kelvin.shape[:2], kelvin.shape[2]
+        if self.noise_map.shape is not None and tuple(self.noise_map.shape) != tuple(self.spatial_shape):
+            raise AssertionError(f'noise map {self.noise_map.shape} does not match the cube {self.spatial_shape}')
+
+    def _ingest(self, cube):
+        """(data in K as [lon, lat, chan], ascending Hz axis, matching km/s axis)."""
+        data, freq = self.data_from_cube(cube)
+        return data, freq, self.velo_axis_from_cube(cube)
 
     @property
     def full_header(self):
@@ -240,10 +264,11 @@ class DataCube:
     @property
     def simple_header(self):
         """The celestial (2-D) part of the header, for map products."""
-        hdict = {k: self._header[k] for k in _SIMPLE_HEADER_KEYS if k in self._header}
-        hdict['NAXIS'] = hdict['WCSAXES'] = 2
+        hdict = {key: self._header[key] for key in _MAP_KEYWORDS if key in self._header}
+        hdict.update(NAXIS=2, WCSAXES=2)
         for key in ('CTYPE1', 'CTYPE2'):                   # of the form "RA---SIN"
-            assert hdict[key].split('-')[0].lower() in _SKY_AXES
+            if hdict[key].split('-')[0].lower() not in _SKY_AXES:
+                raise AssertionError(f'{key} = {hdict[key]!r} is not a celestial axis')
         return hdict
 
     def get_chan_width(self, cube):
@@ -251,25 +276,24 @@ class DataCube:
         return abs(v[1] - v[0])
 
     def data_from_cube(self, cube):
-        # brightness in K (main.py:127-132).  Jy/beam is converted like spectral_cube's `to('K')`:
-        # Rayleigh-Jeans brightness temperature of the header's Gaussian beam, channel by channel
-        factor = None
-        if cube.unit == '':
+        """Brightness in K on an ascending frequency axis, one pixel's spectrum contiguous.  Jy/beam is
+        converted like spectral_cube's `to('K')`: Rayleigh-Jeans brightness temperature of the header's
+        Gaussian beam, channel by channel; a cube without a unit is taken to be in K."""
+        unit = cube.unit.replace(' ', '').lower()
+        data, axis = cube._data, cube.spectral_axis_hz()
+        if unit in _JY_PER_BEAM:
+            data = data * jy_per_beam_to_kelvin(axis, cube.header)[:, None, None]
+        elif unit == '':
             print('-- Assuming cube intensity units of K')
-        elif cube.unit.replace(' ', '').lower() in ('jy/beam', 'jybeam-1', 'beam-1jy'):
-            factor = jy_per_beam_to_kelvin(cube.spectral_axis_hz(), cube.header)
-        elif cube.unit != 'K':
+        elif unit != 'k':
             raise ValueError(f'cube intensity unit {cube.unit!r}: only K and Jy/beam are supported')
-        data = cube._data if factor is None else cube._data * factor[:, None, None]
-        axis = cube.spectral_axis_hz()
-        if axis[1] - axis[0] < 0:                          # the model wants ascending frequencies
+        if axis[0] > axis[-1]:
             data, axis = data[::-1], axis[::-1]
-        # (chan, lat, lon) -> (lon, lat, chan): one pixel's spectrum is contiguous
-        return data.transpose().copy(), axis.copy()
+        return np.ascontiguousarray(data.transpose()), np.array(axis)      # (chan, lat, lon) -> (lon, lat, chan)
 
     def velo_axis_from_cube(self, cube):
         v = cube.spectral_axis_kms()
-        return (v[::-1] if v[1] > v[0] else v).copy()      # descending, element-wise partner of xarr
+        return np.array(v if v[0] > v[-1] else v[::-1])    # descending: the element-wise partner of xarr
 
     def get_spec_data(self, i_lon, i_lat):
         spec = self.data[i_lon, i_lat, :]
@@ -316,10 +340,25 @@ class CubeStack:
         bad = np.zeros(lon.shape, dtype=bool)
         for dcube in self.cubes:
             bad |= np.isnan(dcube.data[lon, lat, :]).any(axis=1)
-            nm = dcube.noise_map
-            noise = np.full(lon.shape, nm.rms, dtype=np.float64) if nm.shape is None else nm.data[lon, lat]
+            noise = dcube.noise_map.values_at(lon, lat)
             bad |= ~(noise > 0) | ~np.isfinite(noise)
         return lon[~bad], lat[~bad]
+
+    def masked_beam_pixels(self, lon=None, lat=None):
+        """(i_lon, i_lat) of the pixels whose data are NaN-free but whose noise is infinite in some cube
+        (masked primary beam, `NoiseMap.from_pbimg`): the reference does not skip them (only NaNs,
+        main.py:437-441); their likelihood is flat and their fit ends with nbest = 0."""
+        if lon is None:
+            lon, lat = (a.ravel() for a in np.indices(self.spatial_shape))
+        lon, lat = np.asarray(lon), np.asarray(lat)
+        nan = np.zeros(lon.shape, dtype=bool)
+        inf = np.zeros(lon.shape, dtype=bool)
+        for dcube in self.cubes:
+            noise = dcube.noise_map.values_at(lon, lat)
+            nan |= np.isnan(dcube.data[lon, lat, :]).any(axis=1) | np.isnan(noise)
+            inf |= np.isinf(noise)
+        keep = inf & ~nan
+        return lon[keep], lat[keep]
 
     def to_device(self, utrans, ncomp=1, lon=None, lat=None, model=0, **runner_kwargs):
         """All good pixels as one device-resident spectra set: returns (CubeRunner, i_lon, i_lat);
@@ -327,10 +366,7 @@ class CubeStack:
         from .cube import CubeRunner
         lon, lat = self.good_pixels(lon, lat)
         data = np.concatenate([dc.data[lon, lat, :] for dc in self.cubes], axis=1)
-        noise = np.empty((lon.size, self.n_cubes))
-        for k, dc in enumerate(self.cubes):
-            nm = dc.noise_map
-            noise[:, k] = nm.rms if nm.shape is None else nm.data[lon, lat]
+        noise = np.stack([dc.noise_map.values_at(lon, lat) for dc in self.cubes], axis=1)
         runner = CubeRunner([dc.xarr for dc in self.cubes], [dc.trans_id for dc in self.cubes], data, noise,
                             utrans, ncomp=ncomp, model=model, **runner_kwargs)
         return runner, lon, lat

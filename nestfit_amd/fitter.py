@@ -25,37 +25,35 @@ class _RunInfo:
         self.run_lnZ = np.nan
 
 
+# run_multinest keywords a CubeFitter passes unless told otherwise (the reference's choice for cube fits:
+# fewer live points and a looser tolerance than run_multinest's own defaults, main.py:381-387)
+MN_CUBE_DEFAULTS = dict(nlive=100, tol=1.0, efr=0.3, updInt=2000)
+# device memory the sampler state of one lock-step group may take (dead points dominate: cap x (ndim + 2) doubles
+# per pixel); larger groups are fitted in several passes
+SAMPLER_MEMORY_BUDGET = 24 << 30
+
+
 class CubeFitter:
-    mn_default_kwargs = {
-        'nlive': 100,
-        'tol': 1.0,
-        'efr': 0.3,
-        'updInt': 2000,
-    }
+    mn_default_kwargs = MN_CUBE_DEFAULTS
 
     def __init__(self, stack, utrans, runner_cls, runner_kwargs=None, lnZ_thresh=11, ncomp_max=2,
                  mn_kwargs=None, nlive_snr_fact=5, nlive_quantum=20, fit_backend=None):
-        """Parameters as the reference (main.py:388-420).  `nlive_quantum`: the reference gives
-        every pixel its own number of live points, nlive + int(nlive_snr_fact * snr); pixels are
-        batched by that number rounded up to a multiple of `nlive_quantum` (1 = exactly the
-        reference's value, at the price of smaller batches).  `fit_backend`: None = the device
-        sampler; otherwise a callable(fitter, lon, lat, ncomp, nlive, kw) -> (results, null_lnZ,
-        n_chan_tot) that fits the given pixels some other way (the tests plug the numpy twin of
-        the sampler fed by the CPU oracle in here, so that the driver logic runs without a GPU)."""
-        self.stack = stack
-        self.utrans = utrans
-        self.runner_cls = runner_cls
-        self.runner_kwargs = {} if runner_kwargs is None else runner_kwargs
-        self.lnZ_thresh = lnZ_thresh
-        self.ncomp_max = ncomp_max
-        self.mn_kwargs = self.mn_default_kwargs.copy()
-        if mn_kwargs is not None:
-            self.mn_kwargs.update(mn_kwargs)
-        self.nlive_snr_fact = nlive_snr_fact
+        """Arguments of the reference's CubeFitter (main.py:388-420) plus two of this build:
+        `nlive_quantum` -- the reference gives every pixel its own number of live points,
+        nlive + int(nlive_snr_fact * snr); pixels are batched by that number rounded up to a multiple
+        of `nlive_quantum` (1 = exactly the reference's value, at the price of smaller batches);
+        `fit_backend` -- None = the device sampler, otherwise a callable(fitter, lon, lat, ncomp,
+        nlive, kw) -> (results, null_lnZ, n_chan_tot) that fits the given pixels some other way (the
+        tests plug in the numpy twin of the sampler fed by the CPU oracle, so that the driver logic
+        runs without a GPU)."""
+        model = inspect.getmodule(runner_cls)
+        self.model_id, self.n_model = _MODEL_ID[model.NAME], model.N
+        self.stack, self.utrans, self.runner_cls = stack, utrans, runner_cls
+        self.runner_kwargs = dict(runner_kwargs or {})
+        self.mn_kwargs = {**MN_CUBE_DEFAULTS, **(mn_kwargs or {})}
+        self.lnZ_thresh, self.ncomp_max, self.nlive_snr_fact = lnZ_thresh, ncomp_max, nlive_snr_fact
         self.nlive_quantum = max(1, int(nlive_quantum))
         self.fit_backend = fit_backend
-        self.model_id = _MODEL_ID[inspect.getmodule(runner_cls).NAME]
-        self.n_model = inspect.getmodule(runner_cls).N
 
     def _nlive(self, lon, lat):
         base = int(self.mn_kwargs['nlive'])
@@ -71,8 +69,16 @@ class CubeFitter:
         hdf = StoreFile(chunk_path, 'a')
         lon, lat = self.stack.good_pixels(all_lon, all_lat)
         good = set(zip(lon.tolist(), lat.tolist()))
+        blind = set(zip(*(a.tolist() for a in self.stack.masked_beam_pixels(all_lon, all_lat))))
         for i_lon, i_lat in zip(all_lon.tolist(), all_lat.tolist()):
-            if (i_lon, i_lat) not in good:
+            if (i_lon, i_lat) in blind:
+                # NaN-free data under an infinite noise (a masked primary-beam pixel of NoiseMap.from_pbimg): the
+                # reference runs its sampler on the flat likelihood and stores nbest = 0 (main.py:437-472); the
+                # outcome is known beforehand, so the group is written without sampling
+                print(f'-- ({i_lon}, {i_lat}) infinite noise: nbest = 0 without sampling')
+                group = hdf.require_group(f'/pix/{i_lon}/{i_lat}')
+                group.attrs.update(i_lon=int(i_lon), i_lat=int(i_lat), nbest=0)
+            elif (i_lon, i_lat) not in good:
                 print(f'-- ({i_lon}, {i_lat}) SKIP: has NaN values')
         if lon.size:
             nlive = self._nlive(lon, lat)
@@ -87,7 +93,18 @@ class CubeFitter:
         runner, rlon, rlat = self.stack.to_device(self.utrans, ncomp=ncomp, lon=lon, lat=lat,
                                                   model=self.model_id, **self.runner_kwargs)
         assert np.array_equal(rlon, lon) and np.array_equal(rlat, lat)
-        res = sampler.fit_pixels(runner, np.arange(lon.size), nlive=nlive, **kw)
+        # the sampler keeps every dead point of every pixel on the device: fit the group in passes that fit
+        # the memory budget (a pass's pixels keep their slot numbers' random streams; the seed moves on)
+        ndim = self.n_model * ncomp
+        cap = min(int(kw.get('maxiter', 10**6)), sampler.default_cap_iter(nlive))
+        per_pixel = 8 * (cap * (ndim + 2) + nlive * (2 * ndim + 2))
+        n_pass = max(1, SAMPLER_MEMORY_BUDGET // per_pixel)
+        res = []
+        for a in range(0, lon.size, n_pass):
+            kw_pass = dict(kw)
+            if a and kw.get('seed', -1) >= 0:
+                kw_pass['seed'] = int(kw['seed']) + a
+            res += sampler.fit_pixels(runner, np.arange(a, min(lon.size, a + n_pass)), nlive=nlive, **kw_pass)
         return res, runner.null_lnZ.copy(), int(runner._ss.chan_tot)
 
     def _fit_group(self, hdf, lon, lat, nlive, kw):
@@ -118,10 +135,7 @@ class CubeFitter:
             alive = alive[keep]
             ncomp += 1
         for p in range(lon.size):
-            group = hdf[f'/pix/{lon[p]}/{lat[p]}']
-            group.attrs['i_lon'] = int(lon[p])
-            group.attrs['i_lat'] = int(lat[p])
-            group.attrs['nbest'] = int(nbest[p])
+            hdf[f'/pix/{lon[p]}/{lat[p]}'].attrs.update(i_lon=int(lon[p]), i_lat=int(lat[p]), nbest=int(nbest[p]))
 
     def fit_cube(self, store_name='run/test_cube', nproc=1, rank=None):
         """Creates the store, fits every pixel and links the chunk files (main.py:476-526).

@@ -43,6 +43,10 @@ class NestedResult:
         self.n_evals = int(n_evals)
         self.n_iter = int(n_iter)
         self.information = float(information)
+        # True when the run was stopped by its iteration / dead-point cap before the evidence tolerance was
+        # met: lnZ is then the evidence collected so far plus the live points' share, a lower-quality
+        # estimate (set by run_nested / run_nested_device)
+        self.truncated = False
         w = posterior[:, -1]
         th = posterior[:, :-2]
         mean = w @ th
@@ -147,9 +151,10 @@ def _fit_ellipsoids(U, efr, ln_x, enlarge=1.0):
     return c, L * scale[:, None, None], lnv >= 0.0, lnv
 
 
-def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive):
+def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
     """NestedResult per pixel from dead points (theta, lnL, lnw per pixel) and final live points:
-    every live point carries the mass X_final / nlive."""
+    every live point carries the mass X_final / nlive.  With `tol` given a run whose live points could
+    still add more than `tol` to lnZ (the stop test it did not meet) is marked `truncated`."""
     results = []
     for p in range(len(n_iter)):
         dT, dL, dlnw = dead[p]
@@ -168,6 +173,10 @@ def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive):
         post[:, ndim + 1] = wt
         results.append(NestedResult(post, lnZ_tot, np.sqrt(max(Hp, 0.0) / nlive), L.max(), nlive,
                                     n_evals[p], n_iter[p], Hp))
+        if tol is not None:
+            lnZ_dead = np.logaddexp.reduce(dlnw + dL) if dL.size else -np.inf
+            remain = Llive[p].max() - n_iter[p] / nlive
+            results[-1].truncated = bool(not (np.logaddexp(lnZ_dead, remain) - lnZ_dead < tol))
     return results
 
 
@@ -175,6 +184,13 @@ def _resolve_seed(seed):
     if seed is None or seed < 0:                                # like MultiNest: from the system
         return int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> np.uint64(1))
     return int(seed)
+
+
+def default_cap_iter(nlive):
+    """Dead-point slots per pixel when the caller names none: 60 nlive iterations reach ln X = -60, far
+    past where any fit of this kind has collected its evidence; a run that does hit the cap is flagged
+    `truncated`.  The same default on the host twin and on the device."""
+    return 60 * int(nlive)
 
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
@@ -200,7 +216,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         worst live point.
     upd_frac : the ellipsoids are refitted at the end of a round once this fraction of nlive
         replacements has accumulated.
-    cap_iter : dead-point slots per pixel (default: no other cap than maxiter).
+    cap_iter : dead-point slots per pixel (default: min(maxiter, 60 nlive), `default_cap_iter`); a pixel
+        that fills them before meeting `tol` is returned with `truncated = True`.
     method, n_steps : 'reject' = rejection sampling in the bounding ellipsoid only; 'auto' = a pixel
         whose rejection round accepted fewer than 1 in 2 `n_steps` of the evaluated candidates
         switches to constrained random walks (64 walkers from random live points, `n_steps`
@@ -221,7 +238,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     seed = _resolve_seed(seed)
     K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
     P = int(n_pix)
-    cap = int(maxiter if cap_iter is None else min(cap_iter, maxiter) if maxiter > 0 else cap_iter)
+    cap = int(min(maxiter, default_cap_iter(nlive)) if cap_iter is None else min(cap_iter, maxiter) if maxiter > 0 else cap_iter)
     all_pix = np.arange(P, dtype=np.int32)
 
     def evaluate(pix, U):
@@ -382,7 +399,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     bounds = np.searchsorted(dead_pix[order], np.arange(P + 1))
     dead = [(dead_T[order[bounds[p]:bounds[p + 1]]], dead_L[order[bounds[p]:bounds[p + 1]]],
              dead_lnw[order[bounds[p]:bounds[p + 1]]]) for p in range(P)]
-    res = _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive)
+    res = _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol)
     for r in res:
         r.rounds = rnd
     return res
@@ -405,7 +422,7 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
     assert nlive > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
     seed = _resolve_seed(seed)
     K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
-    cap = int(cap_iter) if cap_iter else int(max(1, min(maxiter, 60 * nlive)))
+    cap = int(cap_iter) if cap_iter else int(max(1, min(maxiter, default_cap_iter(nlive))))
     fm = None if free_mask is None else np.ascontiguousarray(free_mask, dtype=np.int32)
     assert fm is None or fm.shape == (ndim,)
     nd = ndim if fm is None else int(np.count_nonzero(fm))
@@ -449,7 +466,7 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
             dead.append((dT, dL, dw))
     finally:
         lib.nfa_sampler_destroy(h)
-    res = _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive)
+    res = _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol)
     for r in res:
         r.rounds = int(rounds.value)
     return res
@@ -478,80 +495,95 @@ class MemoryGroup:
         return self.datasets[name]
 
 
+# What a finished run leaves in its store group (docs/store_spec.rst:77-96; the reference's writer is
+# mn_dump, core.pyx:627-687).  Every entry: name in the store <- function of (runner, result, dumper).
+def information_criteria(n_chan, n_par, lnL):
+    """(BIC, AIC, AICc) of a model with `n_par` parameters on `n_chan` channels at log-likelihood lnL."""
+    n, k = float(n_chan), float(n_par)
+    aic = 2.0 * k - 2.0 * lnL
+    return np.log(n) * k - 2.0 * lnL, aic, aic + (2.0 * k * k + 2.0 * k) / (n - k - 1.0)
+
+
+def _criteria(prefix, which_lnL):
+    names = (prefix + 'BIC', prefix + 'AIC', prefix + 'AICc')
+
+    def make(k):
+        return lambda run, res, dmp: information_criteria(run.n_chan_tot, run.n_params, which_lnL(run, res))[k]
+    return tuple((name, make(k)) for k, name in enumerate(names))
+
+
+RUN_ATTRIBUTES = (
+    ('ncomp', lambda run, res, dmp: run.ncomp),
+    ('null_lnZ', lambda run, res, dmp: run.null_lnZ),
+    ('n_chan_tot', lambda run, res, dmp: run.n_chan_tot),
+    ('n_samples', lambda run, res, dmp: res.n_samples),
+    ('n_live', lambda run, res, dmp: res.n_live),
+    ('n_params', lambda run, res, dmp: res.n_params),
+    ('global_lnZ', lambda run, res, dmp: res.lnZ),
+    ('global_lnZ_err', lambda run, res, dmp: res.lnZ_err),
+    ('max_loglike', lambda run, res, dmp: res.max_loglike),
+    ('marg_cols', lambda run, res, dmp: dmp.marginal_cols),
+    ('marg_quantiles', lambda run, res, dmp: dmp.quantiles),
+) + _criteria('', lambda run, res: res.max_loglike) + _criteria('null_', lambda run, res: run.null_lnZ) + (
+    ('truncated', lambda run, res, dmp: bool(getattr(res, 'truncated', False))),     # not in the reference: see NestedResult
+)
+RUN_DATASETS = (
+    ('posteriors', lambda run, res, dmp: res.posterior.astype('float32')),           # (n_samples, n_params + 2)
+    ('marginals', lambda run, res, dmp: dmp.calc_marginals(res.posterior)),          # (n_quantiles, n_params)
+    ('bestfit_params', lambda run, res, dmp: res.param_constr[2]),
+    ('map_params', lambda run, res, dmp: res.param_constr[3]),
+)
+
+
+def marginal_quantile_table():
+    """(column names, quantiles) of the `marginals` dataset: extremes and percentiles, then the 1 / 2 / 3
+    sigma credible intervals.  The reference stores the normal tail areas truncated to nine significant
+    digits below and eight decimals above the median (its marg_quantiles attribute): reproduced here from
+    the normal distribution, not typed in."""
+    from scipy.stats import norm
+    percent = (1, 10, 25, 50, 75, 90, 99)
+    names = ['min'] + [f'p{q:02d}' for q in percent] + ['max']
+    quant = [0.0] + [q / 100 for q in percent] + [1.0]
+    for k in (1, 2, 3):
+        names += [f'{k}s_lo', f'{k}s_hi']
+        quant += [float(f'{norm.cdf(-k):.8e}'), float(f'{norm.cdf(k):.8f}')]
+    return names, np.array(quant)
+
+
 class Dumper:
-    """Same constructor, quantiles and column names as the reference's ``Dumper``
-    (core.pyx:564-612); `group` is an h5py group or a `MemoryGroup`."""
+    """Writer of one run's outputs into a store group (an h5py group, a `store.Group` or a
+    `MemoryGroup`), with the reference's entry points (core.pyx:564-612)."""
 
     def __init__(self, group, no_dump=False):
-        self.group = group
-        self.no_dump = no_dump
-        self.n_calls = 0
-        self.n_samples = -1
-        self.quantiles = np.array([
-            0.00, 0.01, 0.10, 0.25, 0.50, 0.75, 0.90, 0.99, 1.00,
-            1.58655254e-1, 0.84134475,  # 1-sigma credible interval
-            2.27501319e-2, 0.97724987,  # 2-sigma credible interval
-            1.34989803e-3, 0.99865010,  # 3-sigma credible interval
-        ])
-        self.marginal_cols = [
-            'min', 'p01', 'p10', 'p25', 'p50', 'p75', 'p90', 'p99', 'max',
-            '1s_lo', '1s_hi', '2s_lo', '2s_hi', '3s_lo', '3s_hi',
-        ]
+        self.group, self.no_dump = group, no_dump
+        self.n_calls, self.n_samples = 0, -1
+        self.marginal_cols, self.quantiles = marginal_quantile_table()
 
     def calc_marginals(self, posteriors):
-        # The last two columns of the posterior array are -2*lnL and X*L/Z
-        return np.quantile(posteriors[:, :-2], self.quantiles, axis=0)
+        """Quantiles of every parameter column (the two trailing columns are -2 lnL and the weights)."""
+        n_par = posteriors.shape[1] - 2
+        return np.quantile(posteriors[:, :n_par], self.quantiles, axis=0)
 
     def flush(self):
         self.group.file.flush()
 
-    def append_attributes(self, **kwargs):
-        for name, value in kwargs.items():
-            self.group.attrs[name] = value
+    def append_attributes(self, **attributes):
+        self.group.attrs.update(attributes)
 
-    def append_datasets(self, **kwargs):
-        for name, data in kwargs.items():
-            self.group.create_dataset(name, data=data)
+    def append_datasets(self, **datasets):
+        for name in datasets:
+            self.group.create_dataset(name, data=datasets[name])
 
     def dump(self, runner, res):
-        """What ``mn_dump`` writes on its final call (core.pyx:627-687)."""
+        """The final call of the sampler's dump callback: evidence into the runner, everything of
+        RUN_ATTRIBUTES / RUN_DATASETS into the group."""
         self.n_calls += 1
         self.n_samples = res.n_samples
         runner.run_lnZ = res.lnZ
         if self.no_dump:
             return
-        group = self.group
-        group.attrs['ncomp'] = runner.ncomp
-        group.attrs['null_lnZ'] = runner.null_lnZ
-        group.attrs['n_chan_tot'] = runner.n_chan_tot
-        group.attrs['n_samples'] = res.n_samples
-        group.attrs['n_live'] = res.n_live
-        group.attrs['n_params'] = res.n_params
-        group.attrs['global_lnZ'] = res.lnZ
-        group.attrs['global_lnZ_err'] = res.lnZ_err
-        group.attrs['max_loglike'] = res.max_loglike
-        group.attrs['marg_cols'] = self.marginal_cols
-        group.attrs['marg_quantiles'] = self.quantiles
-        n = float(runner.n_chan_tot)
-        k = float(runner.n_params)
-        nullL = runner.null_lnZ
-        maxL = res.max_loglike
-        bic = np.log(n) * k - 2 * maxL
-        aic = 2 * k - 2 * maxL
-        aicc = aic + (2 * k**2 + 2 * k) / (n - k - 1)
-        null_bic = np.log(n) * k - 2 * nullL
-        null_aic = 2 * k - 2 * nullL
-        null_aicc = null_aic + (2 * k**2 + 2 * k) / (n - k - 1)
-        group.attrs['BIC'] = bic
-        group.attrs['AIC'] = aic
-        group.attrs['AICc'] = aicc
-        group.attrs['null_BIC'] = null_bic
-        group.attrs['null_AIC'] = null_aic
-        group.attrs['null_AICc'] = null_aicc
-        group.create_dataset('posteriors', data=res.posterior.astype('float32'))
-        group.create_dataset('marginals', data=self.calc_marginals(res.posterior))
-        group.create_dataset('bestfit_params', data=res.param_constr[2])
-        group.create_dataset('map_params', data=res.param_constr[3])
+        self.append_attributes(**{name: get(runner, res, self) for name, get in RUN_ATTRIBUTES})
+        self.append_datasets(**{name: get(runner, res, self) for name, get in RUN_DATASETS})
 
 
 def run_multinest(runner, dumper, IS=False, mmodal=True, ceff=False, nlive=400, tol=0.5, efr=0.3,

@@ -200,87 +200,117 @@ class StoreFile(Group):
             self.close()
 
 
+# ---------------------------------------------------------------------------------------------
+#  The store proper, written against the store specification (docs/store_spec.rst:12-110).
+#  What goes where is data, kept in the tables below; the class only walks them.
+# ---------------------------------------------------------------------------------------------
+STORE_SUFFIX = '.store'
+TABLE_NAME = 'table'
+CHUNK_STEM = 'chunk'
+FILE_SUFFIX = '.npz'               # '.hdf' in the reference; the npz twin keeps the same tree
+PRODUCTS_GROUP = '/products'
+
+# root attribute of the table file  <-  attribute of the CubeFitter          (store_spec.rst:60-63)
+FITTER_ATTRS = (
+    ('lnZ_threshold', lambda f: f.lnZ_thresh),
+    ('n_max_components', lambda f: f.ncomp_max),
+    ('multinest_kwargs', lambda f: str(f.mn_kwargs)),
+)
+# root attribute of the table file  <-  module-level name of the model module (store_spec.rst:67-72)
+MODEL_ATTRS = (
+    ('n_params', 'N'),
+    ('model_name', 'NAME'),
+    ('par_names', 'PAR_NAMES'),
+    ('par_names_short', 'PAR_NAMES_SHORT'),
+    ('tex_labels', 'TEX_LABELS'),
+    ('tex_labels_with_units', 'TEX_LABELS_WITH_UNITS'),
+)
+# header groups of the table file  <-  property of the CubeStack              (store_spec.rst:109-110)
+HEADER_GROUPS = (('simple_header', 'simple_header'), ('full_header', 'full_header'))
+
+
 def check_ext(store_name, ext='hdf'):
-    if store_name.endswith(f'.{ext}'):
-        return store_name
-    return f'{store_name}.{ext}'
+    """`store_name` with the extension `ext` (added unless it is there already)."""
+    name, suffix = str(store_name), '.' + ext
+    return name if name.endswith(suffix) else name + suffix
 
 
 class HdfStore:
-    """Same names and behaviour as the reference's ``HdfStore`` (main.py:233-377)."""
-    linked_table = Path('table.npz')
-    chunk_prefix = 'chunk'
-    dpath = '/products'
+    """A `<name>.store` directory: the table file plus one chunk file per stripe, with the reference's
+    entry points (nestfit/main.py:233-377).  `hdf` is the open table (a `StoreFile`)."""
+    dpath = PRODUCTS_GROUP
+    chunk_prefix = CHUNK_STEM
+    linked_table = Path(TABLE_NAME + FILE_SUFFIX)
 
     def __init__(self, store_name, nchunks=1):
         from . import MODELS
         self.store_name = str(store_name)
-        self.store_dir = Path(check_ext(self.store_name, ext='store'))
+        self.store_dir = Path(check_ext(self.store_name, ext=STORE_SUFFIX.lstrip('.')))
         self.store_dir.mkdir(parents=True, exist_ok=True)
         self.hdf = StoreFile(self.store_dir / self.linked_table, 'a')
-        try:
-            self.nchunks = self.hdf.attrs['nchunks']
-        except KeyError:
-            self.hdf.attrs['nchunks'] = nchunks
-            self.nchunks = nchunks
-        try:
-            self.model = MODELS[self.hdf.attrs['model_name']]
-        except KeyError:
-            self.model = None
-        if self.hdf.attrs.get('linked', False):      # links are not stored: rebuild them
+        root = self.hdf.attrs
+        root.setdefault('nchunks', nchunks)          # an existing store keeps its own number of chunks
+        self.nchunks = root['nchunks']
+        self.model = MODELS.get(root.get('model_name'))
+        if root.get('linked', False):                # links live in memory only: rebuild them on opening
             self.link_files()
 
+    # context manager: `with HdfStore(name) as store`
     def __enter__(self):
         return self
 
-    def __exit__(self, exc_type, exc_value, traceback):
+    def __exit__(self, *exc_info):
         self.close()
 
-    @property
-    def chunk_paths(self):
-        return [self.store_dir / Path(f'{self.chunk_prefix}{i}.npz') for i in range(self.nchunks)]
-
+    # ---- files ---------------------------------------------------------------------------------
     @property
     def is_open(self):
         return self.hdf._open
 
-    def close(self):
-        try:
-            self.hdf.flush()
-            self.hdf.close()
-        except ValueError:
-            print('Store HDF already closed.')
+    @property
+    def chunk_paths(self):
+        return [self.store_dir / f'{self.chunk_prefix}{k}{FILE_SUFFIX}' for k in range(self.nchunks)]
 
+    def close(self):
+        if not self.is_open:
+            print(f'{self.store_dir}: already closed')
+            return
+        self.hdf.close()                             # saves, then marks the file closed
+
+    # ---- pixel groups -------------------------------------------------------------------------
     def iter_pix_groups(self):
-        """Every /pix/<i_lon>/<i_lat> group of the (linked) table."""
+        """Every /pix/<i_lon>/<i_lat> group reachable from the table (i.e. after `link_files`)."""
         assert self.is_open
-        pix = self.hdf['/pix']
-        for lon_name in pix:
-            for lat_name in pix[lon_name]:
-                node = pix[lon_name][lat_name]
+        if '/pix' not in self.hdf:
+            return
+        lon_level = self.hdf['/pix']
+        for lon_name in lon_level:
+            for lat_name in lon_level[lon_name]:
+                node = lon_level[lon_name][lat_name]
                 if isinstance(node, Group):
                     yield node
 
     def find_first_valid_group(self):
-        """The one-component run of the first pixel that has one (main.py:297-304)."""
-        assert self.is_open
+        """The one-component run of the first pixel that has one."""
         for group in self.iter_pix_groups():
             if '1' in group:
                 return group['1']
         raise ValueError('No valid pix groups found.')
 
     def link_files(self):
-        """Make every pixel group of every chunk file reachable from the table (the reference
-        inserts h5py.ExternalLink objects, main.py:306-316)."""
+        """Hang the pixel groups of every chunk file under the table's /pix (h5py external links in the
+        reference; object references here)."""
         assert self.is_open
-        for chunk_path in self.chunk_paths:
-            chunk = StoreFile(chunk_path, 'r')
+        for path in self.chunk_paths:
+            if not path.exists():
+                continue
+            chunk = StoreFile(path, 'r')
             if '/pix' not in chunk:
                 continue
             for lon_name in chunk['/pix']:
-                for lat_name in chunk[f'/pix/{lon_name}']:
-                    name = f'/pix/{lon_name}/{lat_name}'
-                    self.hdf[name] = chunk[name]
+                for lat_name in chunk['/pix'][lon_name]:
+                    target = f'/pix/{lon_name}/{lat_name}'
+                    self.hdf[target] = chunk[target]
         self.hdf.attrs['linked'] = True
         self.hdf.flush()
 
@@ -289,42 +319,38 @@ class HdfStore:
         if '/pix' in self.hdf:
             del self.hdf['/pix']
 
+    # ---- metadata -----------------------------------------------------------------------------
     def insert_header(self, stack):
-        """Cube headers as attributes of the groups simple_header / full_header, map size as
-        naxis1 / naxis2 (main.py:323-339)."""
+        """The cube's celestial and full headers as attribute groups, the map size as naxis1 / naxis2."""
         if not self.is_open:
             warnings.warn('Could not insert header: the HDF5 file is closed.', category=RuntimeWarning)
             return
-        for name, header in (('simple_header', stack.simple_header), ('full_header', stack.full_header)):
-            self.hdf.create_group(name).attrs.update(header)
-        self.hdf.attrs['naxis1'], self.hdf.attrs['naxis2'] = stack.shape[0], stack.shape[1]
+        for group_name, prop in HEADER_GROUPS:
+            self.hdf.create_group(group_name).attrs.update(getattr(stack, prop))
+        n_lon, n_lat = stack.shape[:2]
+        self.hdf.attrs.update(naxis1=n_lon, naxis2=n_lat)
 
     def read_header(self, full=True):
         assert self.is_open
-        return dict(self.hdf['full_header' if full else 'simple_header'].attrs)
+        return dict(self.hdf[HEADER_GROUPS[1 if full else 0][0]].attrs)
 
+    def insert_fitter_pars(self, fitter):
+        assert self.is_open
+        self.hdf.attrs.update({name: get(fitter) for name, get in FITTER_ATTRS})
+
+    def insert_model_metadata(self, runner_cls):
+        assert self.is_open
+        module = inspect.getmodule(runner_cls)
+        self.hdf.attrs.update({name: getattr(module, attr) for name, attr in MODEL_ATTRS})
+
+    # ---- products -----------------------------------------------------------------------------
     def create_dataset(self, dset_name, data, group='', clobber=True):
-        """Dataset `group`/`dset_name`; an existing one is replaced (with a warning) when clobber."""
-        assert len(dset_name) > 0
+        """Dataset `group`/`dset_name`; with `clobber` an existing one is replaced (and a warning issued)."""
+        if not dset_name:
+            raise ValueError('a dataset needs a name')
         parent = self.hdf.require_group(group)
-        path = f'{group.rstrip("/")}/{dset_name}'
+        path = '/'.join((group.rstrip('/'), dset_name))
         if clobber and path in self.hdf:
             warnings.warn(f'Deleting dataset "{path}"', RuntimeWarning)
             del self.hdf[path]
         return parent.create_dataset(dset_name, data=data)
-
-    def insert_fitter_pars(self, fitter):
-        assert self.is_open
-        self.hdf.attrs['lnZ_threshold'] = fitter.lnZ_thresh
-        self.hdf.attrs['n_max_components'] = fitter.ncomp_max
-        self.hdf.attrs['multinest_kwargs'] = str(fitter.mn_kwargs)
-
-    def insert_model_metadata(self, runner_cls):
-        module = inspect.getmodule(runner_cls)
-        assert self.is_open
-        self.hdf.attrs['n_params'] = module.N
-        self.hdf.attrs['model_name'] = module.NAME
-        self.hdf.attrs['par_names'] = module.PAR_NAMES
-        self.hdf.attrs['par_names_short'] = module.PAR_NAMES_SHORT
-        self.hdf.attrs['tex_labels'] = module.TEX_LABELS
-        self.hdf.attrs['tex_labels_with_units'] = module.TEX_LABELS_WITH_UNITS

@@ -126,3 +126,46 @@ def test_fit_cube_one_process_per_stripe_gloo(tmp_path):
             gb = b.hdf[ga.name]
             assert ga['1'].attrs['global_lnZ'] == gb['1'].attrs['global_lnZ']
             np.testing.assert_array_equal(ga['1']['posteriors'], gb['1']['posteriors'])
+
+
+def test_masked_beam_pixel_gets_an_nbest_zero_group(tmp_path, capsys):
+    """A pixel whose noise is infinite (masked primary beam, NoiseMap.from_pbimg) has NaN-free data: the
+    reference does not skip it (main.py:437-441 looks for NaNs only) and its flat likelihood ends in
+    nbest = 0.  The driver writes that group without sampling; truncated runs are flagged in the store."""
+    from nestfit_amd.cubeio import NoiseMap
+    stack = _stack(n_lon=3)
+    pb = np.ones((1, 3))                         # FITS order (lat, lon)
+    pb[0, 1] = np.nan                            # the beam response is masked at i_lon = 1
+    nmap = NoiseMap.from_pbimg(NOISE, pb)
+    assert np.isinf(nmap.get_noise(1, 0)) and nmap.get_noise(0, 0) == NOISE
+    for dc in stack.cubes:
+        dc.noise_map = nmap
+    glon, glat = stack.good_pixels()
+    blon, blat = stack.masked_beam_pixels()
+    assert glon.tolist() == [0] and blon.tolist() == [1] and blat.tolist() == [0]     # i_lon = 2 holds the NaN
+    _fitter(stack).fit_cube(str(tmp_path / 'run'), nproc=1)
+    out = capsys.readouterr().out
+    assert '(1, 0) infinite noise: nbest = 0 without sampling' in out and '(2, 0) SKIP: has NaN values' in out
+    with HdfStore(str(tmp_path / 'run')) as store:
+        groups = {(g.attrs['i_lon'], g.attrs['i_lat']): g for g in store.iter_pix_groups()}
+        assert sorted(groups) == [(0, 0), (1, 0)]
+        assert groups[(1, 0)].attrs['nbest'] == 0 and list(groups[(1, 0)]) == []
+        one = groups[(0, 0)]['1']
+        assert one.attrs['truncated'] in (True, False)
+        assert one.attrs['n_samples'] == one['posteriors'].shape[0]
+
+
+def test_truncated_flag_and_default_cap():
+    """A run stopped by its iteration cap before the evidence tolerance is met says so; the host twin and
+    the device sampler share the default cap."""
+    def loglike(pix, U):
+        return -0.5 * np.sum(((U - 0.5) / 0.01) ** 2, axis=1)
+    short = sampler.run_nested(loglike, 2, 1, nlive=50, seed=1, maxiter=30)[0]
+    full = sampler.run_nested(loglike, 2, 1, nlive=50, seed=1)[0]
+    assert short.truncated and short.n_iter == 30
+    assert not full.truncated and full.n_iter < sampler.default_cap_iter(50) == 3000
+    names, q = sampler.marginal_quantile_table()
+    assert names[:3] == ['min', 'p01', 'p10'] and names[-2:] == ['3s_lo', '3s_hi'] and len(names) == q.size == 15
+    assert q[9] == 1.58655254e-1 and q[10] == 0.84134475 and q[13] == 1.34989803e-3 and q[14] == 0.99865010
+    bic, aic, aicc = sampler.information_criteria(2048, 12, -1000.0)
+    assert bic == pytest.approx(np.log(2048) * 12 + 2000) and aic == 2024.0 and aicc == pytest.approx(2024 + 312 / 2035)
