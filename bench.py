@@ -236,6 +236,8 @@ def main():
     import nestfit_amd as na
     from nestfit_amd import _ffi, comm as nfcomm
     na.set_device(0 if same_gpu else local_rank)      # one process per GPU, before any other call
+    if args.ablate and 'NFA_ENGINE_LIB' not in os.environ:
+        raise SystemExit('--ablate needs the test library: NFA_ENGINE_LIB=nestfit_amd/lib/libnestfit_amd_test.so')
     for key, val in (('wpb', args.wpb), ('streams', args.streams), ('ablate', args.ablate)):
         if val:
             _ffi.set_option(key, val)

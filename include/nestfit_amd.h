@@ -223,12 +223,6 @@ int  nfa_broker_loglike(nfa_broker *b, int32_t pix, double *cube, double *lnew);
 void nfa_broker_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx);
 /* out[0] batches launched, out[1] evaluations served, out[2] largest batch */
 int  nfa_broker_stats(nfa_broker *b, int64_t *out);
-/* test / measurement support: n_threads native threads (one per would-be serial sampler, thread
- * k bound to pixel pix[k], NULL = the only pixel) each make n_calls blocking calls on their own
- * rows of U[n_threads][n_calls][ndim] (overwritten); lnL[n_threads][n_calls]; wall time out. */
-int  nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int32_t *pix, double *U,
-                           double *lnL, double *seconds_out);
-
 /* ---- device-resident batched nested sampler --------------------
  * Stand-in for one serial MultiNest run per pixel (run_multinest, nestfit/core/core.pyx:727-823,
  * pixel loop nestfit/main.py:452-469) when libmultinest is absent: all pixels' runs advance in
@@ -299,13 +293,6 @@ int nfa_event_destroy(void *ev);
 int nfa_event_record(void *ev, nfa_runner *r);       /* on the runner's stream */
 int nfa_event_synchronize(void *ev);
 int nfa_event_elapsed_ms(void *start, void *stop, float *ms);
-
-/* ---- unit-test hooks (device evaluation of the scalar building blocks) ---- */
-int nfa_test_fastexp(const double *x, double *out, int64_t n, int mode);    /* fastexp.c:234-283 via math.pxd:17; mode 3: 1 - FastExp(x) of the fast mode */
-int nfa_test_iemtex(const double *x, double *out, int64_t n);               /* hyperfine.pyx:23-45 */
-int nfa_test_partition(const double *trot, double *qpara, double *qorth, int64_t n); /* ammonia.pyx:304-315 */
-int nfa_test_windows(nfa_runner *r, int spec, double voff, double sigm,
-                     int32_t *lo, int32_t *hi);                             /* hyperfine.pyx:70-93 */
 
 #ifdef __cplusplus
 }

@@ -79,7 +79,6 @@ SIGNATURES = {
     'nfa_broker_loglike': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
     'nfa_broker_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
     'nfa_broker_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
-    'nfa_test_broker_storm': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp]),
     'nfa_sampler_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, _ip, C.c_int64, C.c_int, C.c_int,
                                      C.c_int64, C.c_int64, _ip]),
     'nfa_sampler_destroy': (C.c_int, [C.c_void_p]),
@@ -108,13 +107,20 @@ SIGNATURES = {
     'nfa_event_record': (C.c_int, [C.c_void_p, C.c_void_p]),
     'nfa_event_synchronize': (C.c_int, [C.c_void_p]),
     'nfa_event_elapsed_ms': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+# include/nestfit_amd_test.h: only in libnestfit_amd_test.so (the engine built with the unit-test hooks)
+TEST_SIGNATURES = {
     'nfa_test_fastexp': (C.c_int, [_dp, _dp, C.c_int64, C.c_int]),
     'nfa_test_iemtex': (C.c_int, [_dp, _dp, C.c_int64]),
     'nfa_test_partition': (C.c_int, [_dp, _dp, _dp, C.c_int64]),
     'nfa_test_windows': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _ip, _ip]),
+    'nfa_test_broker_storm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp]),
 }
+TEST_LIB_PATH = HERE / 'lib' / 'libnestfit_amd_test.so'
 
 _lib = None
+_test_lib = None
 _tables_installed = False
 
 
@@ -137,9 +143,35 @@ def load():
     return lib
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        raise EngineError(load().nfa_last_error().decode() or f'engine error {rc}')
+        raise EngineError((lib or load()).nfa_last_error().decode() or f'engine error {rc}')
+
+
+def test_engine():
+    """The test library (tests and measurement scripts only): a second instance of the engine with the
+    unit-test hooks of include/nestfit_amd_test.h and the "ablate" option, its tables installed."""
+    global _test_lib
+    if _test_lib is None:
+        if not TEST_LIB_PATH.exists():
+            raise EngineError(f'{TEST_LIB_PATH} is missing: build it with `python -m nestfit_amd.build`')
+        lib = C.CDLL(str(TEST_LIB_PATH))
+        for name, (res, args) in {**SIGNATURES, **TEST_SIGNATURES}.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        t0_x, t0_y = iemtex_tables()
+        check(lib.nfa_set_iemtex_table(dptr(t0_x), dptr(t0_y), t0_x.size), lib)
+        _test_lib = lib
+    return _test_lib
+
+
+def test_check(rc):
+    check(rc, _test_lib)
+
+
+def broker_loglike_address():
+    """Address of the product library's nfa_broker_loglike, for nfa_test_broker_storm."""
+    return C.cast(load().nfa_broker_loglike, C.c_void_p)
 
 
 def dptr(a):

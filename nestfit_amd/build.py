@@ -12,6 +12,10 @@ HERE = Path(__file__).resolve().parent
 SRC = HERE / 'csrc' / 'nfa_engine.hip'
 DEPS = sorted((HERE / 'csrc').glob('*.h*')) + [HERE.parent / 'include' / 'nestfit_amd.h']
 OUT = HERE / 'lib' / 'libnestfit_amd.so'
+# the same engine with the unit-test hooks and the "ablate" timing option compiled in: tests and
+# measurement scripts only (include/nestfit_amd_test.h); the product library has neither
+OUT_TEST = HERE / 'lib' / 'libnestfit_amd_test.so'
+TEST_FLAGS = ['-DNFA_TEST_HOOKS', '-DNFA_ABLATE']
 
 FLAGS = [
     '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared',
@@ -23,26 +27,35 @@ FLAGS = [
 ]
 
 
-def needs_build():
-    if not OUT.exists():
+def needs_build(out=OUT):
+    if not out.exists():
         return True
-    t = OUT.stat().st_mtime
+    t = out.stat().st_mtime
     return any(d.stat().st_mtime > t for d in DEPS)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
-        return OUT
-    OUT.parent.mkdir(exist_ok=True)
+def _compile(out, flags, verbose):
+    out.parent.mkdir(exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + list(extra) + ['-o', str(OUT), str(SRC)]
+    cmd = [hipcc] + FLAGS + list(flags) + ['-o', str(out), str(SRC)]
     if verbose:
         print(' '.join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
-    if verbose and res.stderr:
-        print(res.stderr)
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def build(force=False, verbose=False, extra=(), test_lib=True):
+    """Compile the product library and (test_lib) the test library, side by side."""
+    jobs = []
+    if force or needs_build(OUT):
+        jobs.append((OUT, _compile(OUT, extra, verbose)))
+    if test_lib and (force or needs_build(OUT_TEST)):
+        jobs.append((OUT_TEST, _compile(OUT_TEST, list(extra) + TEST_FLAGS, verbose)))
+    for out, proc in jobs:
+        text, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {out.name}:\n' + text)
+        if verbose and text:
+            print(text)
     return OUT
 
 

@@ -146,29 +146,4 @@ int nfa_broker_stats(nfa_broker *b, int64_t *out) {
     return NFA_OK;
 }
 
-// Measurement / test support: n_threads native threads, each a stand-in for one serial sampler,
-// make n_calls blocking nfa_broker_loglike calls on their own rows of U[n_threads][n_calls][ndim]
-// (overwritten with theta); lnL[n_threads][n_calls].  Returns the wall time in *seconds_out.
-int nfa_test_broker_storm(nfa_broker *b, int n_threads, int n_calls, const int32_t *pix, double *U,
-                          double *lnL, double *seconds_out) {
-    if (!b || !U || !lnL || n_threads < 1 || n_calls < 1) return fail(NFA_ERR_ARG, "bad argument");
-    const int ndim = b->r->ndim;
-    std::vector<std::thread> th;
-    std::vector<int> rcs((size_t)n_threads, NFA_OK);
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < n_threads; ++k)
-        th.emplace_back([=, &rcs] {
-            for (int j = 0; j < n_calls; ++j) {
-                const size_t row = (size_t)k * n_calls + j;
-                const int rc = nfa_broker_loglike(b, pix ? pix[k] : -1, U + row * ndim, lnL + row);
-                if (rc != NFA_OK) rcs[k] = rc;
-            }
-        });
-    for (auto &t : th) t.join();
-    if (seconds_out)
-        *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (int rc : rcs) if (rc != NFA_OK) return rc;
-    return NFA_OK;
-}
-
 }  // extern "C"

@@ -713,59 +713,3 @@ __global__ void null_lnz_kernel(SpecDev S, long n_pix, double *__restrict__ out)
     const double noise = S.noise[p * S.n_spec + s];
     if (lane == 0) out[w] = -acc / (2 * (noise * noise));
 }
-
-// ---------------------------------------------------------------------------
-//  unit-test kernels (device evaluation of the scalar building blocks)
-// ---------------------------------------------------------------------------
-template <int MODE>
-__global__ void test_fastexp_kernel(const double *x, double *out, long n, const double *g_tabs) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    int n_shared;
-    const double *sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ((n + 63) & ~63L);
-         i += (long)gridDim.x * blockDim.x) {
-        const double xi = i < n ? x[i] : 1.0;
-        double v;
-        if (MODE == 2) v = (double)exp_neg_f32((float)xi);
-        else v = nf_fastexp<MODE == 2 ? 1 : MODE>(xi, sm);
-        if (i < n) out[i] = v;
-    }
-}
-
-// 1 - FastExp(tau) as the fast mode evaluates it
-__global__ void test_one_minus_fastexp_kernel(const double *x, double *out, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = one_minus_fastexp_f32((float)x[i]);
-}
-
-__global__ void test_iemtex_kernel(const double *x, double *out, long n, const double *g_tabs,
-                                   double xmin, double xmax, double inv_dx) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long)gridDim.x * blockDim.x)
-        out[i] = nf_iemtex(x[i], g_tabs + SM_T0X, g_tabs + SM_T0Y, xmin, xmax, inv_dx);
-}
-
-template <int MODE>
-__global__ void test_partition_kernel(const double *trot, double *qpara, double *qorth, long n,
-                                      const double *g_tabs) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    int n_shared;
-    const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
-    const int lane = threadIdx.x & 63;
-    const long w = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (w >= n) return;
-    double lev = 0.0;
-    if (lane < NFA_NPART) lev = nf_partition_level<MODE>(lane, trot[w], sm);
-    const bool is_orth = (lane % 3) == 0;
-    const double qp = wave_sum((lane < NFA_NPART && !is_orth) ? lev : 0.0);
-    const double qo = wave_sum((lane < NFA_NPART && is_orth) ? 2 * lev : 0.0);
-    if (lane == 0) { qpara[w] = qp; qorth[w] = qo; }
-}
-
-__global__ void test_windows_kernel(SpecDev S, int s, double voff, double sigm, int *lo, int *hi) {
-    const int t = S.trans[s] - 1, i = threadIdx.x;
-    if (i >= c_nhf[t]) return;
-    const LineConst lc = nf_line(t, i, voff / NFA_CKMS, sigm / NFA_CKMS, S.rest[s], S.nu_min[s], S.nu_chan[s],
-                                 S.size[s]);
-    lo[i] = lc.lo; hi[i] = lc.hi;
-}

@@ -945,96 +945,11 @@ int nfa_event_elapsed_ms(void *start, void *stop, float *ms) {
     HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop)); return NFA_OK;
 }
 
-// ---- unit-test hooks ---------------------------------------------------------
-int nfa_test_fastexp(const double *x, double *out, int64_t n, int mode) {
-    int rc = engine_init(); if (rc) return rc;
-    if (n <= 0) return NFA_OK;
-    double *dx = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&dx, sizeof(double) * n));
-    HIP_TRY(hipMalloc(&dout, sizeof(double) * n));
-    HIP_TRY(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
-    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
-    if (mode == 0) {
-        const size_t lds = sizeof(double) * (SM_END_TABLE - SM_EXP2);
-        HIP_TRY(hipFuncSetAttribute((const void *)test_fastexp_kernel<0>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(test_fastexp_kernel<0>, dim3(blocks), dim3(256), lds, 0, dx, dout, (long)n,
-                           (const double *)g_eng.d_tabs);
-    } else if (mode == 1) {
-        hipLaunchKernelGGL(test_fastexp_kernel<1>, dim3(blocks), dim3(256), sizeof(double) * 32, 0,
-                           dx, dout, (long)n, (const double *)g_eng.d_tabs);
-    } else if (mode == 2) {
-        hipLaunchKernelGGL(test_fastexp_kernel<2>, dim3(blocks), dim3(256), sizeof(double) * 32, 0,
-                           dx, dout, (long)n, (const double *)g_eng.d_tabs);
-    } else {   // 3: 1 - FastExp(x) as the fast mode's Tb pass evaluates it
-        hipLaunchKernelGGL(test_one_minus_fastexp_kernel, dim3(blocks), dim3(256), 0, 0, dx, dout, (long)n);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dout);
-    return NFA_OK;
-}
-
-int nfa_test_iemtex(const double *x, double *out, int64_t n) {
-    int rc = engine_init(); if (rc) return rc;
-    if (!g_eng.have_t0) return fail(NFA_ERR_STATE, "nfa_set_iemtex_table has not been called");
-    if (n <= 0) return NFA_OK;
-    double *dx = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&dx, sizeof(double) * n));
-    HIP_TRY(hipMalloc(&dout, sizeof(double) * n));
-    HIP_TRY(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
-    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(test_iemtex_kernel, dim3(blocks), dim3(256), 0, 0, dx, dout,
-                       (long)n, (const double *)g_eng.d_tabs, g_eng.t0_xmin, g_eng.t0_xmax, g_eng.t0_inv_dx);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dout);
-    return NFA_OK;
-}
-
-int nfa_test_partition(const double *trot, double *qpara, double *qorth, int64_t n) {
-    int rc = engine_init(); if (rc) return rc;
-    if (n <= 0) return NFA_OK;
-    double *dt = nullptr, *dp = nullptr, *dq = nullptr;
-    HIP_TRY(hipMalloc(&dt, sizeof(double) * n));
-    HIP_TRY(hipMalloc(&dp, sizeof(double) * n));
-    HIP_TRY(hipMalloc(&dq, sizeof(double) * n));
-    HIP_TRY(hipMemcpy(dt, trot, sizeof(double) * n, hipMemcpyHostToDevice));
-    const unsigned blocks = (unsigned)((n * 64 + 255) / 256);
-    if (g_eng.exp_mode == 0) {
-        const size_t lds = sizeof(double) * (SM_END_TABLE - SM_EXP2);
-        HIP_TRY(hipFuncSetAttribute((const void *)test_partition_kernel<0>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(test_partition_kernel<0>, dim3(blocks), dim3(256), lds, 0, dt, dp, dq, (long)n,
-                           (const double *)g_eng.d_tabs);
-    } else {
-        hipLaunchKernelGGL(test_partition_kernel<1>, dim3(blocks), dim3(256), sizeof(double) * 32, 0,
-                           dt, dp, dq, (long)n, (const double *)g_eng.d_tabs);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(qpara, dp, sizeof(double) * n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(qorth, dq, sizeof(double) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(dt); (void)hipFree(dp); (void)hipFree(dq);
-    return NFA_OK;
-}
-
-int nfa_test_windows(nfa_runner *r, int spec, double voff, double sigm, int32_t *lo, int32_t *hi) {
-    if (!r || spec < 0 || spec >= r->ss->dev.n_spec) return fail(NFA_ERR_ARG, "bad spectrum index");
-    int *dl = nullptr, *dh = nullptr;
-    const int tg = r->ss->dev.trans[spec] - 1;          // index into the combined tables
-    const int nhf = tg < NFA_T_N2HP ? nfa_nhf[tg] : tg < NFA_T_GAUSS ? nfa_n2hp_nhf[tg - NFA_T_N2HP] : 1;
-    HIP_TRY(hipMalloc(&dl, sizeof(int) * 64));
-    HIP_TRY(hipMalloc(&dh, sizeof(int) * 64));
-    hipLaunchKernelGGL(test_windows_kernel, dim3(1), dim3(64), 0, 0, r->ss->dev, spec, voff, sigm, dl, dh);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(lo, dl, sizeof(int) * nhf, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hi, dh, sizeof(int) * nhf, hipMemcpyDeviceToHost));
-    (void)hipFree(dl); (void)hipFree(dh);
-    return NFA_OK;
-}
-
 }  // extern "C"
 
 #include "nfa_broker.h"
 #include "nfa_sampler.h"
 #include "nfa_comm.h"
+#ifdef NFA_TEST_HOOKS
+#include "nfa_testhooks.h"      // libnestfit_amd_test.so only
+#endif

@@ -59,7 +59,7 @@ def main():
         U = rng.uniform(size=(n_threads, n_calls, run.ndim))
         lnL = np.empty((n_threads, n_calls))
         sec = C.c_double()
-        _ffi.check(_ffi.load().nfa_test_broker_storm(broker.handle, n_threads, n_calls, None, _ffi.dptr(U),
+        _ffi.test_check(_ffi.test_engine().nfa_test_broker_storm(broker.handle, _ffi.broker_loglike_address(), n_threads, n_calls, None, _ffi.dptr(U),
                                                      _ffi.dptr(lnL), C.byref(sec)))
         st = broker.stats()
         print(f'native {n_threads:4d} threads: {n_threads*n_calls/sec.value/1e3:8.1f} k evals/s, '

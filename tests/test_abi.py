@@ -9,10 +9,10 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _declared():
-    text = (ROOT / 'include' / 'nestfit_amd.h').read_text()
+def _declared(header='nestfit_amd.h'):
+    text = (ROOT / 'include' / header).read_text()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(nfa_[a-z0-9_]+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(nfa_[a-z0-9_]+)\s*\(', text)) - {'nfa_broker_loglike_fn'})
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,6 +24,23 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in include/nestfit_amd.h but not exported'
     assert sorted(_ffi.SIGNATURES) == names
     assert lib.nfa_version() >= 100
+
+
+def test_test_hooks_live_in_the_test_library_only():
+    """include/nestfit_amd_test.h is what libnestfit_amd_test.so adds; the product library exports none of
+    it (no unit-test hooks, no timing ablation in what ships)."""
+    import ctypes as C
+    from nestfit_amd import _ffi
+    product = _ffi.load()
+    hooks = _declared('nestfit_amd_test.h')
+    assert sorted(_ffi.TEST_SIGNATURES) == hooks and len(hooks) == 5
+    test_lib = C.CDLL(str(_ffi.TEST_LIB_PATH))
+    for n in hooks:
+        assert hasattr(test_lib, n), f'{n} declared in include/nestfit_amd_test.h but not exported'
+        assert not hasattr(product, n), f'{n} must not be in the product library'
+    for n in _declared():
+        assert hasattr(test_lib, n)                       # the test library is the whole engine plus the hooks
+    assert product.nfa_set_option(b'ablate', 1) != 0      # the shipped library rejects the timing experiment key
 
 
 def test_product_fails_loudly_without_gpu():

@@ -41,7 +41,7 @@ def _test_fastexp(engine, x, mode):
     from nestfit_amd import _ffi
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.empty_like(x)
-    _ffi.check(_ffi.engine().nfa_test_fastexp(_ffi.dptr(x), _ffi.dptr(out), x.size,
+    _ffi.test_check(_ffi.test_engine().nfa_test_fastexp(_ffi.dptr(x), _ffi.dptr(out), x.size,
                                               {'table': 0, 'poly': 1, 'fast': 2, '1m': 3}[mode]))
     return out
 
@@ -105,21 +105,21 @@ def test_fastexp_fast_mode(engine, nfo):
 
 def test_iemtex_and_partition(engine, nfo):
     from nestfit_amd import _ffi
-    lib = _ffi.engine()
+    lib = _ffi.test_engine()                     # the hooks live in the test library (its own engine instance)
     lo, hi = nfo.lib().nfo_t0_xmin(), nfo.lib().nfo_t0_xmax()
     x = np.concatenate([np.linspace(0.05, 1.0, 2000), [lo, hi, np.nextafter(lo, 1), np.nextafter(hi, 0)],
                         np.random.default_rng(3).uniform(lo, hi, 20000)])
     out = np.empty_like(x)
-    _ffi.check(lib.nfa_test_iemtex(_ffi.dptr(x), _ffi.dptr(out), x.size))
+    _ffi.test_check(lib.nfa_test_iemtex(_ffi.dptr(x), _ffi.dptr(out), x.size))
     want = nfo.iemtex_interp(x)
     inside = (x > lo) & (x < hi)
     assert np.array_equal(out[inside].view(np.uint64), want[inside].view(np.uint64))  # same index, same lerp
     np.testing.assert_allclose(out[~inside], want[~inside], rtol=1e-15)               # expm1 branch
     for mode in ('table', 'poly'):
-        engine.set_exp_mode(mode)
+        _ffi.test_check(lib.nfa_set_exp_mode({'table': 0, 'poly': 1}[mode]))
         trot = np.concatenate([np.linspace(3, 300, 500), [2.0, 7.0, 1000.0]])
         qp, qo = np.empty_like(trot), np.empty_like(trot)
-        _ffi.check(lib.nfa_test_partition(_ffi.dptr(trot), _ffi.dptr(qp), _ffi.dptr(qo), trot.size))
+        _ffi.test_check(lib.nfa_test_partition(_ffi.dptr(trot), _ffi.dptr(qp), _ffi.dptr(qo), trot.size))
         np.testing.assert_allclose(qp, [nfo.partition_func(True, t) for t in trot], rtol=1e-14)
         np.testing.assert_allclose(qo, [nfo.partition_func(False, t) for t in trot], rtol=1e-14)
 
@@ -140,7 +140,7 @@ def test_hyperfine_window_indices_bit_exact(engine, nfo):
                 sigm = 10 ** rng.uniform(-2.5, 0.5)
                 lo = np.zeros(64, dtype=np.int32)
                 hi = np.zeros(64, dtype=np.int32)
-                _ffi.check(_ffi.load().nfa_test_windows(run.handle, 0, voff, sigm,
+                _ffi.test_check(_ffi.test_engine().nfa_test_windows(run.handle, 0, voff, sigm,
                                                         lo.ctypes.data_as(_ffi._ip),
                                                         hi.ctypes.data_as(_ffi._ip)))
                 clo, chi = s_cpu.hf_windows(voff, sigm)

@@ -158,7 +158,7 @@ def test_n2hp_window_indices_bit_exact(engine, nfo, mode_guard):
                 voff, sigm = rng.uniform(-25, 25), 10 ** rng.uniform(-2, 0.5)
                 lo = np.zeros(64, dtype=np.int32)
                 hi = np.zeros(64, dtype=np.int32)
-                _ffi.check(_ffi.load().nfa_test_windows(run.handle, 0, voff, sigm,
+                _ffi.test_check(_ffi.test_engine().nfa_test_windows(run.handle, 0, voff, sigm,
                                                         lo.ctypes.data_as(_ffi._ip),
                                                         hi.ctypes.data_as(_ffi._ip)))
                 clo, chi = sc.hf_windows(voff, sigm)
