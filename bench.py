@@ -378,15 +378,32 @@ def main():
         roof['pipeline'] = {'us_per_step': step_s * 1e6, 'achieved': pipe, 'frac': pipe / (HBM_PEAK_GBS * world),
                             'note': 'the same bytes / the time per step of the timed blocks (stream lanes overlap the '
                                     'launches): the rate the job sustains, a hard bound on the kernel'}
-        for name, key in (('pmc_lnl_fast.json', 'valu'), ('pmc_traffic.json', 'traffic_detail')):
-            f = PROFILE_DIR / name
-            if f.exists():
-                try:
-                    roof[key] = json.loads(f.read_text())
-                except Exception:
-                    pass
-        if isinstance(roof.get('traffic_detail'), dict):
-            roof['traffic'] = roof['traffic_detail'].get('bytes_per_launch')
+        # figures that need their own profiler passes come from the committed summaries of the round
+        try:
+            pmc = json.loads((PROFILE_DIR / 'pmc_lnl_fast.json').read_text())
+            roof['valu'] = {'busy_frac_one_lane': pmc.get('valu_busy_frac'),
+                            'valu_instructions_per_eval': pmc['instructions_per_eval'].get('valu'),
+                            'salu_instructions_per_eval': pmc['instructions_per_eval'].get('salu'),
+                            'source': 'profiles/r02/pmc_lnl_fast.json (rocprofv3 --pmc passes of bench.py --streams 1)'}
+        except Exception:
+            pass
+        try:
+            tr = json.loads((PROFILE_DIR / 'pmc_traffic.json').read_text())
+            key = 'pixel_per_item' if per_row else 'one_pixel'
+            roof['traffic'] = tr['detail'][args.exp_mode][key]['total_bytes'] if args.workload == 'C2' and B == 4096 else None
+            roof['traffic_source'] = 'profiles/r02/pmc_traffic.json (FETCH_SIZE x calibration + WRITE_SIZE, separate passes)'
+        except Exception:
+            pass
+        try:
+            import csv
+            with open(PROFILE_DIR / 'onelane_kernel_stats.csv') as f:
+                for row in csv.DictReader(f):
+                    if row['Name'].startswith('void lnl_kernel<2, false, false, 2>') and args.workload == 'C2' and B == 4096:
+                        us = float(row['AverageNs']) * 1e-3
+                        roof['rocprof_avg_launch_us'] = us
+                        roof['rocprof_frac'] = bytes_eval * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        except Exception:
+            pass
         roof['note'] = ('achieved / frac: algorithmic bytes (SURVEY 8d) per launch / lnl_kernel time per launch, HIP events on a '
                         'one-lane runner after the timed blocks; `rocprof` names the committed summary of the one-lane command '
                         'whose average agrees. The kernel is VALU bound: `valu` = busy fraction of the vector ALUs from '

@@ -649,19 +649,22 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
     }
     flush_empty((n_rows - 1) & ~63);
     acc = wave_sum(acc);
-    if (lane == 0 && part) {
-        const double noise = S.noise[p_ix * nspec + s];
-        part[unit] = -acc / (2 * (noise * noise));                // core.pyx:530
-    }
+    if (lane == 0 && part) part[unit] = acc;                       // sum of squared deviations; lnl_sum_kernel scales it
 }
 
-// lnL[b] = sum over the spectra of the item, in order (ammonia.pyx:425-432)
-__global__ void lnl_sum_kernel(const double *__restrict__ part, double *__restrict__ lnL, long B, int nspec) {
+// lnL[b] = sum over the spectra of the item, in order (ammonia.pyx:425-432), of -chi2_s / (2 noise_s^2)
+// (core.pyx:530).  The division happens here, lanes = items, instead of once per likelihood wave.
+__global__ void lnl_sum_kernel(const double *__restrict__ part, const double *__restrict__ noise,
+                               const int *__restrict__ pix, double *__restrict__ lnL, long B, int nspec) {
     __builtin_amdgcn_s_setprio(3);
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const long p_ix = pix ? (long)pix[b] : 0;
     double tot = 0.0;
-    for (int s = 0; s < nspec; ++s) tot += part[b * nspec + s];
+    for (int s = 0; s < nspec; ++s) {
+        const double sigma = noise[p_ix * nspec + s];
+        tot += -part[b * nspec + s] / (2 * (sigma * sigma));
+    }
     lnL[b] = tot;
 }
 

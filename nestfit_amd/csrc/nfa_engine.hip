@@ -656,7 +656,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     if (r->ev_after_lnl) { HIP_TRY(hipEventRecord(r->ev_after_lnl, st)); r->ev_after_lnl = nullptr; }
     if (d_lnL) {
         hipLaunchKernelGGL(lnl_sum_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st,
-                           (const double *)r->d_part[slot], d_lnL, (long)B, S.n_spec);
+                           (const double *)r->d_part[slot], S.noise, d_pix, d_lnL, (long)B, S.n_spec);
         HIP_TRY(hipGetLastError());
     }
     return NFA_OK;
