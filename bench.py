@@ -215,6 +215,7 @@ def main():
     ap.add_argument('--modes', default='all', choices=['all', 'one'], help='time all three numerical modes or only --exp-mode')
     ap.add_argument('--wpb', type=int, default=0, help='engine A/B knob: waves per workgroup (0 = default)')
     ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
+    ap.add_argument('--lnl-split', type=int, default=-1, help='engine A/B knob: waves per (item, spectrum) unit (0 = by launch size)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
     ap.add_argument('--ablate', type=int, default=0, help='timing experiment with the -DNFA_ABLATE build (INVALID results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -243,6 +244,8 @@ def main():
             _ffi.set_option(key, val)
     if args.lnl_cap >= 0:
         _ffi.set_option('lnl_cap', args.lnl_cap)
+    if args.lnl_split >= 0:
+        _ffi.set_option('lnl_split', args.lnl_split)
     lib = _ffi.engine()
     if world == 1:
         comm = nfcomm.SoloComm()
@@ -305,8 +308,8 @@ def main():
             for k in range(args.warmup, n_steps):
                 step(handle, k)
             sync(handle)
+            out.append(time.perf_counter() - t0)     # this rank's K steps; the block is the slowest rank's
             comm.barrier()
-            out.append(time.perf_counter() - t0)
         return comm.allreduce(np.array(out), 'max')
 
     def one_lane_kernel_times():

@@ -54,6 +54,13 @@ int nfa_get_exp_mode(void);
  *   "wpb"           waves per workgroup of the likelihood kernel (1..16, default 4), and
  *   "wpb_table"     the same in table mode (0 = chosen per spectra set, the default): both are
  *                   taken over by runners created afterwards;
+ *   "lnl_split"     waves that share one (item, spectrum) unit of the likelihood kernel, each taking every
+ *                   split-th row of 64 channels: 1 (default), 2, 4, 8, or 0 = chosen per launch (up to 8 for
+ *                   single points, 1 for batches that fill the GPU's wave slots several times).  More, shorter
+ *                   waves balance a small launch better (a lone 4096-row batch: -20 % kernel time with 2) at
+ *                   ~5 % more instructions; the parts of a unit are summed in their own order, so log-
+ *                   likelihoods then differ at the 1e-16 level from the default's, whose results are bitwise
+ *                   independent of the batch an evaluation travels in;
  *   "lnl_cap"       workgroups of the likelihood kernel resident per CU at most (fast and poly mode,
  *                   0 = no cap, the default; 1..8): A/B knob, see DESIGN.md;
  *   "streams"       number of HIP streams ("lanes", 1..8, default 4) that runners created

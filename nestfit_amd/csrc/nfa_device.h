@@ -108,6 +108,7 @@ struct LnlGeom {
     int nhf_max;       // lines per component slot in the LDS line table
     int wave_doubles;  // LDS doubles per wave
     unsigned inv_nspec; // floor(2^32 / nspec) + 1: unit / nspec = mulhi(unit, inv_nspec) for unit < 2^28; 0: nspec == 1
+    int split;          // waves that share one (item, spectrum) unit, each taking every split-th row (1, 2, 4, 8)
     int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 4 skip rows, 8 skip line set-up
 };
 
@@ -441,16 +442,26 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ncomp = NCOMP > 0 ? NCOMP : S.ncomp, nspec = S.n_spec;
     const int drec = drec_size(ncomp, nspec);
-    LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)wave * G.wave_doubles);
 
-    // one unit per wave; the grid covers them all (the host keeps B * nspec below 2^28).  Waves of a
-    // workgroup land on the SIMDs of a CU in order, so the unit -> wave assignment is rotated per
+    // One unit per wave, or `split` waves per unit (small launches: more, shorter waves than wave slots, so
+    // that the hardware places them as slots free up; the waves of a unit share its line table and take
+    // every split-th row).  The grid covers all units (the host keeps B * nspec * split below 2^28).  Waves
+    // of a workgroup land on the SIMDs of a CU in order, so the unit -> wave assignment is rotated per
     // workgroup: otherwise one SIMD would only ever see the spectrum with the most hyperfine lines.
+    const int split = G.split;
     const unsigned units = (unsigned)B * (unsigned)nspec;
     const unsigned rot = __builtin_amdgcn_readfirstlane((blockIdx.x * 0x9E3779B1u) >> 28);
-    const unsigned wsel = (unsigned)wave + rot;
-    const unsigned unit = blockIdx.x * (unsigned)waves + (waves == 4 ? (wsel & 3u) : wsel % (unsigned)waves);
-    if (unit >= units) return;
+    const unsigned wsel0 = (unsigned)wave + rot;
+    const unsigned wsel = waves == 4 ? (wsel0 & 3u) : wsel0 % (unsigned)waves;
+    const unsigned upw = (unsigned)(waves / split);                 // units per workgroup
+    const unsigned ulocal = split == 1 ? wsel : wsel / (unsigned)split;
+    const int rpart = split == 1 ? 0 : (int)(wsel - ulocal * (unsigned)split);
+    const unsigned unit = blockIdx.x * upw + ulocal;
+    LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)ulocal * G.wave_doubles);
+    if (unit >= units) {
+        if (split > 1) __syncthreads();                              // the barrier behind the line set-up below
+        return;
+    }
     const unsigned bu = G.inv_nspec ? __umulhi(unit, G.inv_nspec) : unit;      // unit / nspec without a division
     const long b = (long)bu;
     const int s = (int)(unit - bu * (unsigned)nspec);
@@ -461,7 +472,7 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
     const double *xs = S.xarr + off;
     const k_dbl_p Dk = (k_dbl_p)(D + b * drec);                    // the item's record: scalar loads
     // --- line constants + windows, lanes = (component, line) pairs (hyperfine.pyx:68-91)
-    for (int p = lane; p < ncomp * G.nhf_max && !(ablate & 8); p += 64) {
+    for (int p = lane; p < ncomp * G.nhf_max && !(ablate & 8) && rpart == 0; p += 64) {
         const int c = p / G.nhf_max, i = p - c * G.nhf_max;
         LineRec rec;
         rec.nucen = 0.0; rec.idenom = 0.0; rec.htau = 0.0; rec.lo = 0; rec.len = 0;   // slots beyond the last line
@@ -488,7 +499,7 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
         }
         w_line[p] = rec;
     }
-    wave_lds_sync();
+    if (split > 1) __syncthreads(); else wave_lds_sync();
     // windows [lo, hi) of the lines of each component, lane = line (an empty window is [0, 0):
     // it fails `hi > r0` for every row), and the component's constants of the Tb pass
     int wlo[NC], whi[NC];
@@ -526,7 +537,7 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
         empt = 0ull;
     };
     const int n_rows = (ablate & 4) ? 0 : (N + 63) >> 6;
-    for (int row = 0; row < n_rows; ++row) {
+    for (int row = rpart; row < n_rows; row += split) {
         const int r0 = row << 6;
         const int j = r0 + lane;
         // lines of each component that touch this row
@@ -645,17 +656,19 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
             }
         }
         if (!any) empt |= 1ull << (row & 63);
-        if ((row & 63) == 63) flush_empty(row & ~63);
+        if (((row + split) >> 6) != (row >> 6)) flush_empty(row & ~63);      // the wave's last row of this block of 64
     }
     flush_empty((n_rows - 1) & ~63);
     acc = wave_sum(acc);
-    if (lane == 0 && part) part[unit] = acc;                       // sum of squared deviations; lnl_sum_kernel scales it
+    // sum of squared deviations of the wave's rows; lnl_sum_kernel scales and adds
+    if (lane == 0 && part) part[(long)unit * split + rpart] = acc;
 }
 
 // lnL[b] = sum over the spectra of the item, in order (ammonia.pyx:425-432), of -chi2_s / (2 noise_s^2)
 // (core.pyx:530).  The division happens here, lanes = items, instead of once per likelihood wave.
 __global__ void lnl_sum_kernel(const double *__restrict__ part, const double *__restrict__ noise,
-                               const int *__restrict__ pix, double *__restrict__ lnL, long B, int nspec) {
+                               const int *__restrict__ pix, double *__restrict__ lnL, long B, int nspec,
+                               int split) {
     __builtin_amdgcn_s_setprio(3);
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -663,7 +676,9 @@ __global__ void lnl_sum_kernel(const double *__restrict__ part, const double *__
     double tot = 0.0;
     for (int s = 0; s < nspec; ++s) {
         const double sigma = noise[p_ix * nspec + s];
-        tot += -part[b * nspec + s] / (2 * (sigma * sigma));
+        double chi2 = 0.0;
+        for (int h = 0; h < split; ++h) chi2 += part[(b * nspec + s) * split + h];      // the unit's row parts, in order
+        tot += -chi2 / (2 * (sigma * sigma));
     }
     lnL[b] = tot;
 }

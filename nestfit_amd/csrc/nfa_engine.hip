@@ -45,6 +45,11 @@ struct Engine {
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
     int    wpb = 4;                  // waves per workgroup of the likelihood kernel
     int    wpb_table = 0;            // the same in table mode; 0 = chosen per spectra set (launch_lnl_t)
+    int    lnl_split = 1;            // waves per (item, spectrum) unit of the likelihood kernel (1 / 2 / 4 / 8), or
+                                     // 0 = by launch size (launch_lnl_t).  Opt-in: the row parts of a unit are summed
+                                     // in their own order, so a result then depends (at the 1e-16 level) on the split
+                                     // -- with 0 on the batch size -- and the default keeps every evaluation bitwise
+                                     // independent of the batch it travels in (the sampler twin relies on that)
     int    lnl_cap = 0;              // fast / poly mode: workgroups of the likelihood kernel resident per CU at most
                                      // (LDS padding; 0 = no cap).  A/B knob: leaving one slot per CU to the set-up
                                      // kernels of the next batch paid off (+7 %) until those kernels got a raised wave
@@ -158,7 +163,7 @@ struct nfa_runner {
     // numerical mode: -1 = the process default at call time (nfa_set_exp_mode), 0..2 = pinned to
     // this runner (nfa_runner_set_exp_mode): runners of different modes may then work side by side
     int exp_mode = -1;
-    int wpb = 4, wpb_table = 0, lnl_cap = 0;   // launch geometry, taken from the process options at creation
+    int wpb = 4, wpb_table = 0, lnl_cap = 0, lnl_split = 1;   // launch geometry, taken from the process options at creation
     // Stream lanes: consecutive batches go to different HIP streams (round robin), so the
     // tail of one batch (few workgroups left, SIMDs draining) overlaps the start of the
     // next; inside a lane the set-up kernel and the likelihood kernel run in order and own
@@ -226,6 +231,7 @@ int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "lnl_cap") && value >= 0 && value <= 8) { g_eng.lnl_cap = value; return NFA_OK; }
+    if (key && !strcmp(key, "lnl_split") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_eng.lnl_split = value; return NFA_OK; }
     if (key && !strcmp(key, "graph") && (value == 0 || value == 1)) { g_eng.graph = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
@@ -518,7 +524,7 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors, int
     r->ss = ss; r->pr = priors; r->ncomp = ncomp; r->cold = cold ? 1 : 0; r->lte = lte ? 1 : 0;
     r->ndim = ss->dev.npar * ncomp;
     r->n_lanes = std::max(1, std::min(g_eng.streams, NFA_MAX_LANES));
-    r->wpb = g_eng.wpb; r->wpb_table = g_eng.wpb_table; r->lnl_cap = g_eng.lnl_cap;
+    r->wpb = g_eng.wpb; r->wpb_table = g_eng.wpb_table; r->lnl_cap = g_eng.lnl_cap; r->lnl_split = g_eng.lnl_split;
     for (int k = 0; k < r->n_lanes; ++k) HIP_TRY(hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking));
     r->stream = r->lanes[0];
     *out = r;
@@ -589,7 +595,7 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
         r->d_D[slot] = nullptr; r->d_part[slot] = nullptr; r->cap_D[slot] = 0;
         const int64_t cap = std::max<int64_t>(B, 4096);
         HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec));
-        HIP_TRY(hipMalloc(&r->d_part[slot], sizeof(double) * cap * S.n_spec));
+        HIP_TRY(hipMalloc(&r->d_part[slot], sizeof(double) * cap * S.n_spec * 8));      // up to 8 row parts per unit
         r->cap_D[slot] = cap;
     }
     if (has_prior && !r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
@@ -618,7 +624,20 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     G.ablate = g_eng.ablate;
     G.nhf_max = r->ss->nhf_max;
     G.inv_nspec = S.n_spec == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)S.n_spec) + 1u;
-    if (B * S.n_spec >= (1LL << 28)) return fail(NFA_ERR_ARG, "batch too large for one launch");
+    if (B * S.n_spec * 8 >= (1LL << 28)) return fail(NFA_ERR_ARG, "batch too large for one launch");
+    // Waves per unit.  A launch with fewer units than a few per wave slot is latency bound: its waves are
+    // placed once and every SIMD waits for its own longest; splitting the rows of a unit over 2 .. 8 waves
+    // gives the hardware shorter waves to place as slots free up (a single point: 2 units -> 16 waves).
+    int split = r->lnl_split;
+    if (split == 0) {
+        const int64_t slots = (int64_t)g_eng.n_cu * 32;
+        split = 1;
+        while (split < 8 && B * S.n_spec * split * 4 <= slots) split *= 2;
+    }
+    int min_rows = 1 << 30;
+    for (int k = 0; k < S.n_spec; ++k) min_rows = std::min(min_rows, (S.size[k] + 63) / 64);
+    while (split > 1 && split > min_rows) split /= 2;
+    G.split = split;
     // LDS per wave: the line table of one spectrum (32-byte records, nhf_max per component)
     G.wave_doubles = r->ncomp * G.nhf_max * (int)(sizeof(LineRec) / sizeof(double));
     const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
@@ -626,7 +645,10 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     // workgroup is made as fat as keeps the most waves resident per CU (ties: more workgroups,
     // so that one stages while another computes).
     int waves = std::max(1, std::min(r->wpb, 16));
-    if (MODE == 0) {
+    waves = std::max(waves, split);
+    waves -= waves % split;
+    if (MODE == 0 && split > 1) waves = std::max(8, split);
+    if (MODE == 0 && split == 1) {
         waves = r->wpb_table;
         if (waves <= 0) {
             int best = -1, best_blocks = 0;
@@ -638,7 +660,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
             }
         }
     }
-    size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * waves);
+    size_t lds = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * (waves / split));
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "ncomp too large for the LDS line table");
     if (MODE != 0 && r->lnl_cap > 0 && waves * r->lnl_cap < 32)      // residency cap: see Engine::lnl_cap
         lds = std::max(lds, (size_t)((160 * 1024) / r->lnl_cap) & ~(size_t)15);
@@ -646,7 +668,8 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t units = B * S.n_spec;
-    const int64_t blocks = (units + waves - 1) / waves;
+    const int64_t upw = waves / split;
+    const int64_t blocks = (units + upw - 1) / upw;
     if (blocks > 0x7fffffffLL) return fail(NFA_ERR_ARG, "batch too large for one launch");
     hipStream_t st = r->lanes[slot];
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, st, S, d_pix,
@@ -656,7 +679,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     if (r->ev_after_lnl) { HIP_TRY(hipEventRecord(r->ev_after_lnl, st)); r->ev_after_lnl = nullptr; }
     if (d_lnL) {
         hipLaunchKernelGGL(lnl_sum_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st,
-                           (const double *)r->d_part[slot], S.noise, d_pix, d_lnL, (long)B, S.n_spec);
+                           (const double *)r->d_part[slot], S.noise, d_pix, d_lnL, (long)B, S.n_spec, split);
         HIP_TRY(hipGetLastError());
     }
     return NFA_OK;

@@ -1,0 +1,44 @@
+"""The likelihood kernel with 2, 4 or 8 waves per (item, spectrum) unit (row parts) against the one-wave
+form: same model spectra bit for bit, log-likelihoods equal to rounding (the parts' sums meet in a
+different order), and against the oracle; the automatic choice for small launches."""
+import numpy as np
+import pytest
+
+from nestfit_amd.synth import TRUTH_2COMP, TRUTH_3COMP, freq_axis
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('mode', ['table', 'fast'])
+def test_row_split_matches_one_wave_per_unit(engine, nfo, mode):
+    from nestfit_amd import _ffi
+    engine.set_exp_mode(mode)
+    try:
+        for trans, n, ncomp, truth in (((1, 2), 1024, 2, TRUTH_2COMP), ((1, 2, 3), 200, 3, TRUTH_3COMP), ((9,), 70, 1, None)):
+            rng = np.random.default_rng(5)
+            axes = [freq_axis(t, n) for t in trans]
+            spec_data = [[x, rng.normal(0, 0.2, n), 0.2, t] for x, t in zip(axes, trans)]
+            ut = engine.get_irdc_priors(size=500, vsys=0.0)
+            U = np.random.default_rng(7).uniform(size=(300, 6 * ncomp))
+            out = {}
+            for split in (1, 2, 4, 8, 0):
+                _ffi.set_option('lnl_split', split)
+                run = engine.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp)
+                Us = U.copy()
+                lnl = run.loglikelihood_batch(Us)
+                spec, lp = run.predict_batch(Us[:32])
+                one = run.loglikelihood(U[0].copy())
+                out[split] = (lnl, Us, spec, lp, one)
+            base = out[1]
+            for split in (2, 4, 8, 0):
+                lnl, Us, spec, lp, one = out[split]
+                assert np.array_equal(Us, base[1]) and np.array_equal(spec, base[2])
+                np.testing.assert_allclose(lnl, base[0], rtol=1e-13)
+                np.testing.assert_allclose(lp, base[3], rtol=1e-13)
+                assert one == pytest.approx(base[4], rel=1e-13) and one == pytest.approx(lnl[0], rel=1e-13)
+            cpu = nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(*sd) for sd in spec_data], nfo.PriorSet(ut.lower()), ncomp=ncomp)
+            Uc = U.copy()
+            np.testing.assert_allclose(out[4][0], cpu.loglikelihood_batch(Uc), rtol=1e-9 if mode == 'table' else 1e-6)
+    finally:
+        _ffi.set_option('lnl_split', 1)
+        engine.set_exp_mode('fast')
