@@ -420,17 +420,16 @@ __device__ __forceinline__ void line_step_fast(float &tau, int j, double xj, dou
                  : "vcc");
 }
 
-// WIDE (fast mode only): the spectra set holds a transition with more than 26 lines (N2H+)
+// The body of the likelihood kernel for workgroup `block_id` of a launch (lnl_kernel: the hardware's
+// workgroup; point_kernel: the one workgroup walks the few of a single point).  `sm` = the staged
+// exponential tables (n_shared doubles at the start of smem), the line tables follow them.
 template <int MODE, bool WRITE_SPEC, bool WIDE, int NCOMP>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))
-lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D, double *__restrict__ part,
-           double *__restrict__ spec_out, long B, LnlGeom G, const double *__restrict__ g_tabs) {
+__device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict__ pix, const double *__restrict__ D,
+                                         double *__restrict__ part, double *__restrict__ spec_out, long B,
+                                         const LnlGeom &G, const double *__restrict__ g_tabs, double *smem,
+                                         const double *sm, int n_shared, unsigned block_id) {
     typedef typename std::conditional<MODE == 2, float, double>::type tau_t;
     constexpr int NC = NCOMP > 0 ? NCOMP : 1;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    int n_shared = 0;
-    const double *sm = smem;
-    if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);   // fast: no tables
     const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
 
 #ifdef NFA_ABLATE
@@ -450,13 +449,13 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
     // workgroup: otherwise one SIMD would only ever see the spectrum with the most hyperfine lines.
     const int split = G.split;
     const unsigned units = (unsigned)B * (unsigned)nspec;
-    const unsigned rot = __builtin_amdgcn_readfirstlane((blockIdx.x * 0x9E3779B1u) >> 28);
+    const unsigned rot = __builtin_amdgcn_readfirstlane((block_id * 0x9E3779B1u) >> 28);
     const unsigned wsel0 = (unsigned)wave + rot;
     const unsigned wsel = waves == 4 ? (wsel0 & 3u) : wsel0 % (unsigned)waves;
     const unsigned upw = (unsigned)(waves / split);                 // units per workgroup
     const unsigned ulocal = split == 1 ? wsel : wsel / (unsigned)split;
     const int rpart = split == 1 ? 0 : (int)(wsel - ulocal * (unsigned)split);
-    const unsigned unit = blockIdx.x * upw + ulocal;
+    const unsigned unit = block_id * upw + ulocal;
     LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)ulocal * G.wave_doubles);
     if (unit >= units) {
         if (split > 1) __syncthreads();                              // the barrier behind the line set-up below
@@ -664,15 +663,22 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
     if (lane == 0 && part) part[(long)unit * split + rpart] = acc;
 }
 
-// lnL[b] = sum over the spectra of the item, in order (ammonia.pyx:425-432), of -chi2_s / (2 noise_s^2)
-// (core.pyx:530).  The division happens here, lanes = items, instead of once per likelihood wave.
-__global__ void lnl_sum_kernel(const double *__restrict__ part, const double *__restrict__ noise,
-                               const int *__restrict__ pix, double *__restrict__ lnL, long B, int nspec,
-                               int split) {
-    __builtin_amdgcn_s_setprio(3);
-    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const long p_ix = pix ? (long)pix[b] : 0;
+// WIDE (fast mode only): the spectra set holds a transition with more than 26 lines (N2H+)
+template <int MODE, bool WRITE_SPEC, bool WIDE, int NCOMP>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))
+lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D, double *__restrict__ part,
+           double *__restrict__ spec_out, long B, LnlGeom G, const double *__restrict__ g_tabs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int n_shared = 0;
+    const double *sm = smem;
+    if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);   // fast: no tables
+    lnl_body<MODE, WRITE_SPEC, WIDE, NCOMP>(S, pix, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x);
+}
+
+// chi^2 parts of one item -> its log-likelihood: the sum over the spectra, in order (ammonia.pyx:425-432), of
+// -chi2_s / (2 noise_s^2) (core.pyx:530)
+__device__ __forceinline__ double lnl_of_item(const double *__restrict__ part, const double *__restrict__ noise,
+                                              long p_ix, long b, int nspec, int split) {
     double tot = 0.0;
     for (int s = 0; s < nspec; ++s) {
         const double sigma = noise[p_ix * nspec + s];
@@ -680,7 +686,17 @@ __global__ void lnl_sum_kernel(const double *__restrict__ part, const double *__
         for (int h = 0; h < split; ++h) chi2 += part[(b * nspec + s) * split + h];      // the unit's row parts, in order
         tot += -chi2 / (2 * (sigma * sigma));
     }
-    lnL[b] = tot;
+    return tot;
+}
+
+// lnL of the items of a batch, lanes = items (the division happens here instead of once per likelihood wave)
+__global__ void lnl_sum_kernel(const double *__restrict__ part, const double *__restrict__ noise,
+                               const int *__restrict__ pix, double *__restrict__ lnL, long B, int nspec,
+                               int split) {
+    __builtin_amdgcn_s_setprio(3);
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    lnL[b] = lnl_of_item(part, noise, pix ? (long)pix[b] : 0, b, nspec, split);
 }
 
 #include "nfa_setup.h"

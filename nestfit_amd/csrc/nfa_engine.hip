@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -58,6 +59,7 @@ struct Engine {
     int    streams = 4;              // stream lanes of new runners
     int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
     int    graph = -1;               // single-point graph replay: -1 = decide at first use, 0 off, 1 on
+    int    point = 1;                // single points: 1 = the one-launch point kernel, 0 = the batch kernels (graph replay)
     bool   have_t0 = false;
     double *d_tabs = nullptr;                      // SM_END_TABLE doubles
     double t0_xmin = 0, t0_xmax = 0, t0_inv_dx = 0;
@@ -185,6 +187,9 @@ struct nfa_runner {
     int     g1_mode = -1;
     double *h_pin = nullptr;         // pinned staging: ndim + 1 doubles
     uint64_t n_single = 0;
+    double *h_point = nullptr;       // mapped host buffer of the point kernel: theta[ndim], lnL, sequence number
+    double *d_point = nullptr;       // the same buffer as the device sees it
+    uint64_t pt_seq = 0;
     // optional per-kernel timing (HIP events on the runner's stream)
     bool profiling = false;
     std::vector<hipEvent_t> ev;      // triples: before the set-up kernel, before lnl_kernel, after lnl_kernel
@@ -233,6 +238,7 @@ int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "lnl_cap") && value >= 0 && value <= 8) { g_eng.lnl_cap = value; return NFA_OK; }
     if (key && !strcmp(key, "lnl_split") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_eng.lnl_split = value; return NFA_OK; }
     if (key && !strcmp(key, "graph") && (value == 0 || value == 1)) { g_eng.graph = value; return NFA_OK; }
+    if (key && !strcmp(key, "point") && (value == 0 || value == 1)) { g_eng.point = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }
@@ -538,6 +544,7 @@ int nfa_runner_destroy(nfa_runner *r) {
     for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_part[k]); }
     if (r->g1) (void)hipGraphExecDestroy(r->g1);
     if (r->h_pin) (void)hipHostFree(r->h_pin);
+    if (r->h_point) (void)hipHostFree(r->h_point);
     for (hipEvent_t x : r->ev) (void)hipEventDestroy(x);
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamDestroy(r->lanes[k]);
     delete r;
@@ -584,28 +591,38 @@ static SpecDev runner_specdev(const nfa_runner *r) {
 
 // Set-up stage of a batch on stream lane `slot`: [unit cube -> theta in place] -> partition sums ->
 // derived records r->d_D[slot], one launch (setup_kernel, nfa_setup.h)
+// derived records and chi^2 parts of stream lane `slot` for B items
+static int reserve_lane(nfa_runner *r, int slot, int64_t B) {
+    if (B <= r->cap_D[slot]) return NFA_OK;  // grown outside any timed loop
+    const int n_spec = r->ss->dev.n_spec;
+    if (slot == 0 && r->g1) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
+    HIP_TRY(hipStreamSynchronize(r->lanes[slot]));
+    (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_part[slot]);
+    r->d_D[slot] = nullptr; r->d_part[slot] = nullptr; r->cap_D[slot] = 0;
+    const int64_t cap = std::max<int64_t>(B, 4096);
+    HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec_size(r->ncomp, n_spec)));
+    HIP_TRY(hipMalloc(&r->d_part[slot], sizeof(double) * cap * n_spec * 8));      // up to 8 row parts per unit
+    r->cap_D[slot] = cap;
+    return NFA_OK;
+}
+
+// LDS of the set-up stage: exponential tables, theta + partition records + the prior program and its tables
+static bool setup_uses_tables(const nfa_runner *r, int mode) { return mode == 0 && r->ss->dev.model == NFA_MODEL_AMMONIA; }
+static size_t setup_lds_bytes(const nfa_runner *r, int mode, bool has_prior) {
+    const size_t work = (size_t)64 * r->ndim + (size_t)SETUP_TI * r->ncomp * QREC + sizeof(PriorProg) / sizeof(double) + 1
+                        + (has_prior ? (size_t)r->pr->prog.stage_doubles : 0);
+    return sizeof(double) * ((setup_uses_tables(r, mode) ? (SM_END_TABLE - SM_EXP2) : 32) + work);
+}
+
 static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot, int mode) {
     const SpecDev S = runner_specdev(r);
-    const int drec = drec_size(r->ncomp, S.n_spec);
     hipStream_t st = r->lanes[slot];
-    if (B > r->cap_D[slot]) {                // grown outside any timed loop
-        if (slot == 0 && r->g1) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
-        HIP_TRY(hipStreamSynchronize(st));
-        (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_part[slot]);
-        r->d_D[slot] = nullptr; r->d_part[slot] = nullptr; r->cap_D[slot] = 0;
-        const int64_t cap = std::max<int64_t>(B, 4096);
-        HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec));
-        HIP_TRY(hipMalloc(&r->d_part[slot], sizeof(double) * cap * S.n_spec * 8));      // up to 8 row parts per unit
-        r->cap_D[slot] = cap;
-    }
+    int rc = reserve_lane(r, slot, B); if (rc) return rc;
     if (has_prior && !r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     const PriorProg *prog = has_prior ? (const PriorProg *)r->pr->d_prog : nullptr;
     const unsigned blocks = (unsigned)((B + SETUP_TI - 1) / SETUP_TI);
-    // theta + partition records + the program and its tables
-    const size_t work = (size_t)64 * r->ndim + (size_t)SETUP_TI * r->ncomp * QREC + sizeof(PriorProg) / sizeof(double) + 1
-                        + (has_prior ? (size_t)r->pr->prog.stage_doubles : 0);
-    const bool tables = mode == 0 && S.model == NFA_MODEL_AMMONIA;
-    const size_t lds = sizeof(double) * ((tables ? (SM_END_TABLE - SM_EXP2) : 32) + work);
+    const bool tables = setup_uses_tables(r, mode);
+    const size_t lds = setup_lds_bytes(r, mode, has_prior);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "too many parameters for the set-up kernel");
     auto kern = tables ? setup_kernel<0> : setup_kernel<1>;
     if (lds > 64 * 1024)
@@ -614,6 +631,20 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
                        has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate);
     HIP_TRY(hipGetLastError());
     return NFA_OK;
+}
+
+// waves per unit of a launch of B items (runner option lnl_split; 0 = by the size of the launch)
+static int resolve_split(const nfa_runner *r, const SpecDev &S, int64_t B) {
+    int split = r->lnl_split;
+    if (split == 0) {
+        const int64_t slots = (int64_t)g_eng.n_cu * 32;
+        split = 1;
+        while (split < 8 && B * S.n_spec * split * 4 <= slots) split *= 2;
+    }
+    int min_rows = 1 << 30;
+    for (int k = 0; k < S.n_spec; ++k) min_rows = std::min(min_rows, (S.size[k] + 63) / 64);
+    while (split > 1 && split > min_rows) split /= 2;
+    return split;
 }
 
 template <int MODE, bool WS, bool WIDE, int NCOMP>
@@ -628,15 +659,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     // Waves per unit.  A launch with fewer units than a few per wave slot is latency bound: its waves are
     // placed once and every SIMD waits for its own longest; splitting the rows of a unit over 2 .. 8 waves
     // gives the hardware shorter waves to place as slots free up (a single point: 2 units -> 16 waves).
-    int split = r->lnl_split;
-    if (split == 0) {
-        const int64_t slots = (int64_t)g_eng.n_cu * 32;
-        split = 1;
-        while (split < 8 && B * S.n_spec * split * 4 <= slots) split *= 2;
-    }
-    int min_rows = 1 << 30;
-    for (int k = 0; k < S.n_spec; ++k) min_rows = std::min(min_rows, (S.size[k] + 63) / 64);
-    while (split > 1 && split > min_rows) split /= 2;
+    const int split = resolve_split(r, S, B);
     G.split = split;
     // LDS per wave: the line table of one spectrum (32-byte records, nhf_max per component)
     G.wave_doubles = r->ncomp * G.nhf_max * (int)(sizeof(LineRec) / sizeof(double));
@@ -822,6 +845,84 @@ int nfa_runner_synchronize(nfa_runner *r) {
 
 }  // extern "C"
 
+// One point through the point kernel (nfa_setup.h); returns 1 when the call was served, 0 when another
+// path has to do it, a negative value on a device error.
+template <int MODE, int NCOMP>
+static void launch_point_t(nfa_runner *r, const SpecDev &S, const PointIn &in, const LnlGeom &G, size_t lds) {
+    auto kern = point_kernel<MODE, NCOMP>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(SETUP_THREADS), lds, r->lanes[0], (const PriorProg *)r->pr->d_prog, S, in,
+                       r->d_pix, r->d_U, r->d_D[0], r->d_part[0], r->d_point, G, (const double *)g_eng.d_tabs);
+}
+template <int MODE>
+static void launch_point_n(nfa_runner *r, const SpecDev &S, const PointIn &in, const LnlGeom &G, size_t lds) {
+    switch (r->ncomp) {
+    case 1: return launch_point_t<MODE, 1>(r, S, in, G, lds);
+    case 2: return launch_point_t<MODE, 2>(r, S, in, G, lds);
+    case 3: return launch_point_t<MODE, 3>(r, S, in, G, lds);
+    default: return launch_point_t<MODE, 0>(r, S, in, G, lds);
+    }
+}
+
+static int single_point_kernel(nfa_runner *r, const int32_t *pix, double *U, double *lnL) {
+    const int ndim = r->ndim;
+    if (!g_eng.point || r->profiling || ndim > NFA_POINT_MAXDIM || r->ss->nhf_max > 26) return 0;
+    const int mode = r->exp_mode >= 0 ? r->exp_mode : g_eng.exp_mode;
+    const SpecDev S = runner_specdev(r);
+    LnlGeom G;
+    G.ablate = 0;
+    G.nhf_max = r->ss->nhf_max;
+    G.inv_nspec = S.n_spec == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)S.n_spec) + 1u;
+    G.split = resolve_split(r, S, 1);
+    if (G.split > POINT_WAVES) return 0;
+    G.wave_doubles = r->ncomp * G.nhf_max * (int)(sizeof(LineRec) / sizeof(double));
+    const int upw = POINT_WAVES / G.split;                       // units per pass of the workgroup
+    const int n_shared = mode == 0 ? (SM_END_TABLE - SM_EXP2) : (mode == 1 ? 32 : 0);
+    // the set-up stage and the likelihood waves use the same LDS one after the other, behind the staged tables
+    const size_t n_staged = mode == 0 ? (SM_END_TABLE - SM_EXP2) : 32;
+    const size_t lds = std::max(setup_lds_bytes(r, 1, true) + sizeof(double) * (n_staged - 32),
+                                sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * upw));
+    if (lds > 160 * 1024) return 0;
+    if (reserve_lane(r, 0, 1) != NFA_OK) return -1;
+    if (!r->h_point) {
+        if (hipHostMalloc((void **)&r->h_point, sizeof(double) * (NFA_POINT_MAXDIM + 2), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+            || hipHostGetDevicePointer((void **)&r->d_point, r->h_point, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (r->h_point) (void)hipHostFree(r->h_point);
+            r->h_point = nullptr;
+            g_eng.point = 0;
+            return 0;
+        }
+        memset(r->h_point, 0, sizeof(double) * (NFA_POINT_MAXDIM + 2));
+    }
+    PointIn in;
+    memcpy(in.u, U, sizeof(double) * ndim);
+    for (int k = ndim; k < NFA_POINT_MAXDIM; ++k) in.u[k] = 0.0;
+    in.seq = ++r->pt_seq;
+    in.pix = pix ? pix[0] : -1;
+    in.n_blocks = (S.n_spec + upw - 1) / upw;
+    switch (mode) {
+    case 0: launch_point_n<0>(r, S, in, G, lds); break;
+    case 1: launch_point_n<1>(r, S, in, G, lds); break;
+    default: launch_point_n<2>(r, S, in, G, lds); break;
+    }
+    if (hipGetLastError() != hipSuccess) { fail(NFA_ERR_DEVICE, "point kernel launch failed"); return -1; }
+    // the kernel's last store is the sequence number; the host reads it straight from the mapped buffer
+    const volatile unsigned long long *flag = (const volatile unsigned long long *)(r->h_point + ndim + 1);
+    const auto t_start = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == in.seq) break;
+        if ((spins & 0xffff) == 0xffff
+            && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) {
+            // nothing came back: let the runtime say why (a fault surfaces here), or finish a very slow kernel
+            if (hipStreamSynchronize(r->lanes[0]) != hipSuccess) { fail(NFA_ERR_DEVICE, "point kernel failed"); return -1; }
+        }
+    }
+    memcpy(U, r->h_point, sizeof(double) * ndim);
+    *lnL = r->h_point[ndim];
+    return 1;
+}
+
 // One point through a captured graph; returns 1 when the call was served, 0 when the plain path
 // has to do it (first calls, table mode whose launch sets a function attribute, profiling on).
 static int single_point_graph(nfa_runner *r, double *U, double *lnL) {
@@ -878,7 +979,12 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     rc = sync_all_lanes(r); if (rc) return rc;           // the staging buffers are shared
     rc = runner_reserve(r, B, false); if (rc) return rc;
-    if (B == 1 && !pix) {                                // MultiNest-style single points: one graph launch
+    if (B == 1) {                                        // MultiNest-style single points: one launch, no copies
+        const int served = single_point_kernel(r, pix, U, lnL);
+        if (served < 0) return NFA_ERR_DEVICE;
+        if (served) return NFA_OK;
+    }
+    if (B == 1 && !pix) {                                // ... or the batch kernels replayed as a graph
         r->n_single += 1;
         if (single_point_graph(r, U, lnL)) return NFA_OK;
     }

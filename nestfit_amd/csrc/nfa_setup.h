@@ -392,20 +392,18 @@ __device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const doubl
 // ---------------------------------------------------------------------------
 #define SETUP_TI 64
 #define SETUP_THREADS 256
+// the set-up stage of the 64 items of workgroup `block_id` (SETUP_THREADS threads; `sm` = the staged
+// exponential tables, n_shared doubles at the start of smem)
 template <int MODE>
-__global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
-                                                              double *__restrict__ U, double *__restrict__ D,
-                                                              long B, int has_prior,
-                                                              const double *__restrict__ g_tabs, int ablate_in) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __builtin_amdgcn_s_setprio(3);
+__device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, const SpecDev &S,
+                                           double *__restrict__ U, double *__restrict__ D, long B, int has_prior,
+                                           const double *__restrict__ g_tabs, int ablate_in, double *smem,
+                                           const double *sm, int n_shared, unsigned block_id) {
 #ifdef NFA_ABLATE
     const int ablate = ablate_in;      // timing experiments: 16 skip the priors, 32 the partition sums, 64 the derive phase
 #else
     const int ablate = 0;
 #endif
-    int n_shared;
-    const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
     const int tid = threadIdx.x;
     const int ncomp = S.ncomp, nspec = S.n_spec, ndim = S.npar * ncomp;
     const int drec = drec_size(ncomp, nspec);
@@ -413,7 +411,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(const PriorProg *_
     double *q_all = th_all + 64 * ndim;
     PriorProg *lp = (PriorProg *)(q_all + SETUP_TI * ncomp * QREC);
     double *tab = (double *)(lp + 1);
-    const long b0 = (long)blockIdx.x * SETUP_TI;
+    const long b0 = (long)block_id * SETUP_TI;
     const int n_it = (int)(B - b0 < SETUP_TI ? B - b0 : SETUP_TI);
     const bool do_prior = has_prior && !(ablate & 16);
     // ---- phase 0: the program and its tables -> LDS; theta of the items -> LDS
@@ -471,6 +469,74 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(const PriorProg *_
         double *Db = D + (b0 + it) * drec;
         if (ammonia) derive_lane(S, th_all + it, q_all + (it * ncomp + c) * QREC, Db, c, s, g_tabs);
         else derive_simple_lane(S, th_all + it, Db, c, s, g_tabs);
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
+                                                              double *__restrict__ U, double *__restrict__ D,
+                                                              long B, int has_prior,
+                                                              const double *__restrict__ g_tabs, int ablate_in) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __builtin_amdgcn_s_setprio(3);
+    int n_shared;
+    const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
+    setup_body<MODE>(ppp, S, U, D, B, has_prior, g_tabs, ablate_in, smem, sm, n_shared, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+//  One point per call (MultiNest's callback, core.pyx:513-531 through ammonia.pyx:405-432): the whole path in
+//  ONE launch of ONE workgroup -- the unit cube arrives in the kernel arguments, the set-up stage, the
+//  likelihood waves and the sum follow each other across workgroup barriers, and theta, lnL and a sequence
+//  number are written straight into a mapped host buffer the caller spins on.  No copy commands, no second
+//  and third launch, no stream synchronisation: what is left is one dispatch and the dependent chain of the
+//  arithmetic itself.  Same device functions as the batch kernels, so a point gives the same bits either way.
+// ---------------------------------------------------------------------------
+#define NFA_POINT_MAXDIM 24
+#define POINT_WAVES (SETUP_THREADS / 64)
+struct PointIn {
+    double u[NFA_POINT_MAXDIM];
+    unsigned long long seq;            // written to the host buffer last
+    int pix;                           // < 0: the runner has one pixel
+    int n_blocks;                      // likelihood workgroups the one workgroup stands in for
+};
+template <int MODE, int NCOMP>
+__global__ void __launch_bounds__(SETUP_THREADS) point_kernel(const PriorProg *__restrict__ ppp, SpecDev S, PointIn in,
+                                                              int *__restrict__ d_pix, double *__restrict__ U,
+                                                              double *__restrict__ D, double *__restrict__ part,
+                                                              double *__restrict__ out, LnlGeom G,
+                                                              const double *__restrict__ g_tabs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int SMODE = MODE == 0 ? 0 : 1;                   // fast mode: the set-up stage runs its polynomial form
+    int n_shared;
+    const double *sm = stage_exp_tables<SMODE>(smem, g_tabs, &n_shared);
+    const int tid = threadIdx.x;
+    const int ndim = S.npar * S.ncomp;
+    {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < NFA_POINT_MAXDIM; ++k) v = tid == k ? in.u[k] : v;      // kernel arguments: no dynamic index
+        if (tid < ndim) U[tid] = v;
+        if (tid == 0 && in.pix >= 0) d_pix[0] = in.pix;
+    }
+    __syncthreads();
+    setup_body<SMODE>(ppp, S, U, D, 1, 1, g_tabs, 0, smem, sm, n_shared, 0u);
+    __threadfence();                                            // theta in U, the derived record in D: at L2 ...
+    __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();                            // ... where the scalar loads of the record find them
+    if (tid < ndim) out[tid] = U[tid];
+    const int *pix = in.pix >= 0 ? d_pix : nullptr;
+    for (int blk = 0; blk < in.n_blocks; ++blk) {
+        if (blk) __syncthreads();                               // the line tables are reused
+        lnl_body<MODE, false, false, NCOMP>(S, pix, D, part, nullptr, 1, G, g_tabs, smem, MODE == 2 ? smem : sm,
+                                            MODE == 2 ? 0 : n_shared, (unsigned)blk);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        out[ndim] = lnl_of_item(part, S.noise, in.pix >= 0 ? (long)in.pix : 0, 0, S.n_spec, G.split);
+        __threadfence_system();
+        __hip_atomic_store((unsigned long long *)(out + ndim + 1), in.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 #undef TH

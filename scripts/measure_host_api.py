@@ -15,6 +15,19 @@ for t, x in zip((1, 2), axes):
     na.amm_predict(s, TRUTH_2COMP)
     spec.append([x, s.get_spec() + rng.normal(0, 0.2, n), 0.2, t])
 run = na.AmmoniaRunner.from_data(spec, na.get_irdc_priors(), ncomp=2)
+from nestfit_amd import _ffi
+for point in (1, 0):
+    _ffi.set_option('point', point)
+    u0 = rng.uniform(size=12)
+    for _ in range(20):
+        run.loglikelihood(u0.copy())
+    bufs = [u0.copy() for _ in range(2000)]
+    t0 = time.perf_counter()
+    for b in bufs:
+        run.loglikelihood(b)
+    dt = (time.perf_counter() - t0) / len(bufs)
+    print(f'single point, {"point kernel" if point else "batch kernels as a graph"}: {dt*1e6:.1f} us per call', flush=True)
+_ffi.set_option('point', 1)
 for B in (1, 400, 4096, 65536):
     U = rng.uniform(size=(B, 12))
     run.loglikelihood_batch(U.copy())
