@@ -54,20 +54,21 @@ int nfa_get_exp_mode(void);
  *   "wpb"           waves per workgroup of the likelihood kernel (1..16, default 4), and
  *   "wpb_table"     the same in table mode (0 = chosen per spectra set, the default): both are
  *                   taken over by runners created afterwards;
- *   "lnl_split"     waves that share one (item, spectrum) unit of the likelihood kernel, each taking every
- *                   split-th row of 64 channels: 1 (default), 2, 4, 8, or 0 = chosen per launch (up to 8 for
- *                   single points, 1 for batches that fill the GPU's wave slots several times).  More, shorter
- *                   waves balance a small launch better (a lone 4096-row batch: -20 % kernel time with 2) at
- *                   ~5 % more instructions; the parts of a unit are summed in their own order, so log-
- *                   likelihoods then differ at the 1e-16 level from the default's, whose results are bitwise
- *                   independent of the batch an evaluation travels in;
+ *   "lnl_split"     waves that share one (item, spectrum) unit of the likelihood kernel: 1, 2, 4, or 0 = chosen per
+ *                   launch (the default: 4 for single points and small batches, 1 for batches that fill the
+ *                   GPU's wave slots).  More, shorter waves balance a small launch better at a few per cent more
+ *                   instructions.  The chi^2 of a unit is always the sum of four blocks of consecutive rows
+ *                   taken in order, whoever computed them, so log-likelihoods are bitwise independent of this
+ *                   option and of the batch an evaluation travels in;
  *   "lnl_cap"       workgroups of the likelihood kernel resident per CU at most (fast and poly mode,
  *                   0 = no cap, the default; 1..8): A/B knob, see DESIGN.md;
  *   "streams"       number of HIP streams ("lanes", 1..8, default 4) that runners created
  *                   afterwards spread consecutive nfa_runner_loglike_batch_dev calls over;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
- *   "graph"         1 / 0: replay single-point calls as one captured hipGraph or not (default: on,
- *                   off when the rocprofiler tool library is attached: capture crashed under it);
+ *   "point"         1 / 0: single points (nfa_runner_loglike_batch with B = 1, nfa_loglike_callback) go
+ *                   through the one-launch point kernel (default) or through the batch kernels;
+ *   "graph"         1 / 0: with "point" 0, replay single-point calls as one captured hipGraph or not (default:
+ *                   on, off when the rocprofiler tool library is attached: capture crashed under it);
  *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid; the
  *                   shipped library rejects the key): bit mask, 1 skip the Tb pass, 2 skip the
  *                   hyperfine-line loop, 4 skip the rows, 8 skip the line set-up.

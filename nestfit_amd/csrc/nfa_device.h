@@ -104,11 +104,12 @@ struct SpecDev {
 #define DK_Q 10
 __host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncomp + ncomp * nspec * DREC_CS; }
 
+#define LNL_PARTS 4      // row blocks of a unit: the fixed shape of its chi^2 sum
 struct LnlGeom {
     int nhf_max;       // lines per component slot in the LDS line table
     int wave_doubles;  // LDS doubles per wave
     unsigned inv_nspec; // floor(2^32 / nspec) + 1: unit / nspec = mulhi(unit, inv_nspec) for unit < 2^28; 0: nspec == 1
-    int split;          // waves that share one (item, spectrum) unit, each taking every split-th row (1, 2, 4, 8)
+    int split;          // waves that share one (item, spectrum) unit (1, 2, 4), each taking LNL_PARTS / split row blocks
     int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 4 skip rows, 8 skip line set-up
 };
 
@@ -442,9 +443,12 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const int ncomp = NCOMP > 0 ? NCOMP : S.ncomp, nspec = S.n_spec;
     const int drec = drec_size(ncomp, nspec);
 
-    // One unit per wave, or `split` waves per unit (small launches: more, shorter waves than wave slots, so
-    // that the hardware places them as slots free up; the waves of a unit share its line table and take
-    // every split-th row).  The grid covers all units (the host keeps B * nspec * split below 2^28).  Waves
+    // One unit per wave, or `split` = 2 or 4 waves per unit (small launches: more, shorter waves than wave
+    // slots, so that the hardware places them as slots free up; the waves of a unit share its line table).
+    // The rows of a unit form LNL_PARTS blocks of consecutive rows; chi^2 is, per lane, the sum of the
+    // blocks' sums taken in block order, whatever the number of waves that worked on them: the result does
+    // not depend on `split` (nor on the size of the batch an item travels in) to the last bit.
+    // The grid covers all units (the host keeps B * nspec * split below 2^28).  Waves
     // of a workgroup land on the SIMDs of a CU in order, so the unit -> wave assignment is rotated per
     // workgroup: otherwise one SIMD would only ever see the spectrum with the most hyperfine lines.
     const int split = G.split;
@@ -457,8 +461,10 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const int rpart = split == 1 ? 0 : (int)(wsel - ulocal * (unsigned)split);
     const unsigned unit = block_id * upw + ulocal;
     LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)ulocal * G.wave_doubles);
+    // split > 1: the blocks' per-lane sums meet here, [unit of the workgroup][block][lane]
+    double *w_part = smem + n_shared + (size_t)upw * G.wave_doubles + (size_t)ulocal * (LNL_PARTS * 64);
     if (unit >= units) {
-        if (split > 1) __syncthreads();                              // the barrier behind the line set-up below
+        if (split > 1) { __syncthreads(); __syncthreads(); }         // the two barriers of the waves at work
         return;
     }
     const unsigned bu = G.inv_nspec ? __umulhi(unit, G.inv_nspec) : unit;      // unit / nspec without a division
@@ -536,7 +542,15 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
         empt = 0ull;
     };
     const int n_rows = (ablate & 4) ? 0 : (N + 63) >> 6;
-    for (int row = rpart; row < n_rows; row += split) {
+    const int rows_per_part = (n_rows + LNL_PARTS - 1) / LNL_PARTS;
+    const int parts_per_wave = LNL_PARTS / split;
+    double tot = 0.0;
+    for (int hp = 0; hp < parts_per_wave; ++hp) {
+    const int h = rpart * parts_per_wave + hp;
+    const int row_a = h * rows_per_part;
+    const int row_b = row_a + rows_per_part < n_rows ? row_a + rows_per_part : n_rows;
+    acc = 0.0;
+    for (int row = row_a; row < row_b; ++row) {
         const int r0 = row << 6;
         const int j = r0 + lane;
         // lines of each component that touch this row
@@ -655,12 +669,19 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             }
         }
         if (!any) empt |= 1ull << (row & 63);
-        if (((row + split) >> 6) != (row >> 6)) flush_empty(row & ~63);      // the wave's last row of this block of 64
+        if ((row & 63) == 63) flush_empty(row & ~63);                // the last row of this group of 64
     }
-    flush_empty((n_rows - 1) & ~63);
-    acc = wave_sum(acc);
-    // sum of squared deviations of the wave's rows; lnl_sum_kernel scales and adds
-    if (lane == 0 && part) part[(long)unit * split + rpart] = acc;
+    flush_empty((row_b - 1) & ~63);
+    if (split == 1) tot += acc; else w_part[h * 64 + lane] = acc;
+    }
+    if (split > 1) {
+        __syncthreads();
+        if (rpart != 0) return;
+        for (int h = 0; h < LNL_PARTS; ++h) tot += w_part[h * 64 + lane];
+    }
+    tot = wave_sum(tot);
+    // sum of squared deviations of the unit; lnl_sum_kernel scales and adds
+    if (lane == 0 && part) part[unit] = tot;
 }
 
 // WIDE (fast mode only): the spectra set holds a transition with more than 26 lines (N2H+)
@@ -678,25 +699,22 @@ lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D,
 // chi^2 parts of one item -> its log-likelihood: the sum over the spectra, in order (ammonia.pyx:425-432), of
 // -chi2_s / (2 noise_s^2) (core.pyx:530)
 __device__ __forceinline__ double lnl_of_item(const double *__restrict__ part, const double *__restrict__ noise,
-                                              long p_ix, long b, int nspec, int split) {
+                                              long p_ix, long b, int nspec) {
     double tot = 0.0;
     for (int s = 0; s < nspec; ++s) {
         const double sigma = noise[p_ix * nspec + s];
-        double chi2 = 0.0;
-        for (int h = 0; h < split; ++h) chi2 += part[(b * nspec + s) * split + h];      // the unit's row parts, in order
-        tot += -chi2 / (2 * (sigma * sigma));
+        tot += -part[b * nspec + s] / (2 * (sigma * sigma));
     }
     return tot;
 }
 
 // lnL of the items of a batch, lanes = items (the division happens here instead of once per likelihood wave)
 __global__ void lnl_sum_kernel(const double *__restrict__ part, const double *__restrict__ noise,
-                               const int *__restrict__ pix, double *__restrict__ lnL, long B, int nspec,
-                               int split) {
+                               const int *__restrict__ pix, double *__restrict__ lnL, long B, int nspec) {
     __builtin_amdgcn_s_setprio(3);
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    lnL[b] = lnl_of_item(part, noise, pix ? (long)pix[b] : 0, b, nspec, split);
+    lnL[b] = lnl_of_item(part, noise, pix ? (long)pix[b] : 0, b, nspec);
 }
 
 #include "nfa_setup.h"

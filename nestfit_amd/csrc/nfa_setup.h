@@ -40,6 +40,8 @@ struct PriorProg {
     nfa_prior_desc pr[MAXPRIOR];
     DistDev        ds[MAXDIST];
     int            n_stage, stage_doubles;          // 0: the tables stay in global memory
+    int            parallel, pad;                   // 1: no two priors share a parameter slot (one wave each)
+    const double  *stage_image;                     // the staged tables back to back, in LDS order
     StageItem      stage[MAXSTAGE];
 };
 
@@ -144,9 +146,9 @@ __device__ double d_placement_draw(const DistDev &d, double x_lo, double x_hi, d
     return 1 / slope * (u - y_lo) + xl;
 }
 
-// PriorTransformer.c_transform (core.pyx:459-476) for the item of this lane
-__device__ void prior_transform_lane(const PriorProg &pp, double *u, int n) {
-    for (int k = 0; k < pp.n_prior; ++k) {
+// prior k of PriorTransformer.c_transform (core.pyx:459-476) for the item of this lane
+__device__ void prior_apply_lane(const PriorProg &pp, int k, double *u, int n) {
+    {
         const nfa_prior_desc &p = pp.pr[k];
         const int ix = p.p_ix * n;
         switch (p.kind) {
@@ -224,6 +226,11 @@ __device__ void prior_transform_lane(const PriorProg &pp, double *u, int n) {
     }
 }
 
+// PriorTransformer.c_transform (core.pyx:459-476) for the item of this lane
+__device__ __forceinline__ void prior_transform_lane(const PriorProg &pp, double *u, int n) {
+    for (int k = 0; k < pp.n_prior; ++k) prior_apply_lane(pp, k, u, n);
+}
+
 // prior_items_kernel: one lane per item.  LDS: theta transposed, [ndim][64] doubles.
 __global__ void __launch_bounds__(64) prior_items_kernel(const PriorProg *__restrict__ ppp,
                                                          double *__restrict__ U, long B, int n) {
@@ -242,27 +249,31 @@ __global__ void __launch_bounds__(64) prior_items_kernel(const PriorProg *__rest
 #undef TH
 
 // ---------------------------------------------------------------------------
-//  partition sums (ammonia.pyx:289-315): lane = (item, component, quarter of the 51 J levels)
+//  partition sums (ammonia.pyx:289-315): lane = (item, component, eighth of the 51 J levels)
 //  qrec[{0: qpara, 1: qorth, 2: trot', 3..11: (2J+1) FastExp(E_J/kT), J = 1..9}] per (item, component)
+//  Eight lanes of seven levels each: the chain of dependent exponentials a lone item waits for is 7
+//  long instead of 51, and the eight partial sums meet through three DPP steps.
 // ---------------------------------------------------------------------------
 #define QREC 12
+#define QSUM_LANES 8
+#define QSUM_LEVELS 7          // QSUM_LANES * QSUM_LEVELS >= NFA_NPART
 template <int MODE>
 __device__ __forceinline__ void qsum_lane(bool on, double trot_in, int cold, int chunk, double *qrec,
                                           const double *sm) {
     double trot = trot_in;
     if (cold) trot = nf_swift(trot);                          // ammonia.pyx:344-345
     double qp = 0.0, qo = 0.0;
-    for (int k = 0; k < 13; ++k) {
-        const int j = chunk * 13 + k;
+    for (int k = 0; k < QSUM_LEVELS; ++k) {
+        const int j = chunk * QSUM_LEVELS + k;
         const bool lev_on = on && j < NFA_NPART;
         double lev = nf_partition_level<MODE>(lev_on ? j : 0, trot, sm);
         if (!lev_on) lev = 0.0;
         if (j % 3 == 0) qo += 2 * lev; else qp += lev;
         if (lev_on && j >= 1 && j <= NFA_N_LEVELS) qrec[2 + j] = lev;
     }
-    // the four quarters of one (item, component) sit in one quad
-    qp += dpp_move<0xB1>(qp); qp += dpp_move<0x4E>(qp);
-    qo += dpp_move<0xB1>(qo); qo += dpp_move<0x4E>(qo);
+    // the eight lanes of one (item, component) are neighbours: pairs, quads, then the two quads (row_half_mirror)
+    qp += dpp_move<0xB1>(qp); qp += dpp_move<0x4E>(qp); qp += dpp_move<0x141>(qp);
+    qo += dpp_move<0xB1>(qo); qo += dpp_move<0x4E>(qo); qo += dpp_move<0x141>(qo);
     if (on && chunk == 0) { qrec[0] = qp; qrec[1] = qo; qrec[2] = trot; }
 }
 
@@ -392,8 +403,8 @@ __device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const doubl
 // ---------------------------------------------------------------------------
 #define SETUP_TI 64
 #define SETUP_THREADS 256
-// the set-up stage of the 64 items of workgroup `block_id` (SETUP_THREADS threads; `sm` = the staged
-// exponential tables, n_shared doubles at the start of smem)
+// the set-up stage of the 64 items of workgroup `block_id`, by the blockDim.x threads of the workgroup (`sm` =
+// the staged exponential tables, n_shared doubles at the start of smem)
 template <int MODE>
 __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, const SpecDev &S,
                                            double *__restrict__ U, double *__restrict__ D, long B, int has_prior,
@@ -404,7 +415,7 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
 #else
     const int ablate = 0;
 #endif
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int ncomp = S.ncomp, nspec = S.n_spec, ndim = S.npar * ncomp;
     const int drec = drec_size(ncomp, nspec);
     double *th_all = smem + n_shared;                          // theta of item `it`: th_all[k * 64 + it]
@@ -414,24 +425,20 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
     const long b0 = (long)block_id * SETUP_TI;
     const int n_it = (int)(B - b0 < SETUP_TI ? B - b0 : SETUP_TI);
     const bool do_prior = has_prior && !(ablate & 16);
-    // ---- phase 0: the program and its tables -> LDS; theta of the items -> LDS
+    // ---- phase 0: the program and its tables -> LDS (flat copies: all loads in flight at once); theta -> LDS
     if (do_prior) {
         const int nw = (int)(sizeof(PriorProg) / sizeof(int));
-        for (int k = tid; k < nw; k += SETUP_THREADS) ((int *)lp)[k] = ((const int *)ppp)[k];
-        for (int q = 0; q < ppp->n_stage; ++q) {
-            const StageItem it = ppp->stage[q];
-            const DistDev &d = ppp->ds[it.dist];
-            const double *src = it.field == ST_XAX ? d.xax : it.field == ST_PDF ? d.pdf : it.field == ST_PPF ? d.ppf
-                              : it.field == ST_M0 ? d.m0 : it.field == ST_M1 ? d.m1 : d.m2;
-            for (int k = tid; k < it.n; k += SETUP_THREADS) tab[it.off + k] = src[k];
-        }
+        for (int k = tid; k < nw; k += nthr) ((int *)lp)[k] = ((const int *)ppp)[k];
+        const double *image = ppp->stage_image;
+        const int n_tab = ppp->stage_doubles;
+        for (int k = tid; k < n_tab; k += nthr) tab[k] = image[k];
     }
-    for (int q = tid; q < n_it * ndim; q += SETUP_THREADS) {   // coalesced; LDS holds it transposed
+    for (int q = tid; q < n_it * ndim; q += nthr) {            // coalesced; LDS holds it transposed
         const int it = q / ndim, k = q - it * ndim;
         th_all[k * 64 + it] = U[b0 * ndim + q];
     }
     __syncthreads();
-    if (do_prior && tid < ppp->n_stage) {                      // the LDS copy of the program points at the LDS tables
+    if (do_prior && tid < lp->n_stage) {                       // the LDS copy of the program points at the LDS tables
         const StageItem it = lp->stage[tid];
         DistDev &d = lp->ds[it.dist];
         const double *p = tab + it.off;
@@ -439,23 +446,32 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
         else if (it.field == ST_M0) d.m0 = p; else if (it.field == ST_M1) d.m1 = p; else d.m2 = p;
     }
     __syncthreads();
-    // ---- phase 1: wave 0, lanes = items (core.pyx:459-476)
-    if (do_prior && tid < n_it) prior_transform_lane(*lp, th_all + tid, ncomp);
+    // ---- phase 1: lanes = items (core.pyx:459-476); priors that share no parameter slot take a wave each
+    // (a wave interprets ONE prior for its 64 items: no divergence, and the longest prior sets the time)
+    if (do_prior) {
+        const int lane = tid & 63, wave = tid >> 6, n_waves = nthr >> 6;
+        if (lp->parallel) {
+            for (int k = wave; k < lp->n_prior; k += n_waves)
+                if (lane < n_it) prior_apply_lane(*lp, k, th_all + lane, ncomp);
+        } else if (tid < n_it) {
+            prior_transform_lane(*lp, th_all + tid, ncomp);
+        }
+    }
     __syncthreads();
     if (do_prior)
-        for (int q = tid; q < n_it * ndim; q += SETUP_THREADS) {
+        for (int q = tid; q < n_it * ndim; q += nthr) {
             const int it = q / ndim, k = q - it * ndim;
             U[b0 * ndim + q] = th_all[k * 64 + it];
         }
     const bool ammonia = S.model == NFA_MODEL_AMMONIA;
-    // ---- phase 2: lanes = (item, component, quarter)
+    // ---- phase 2: lanes = (item, component, eighth)
     if (ammonia && !(ablate & 32)) {
-        const int n_task = SETUP_TI * ncomp * 4;               // padded: whole quads are on or off
-        for (int q0 = 0; q0 < n_task; q0 += SETUP_THREADS) {
+        const int n_task = n_it * ncomp * QSUM_LANES;           // whole groups of eight are on or off
+        for (int q0 = 0; q0 < n_task; q0 += nthr) {
             const int q = q0 + tid;
-            const int pair = q >> 2, chunk = q & 3;
+            const int pair = q / QSUM_LANES, chunk = q % QSUM_LANES;
             const int it = pair / ncomp, c = pair - it * ncomp;
-            const bool on = q < n_task && it < n_it;
+            const bool on = q < n_task;
             const double trot = on ? th_all[(ncomp + c) * 64 + it] : 1.0;
             qsum_lane<MODE>(on, trot, S.cold, chunk, q_all + (on ? pair : 0) * QREC, sm);
         }
@@ -463,7 +479,7 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
     __syncthreads();
     // ---- phase 3: lanes = (item, component, spectrum)
     const int per_item = ncomp * nspec;
-    for (int q = tid; q < n_it * per_item && !(ablate & 64); q += SETUP_THREADS) {
+    for (int q = tid; q < n_it * per_item && !(ablate & 64); q += nthr) {
         const int it = q / per_item, k = q - it * per_item;
         const int c = k / nspec, s = k - c * nspec;
         double *Db = D + (b0 + it) * drec;
@@ -493,7 +509,8 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(const PriorProg *_
 //  arithmetic itself.  Same device functions as the batch kernels, so a point gives the same bits either way.
 // ---------------------------------------------------------------------------
 #define NFA_POINT_MAXDIM 24
-#define POINT_WAVES (SETUP_THREADS / 64)
+#define POINT_THREADS 512
+#define POINT_WAVES (POINT_THREADS / 64)
 struct PointIn {
     double u[NFA_POINT_MAXDIM];
     unsigned long long seq;            // written to the host buffer last
@@ -501,7 +518,7 @@ struct PointIn {
     int n_blocks;                      // likelihood workgroups the one workgroup stands in for
 };
 template <int MODE, int NCOMP>
-__global__ void __launch_bounds__(SETUP_THREADS) point_kernel(const PriorProg *__restrict__ ppp, SpecDev S, PointIn in,
+__global__ void __launch_bounds__(POINT_THREADS) point_kernel(const PriorProg *__restrict__ ppp, SpecDev S, PointIn in,
                                                               int *__restrict__ d_pix, double *__restrict__ U,
                                                               double *__restrict__ D, double *__restrict__ part,
                                                               double *__restrict__ out, LnlGeom G,
@@ -534,7 +551,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) point_kernel(const PriorProg *_
     __threadfence_system();
     __syncthreads();
     if (tid == 0) {
-        out[ndim] = lnl_of_item(part, S.noise, in.pix >= 0 ? (long)in.pix : 0, 0, S.n_spec, G.split);
+        out[ndim] = lnl_of_item(part, S.noise, in.pix >= 0 ? (long)in.pix : 0, 0, S.n_spec);
         __threadfence_system();
         __hip_atomic_store((unsigned long long *)(out + ndim + 1), in.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

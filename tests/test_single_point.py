@@ -26,7 +26,7 @@ def test_point_kernel_gives_the_bits_of_the_batch_kernels(engine, nfo, mode):
             spec_data = _spec_data(trans, n)
             ut = engine.get_irdc_priors(size=300, vsys=0.0)
             U = np.random.default_rng(11).uniform(size=(12, 6 * ncomp))
-            for split in (1, 2, 4):
+            for split in (1, 2, 4, 0):
                 _ffi.set_option('lnl_split', split)
                 run = engine.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp)
                 Ub = U.copy()
@@ -42,7 +42,7 @@ def test_point_kernel_gives_the_bits_of_the_batch_kernels(engine, nfo, mode):
             Uc = U.copy()
             np.testing.assert_allclose(want, cpu.loglikelihood_batch(Uc), rtol=LNL_RTOL[mode])
     finally:
-        _ffi.set_option('lnl_split', 1)
+        _ffi.set_option('lnl_split', 0)
         _ffi.set_option('point', 1)
         engine.set_exp_mode('fast')
 
