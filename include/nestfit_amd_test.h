@@ -28,6 +28,13 @@ typedef int (*nfa_broker_loglike_fn)(nfa_broker *b, int32_t pix, double *cube, d
 int nfa_test_broker_storm(nfa_broker *b, nfa_broker_loglike_fn loglike, int n_threads, int n_calls,
                           const int32_t *pix, double *U, double *lnL, double *seconds_out);
 
+/* n_calls serial calls of `callback` -- the address of the product library's nfa_loglike_callback, the
+ * LogLike a serial MultiNest would be handed (wrapped.pyx:56-99), with `runner` as its context -- on copies
+ * of the unit-cube point u[ndim]: the per-call latency of the drop-in with no host language in the way. */
+typedef void (*nfa_loglike_callback_fn)(double *cube, int *ndim, int *npars, double *lnew, void *ctx);
+int nfa_test_callback_latency(nfa_loglike_callback_fn callback, void *runner, int ndim, const double *u,
+                              int n_calls, double *lnew_out, double *seconds_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,6 +116,7 @@ TEST_SIGNATURES = {
     'nfa_test_partition': (C.c_int, [_dp, _dp, _dp, C.c_int64]),
     'nfa_test_windows': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _ip, _ip]),
     'nfa_test_broker_storm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp]),
+    'nfa_test_callback_latency': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, C.c_int, _dp, _dp]),
 }
 TEST_LIB_PATH = HERE / 'lib' / 'libnestfit_amd_test.so'
 
@@ -172,6 +173,11 @@ def test_check(rc):
 def broker_loglike_address():
     """Address of the product library's nfa_broker_loglike, for nfa_test_broker_storm."""
     return C.cast(load().nfa_broker_loglike, C.c_void_p)
+
+
+def loglike_callback_address():
+    """Address of the product library's nfa_loglike_callback (MultiNest's LogLike), for nfa_test_callback_latency."""
+    return C.cast(load().nfa_loglike_callback, C.c_void_p)
 
 
 def dptr(a):

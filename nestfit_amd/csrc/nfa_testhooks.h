@@ -180,5 +180,20 @@ int nfa_test_broker_storm(nfa_broker *b, nfa_broker_loglike_fn loglike, int n_th
     return NFA_OK;
 }
 
+int nfa_test_callback_latency(nfa_loglike_callback_fn callback, void *runner, int ndim, const double *u,
+                              int n_calls, double *lnew_out, double *seconds_out) {
+    if (!callback || !runner || !u || ndim < 1 || ndim > 64 || n_calls < 1) return fail(NFA_ERR_ARG, "bad argument");
+    double cube[64], lnew = 0.0;
+    int nd = ndim, npars = ndim;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int j = 0; j < n_calls; ++j) {
+        memcpy(cube, u, sizeof(double) * ndim);
+        callback(cube, &nd, &npars, &lnew, runner);
+    }
+    if (seconds_out)
+        *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (lnew_out) *lnew_out = lnew;
+    return NFA_OK;
+}
 
 }  // extern "C"

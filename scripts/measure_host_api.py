@@ -28,6 +28,18 @@ for point in (1, 0):
     dt = (time.perf_counter() - t0) / len(bufs)
     print(f'single point, {"point kernel" if point else "batch kernels as a graph"}: {dt*1e6:.1f} us per call', flush=True)
 _ffi.set_option('point', 1)
+# the same without Python in the loop: MultiNest's LogLike (nfa_loglike_callback) called from native code
+import ctypes as C
+tl = _ffi.test_engine()
+sec, last = np.zeros(1), np.zeros(1)
+for point in (1, 0):
+    _ffi.set_option('point', point)
+    for n_calls in (50, 5000):
+        _ffi.test_check(tl.nfa_test_callback_latency(_ffi.loglike_callback_address(), run._run.handle, 12, _ffi.dptr(u0),
+                                                     n_calls, _ffi.dptr(last), _ffi.dptr(sec)))
+    print(f'native callback, {"point kernel" if point else "batch kernels as a graph"}: {sec[0] / 5000 * 1e6:.1f} us per call '
+          f'(lnL {last[0]:.6f})', flush=True)
+_ffi.set_option('point', 1)
 for B in (1, 400, 4096, 65536):
     U = rng.uniform(size=(B, 12))
     run.loglikelihood_batch(U.copy())
