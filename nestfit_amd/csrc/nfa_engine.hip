@@ -189,6 +189,7 @@ struct nfa_runner {
     uint64_t n_single = 0;
     double *h_point = nullptr;       // mapped host buffer of the point kernel: theta[ndim], lnL, sequence number
     double *d_point = nullptr;       // the same buffer as the device sees it
+    unsigned *d_point_done = nullptr; // workgroups of a point launch that have finished
     uint64_t pt_seq = 0;
     // optional per-kernel timing (HIP events on the runner's stream)
     bool profiling = false;
@@ -575,6 +576,7 @@ int nfa_runner_destroy(nfa_runner *r) {
     if (r->g1) (void)hipGraphExecDestroy(r->g1);
     if (r->h_pin) (void)hipHostFree(r->h_pin);
     if (r->h_point) (void)hipHostFree(r->h_point);
+    if (r->d_point_done) (void)hipFree(r->d_point_done);
     for (hipEvent_t x : r->ev) (void)hipEventDestroy(x);
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamDestroy(r->lanes[k]);
     delete r;
@@ -875,14 +877,16 @@ int nfa_runner_synchronize(nfa_runner *r) {
 
 }  // extern "C"
 
-// One point through the point kernel (nfa_setup.h); returns 1 when the call was served, 0 when another
-// path has to do it, a negative value on a device error.
+// One point, or the few a broker gathered, through the point kernel (nfa_setup.h); returns 1 when the call
+// was served, 0 when another path has to do it, a negative value on a device error.
+#define POINT_HOST_DOUBLES (NFA_POINT_MAXB * (2 * NFA_POINT_MAXDIM + 2) + 8)
 template <int MODE, int NCOMP>
 static void launch_point_t(nfa_runner *r, const SpecDev &S, const PointIn &in, const LnlGeom &G, size_t lds) {
     auto kern = point_kernel<MODE, NCOMP>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(1), dim3(POINT_THREADS), lds, r->lanes[0], (const PriorProg *)r->pr->d_prog, S, in,
-                       r->d_pix, r->d_U, r->d_D[0], r->d_part[0], r->d_point, G, (const double *)g_eng.d_tabs);
+    hipLaunchKernelGGL(kern, dim3((unsigned)in.n), dim3(POINT_THREADS), lds, r->lanes[0], (const PriorProg *)r->pr->d_prog, S, in,
+                       r->d_pix, r->d_U, r->d_D[0], r->d_part[0], r->d_point, r->d_point_done, G,
+                       (const double *)g_eng.d_tabs);
 }
 template <int MODE>
 static void launch_point_n(nfa_runner *r, const SpecDev &S, const PointIn &in, const LnlGeom &G, size_t lds) {
@@ -894,9 +898,9 @@ static void launch_point_n(nfa_runner *r, const SpecDev &S, const PointIn &in, c
     }
 }
 
-static int single_point_kernel(nfa_runner *r, const int32_t *pix, double *U, double *lnL) {
+static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, double *lnL, int64_t B) {
     const int ndim = r->ndim;
-    if (!g_eng.point || r->profiling || ndim > NFA_POINT_MAXDIM || r->ss->nhf_max > 26) return 0;
+    if (!g_eng.point || r->profiling || ndim > NFA_POINT_MAXDIM || r->ss->nhf_max > 26 || B > NFA_POINT_MAXB) return 0;
     const int mode = r->exp_mode >= 0 ? r->exp_mode : g_eng.exp_mode;
     const SpecDev S = runner_specdev(r);
     LnlGeom G;
@@ -913,24 +917,40 @@ static int single_point_kernel(nfa_runner *r, const int32_t *pix, double *U, dou
     const size_t lds = std::max(setup_lds_bytes(r, 1, true) + sizeof(double) * (n_staged - 32),
                                 sizeof(double) * ((size_t)n_shared + ((size_t)G.wave_doubles + (G.split > 1 ? LNL_PARTS * 64 : 0)) * upw));
     if (lds > 160 * 1024) return 0;
-    if (reserve_lane(r, 0, 1) != NFA_OK) return -1;
+    if (reserve_lane(r, 0, B) != NFA_OK) return -1;
     if (!r->h_point) {
-        if (hipHostMalloc((void **)&r->h_point, sizeof(double) * (NFA_POINT_MAXDIM + 2), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
-            || hipHostGetDevicePointer((void **)&r->d_point, r->h_point, 0) != hipSuccess) {
+        bool ok = hipHostMalloc((void **)&r->h_point, sizeof(double) * POINT_HOST_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess
+                  && hipHostGetDevicePointer((void **)&r->d_point, r->h_point, 0) == hipSuccess
+                  && hipMalloc((void **)&r->d_point_done, sizeof(unsigned)) == hipSuccess
+                  && hipMemset(r->d_point_done, 0, sizeof(unsigned)) == hipSuccess;
+        if (!ok) {
             (void)hipGetLastError();
             if (r->h_point) (void)hipHostFree(r->h_point);
-            r->h_point = nullptr;
+    if (r->d_point_done) (void)hipFree(r->d_point_done);
+            if (r->d_point_done) (void)hipFree(r->d_point_done);
+            r->h_point = nullptr; r->d_point_done = nullptr;
             g_eng.point = 0;
             return 0;
         }
-        memset(r->h_point, 0, sizeof(double) * (NFA_POINT_MAXDIM + 2));
+        memset(r->h_point, 0, sizeof(double) * POINT_HOST_DOUBLES);
     }
     PointIn in;
-    memcpy(in.u, U, sizeof(double) * ndim);
-    for (int k = ndim; k < NFA_POINT_MAXDIM; ++k) in.u[k] = 0.0;
+    memset(&in, 0, sizeof in);
     in.seq = ++r->pt_seq;
-    in.pix = pix ? pix[0] : -1;
+    in.n = (int)B;
     in.n_blocks = (S.n_spec + upw - 1) / upw;
+    if (B == 1) {
+        memcpy(in.u, U, sizeof(double) * ndim);
+        in.pix = pix ? pix[0] : -1;
+    } else {                                                     // the unit cubes travel through the mapped buffer
+        double *in_u = r->h_point + B * (ndim + 1) + 1;
+        memcpy(in_u, U, sizeof(double) * B * ndim);
+        if (pix) memcpy(in_u + B * ndim, pix, sizeof(int32_t) * B);
+        in.pix = pix ? 0 : -1;
+    }
+    volatile unsigned long long *flag = (volatile unsigned long long *)(r->h_point + B * (ndim + 1));
+    *flag = 0;                                                   // the slot holds other data when B changes
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
     switch (mode) {
     case 0: launch_point_n<0>(r, S, in, G, lds); break;
     case 1: launch_point_n<1>(r, S, in, G, lds); break;
@@ -938,7 +958,6 @@ static int single_point_kernel(nfa_runner *r, const int32_t *pix, double *U, dou
     }
     if (hipGetLastError() != hipSuccess) { fail(NFA_ERR_DEVICE, "point kernel launch failed"); return -1; }
     // the kernel's last store is the sequence number; the host reads it straight from the mapped buffer
-    const volatile unsigned long long *flag = (const volatile unsigned long long *)(r->h_point + ndim + 1);
     const auto t_start = std::chrono::steady_clock::now();
     for (uint64_t spins = 0;; ++spins) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == in.seq) break;
@@ -948,8 +967,8 @@ static int single_point_kernel(nfa_runner *r, const int32_t *pix, double *U, dou
             if (hipStreamSynchronize(r->lanes[0]) != hipSuccess) { fail(NFA_ERR_DEVICE, "point kernel failed"); return -1; }
         }
     }
-    memcpy(U, r->h_point, sizeof(double) * ndim);
-    *lnL = r->h_point[ndim];
+    memcpy(U, r->h_point, sizeof(double) * B * ndim);
+    memcpy(lnL, r->h_point + B * ndim, sizeof(double) * B);
     return 1;
 }
 
@@ -1009,8 +1028,8 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     rc = sync_all_lanes(r); if (rc) return rc;           // the staging buffers are shared
     rc = runner_reserve(r, B, false); if (rc) return rc;
-    if (B == 1) {                                        // MultiNest-style single points: one launch, no copies
-        const int served = single_point_kernel(r, pix, U, lnL);
+    if (B <= NFA_POINT_MAXB) {                           // MultiNest-style single points, a broker's handful: one launch, no copies
+        const int served = few_points_kernel(r, pix, U, lnL, B);
         if (served < 0) return NFA_ERR_DEVICE;
         if (served) return NFA_OK;
     }

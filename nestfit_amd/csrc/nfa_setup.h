@@ -501,48 +501,63 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(const PriorProg *_
 }
 
 // ---------------------------------------------------------------------------
-//  One point per call (MultiNest's callback, core.pyx:513-531 through ammonia.pyx:405-432): the whole path in
-//  ONE launch of ONE workgroup -- the unit cube arrives in the kernel arguments, the set-up stage, the
-//  likelihood waves and the sum follow each other across workgroup barriers, and theta, lnL and a sequence
-//  number are written straight into a mapped host buffer the caller spins on.  No copy commands, no second
-//  and third launch, no stream synchronisation: what is left is one dispatch and the dependent chain of the
-//  arithmetic itself.  Same device functions as the batch kernels, so a point gives the same bits either way.
+//  One point per call (MultiNest's callback, core.pyx:513-531 through ammonia.pyx:405-432) and the few points
+//  a broker gathers from concurrent callers: the whole path in ONE launch, one workgroup per point -- the set-up
+//  stage, the likelihood waves and the sum follow each other across workgroup barriers, and theta, lnL and a
+//  sequence number are written straight into a mapped host buffer the caller spins on.  A single point arrives in
+//  the kernel arguments, several are read from the mapped buffer.  No copy commands, no second and third launch,
+//  no stream synchronisation: what is left is one dispatch and the dependent chain of the arithmetic itself.
+//  Same device functions as the batch kernels, so a point gives the same bits either way.
+//  Mapped buffer (doubles): [theta out: n x ndim][lnL out: n][sequence number][unit cube in: n x ndim][pixel in: n ints]
 // ---------------------------------------------------------------------------
 #define NFA_POINT_MAXDIM 24
+#define NFA_POINT_MAXB 128
 #define POINT_THREADS 512
 #define POINT_WAVES (POINT_THREADS / 64)
 struct PointIn {
-    double u[NFA_POINT_MAXDIM];
+    double u[NFA_POINT_MAXDIM];        // n == 1: the point
     unsigned long long seq;            // written to the host buffer last
-    int pix;                           // < 0: the runner has one pixel
+    int n;                             // points of this launch = workgroups
+    int pix;                           // n == 1: its pixel (< 0: the runner has one pixel); n > 1: pixels given or not
     int n_blocks;                      // likelihood workgroups the one workgroup stands in for
+    int pad;
 };
 template <int MODE, int NCOMP>
 __global__ void __launch_bounds__(POINT_THREADS) point_kernel(const PriorProg *__restrict__ ppp, SpecDev S, PointIn in,
-                                                              int *__restrict__ d_pix, double *__restrict__ U,
-                                                              double *__restrict__ D, double *__restrict__ part,
-                                                              double *__restrict__ out, LnlGeom G,
-                                                              const double *__restrict__ g_tabs) {
+                                                              int *__restrict__ d_pix, double *__restrict__ U_all,
+                                                              double *__restrict__ D_all, double *__restrict__ part_all,
+                                                              double *__restrict__ host, unsigned *__restrict__ n_done,
+                                                              LnlGeom G, const double *__restrict__ g_tabs) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int SMODE = MODE == 0 ? 0 : 1;                   // fast mode: the set-up stage runs its polynomial form
     int n_shared;
     const double *sm = stage_exp_tables<SMODE>(smem, g_tabs, &n_shared);
     const int tid = threadIdx.x;
-    const int ndim = S.npar * S.ncomp;
-    {
+    const int ndim = S.npar * S.ncomp, n = in.n;
+    const long b = blockIdx.x;
+    double *U = U_all + b * ndim, *D = D_all + b * drec_size(S.ncomp, S.n_spec), *part = part_all + b * S.n_spec;
+    double *out_theta = host + b * ndim, *out_lnl = host + (long)n * ndim + b;
+    unsigned long long *out_seq = (unsigned long long *)(host + (long)n * (ndim + 1));
+    const double *in_u = host + (long)n * (ndim + 1) + 1;
+    const int *in_pix = (const int *)(in_u + (long)n * ndim);
+    int my_pix = in.pix;
+    if (n == 1) {
         double v = 0.0;
 #pragma unroll
         for (int k = 0; k < NFA_POINT_MAXDIM; ++k) v = tid == k ? in.u[k] : v;      // kernel arguments: no dynamic index
         if (tid < ndim) U[tid] = v;
-        if (tid == 0 && in.pix >= 0) d_pix[0] = in.pix;
+    } else {
+        if (tid < ndim) U[tid] = in_u[b * ndim + tid];           // one trip over PCIe per workgroup
+        if (in.pix >= 0) my_pix = in_pix[b];
     }
+    if (tid == 0 && in.pix >= 0) d_pix[b] = my_pix;
     __syncthreads();
     setup_body<SMODE>(ppp, S, U, D, 1, 1, g_tabs, 0, smem, sm, n_shared, 0u);
     __threadfence();                                            // theta in U, the derived record in D: at L2 ...
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();                            // ... where the scalar loads of the record find them
-    if (tid < ndim) out[tid] = U[tid];
-    const int *pix = in.pix >= 0 ? d_pix : nullptr;
+    if (tid < ndim) out_theta[tid] = U[tid];
+    const int *pix = in.pix >= 0 ? d_pix + b : nullptr;
     for (int blk = 0; blk < in.n_blocks; ++blk) {
         if (blk) __syncthreads();                               // the line tables are reused
         lnl_body<MODE, false, false, NCOMP>(S, pix, D, part, nullptr, 1, G, g_tabs, smem, MODE == 2 ? smem : sm,
@@ -551,9 +566,16 @@ __global__ void __launch_bounds__(POINT_THREADS) point_kernel(const PriorProg *_
     __threadfence_system();
     __syncthreads();
     if (tid == 0) {
-        out[ndim] = lnl_of_item(part, S.noise, in.pix >= 0 ? (long)in.pix : 0, 0, S.n_spec);
+        *out_lnl = lnl_of_item(part, S.noise, in.pix >= 0 ? (long)my_pix : 0, 0, S.n_spec);
         __threadfence_system();
-        __hip_atomic_store((unsigned long long *)(out + ndim + 1), in.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the last workgroup to get here publishes the sequence number (and leaves the counter at zero)
+        bool last = true;
+        if (n > 1) {
+            const unsigned seen = __hip_atomic_fetch_add(n_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            last = seen == (unsigned)n - 1u;
+            if (last) __hip_atomic_store(n_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last) __hip_atomic_store(out_seq, in.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 #undef TH

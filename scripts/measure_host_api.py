@@ -40,7 +40,7 @@ for point in (1, 0):
     print(f'native callback, {"point kernel" if point else "batch kernels as a graph"}: {sec[0] / 5000 * 1e6:.1f} us per call '
           f'(lnL {last[0]:.6f})', flush=True)
 _ffi.set_option('point', 1)
-for B in (1, 400, 4096, 65536):
+for B in (1, 16, 64, 128, 129, 400, 4096, 65536):
     U = rng.uniform(size=(B, 12))
     run.loglikelihood_batch(U.copy())
     reps = 200 if B <= 4096 else 20

@@ -30,6 +30,7 @@ def test_point_kernel_gives_the_bits_of_the_batch_kernels(engine, nfo, mode):
                 _ffi.set_option('lnl_split', split)
                 run = engine.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp)
                 Ub = U.copy()
+                _ffi.set_option('point', 0)
                 want = run.loglikelihood_batch(Ub)              # the batch kernels; Ub = theta
                 for point in (1, 0):
                     _ffi.set_option('point', point)
@@ -38,6 +39,12 @@ def test_point_kernel_gives_the_bits_of_the_batch_kernels(engine, nfo, mode):
                         got = run.loglikelihood(u)
                         assert np.array_equal(u, Ub[k]), (trans, ncomp, split, point, k)
                         assert got == want[k] or (np.isnan(got) and np.isnan(want[k])), (trans, ncomp, split, point, k)
+                # a broker's handful of points: one workgroup each in the same launch
+                _ffi.set_option('point', 1)
+                for a, b in ((0, 2), (3, 10), (0, 12)):
+                    Uf = U[a:b].copy()
+                    got = run.loglikelihood_batch(Uf)
+                    assert np.array_equal(Uf, Ub[a:b]) and np.array_equal(got, want[a:b], equal_nan=True), (trans, ncomp, split, a, b)
             cpu = nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(*sd) for sd in spec_data], nfo.PriorSet(ut.lower()), ncomp=ncomp)
             Uc = U.copy()
             np.testing.assert_allclose(want, cpu.loglikelihood_batch(Uc), rtol=LNL_RTOL[mode])
@@ -59,12 +66,19 @@ def test_point_kernel_with_a_pixel_index_and_interleaved_batches(engine):
     rc = CubeRunner(axes, (1, 2), data, noise, engine.get_irdc_priors(size=300, vsys=0.0), ncomp=2)
     U = rng.uniform(size=(40, 12))
     pix = rng.integers(0, n_pix, size=40).astype(np.int32)
+    from nestfit_amd import _ffi
     Ub = U.copy()
-    want = rc.loglikelihood_batch(pix, Ub)
+    _ffi.set_option('point', 0)
+    try:
+        want = rc.loglikelihood_batch(pix, Ub)                  # the batch kernels
+    finally:
+        _ffi.set_option('point', 1)
     for k in range(40):
         u = U[k:k + 1].copy()
         assert rc.loglikelihood_batch(pix[k:k + 1], u)[0] == want[k]
         assert np.array_equal(u[0], Ub[k])
         if k % 7 == 0:
             Ub2 = U.copy()
-            assert np.array_equal(rc.loglikelihood_batch(pix, Ub2), want)
+            assert np.array_equal(rc.loglikelihood_batch(pix, Ub2), want)          # 40 points: one launch
+            big = np.tile(U, (3, 1))                                               # 120 points: the batch kernels
+            assert np.array_equal(rc.loglikelihood_batch(np.tile(pix, 3), big), np.tile(want, 3))
