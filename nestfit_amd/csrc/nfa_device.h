@@ -104,12 +104,12 @@ struct SpecDev {
 #define DK_Q 10
 __host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncomp + ncomp * nspec * DREC_CS; }
 
-#define LNL_PARTS 4      // row blocks of a unit: the fixed shape of its chi^2 sum
+#define LNL_PARTS 4      // row parts of a unit: the fixed shape of its chi^2 sum
 struct LnlGeom {
     int nhf_max;       // lines per component slot in the LDS line table
     int wave_doubles;  // LDS doubles per wave
     unsigned inv_nspec; // floor(2^32 / nspec) + 1: unit / nspec = mulhi(unit, inv_nspec) for unit < 2^28; 0: nspec == 1
-    int split;          // waves that share one (item, spectrum) unit (1, 2, 4), each taking LNL_PARTS / split row blocks
+    int split;          // waves that share one (item, spectrum) unit (1, 2, 4), each taking LNL_PARTS / split row parts
     int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 4 skip rows, 8 skip line set-up
 };
 
@@ -445,8 +445,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
 
     // One unit per wave, or `split` = 2 or 4 waves per unit (small launches: more, shorter waves than wave
     // slots, so that the hardware places them as slots free up; the waves of a unit share its line table).
-    // The rows of a unit form LNL_PARTS blocks of consecutive rows; chi^2 is, per lane, the sum of the
-    // blocks' sums taken in block order, whatever the number of waves that worked on them: the result does
+    // The rows of a unit form LNL_PARTS interleaved parts (rows h, h + LNL_PARTS, ...: the hyperfine groups
+    // sit in a few neighbouring rows, so interleaved parts carry like work); chi^2 is, per lane, the sum of the
+    // parts' sums taken in part order, whatever the number of waves that worked on them: the result does
     // not depend on `split` (nor on the size of the batch an item travels in) to the last bit.
     // The grid covers all units (the host keeps B * nspec * split below 2^28).  Waves
     // of a workgroup land on the SIMDs of a CU in order, so the unit -> wave assignment is rotated per
@@ -461,7 +462,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const int rpart = split == 1 ? 0 : (int)(wsel - ulocal * (unsigned)split);
     const unsigned unit = block_id * upw + ulocal;
     LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)ulocal * G.wave_doubles);
-    // split > 1: the blocks' per-lane sums meet here, [unit of the workgroup][block][lane]
+    // split > 1: the parts' per-lane sums meet here, [unit of the workgroup][part][lane]
     double *w_part = smem + n_shared + (size_t)upw * G.wave_doubles + (size_t)ulocal * (LNL_PARTS * 64);
     if (unit >= units) {
         if (split > 1) { __syncthreads(); __syncthreads(); }         // the two barriers of the waves at work
@@ -542,15 +543,14 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
         empt = 0ull;
     };
     const int n_rows = (ablate & 4) ? 0 : (N + 63) >> 6;
-    const int rows_per_part = (n_rows + LNL_PARTS - 1) / LNL_PARTS;
     const int parts_per_wave = LNL_PARTS / split;
     double tot = 0.0;
     for (int hp = 0; hp < parts_per_wave; ++hp) {
-    const int h = rpart * parts_per_wave + hp;
-    const int row_a = h * rows_per_part;
-    const int row_b = row_a + rows_per_part < n_rows ? row_a + rows_per_part : n_rows;
+    const int h = rpart * parts_per_wave + hp;                 // part h = rows h, h + LNL_PARTS, h + 2 LNL_PARTS, ...
     acc = 0.0;
-    for (int row = row_a; row < row_b; ++row) {
+    int row_last = 0;
+    for (int row = h; row < n_rows; row += LNL_PARTS) {
+        row_last = row;
         const int r0 = row << 6;
         const int j = r0 + lane;
         // lines of each component that touch this row
@@ -669,9 +669,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             }
         }
         if (!any) empt |= 1ull << (row & 63);
-        if ((row & 63) == 63) flush_empty(row & ~63);                // the last row of this group of 64
+        if (((row + LNL_PARTS) >> 6) != (row >> 6)) flush_empty(row & ~63);      // the part's last row of this group of 64
     }
-    flush_empty((row_b - 1) & ~63);
+    flush_empty(row_last & ~63);
     if (split == 1) tot += acc; else w_part[h * 64 + lane] = acc;
     }
     if (split > 1) {

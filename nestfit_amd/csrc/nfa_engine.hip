@@ -671,7 +671,7 @@ static int resolve_split(const nfa_runner *r, const SpecDev &S, int64_t B) {
     if (split == 0) {
         const int64_t slots = (int64_t)g_eng.n_cu * 32;
         split = 1;
-        while (split < LNL_PARTS && B * S.n_spec * split * 4 <= slots) split *= 2;
+        while (split < LNL_PARTS && B * S.n_spec * split * 2 <= slots) split *= 2;
     }
     int min_rows = 1 << 30;
     for (int k = 0; k < S.n_spec; ++k) min_rows = std::min(min_rows, (S.size[k] + 63) / 64);
