@@ -42,11 +42,15 @@
 #define SM_T0X    0
 #define SM_T0Y    1000
 #define SM_EXP2   2000        // 2^(i/32), i = 0..31          (poly)
-#define SM_FEA    2032        // exp(-(128+j) 2^(l-12)) [10][128] (table)
-#define SM_FEB    (SM_FEA + 1280)   // exp(-j 2^(l-20)) [10][256]
-#define SM_FEC    (SM_FEB + 2560)   // exp(-j 2^(l-28)) [10][256]
+// (table; C first, A last: a lane outside the tables' range -- it is given its value by the branch for such
+// arguments -- still forms an address from its exponent bits, up to row 15 of a 10-row table: behind C lies B,
+// behind B lies A, behind A at least SM_TABLE_TAIL doubles of whatever the kernel keeps there)
+#define SM_FEC    2032              // exp(-j 2^(l-28)) [10][256]
+#define SM_FEB    (SM_FEC + 2560)   // exp(-j 2^(l-20)) [10][256]
+#define SM_FEA    (SM_FEB + 2560)   // exp(-(128+j) 2^(l-12)) [10][128]
 #define SM_END_POLY   2032
-#define SM_END_TABLE  (SM_FEC + 2560)   // 8432 doubles
+#define SM_END_TABLE  (SM_FEA + 1280)   // 8432 doubles
+#define SM_TABLE_TAIL 768               // doubles that must follow the staged tables in LDS (row 15 of A ends there)
 
 // Transition tables of every model in one index space: 0..8 NH3 (1,1)..(9,9), 9..11 N2H+
 // 1-0, 2-1, 3-2, 12 the Gaussian model's single "line" (offset 0, weight 1, rest frequency
@@ -90,7 +94,12 @@ struct SpecDev {
 // For kind 1 the record also holds the cell written in the frequency x of the channel
 // (T0 = kappa x, kappa = h/k): A0X = A0 kappa, B0X = B0 kappa^2, so that
 //      T0 (y - tbg) = B0X x^2 + A0X x - T0 tbg          (two fused multiply-adds per channel)
-#define DREC_CS 12
+// The exact modes evaluate hyperfine.pyx:23-45 per channel, x = T0 / tex by division; where the first and
+// the last channel fall in ONE table cell (XKIND = 1: the usual case) the cell -- slope XS, x_lo, y_lo -- is
+// in the record and a channel computes slope (x - x_lo) + y_lo without finding the cell again: the same
+// operations on the same operands, hence the same bits (division is monotonic: the cells of the two ends
+// bound the cells of every channel between them).
+#define DREC_CS 16
 #define DK_TMAIN 0
 #define DK_KIND  1
 #define DK_A0X 2
@@ -102,6 +111,10 @@ struct SpecDev {
 #define DK_SPLIT 8
 #define DK_M 9
 #define DK_Q 10
+#define DK_XKIND 11
+#define DK_XS 12
+#define DK_XLO 13
+#define DK_YLO 14
 __host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncomp + ncomp * nspec * DREC_CS; }
 
 #define LNL_PARTS 4      // row parts of a unit: the fixed shape of its chi^2 sum
@@ -192,32 +205,49 @@ __device__ __forceinline__ double exp_neg_poly(double t, const double *sm) {
 }
 
 // MODE 0: the reference's three-table product; MODE 1: polynomial.  The
-// branches of fastexp.c (negative, zero, Taylor, >= 32) are rare per wave and
-// handled under one wave-uniform test.
-template <int MODE>
+// branches of fastexp.c (negative, zero, Taylor, >= 32) are handled under one wave-uniform test.
+// NONNEG: the caller knows x >= +0 or NaN (a square times a positive number; a sum of such terms).
+// BOUNDED: the caller also knows x < 32 and not NaN (the line loop: the window set-up sees to it).
+// Table addresses come straight from the bits of the float: u = bits - (122 << 23) holds l = exponent - 122
+// (fastexp.c:262) in bits 23..26 where l is in range, so (u >> 16) & 0x7ff = l * 128 + j0 and the rows of B and
+// C start at l << 11 bytes.
+template <int MODE, bool NONNEG = false, bool BOUNDED = false>
 __device__ __forceinline__ double nf_fastexp(double xd, const double *sm) {
     const float x = (float)xd;                               // math.pxd:17 narrowing
     const uint32_t bits = __float_as_uint(x);
-    const int l = (int)((bits & 0x7f800000u) >> 23) - 122;    // fastexp.c:262
+    const uint32_t u = (NONNEG ? bits : (bits & 0x7fffffffu)) - (122u << 23);
     double r;
     if (MODE == 0) {
-        const int lc = min(max(l, 0), 9);
-        const int j0 = (bits & 0x007f0000u) >> 16;            // fastexp.c:276-278
-        const int j1 = (bits & 0x0000ff00u) >> 8;
-        const int j2 = (bits & 0x000000ffu);
-        r = sm[SM_FEA + lc * 128 + j0] * sm[SM_FEB + lc * 256 + j1] * sm[SM_FEC + lc * 256 + j2];
+        // bit-field extract + shift-add pairs, the LDS base folded into the adds (the compiler's own form of
+        // this spends two more instructions on adding the base); B sits a constant 2560 doubles behind C
+        typedef const __attribute__((address_space(3))) double *lds_dbl_p;
+        const uint32_t base_a = (uint32_t)(uintptr_t)(sm + SM_FEA), base_c = (uint32_t)(uintptr_t)(sm + SM_FEC);
+        uint32_t oa, ob, oc, rc;
+        asm("v_bfe_u32 %[oa], %[u], 16, 11\n\t"             // l * 128 + j0, fastexp.c:276
+            "v_lshl_add_u32 %[oa], %[oa], 3, %[ba]\n\t"
+            "v_bfe_u32 %[rc], %[u], 23, 4\n\t"              // row l of C
+            "v_lshl_add_u32 %[rc], %[rc], 11, %[bc]\n\t"
+            "v_bfe_u32 %[ob], %[bits], 8, 8\n\t"            // j1, fastexp.c:277
+            "v_lshl_add_u32 %[ob], %[ob], 3, %[rc]\n\t"
+            "v_and_b32 %[oc], 0xff, %[bits]\n\t"            // j2, fastexp.c:278
+            "v_lshl_add_u32 %[oc], %[oc], 3, %[rc]"
+            : [oa] "=&v"(oa), [ob] "=&v"(ob), [oc] "=&v"(oc), [rc] "=&v"(rc)
+            : [u] "v"(u), [bits] "v"(bits), [ba] "s"(base_a), [bc] "s"(base_c));
+        r = *(lds_dbl_p)(uintptr_t)oa * *((lds_dbl_p)(uintptr_t)ob + (SM_FEB - SM_FEC)) * *(lds_dbl_p)(uintptr_t)oc;
     } else {
         r = exp_neg_poly((double)x, sm);                      // out-of-range lanes are replaced below
     }
-    const bool special = (l < 0) || (l >= 10) || (x < 0.0f);
+    bool special = BOUNDED ? (int32_t)u < 0 : u >= (10u << 23);      // l < 0 [or l >= 10 (also NaN, inf)]
+    if (!NONNEG) special = special || (x < 0.0f);
     if (__builtin_amdgcn_ballot_w64(special) != 0ull) {
         const double t = (double)x;                           // fastexp.c:264-270; x == 0 gives exactly 1
         double ty = 1.0 - t * (1.0 / 3.0);
         ty = 1.0 - (t * ty) * 0.5;
         ty = 1.0 - (t * ty);
-        r = (l < 0) ? ty : r;
-        r = (l >= 10) ? 0.0 : r;                              // fastexp.c:272-273 (also NaN, inf)
-        if (x < 0.0f) r = slow_exp(-(double)x);               // fastexp.c:259
+        const bool small = (int32_t)u < 0;                    // l < 0
+        r = small ? ty : r;
+        if (!BOUNDED) r = (special && !small) ? 0.0 : r;      // fastexp.c:272-273
+        if (!NONNEG) { if (x < 0.0f) r = slow_exp(-(double)x); }        // fastexp.c:259
     }
     return r;
 }
@@ -495,6 +525,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                 const float a = (float)(nu * nu * lc.idenom);
                 if (!(a < 32.0f)) lo += 1;
             }
+            // a centre or a width that is not a finite number gives FastExp NaN or inf at every channel: 0 each
+            // time (fastexp.c:272-273), i.e. a line that adds nothing -- an empty window says the same
+            if (!(fabs(lc.nucen) < INFINITY) || !(lc.idenom < INFINITY)) lo = hi;
             rec.nucen = lc.nucen;
             rec.idenom = lc.idenom;
             const double htau = D[b * drec + 4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
@@ -589,17 +622,23 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     const int4 hw = *(const int4 *)(q + 16);          // htau (8 bytes), lo, len
                     if constexpr (MODE == 2 && !WIDE) {
                         line_step_fast(tau, j, xj, ab.x, ab.y, __int_as_float(hw.x), hw.z, hw.w);
-                    } else if ((unsigned)(j - hw.z) < (unsigned)hw.w) {           // the window is the EXEC mask
+                    } else {
+                    // the whole record is read before the window test (left alone the compiler reads lo / len, tests,
+                    // and only then reads the rest: one more trip to LDS in the dependent chain of every step)
+                    double nucen = ab.x, idenom = ab.y;
+                    asm volatile("" : "+v"(nucen), "+v"(idenom));
+                    if ((unsigned)(j - hw.z) < (unsigned)hw.w) {                  // the window is the EXEC mask
                         asm volatile("" ::: "memory");                // keep it a branch (no if-conversion)
-                        const double nu = xj - ab.x;
-                        const double tau_exp = nu * nu * ab.y;
+                        const double nu = xj - nucen;
+                        const double tau_exp = nu * nu * idenom;
                         if constexpr (MODE == 2) {
                             const float e = exp_neg_core_f32((float)tau_exp);          // math.pxd:17 narrowing
                             td = __builtin_fma((double)__int_as_float(hw.x), (double)e, td);
                         } else {
-                            const double e = nf_fastexp<MODE>(tau_exp, sm);
+                            const double e = nf_fastexp<MODE, true, true>(tau_exp, sm);
                             tau = __builtin_fma(__hiloint2double(hw.y, hw.x), e, (double)tau);
                         }
+                    }
                     }
                 };
                 if (ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); }
@@ -640,9 +679,13 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     }
                     pred = __builtin_fma(g, one_minus_fastexp_f32((float)tau), pred);
                 } else {
-                    const double y = nf_iemtex(T0 / Dk[c * 4], g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
+                    const double x = T0 / Dk[c * 4];
+                    double y;
+                    if (Dk[dko + DK_XKIND] == 1.0) y = Dk[dko + DK_XS] * (x - Dk[dko + DK_XLO]) + Dk[dko + DK_YLO];
+                    else y = nf_iemtex(x, g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
                     // the reference's order: pred[i] += T0 * (y - tbg) * (1 - FastExp(tau)), only where tau != 0
-                    const double tb = (T0 * (y - tbg)) * (1.0 - nf_fastexp<MODE>((double)tau, sm));
+                    // (tau is a sum of non-negative terms, or NaN)
+                    const double tb = (T0 * (y - tbg)) * (1.0 - nf_fastexp<MODE, true>((double)tau, sm));
                     pred += !(tau == 0) ? tb : 0.0;
                 }
             };

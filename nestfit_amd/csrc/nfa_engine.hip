@@ -716,6 +716,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
         }
     }
     size_t lds = sizeof(double) * ((size_t)n_shared + ((size_t)G.wave_doubles + (split > 1 ? LNL_PARTS * 64 : 0)) * (waves / split));
+    if (MODE == 0) lds = std::max(lds, sizeof(double) * (size_t)(n_shared + SM_TABLE_TAIL));
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "ncomp too large for the LDS line table");
     if (MODE != 0 && r->lnl_cap > 0 && waves * r->lnl_cap < 32)      // residency cap: see Engine::lnl_cap
         lds = std::max(lds, (size_t)((160 * 1024) / r->lnl_cap) & ~(size_t)15);

@@ -318,7 +318,20 @@ __device__ __forceinline__ void write_y_model(double *dk, const SpecDev &S, int 
     dk[DK_KIND] = kind; dk[DK_A0] = A0; dk[DK_B0] = B0; dk[DK_A1] = A1; dk[DK_B1] = B1;
     dk[DK_SPLIT] = split; dk[DK_M] = m; dk[DK_Q] = q;
     const double kappa = NFA_H / NFA_KB;                       // T0 = kappa x (hyperfine.pyx:106)
-    dk[DK_A0X] = A0 * kappa; dk[DK_B0X] = B0 * (kappa * kappa); dk[11] = 0.0;
+    dk[DK_A0X] = A0 * kappa; dk[DK_B0X] = B0 * (kappa * kappa);
+    // the exact modes' cell (x by division, the cell found exactly as nf_iemtex finds it)
+    const double xad = T0a / tex, xbd = T0b / tex;
+    double xkind = 0.0, xs = 0.0, xlo = 0.0, ylo = 0.0;
+    if (S.t0_xmin < xad && xad < S.t0_xmax && S.t0_xmin < xbd && xbd < S.t0_xmax) {
+        long ia = (long)((xad - S.t0_xmin) * S.t0_inv_dx), ib = (long)((xbd - S.t0_xmin) * S.t0_inv_dx);
+        ia = ia > T0_SIZE - 2 ? T0_SIZE - 2 : ia;
+        ib = ib > T0_SIZE - 2 ? T0_SIZE - 2 : ib;
+        if (ia == ib && ia >= 0) {
+            xkind = 1.0; xlo = t0x[ia]; ylo = t0y[ia];
+            xs = (t0y[ia + 1] - ylo) * S.t0_inv_dx;
+        }
+    }
+    dk[DK_XKIND] = xkind; dk[DK_XS] = xs; dk[DK_XLO] = xlo; dk[DK_YLO] = ylo; dk[15] = 0.0;
 }
 
 // ---------------------------------------------------------------------------

@@ -75,7 +75,7 @@ int nfa_test_fastexp(const double *x, double *out, int64_t n, int mode) {
     HIP_TRY(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
     if (mode == 0) {
-        const size_t lds = sizeof(double) * (SM_END_TABLE - SM_EXP2);
+        const size_t lds = sizeof(double) * (SM_END_TABLE - SM_EXP2 + SM_TABLE_TAIL);
         HIP_TRY(hipFuncSetAttribute((const void *)test_fastexp_kernel<0>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(test_fastexp_kernel<0>, dim3(blocks), dim3(256), lds, 0, dx, dout, (long)n,
@@ -122,7 +122,7 @@ int nfa_test_partition(const double *trot, double *qpara, double *qorth, int64_t
     HIP_TRY(hipMemcpy(dt, trot, sizeof(double) * n, hipMemcpyHostToDevice));
     const unsigned blocks = (unsigned)((n * 64 + 255) / 256);
     if (g_eng.exp_mode == 0) {
-        const size_t lds = sizeof(double) * (SM_END_TABLE - SM_EXP2);
+        const size_t lds = sizeof(double) * (SM_END_TABLE - SM_EXP2 + SM_TABLE_TAIL);
         HIP_TRY(hipFuncSetAttribute((const void *)test_partition_kernel<0>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(test_partition_kernel<0>, dim3(blocks), dim3(256), lds, 0, dt, dp, dq, (long)n,

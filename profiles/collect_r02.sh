@@ -3,6 +3,7 @@
 #   bench    default bench line + C4 / C1 / one-evaluation-per-pixel lines
 #   rocprof  rocprofv3 --kernel-trace --stats of the one-lane command (the roofline's kernel time) and of the default command
 #   pmc      SQ counter passes of the one-lane command -> pmc_lnl_fast.json
+#   pmc_table  LDS counters of the table-mode kernel -> pmc_lnl_table.json
 #   traffic  FETCH_SIZE / WRITE_SIZE passes -> pmc_traffic.json
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -33,6 +34,16 @@ pmc)
   done
   python profiles/pmc_to_json.py "lnl_kernel<2, false" 4096 $out/pmc_lnl_fast.json $out/pmc_*/*/*counter_collection.csv > $out/pmc_lnl_fast.txt
   python profiles/pmc_to_json.py "setup_kernel" 4096 $out/pmc_setup.json $out/pmc_*/*/*counter_collection.csv > $out/pmc_setup.txt
+  ;;
+pmc_table)
+  # table mode: is the likelihood kernel bound by its LDS gathers (three product-table reads per line x row step)?
+  i=0
+  for p in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU_CVT"; do
+    i=$((i+1))
+    timeout -k 10 200 rocprofv3 --pmc $p --output-format csv -d $out/pmct_$i -- python bench.py $ONE --exp-mode table > $out/pmct_$i.log 2>&1 || echo "pmc_table pass $i failed"
+  done
+  python profiles/pmc_to_json.py "lnl_kernel<0, false" 4096 $out/pmc_lnl_table.json $out/pmct_*/*/*counter_collection.csv > $out/pmc_lnl_table.txt
   ;;
 traffic)
   for c in FETCH_SIZE WRITE_SIZE; do

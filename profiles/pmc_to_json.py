@@ -40,5 +40,10 @@ if 'SQ_ACTIVE_INST_VALU' in mean and 'GRBM_GUI_ACTIVE' in mean:
     res['valu_busy_frac'] = busy / elapsed
     if 'SQ_ACTIVE_INST_SCA' in mean:
         res['scalar_busy_frac'] = mean['SQ_ACTIVE_INST_SCA'] * 4 / simds / elapsed      # per wave slot, like VALU
+if 'SQ_ACTIVE_INST_LDS' in mean and 'GRBM_GUI_ACTIVE' in mean:
+    res['lds_inst_busy_frac'] = mean['SQ_ACTIVE_INST_LDS'] * 4 / 1024 / (mean['GRBM_GUI_ACTIVE'] / 8)      # like valu_busy_frac
+if 'SQ_LDS_BANK_CONFLICT' in mean and mean.get('SQ_LDS_IDX_ACTIVE'):
+    # cycles the LDS spent replaying bank conflicts / cycles it was serving indexed accesses
+    res['lds_bank_conflict_frac'] = mean['SQ_LDS_BANK_CONFLICT'] / mean['SQ_LDS_IDX_ACTIVE']
 print(json.dumps(res, indent=1))
 json.dump(res, open(out, 'w'), indent=1)
