@@ -41,6 +41,9 @@ runs = [('auto', 0.3, 1.5, 25), ('auto', 0.3, 1.5, 50), ('walk', 0.3, 1.5, 25), 
 if len(sys.argv) > 1 and sys.argv[1] == 'short':
     nd = 5 * ncomp                                   # sampled dimensions with get_irdc_priors
     runs = [('auto', 0.3, 1.5, 10 * nd), ('walk', 0.3, 1.5, 10 * nd), ('walk', 0.3, 1.5, 4 * nd), ('reject', 0.3, 1.5, 0)]
+if len(sys.argv) > 4:                                # e.g. "sampler_bias_check.py steps 2 24 100,120,150": walk lengths against rejection only
+    lengths = [int(v) for v in sys.argv[4].split(',')]
+    runs = [('walk', 0.3, 1.5, k) for k in lengths] + [('auto', 0.3, 1.5, k) for k in lengths] + [('reject', 0.3, 1.5, 0)]
 for method, efr, enl, steps in runs:
     t0 = time.perf_counter()
     res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=400, tol=0.5, efr=efr, seed=11, enlarge=enl, method=method,
@@ -48,7 +51,7 @@ for method, efr, enl, steps in runs:
     out[(method, efr, enl, steps)] = np.array([x.lnZ for x in res])
     err = np.mean([x.lnZ_err for x in res])
     print(f'{method} efr {efr} enlarge {enl} n_steps {steps}: {time.perf_counter()-t0:.1f} s, {sum(x.n_evals for x in res)/1e6:.0f} M evals, '
-          f'mean lnZ_err {err:.3f}')
+          f'mean lnZ_err {err:.3f}', flush=True)
 ref = out[runs[-1]]
 for key in runs[:-1]:
     d = out[key] - ref
