@@ -16,6 +16,7 @@ bench)
   python bench.py --workload C4 --no-cpu-baseline --side 32 > $out/bench_C4.json 2>> $out/bench_default.err || exit 1
   python bench.py --workload C1 --no-cpu-baseline --side 32 > $out/bench_C1.json 2>> $out/bench_default.err || exit 1
   python bench.py --batch 16384 --steps 50 --no-cpu-baseline --modes one > $out/bench_B16384.json 2>> $out/bench_default.err || exit 1
+  python bench.py --workload C5 > $out/bench_C5.json 2>> $out/bench_default.err || exit 1
   ;;
 rocprof)
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/onelane -- python bench.py $ONE > $out/bench_onelane.json 2> $out/onelane.err || exit 2
