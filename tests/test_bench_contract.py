@@ -1,0 +1,54 @@
+"""bench.py as the driver runs it (short): ONE JSON line with the contract's keys, the three modes, the
+roofline and -- with two ranks sharing the one GPU (`NFA_BENCH_SAME_GPU`, the rehearsal of `--gpus N`) --
+the whole-job value of two stripes."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+SHORT = ['--steps', '6', '--warmup', '2', '--blocks', '3', '--side', '16', '--no-cpu-baseline']
+
+
+def _run(args, env=None):
+    res = subprocess.run([sys.executable, str(ROOT / 'bench.py')] + args, capture_output=True, text=True, timeout=600,
+                         env={**os.environ, **(env or {})}, cwd=str(ROOT))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_keys():
+    d = _run(SHORT)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'modes', 'spread'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 6 and d['warmup'] == 2 and d['unit'] == 'evals/s'
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert set(d['modes']) == {'table', 'poly', 'fast'} and d['modes']['fast']['value'] == d['value']
+    r = d['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in r, key
+    assert r['frac'] == pytest.approx(r['achieved'] / r['peak']) and 0 < r['frac'] < 1
+    # value = evaluations of the timed block / its time
+    assert d['value'] == pytest.approx(4096 / (d['ms_per_step'] * 1e-3), rel=1e-6)
+    assert d['modes']['table']['value'] < d['value']
+
+
+def test_two_ranks_on_one_gpu_report_the_whole_job():
+    d = _run(['--gpus', '2', '--modes', 'one'] + SHORT, env={'NFA_BENCH_SAME_GPU': '1'})
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
+    assert d['value'] == pytest.approx(2 * 4096 / (d['ms_per_step'] * 1e-3), rel=1e-6)
+    assert 'i_lon % 2' in d['config']['workload'] or 'stripe' in d['config']['workload']
+
+
+def test_gpus_flag_must_match_the_world_size():
+    res = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2'] + SHORT, capture_output=True, text=True,
+                         timeout=120, env={**os.environ, 'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0'}, cwd=str(ROOT))
+    assert res.returncode != 0 and 'WORLD_SIZE' in (res.stderr + res.stdout)
