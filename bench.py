@@ -310,7 +310,8 @@ def main():
             sync(handle)
             out.append(time.perf_counter() - t0)     # this rank's K steps; the block is the slowest rank's
             comm.barrier()
-        return comm.allreduce(np.array(out), 'max')
+        mine = np.array(out)
+        return comm.allreduce(mine, 'max'), comm.allreduce(mine, 'min')
 
     def one_lane_kernel_times():
         """(lnl_kernel us, set-up kernel us, launches) on a one-lane runner: launches do not overlap, a
@@ -342,10 +343,15 @@ def main():
     for mode in modes:
         na.set_exp_mode(mode)
         n_blocks = args.blocks if mode == args.exp_mode else max(3, args.blocks // 3)
-        t = timed_blocks(rh, n_blocks)
+        t, t_fastest = timed_blocks(rh, n_blocks)
         med = float(np.median(t))
         entry = {'value': evals_per_block / med, 'ms_per_step': med / args.steps * 1e3, 'blocks': int(n_blocks),
                  'min': evals_per_block / float(t.max()), 'max': evals_per_block / float(t.min()), 'dtype': DTYPES[mode]}
+        if world > 1:
+            # the slowest and the fastest rank of the median block: their ratio - 1 is the imbalance of the stripes
+            k_med = int(np.argsort(t)[len(t) // 2])
+            entry['rank_ms_per_step'] = {'slowest': float(t[k_med]) / args.steps * 1e3,
+                                         'fastest': float(t_fastest[k_med]) / args.steps * 1e3}
         if rank == 0 and world == 1 and not per_row:
             lnl_us, setup_us, n_l = one_lane_kernel_times()
             entry.update({'lnl_kernel_us': lnl_us, 'setup_kernel_us': setup_us, 'one_lane_launches': n_l,
@@ -435,7 +441,8 @@ def main():
                             'barrier / max-time / record gather over RCCL (nfa_comm_*)',
                 'device': name.value.decode(),
             },
-            'spread': {'blocks': head['blocks'], 'statistic': 'median block', 'min': head['min'], 'max': head['max']},
+            'spread': {'blocks': head['blocks'], 'statistic': 'median block', 'min': head['min'], 'max': head['max'],
+                       **({'rank_ms_per_step': head['rank_ms_per_step']} if 'rank_ms_per_step' in head else {})},
             'modes': per_mode, 'roofline': roof, 'cpu_baseline': cpu,
         }
         if cpu:

@@ -46,6 +46,8 @@ def test_two_ranks_on_one_gpu_report_the_whole_job():
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
     assert d['value'] == pytest.approx(2 * 4096 / (d['ms_per_step'] * 1e-3), rel=1e-6)
     assert 'i_lon % 2' in d['config']['workload'] or 'stripe' in d['config']['workload']
+    r = d['spread']['rank_ms_per_step']
+    assert 0 < r['fastest'] <= r['slowest'] == pytest.approx(d['ms_per_step'])
 
 
 def test_gpus_flag_must_match_the_world_size():
