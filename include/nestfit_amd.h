@@ -57,16 +57,17 @@ int nfa_get_exp_mode(void);
  *   "lnl_split"     waves that share one (item, spectrum) unit of the likelihood kernel: 1, 2, 4, or 0 = chosen per
  *                   launch (the default: 4 for single points and small batches, 1 for batches that fill the
  *                   GPU's wave slots).  More, shorter waves balance a small launch better at a few per cent more
- *                   instructions.  The chi^2 of a unit is always the sum of four blocks of consecutive rows
- *                   taken in order, whoever computed them, so log-likelihoods are bitwise independent of this
- *                   option and of the batch an evaluation travels in;
+ *                   instructions.  The chi^2 of a unit is always the sum of four interleaved row parts (rows h,
+ *                   h + 4, ...) taken in order, whoever computed them, so log-likelihoods are bitwise independent
+ *                   of this option and of the batch an evaluation travels in;
  *   "lnl_cap"       workgroups of the likelihood kernel resident per CU at most (fast and poly mode,
  *                   0 = no cap, the default; 1..8): A/B knob, see DESIGN.md;
  *   "streams"       number of HIP streams ("lanes", 1..8, default 4) that runners created
  *                   afterwards spread consecutive nfa_runner_loglike_batch_dev calls over;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
- *   "point"         1 / 0: single points (nfa_runner_loglike_batch with B = 1, nfa_loglike_callback) go
- *                   through the one-launch point kernel (default) or through the batch kernels;
+ *   "point"         1 / 0: single points and small batches (nfa_runner_loglike_batch with B <= 128,
+ *                   nfa_loglike_callback) go through the one-launch point kernel (default: one workgroup per
+ *                   point, the result written to a mapped host buffer) or through the batch kernels;
  *   "graph"         1 / 0: with "point" 0, replay single-point calls as one captured hipGraph or not (default:
  *                   on, off when the rocprofiler tool library is attached: capture crashed under it);
  *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid; the
@@ -177,7 +178,8 @@ int nfa_runner_get_exp_mode(const nfa_runner *r);
 /* AmmoniaRunner.c_loglikelihood (ammonia.pyx:423-432) for B unit-cube rows of
  * pixel `pix[b]` (pix == NULL: pixel 0).  U[B][ndim] host memory, overwritten
  * in place with the physical parameters exactly like the reference mutates
- * `utheta`; lnL[B] out. */
+ * `utheta`; lnL[B] out.  Synchronous.  Up to 128 rows take one launch (point kernel), more go through
+ * the batch kernels with copies in and out; the values do not depend on the route. */
 int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U,
                              double *lnL, int64_t B);
 
