@@ -198,6 +198,7 @@ def relaunch_one_rank_per_gpu(args):
 
 
 def main():
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: what RCCL needs across processes on this driver
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -248,11 +249,11 @@ def main():
         _ffi.set_option('lnl_split', args.lnl_split)
     lib = _ffi.engine()
     if world == 1:
-        comm = nfcomm.SoloComm()
+        comm, comm_kind = nfcomm.SoloComm(), 'solo'
     elif same_gpu:
-        comm = nfcomm.TcpComm.from_env()
+        comm, comm_kind = nfcomm.TcpComm.from_env(), 'tcp'
     else:
-        comm = nfcomm.RcclComm.from_env()             # RCCL over xGMI, through the C ABI
+        comm, comm_kind = nfcomm.comm_from_env()      # RCCL over xGMI through the C ABI (sockets if RCCL cannot start)
 
     trans, n_chan, vhalf, ncomp, truth_key, B = WORKLOADS[args.workload]
     if args.batch:
@@ -438,7 +439,9 @@ def main():
                             + ('ROW (one evaluation per pixel)' if per_row else 'step'),
                 'exp_mode': args.exp_mode, 'stream_lanes': args.streams or 4, 'pixels_per_gpu': int(n_pix),
                 'sharding': 'pixel stripes i_lon % world (nestfit/main.py:565-571), no data-path collective; '
-                            'barrier / max-time / record gather over RCCL (nfa_comm_*)',
+                            'barrier / max-time / record gather over '
+                            + {'rccl': 'RCCL (nfa_comm_*)', 'tcp': 'TCP sockets (ranks share a GPU, or RCCL did not start)',
+                               'solo': 'RCCL (nfa_comm_*) when N > 1'}[comm_kind],
                 'device': name.value.decode(),
             },
             'spread': {'blocks': head['blocks'], 'statistic': 'median block', 'min': head['min'], 'max': head['max'],

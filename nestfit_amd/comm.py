@@ -197,6 +197,51 @@ class TcpComm:
             self._hub = None
 
 
+def comm_from_env(rccl_timeout=90.0):
+    """The communicator of a rank started by a launcher (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT): RCCL over
+    xGMI when every rank gets its RCCL communicator up, the socket communicator otherwise -- decided together, so
+    that a node where RCCL cannot start (a missing library, a bootstrap that finds no interface) still runs the
+    sharded job: the data path has no collective, only the barrier / max-time / record gather travel here.
+    Returns (communicator, 'rccl' | 'tcp' | 'solo')."""
+    import threading
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return SoloComm(), 'solo'
+    rank = int(os.environ['RANK'])
+    tcp = TcpComm.from_env()
+    # rank 0's ncclUniqueId travels over the socket communicator (128 bytes as 16 doubles, bit for bit)
+    uid = np.zeros(17)
+    if rank == 0:
+        try:
+            buf = (C.c_ubyte * 128)()
+            _ffi.check(_ffi.load().nfa_comm_unique_id(buf))
+            uid[:16] = np.frombuffer(bytes(buf), dtype=np.float64)
+            uid[16] = 1.0
+        except Exception as exc:                       # no RCCL on this node: everybody takes the sockets
+            print(f'nestfit_amd.comm: no RCCL unique id ({exc}); using the socket communicator', flush=True)
+    uid = tcp.allgather(uid).reshape(world, 17)[0]
+    state = {}
+
+    def attempt():
+        try:
+            state['comm'] = RcclComm(rank, world, uid[:16].tobytes())
+        except Exception as exc:
+            state['error'] = str(exc)
+    if uid[16] == 1.0:
+        t = threading.Thread(target=attempt, daemon=True)
+        t.start()
+        t.join(rccl_timeout)
+    mine = 1.0 if 'comm' in state else 0.0
+    everyone = tcp.allreduce(np.array([mine]), 'min')[0]
+    if everyone == 1.0:
+        tcp.close()
+        return state['comm'], 'rccl'
+    if rank == 0:
+        print(f'nestfit_amd.comm: RCCL communicator not available on every rank '
+              f'({state.get("error", "timed out" if uid[16] == 1.0 else "no unique id")}); using the socket communicator', flush=True)
+    return tcp, 'tcp'
+
+
 def gather_pixel_records(records, comm):
     """All-gather fixed-size per-pixel result records (float64 [n_local, width]) from every rank;
     returns the concatenation in rank order.  Ranks may own different numbers of pixels (stripes of

@@ -117,3 +117,32 @@ def test_tcp_comm_world_3():
         assert np.array_equal(allrec, got[0][1]) and allrec.shape == (35, 3)
         assert (allrec[:, 0] % 3 == allrec[:, 2]).all()
         assert tmax.tolist() == [3.0, 10.0]
+
+
+def _from_env_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from nestfit_amd.comm import comm_from_env
+    comm, kind = comm_from_env(rccl_timeout=20)
+    tot = comm.allreduce(np.array([float(rank + 1)]), 'sum')
+    comm.barrier()
+    comm.close()
+    q.put((rank, kind, float(tot[0])))
+
+
+def test_comm_from_env_falls_back_to_sockets_together():
+    """Where RCCL cannot start (here: no GPU, so rank 0 gets no unique id) every rank takes the socket
+    communicator -- agreed over the sockets themselves, nobody is left waiting in an RCCL rendezvous."""
+    import multiprocessing as mp
+    import nestfit_amd as na
+    if na.device_count() > 0:
+        pytest.skip('a GPU is visible: RCCL would start (two ranks on one device are refused by RCCL itself)')
+    ctx = mp.get_context('spawn')
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_from_env_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert [g[1] for g in got] == ['tcp', 'tcp'] and [g[2] for g in got] == [3.0, 3.0]
