@@ -218,6 +218,8 @@ def main():
     ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
     ap.add_argument('--lnl-split', type=int, default=-1, help='engine A/B knob: waves per (item, spectrum) unit (0 = by launch size)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
+    ap.add_argument('--setup-ti', type=int, default=0, help='engine A/B knob: items per set-up workgroup (0 = default)')
+    ap.add_argument('--setup-threads', type=int, default=0, help='engine A/B knob: threads per set-up workgroup (0 = default)')
     ap.add_argument('--ablate', type=int, default=0, help='timing experiment with the -DNFA_ABLATE build (INVALID results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -240,7 +242,8 @@ def main():
     na.set_device(0 if same_gpu else local_rank)      # one process per GPU, before any other call
     if args.ablate and 'NFA_ENGINE_LIB' not in os.environ:
         raise SystemExit('--ablate needs the test library: NFA_ENGINE_LIB=nestfit_amd/lib/libnestfit_amd_test.so')
-    for key, val in (('wpb', args.wpb), ('streams', args.streams), ('ablate', args.ablate)):
+    for key, val in (('wpb', args.wpb), ('streams', args.streams), ('ablate', args.ablate), ('setup_ti', args.setup_ti),
+                     ('setup_threads', args.setup_threads)):
         if val:
             _ffi.set_option(key, val)
     if args.lnl_cap >= 0:

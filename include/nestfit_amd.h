@@ -65,6 +65,8 @@ int nfa_get_exp_mode(void);
  *   "streams"       number of HIP streams ("lanes", 1..8, default 4) that runners created
  *                   afterwards spread consecutive nfa_runner_loglike_batch_dev calls over;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
+ *   "setup_ti", "setup_threads"  items (8..64, default 64) and threads (256 / 512, default 256) per workgroup of
+ *                   the set-up kernel: A/B knobs, see DESIGN.md;
  *   "point"         1 / 0: single points and small batches (nfa_runner_loglike_batch with B <= 128,
  *                   nfa_loglike_callback) go through the one-launch point kernel (default: one workgroup per
  *                   point, the result written to a mapped host buffer) or through the batch kernels;

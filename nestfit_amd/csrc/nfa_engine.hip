@@ -59,6 +59,7 @@ struct Engine {
     int    streams = 4;              // stream lanes of new runners
     int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
     int    graph = -1;               // single-point graph replay: -1 = decide at first use, 0 off, 1 on
+    int    setup_ti = 0, setup_threads = 0;   // set-up kernel: items and threads per workgroup (0 = 64 / 256)
     int    point = 1;                // single points: 1 = the one-launch point kernel, 0 = the batch kernels (graph replay)
     bool   have_t0 = false;
     double *d_tabs = nullptr;                      // SM_END_TABLE doubles
@@ -240,6 +241,8 @@ int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "lnl_split") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_eng.lnl_split = value; return NFA_OK; }
     if (key && !strcmp(key, "graph") && (value == 0 || value == 1)) { g_eng.graph = value; return NFA_OK; }
     if (key && !strcmp(key, "point") && (value == 0 || value == 1)) { g_eng.point = value; return NFA_OK; }
+    if (key && !strcmp(key, "setup_ti") && (value == 0 || value == 8 || value == 16 || value == 32 || value == 64)) { g_eng.setup_ti = value; return NFA_OK; }
+    if (key && !strcmp(key, "setup_threads") && (value == 0 || value == 256 || value == 512)) { g_eng.setup_threads = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }
@@ -652,15 +655,18 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     int rc = reserve_lane(r, slot, B); if (rc) return rc;
     if (has_prior && !r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     const PriorProg *prog = has_prior ? (const PriorProg *)r->pr->d_prog : nullptr;
-    const unsigned blocks = (unsigned)((B + SETUP_TI - 1) / SETUP_TI);
+    // items per workgroup and waves per workgroup (options setup_ti, setup_threads: A/B knobs)
+    const int ti = g_eng.setup_ti > 0 ? g_eng.setup_ti : SETUP_TI;
+    const int threads = g_eng.setup_threads > 0 ? g_eng.setup_threads : SETUP_THREADS;
+    const unsigned blocks = (unsigned)((B + ti - 1) / ti);
     const bool tables = setup_uses_tables(r, mode);
     const size_t lds = setup_lds_bytes(r, mode, has_prior);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "too many parameters for the set-up kernel");
     auto kern = tables ? setup_kernel<0> : setup_kernel<1>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(SETUP_THREADS), lds, st, prog, S, d_U, r->d_D[slot], (long)B,
-                       has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, prog, S, d_U, r->d_D[slot], (long)B,
+                       has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti);
     HIP_TRY(hipGetLastError());
     return NFA_OK;
 }

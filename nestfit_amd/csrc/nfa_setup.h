@@ -422,7 +422,7 @@ template <int MODE>
 __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, const SpecDev &S,
                                            double *__restrict__ U, double *__restrict__ D, long B, int has_prior,
                                            const double *__restrict__ g_tabs, int ablate_in, double *smem,
-                                           const double *sm, int n_shared, unsigned block_id) {
+                                           const double *sm, int n_shared, unsigned block_id, int ti = SETUP_TI) {
 #ifdef NFA_ABLATE
     const int ablate = ablate_in;      // timing experiments: 16 skip the priors, 32 the partition sums, 64 the derive phase
 #else
@@ -435,8 +435,8 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
     double *q_all = th_all + 64 * ndim;
     PriorProg *lp = (PriorProg *)(q_all + SETUP_TI * ncomp * QREC);
     double *tab = (double *)(lp + 1);
-    const long b0 = (long)block_id * SETUP_TI;
-    const int n_it = (int)(B - b0 < SETUP_TI ? B - b0 : SETUP_TI);
+    const long b0 = (long)block_id * ti;                       // ti <= SETUP_TI items per workgroup (the LDS layout is SETUP_TI's)
+    const int n_it = (int)(B - b0 < ti ? B - b0 : ti);
     const bool do_prior = has_prior && !(ablate & 16);
     // ---- phase 0: the program and its tables -> LDS (flat copies: all loads in flight at once); theta -> LDS
     if (do_prior) {
@@ -502,15 +502,15 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
-                                                              double *__restrict__ U, double *__restrict__ D,
-                                                              long B, int has_prior,
-                                                              const double *__restrict__ g_tabs, int ablate_in) {
+__global__ void __launch_bounds__(512) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
+                                                    double *__restrict__ U, double *__restrict__ D,
+                                                    long B, int has_prior,
+                                                    const double *__restrict__ g_tabs, int ablate_in, int ti) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __builtin_amdgcn_s_setprio(3);
     int n_shared;
     const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
-    setup_body<MODE>(ppp, S, U, D, B, has_prior, g_tabs, ablate_in, smem, sm, n_shared, blockIdx.x);
+    setup_body<MODE>(ppp, S, U, D, B, has_prior, g_tabs, ablate_in, smem, sm, n_shared, blockIdx.x, ti);
 }
 
 // ---------------------------------------------------------------------------
