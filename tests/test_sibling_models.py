@@ -262,6 +262,11 @@ def test_sibling_runners_with_priors(engine, nfo, mode, mode_guard):
     u1 = U[7].copy()
     assert rg.loglikelihood(u1) == pytest.approx(lc[7], rel=LNL_RTOL[mode])
     np.testing.assert_allclose(u1, Uc[7], rtol=1e-12, atol=1e-13)
+    # one point and a handful go through the point kernel (N2H+ (1-0) has 15 lines; transitions with more than
+    # 26 take the batch kernels): the bits of the 513-row batch either way
+    assert rg.loglikelihood(U[7].copy()) == lg[7] and np.array_equal(u1, Ug[7])
+    few = U[20:31].copy()
+    assert np.array_equal(rg.loglikelihood_batch(few), lg[20:31]) and np.array_equal(few, Ug[20:31])
     with pytest.raises(ValueError, match='Invalid shape for ncomp=2'):
         rg.loglikelihood(np.zeros(6))
     with pytest.raises(ValueError, match='Invalid shape for ncomp=2'):
@@ -288,6 +293,10 @@ def test_sibling_runners_with_priors(engine, nfo, mode, mode_guard):
     lg, lc = gg.loglikelihood_batch(Ug), gc.loglikelihood_batch(Uc)
     np.testing.assert_allclose(Ug, Uc, rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(lg, lc, rtol=LNL_RTOL[mode])
+    ug = U[3].copy()
+    assert gg.loglikelihood(ug) == lg[3] and np.array_equal(ug, Ug[3])           # point kernel, Gaussian model
+    few = U[40:47].copy()
+    assert np.array_equal(gg.loglikelihood_batch(few), lg[40:47]) and np.array_equal(few, Ug[40:47])
 
 
 @pytest.mark.gpu

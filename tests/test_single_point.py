@@ -82,3 +82,56 @@ def test_point_kernel_with_a_pixel_index_and_interleaved_batches(engine):
             assert np.array_equal(rc.loglikelihood_batch(pix, Ub2), want)          # 40 points: one launch
             big = np.tile(U, (3, 1))                                               # 120 points: the batch kernels
             assert np.array_equal(rc.loglikelihood_batch(np.tile(pix, 3), big), np.tile(want, 3))
+
+
+def test_every_prior_kind_through_the_fused_stage_and_the_point_kernel(engine):
+    """PriorTransformer.transform_batch interprets the prior program prior after prior (prior_items_kernel);
+    the set-up stage of a likelihood batch gives every prior its own wave when no two priors write the same
+    parameter slot, and the point kernel does the same on its eight waves: the in-place theta of all three
+    must be the same bits, for every Prior subclass (core.pyx:169-435) and 1 .. 4 components.  Two priors on
+    one slot (the later one wins in the reference's sequence) must still come out in sequence."""
+    from scipy import stats
+    from nestfit_amd import _ffi
+    na = engine
+    u = np.linspace(0, 1, 300)
+    d_v = na.Distribution(8 * u - 4, stats.beta(5, 5).pdf(u))
+    d_sep = na.Distribution(3 * u + 0.7, stats.beta(1.5, 3.5).pdf(u))
+    d_s = na.Distribution(2 * u + 0.067, stats.beta(1.5, 5).pdf(u))
+    d_t = na.Distribution(23 * u + 7, stats.beta(3, 6.7).pdf(u))
+    d_n = na.Distribution(3 * u + 13, stats.beta(2, 2).pdf(u))
+    rest = [na.DuplicatePrior(d_t, 1, 2), na.Prior(d_n, 3), na.ConstantPrior(0.25, 5)]
+    sets = {
+        'ordered': [na.OrderedPrior(d_v, 0), na.Prior(d_s, 4)] + rest,
+        'spaced': [na.SpacedPrior(na.Prior(d_v, 0), na.Prior(d_sep, 0)), na.Prior(d_s, 4)] + rest,
+        'censep': [na.CenSepPrior(na.Prior(d_v, 0), na.Prior(d_sep, 0)), na.Prior(d_s, 4)] + rest,
+        'rcensep': [na.ResolvedCenSepPrior(na.Prior(d_v, 0), na.Prior(d_sep, 0), na.Prior(d_s, 4))] + rest,
+        'rplace': [na.ResolvedPlacementPrior(na.Prior(d_v, 0), na.Prior(d_s, 4), scale=1.2)] + rest,
+        'rplace_const': [na.ResolvedPlacementPrior(na.Prior(d_v, 0), na.ConstantPrior(0.3, 4))] + rest,
+        # slot 3 twice: the second prior overwrites what the first made of it
+        # (slot 5 stays what the unit cube holds: six parameters are declared, and the count has to be six)
+        'shared_slot': [na.Prior(d_v, 0), na.Prior(d_s, 4), na.Prior(d_t, 3), na.DuplicatePrior(d_t, 1, 2), na.Prior(d_n, 3)],
+    }
+    rng = np.random.default_rng(77)
+    spec_data = _spec_data((1, 2), 128)
+    for name, priors in sets.items():
+        ut = na.PriorTransformer(np.array(priors, dtype=object))
+        for ncomp in (1, 2, 3, 4):
+            if name in ('censep', 'rcensep') and ncomp > 2:
+                continue                                  # these leave n > 2 components untransformed: nothing to compare lnL on
+            U = rng.uniform(size=(150, 6 * ncomp))
+            want = U.copy()
+            ut.transform_batch(want, ncomp)               # the sequential interpreter
+            run = na.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp)
+            _ffi.set_option('point', 0)
+            try:
+                got = U.copy()
+                lnl = run.loglikelihood_batch(got)        # set-up stage of the batch kernels
+            finally:
+                _ffi.set_option('point', 1)
+            assert np.array_equal(got, want, equal_nan=True), (name, ncomp)     # (a shrunken placement can be NaN, as in the reference)
+            few = U[:9].copy()
+            lnl_few = run.loglikelihood_batch(few)        # point kernel, nine workgroups
+            assert np.array_equal(few, want[:9], equal_nan=True) and np.array_equal(lnl_few, lnl[:9], equal_nan=True), (name, ncomp)
+            one = U[11].copy()
+            assert run.loglikelihood(one) == lnl[11] or np.isnan(lnl[11])
+            assert np.array_equal(one, want[11], equal_nan=True), (name, ncomp)
