@@ -275,6 +275,10 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
 int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active);
 int nfa_sampler_counts(nfa_sampler *s, int64_t *n_iter, int64_t *n_evals, int64_t *rounds);
 int nfa_sampler_dead(nfa_sampler *s, int64_t p, int64_t n, double *theta, double *lnL, double *lnw);
+/* The same for all pixels in one call: offsets[P + 1] with offsets[0] = 0 and offsets[p + 1] - offsets[p] the
+ * number of dead points wanted of pixel p (at most min(n_iter[p], cap_iter)); rows offsets[p] .. offsets[p + 1]
+ * of theta[.][ndim], lnL[.], lnw[.] are pixel p's. */
+int nfa_sampler_dead_packed(nfa_sampler *s, const int64_t *offsets, double *theta, double *lnL, double *lnw);
 int nfa_sampler_live(nfa_sampler *s, double *theta, double *lnL);
 
 /* ---- the exchange step of a sharded cube fit ---------------------

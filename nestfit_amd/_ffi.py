@@ -89,6 +89,7 @@ SIGNATURES = {
     'nfa_sampler_advance': (C.c_int, [C.c_void_p, C.c_int64, _lp]),
     'nfa_sampler_counts': (C.c_int, [C.c_void_p, _lp, _lp, _lp]),
     'nfa_sampler_dead': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp, _dp]),
+    'nfa_sampler_dead_packed': (C.c_int, [C.c_void_p, _lp, _dp, _dp, _dp]),
     'nfa_sampler_live': (C.c_int, [C.c_void_p, _dp, _dp]),
     'nfa_comm_unique_id': (C.c_int, [C.POINTER(C.c_ubyte)]),
     'nfa_comm_create': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_ubyte), C.c_int, C.c_int]),

@@ -499,6 +499,22 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     if (lane == 0) S.since_fit[p] = since;
 }
 
+// ---- results ---------------------------------------------------------------------------------
+// dead points of all pixels, packed: rows [off[p], off[p + 1]) of the outputs = the first off[p+1] - off[p] dead
+// points of pixel p (one copy off the device instead of three per pixel)
+__global__ void ns_pack_dead_kernel(NsDev S, const long *__restrict__ off, double *__restrict__ outT,
+                                    double *__restrict__ outL, double *__restrict__ outW) {
+    const long p = blockIdx.y;
+    const long n = off[p + 1] - off[p];
+    const int DT = S.DT;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n * DT; e += (long)gridDim.x * blockDim.x)
+        outT[off[p] * DT + e] = S.deadT[p * S.cap * DT + e];
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
+        outL[off[p] + r] = S.deadL[p * S.cap + r];
+        outW[off[p] + r] = S.deadlnw[p * S.cap + r];
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------
 #define NS_KMAX 16384           // most proposals one pixel gets in a round
 #define NS_PARTS 4              // at most this many groups of pixels, each on its own stream lane
@@ -743,6 +759,38 @@ int nfa_sampler_dead(nfa_sampler *s, int64_t p, int64_t n, double *theta, double
     HIP_TRY(hipMemcpy(lnL, d.deadL + (size_t)p * d.cap, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(lnw, d.deadlnw + (size_t)p * d.cap, sizeof(double) * n, hipMemcpyDeviceToHost));
     return NFA_OK;
+}
+
+// dead points of every pixel at once: offsets[P + 1] (host; offsets[0] = 0, offsets[p + 1] - offsets[p] <= min(n_iter[p],
+// cap) rows of pixel p), theta[offsets[P]][DT], lnL[offsets[P]], lnw[offsets[P]]
+int nfa_sampler_dead_packed(nfa_sampler *s, const int64_t *offsets, double *theta, double *lnL, double *lnw) {
+    if (!s || !s->ran || !offsets || !theta || !lnL || !lnw) return fail(NFA_ERR_ARG, "bad argument");
+    const NsDev &d = s->d;
+    const int P = d.P;
+    if (offsets[0] != 0) return fail(NFA_ERR_ARG, "offsets must start at 0");
+    for (int p = 0; p < P; ++p)
+        if (offsets[p + 1] < offsets[p] || offsets[p + 1] - offsets[p] > d.cap) return fail(NFA_ERR_ARG, "bad offsets");
+    const int64_t total = offsets[P];
+    if (total == 0) return NFA_OK;
+    long *d_off = nullptr;
+    double *d_T = nullptr, *d_L = nullptr, *d_W = nullptr;
+    auto release = [&]() { (void)hipFree(d_off); (void)hipFree(d_T); (void)hipFree(d_L); (void)hipFree(d_W); };
+    if (hipMalloc((void **)&d_off, sizeof(long) * (P + 1)) != hipSuccess || hipMalloc((void **)&d_T, sizeof(double) * total * d.DT) != hipSuccess
+        || hipMalloc((void **)&d_L, sizeof(double) * total) != hipSuccess || hipMalloc((void **)&d_W, sizeof(double) * total) != hipSuccess) {
+        release();
+        return fail(NFA_ERR_DEVICE, "out of device memory for the packed dead points");
+    }
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    hipStream_t st = s->r->lanes[0];
+    bool ok = hipMemcpyAsync(d_off, offsets, sizeof(long) * (P + 1), hipMemcpyHostToDevice, st) == hipSuccess;
+    hipLaunchKernelGGL(ns_pack_dead_kernel, dim3(16, (unsigned)P), dim3(256), 0, st, d, (const long *)d_off, d_T, d_L, d_W);
+    ok = ok && hipGetLastError() == hipSuccess;
+    ok = ok && hipMemcpyAsync(theta, d_T, sizeof(double) * total * d.DT, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(lnL, d_L, sizeof(double) * total, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(lnw, d_W, sizeof(double) * total, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    release();
+    return ok ? NFA_OK : fail(NFA_ERR_DEVICE, "copying the dead points failed");
 }
 
 // final live points: theta[P][N][D], lnL[P][N]

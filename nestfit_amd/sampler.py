@@ -155,26 +155,39 @@ def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
     """NestedResult per pixel from dead points (theta, lnL, lnw per pixel) and final live points:
     every live point carries the mass X_final / nlive.  With `tol` given a run whose live points could
     still add more than `tol` to lnZ (the stop test it did not meet) is marked `truncated`."""
+    def log_sum_exp(x):
+        """ln sum exp(x) about the largest term (a sequential logaddexp.reduce costs five times as much: this
+        loop runs once per pixel of a map)."""
+        if x.size == 0:
+            return -np.inf
+        m = x.max()
+        return m if not np.isfinite(m) else m + math.log(np.exp(x - m).sum())
+
     results = []
+    ln_nlive = math.log(nlive)
     for p in range(len(n_iter)):
         dT, dL, dlnw = dead[p]
-        lnw_live = np.full(nlive, -n_iter[p] / nlive - np.log(nlive))
-        T = np.concatenate([dT, Tlive[p]])
-        L = np.concatenate([dL, Llive[p]])
-        lnw = np.concatenate([dlnw, lnw_live])
-        lnZ_tot = np.logaddexp.reduce(lnw + L)
-        wt = np.exp(lnw + L - lnZ_tot)
+        n_dead = dL.shape[0]
+        post = np.empty((n_dead + nlive, ndim + 2))
+        post[:n_dead, :ndim] = dT
+        post[n_dead:, :ndim] = Tlive[p]
+        L = np.empty(n_dead + nlive)
+        L[:n_dead] = dL
+        L[n_dead:] = Llive[p]
+        lw = np.empty(n_dead + nlive)                           # ln(prior mass x likelihood)
+        np.add(dlnw, dL, out=lw[:n_dead])
+        np.add(Llive[p], -n_iter[p] / nlive - ln_nlive, out=lw[n_dead:])
+        lnZ_dead = log_sum_exp(lw[:n_dead])
+        lnZ_tot = np.logaddexp(lnZ_dead, log_sum_exp(lw[n_dead:]))
+        wt = np.exp(lw - lnZ_tot)
         # information H = sum w (lnL - lnZ), for the error estimate sqrt(H / nlive)
         with np.errstate(invalid='ignore'):
             Hp = float(np.sum(np.where(wt > 0, wt * (L - lnZ_tot), 0.0)))
-        post = np.empty((T.shape[0], ndim + 2))
-        post[:, :ndim] = T
-        post[:, ndim] = -2.0 * L
+        np.multiply(L, -2.0, out=post[:, ndim])
         post[:, ndim + 1] = wt
         results.append(NestedResult(post, lnZ_tot, np.sqrt(max(Hp, 0.0) / nlive), L.max(), nlive,
                                     n_evals[p], n_iter[p], Hp))
         if tol is not None:
-            lnZ_dead = np.logaddexp.reduce(dlnw + dL) if dL.size else -np.inf
             remain = Llive[p].max() - n_iter[p] / nlive
             results[-1].truncated = bool(not (np.logaddexp(lnZ_dead, remain) - lnZ_dead < tol))
     return results
@@ -458,12 +471,13 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
         Tlive = np.empty((P, nlive, ndim))
         Llive = np.empty((P, nlive))
         _ffi.check(lib.nfa_sampler_live(h, _ffi.dptr(Tlive), _ffi.dptr(Llive)))
-        dead = []
-        for p in range(P):
-            n = int(min(n_iter[p], cap))
-            dT, dL, dw = np.empty((n, ndim)), np.empty(n), np.empty(n)
-            _ffi.check(lib.nfa_sampler_dead(h, p, n, _ffi.dptr(dT), _ffi.dptr(dL), _ffi.dptr(dw)))
-            dead.append((dT, dL, dw))
+        # the dead points of all pixels in one packed copy; a pixel's arrays are views into it
+        off = np.zeros(P + 1, dtype=np.int64)
+        np.cumsum(np.minimum(n_iter, cap), out=off[1:])
+        tot = int(off[-1])
+        allT, allL, allw = np.empty((tot, ndim)), np.empty(tot), np.empty(tot)
+        _ffi.check(lib.nfa_sampler_dead_packed(h, off.ctypes.data_as(_ffi._lp), _ffi.dptr(allT), _ffi.dptr(allL), _ffi.dptr(allw)))
+        dead = [(allT[off[p]:off[p + 1]], allL[off[p]:off[p + 1]], allw[off[p]:off[p + 1]]) for p in range(P)]
     finally:
         lib.nfa_sampler_destroy(h)
     res = _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol)
