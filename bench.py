@@ -150,6 +150,11 @@ def bench_c5(args):
     from nestfit_amd.cube import CubeRunner
     from nestfit_amd.synth import freq_axis
     na.set_exp_mode(args.exp_mode)
+    for key, val in (('setup_ti', args.setup_ti), ('setup_threads', args.setup_threads)):
+        if val:
+            _ffi.set_option(key, val)
+    if args.prior_stage >= 0:
+        _ffi.set_option('prior_stage', args.prior_stage)
     side, n, noise, nlive = 32, 512, 0.1, 400
     n_pix = side * side
     rng = np.random.default_rng(0)
@@ -218,6 +223,7 @@ def main():
     ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
     ap.add_argument('--lnl-split', type=int, default=-1, help='engine A/B knob: waves per (item, spectrum) unit (0 = by launch size)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
+    ap.add_argument('--prior-stage', type=int, default=-1, help='engine A/B knob: prior tables staged in LDS (1) or left in global memory (0)')
     ap.add_argument('--setup-ti', type=int, default=0, help='engine A/B knob: items per set-up workgroup (0 = default)')
     ap.add_argument('--setup-threads', type=int, default=0, help='engine A/B knob: threads per set-up workgroup (0 = default)')
     ap.add_argument('--ablate', type=int, default=0, help='timing experiment with the -DNFA_ABLATE build (INVALID results)')
@@ -250,6 +256,8 @@ def main():
         _ffi.set_option('lnl_cap', args.lnl_cap)
     if args.lnl_split >= 0:
         _ffi.set_option('lnl_split', args.lnl_split)
+    if args.prior_stage >= 0:
+        _ffi.set_option('prior_stage', args.prior_stage)
     lib = _ffi.engine()
     if world == 1:
         comm, comm_kind = nfcomm.SoloComm(), 'solo'

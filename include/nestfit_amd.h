@@ -65,6 +65,9 @@ int nfa_get_exp_mode(void);
  *   "streams"       number of HIP streams ("lanes", 1..8, default 4) that runners created
  *                   afterwards spread consecutive nfa_runner_loglike_batch_dev calls over;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
+ *   "prior_stage"   1 / 0: the set-up kernel stages the prior tables in LDS (default) or reads them from global
+ *                   memory; taken over by priors created afterwards (A/B knob: no measurable difference in the
+ *                   pipelined rates, the staged form is 5 us shorter when the stage runs alone);
  *   "setup_ti", "setup_threads"  items (8..64, default 64) and threads (256 / 512, default 256) per workgroup of
  *                   the set-up kernel: A/B knobs, see DESIGN.md;
  *   "point"         1 / 0: single points and small batches (nfa_runner_loglike_batch with B <= 128,

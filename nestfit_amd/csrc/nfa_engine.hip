@@ -59,6 +59,7 @@ struct Engine {
     int    streams = 4;              // stream lanes of new runners
     int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
     int    graph = -1;               // single-point graph replay: -1 = decide at first use, 0 off, 1 on
+    int    prior_stage = 1;          // prior tables staged in LDS by the set-up kernel (priors created afterwards)
     int    setup_ti = 0, setup_threads = 0;   // set-up kernel: items and threads per workgroup (0 = 64 / 256)
     int    point = 1;                // single points: 1 = the one-launch point kernel, 0 = the batch kernels (graph replay)
     bool   have_t0 = false;
@@ -241,6 +242,7 @@ int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "lnl_split") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_eng.lnl_split = value; return NFA_OK; }
     if (key && !strcmp(key, "graph") && (value == 0 || value == 1)) { g_eng.graph = value; return NFA_OK; }
     if (key && !strcmp(key, "point") && (value == 0 || value == 1)) { g_eng.point = value; return NFA_OK; }
+    if (key && !strcmp(key, "prior_stage") && (value == 0 || value == 1)) { g_eng.prior_stage = value; return NFA_OK; }
     if (key && !strcmp(key, "setup_ti") && (value == 0 || value == 8 || value == 16 || value == 32 || value == 64)) { g_eng.setup_ti = value; return NFA_OK; }
     if (key && !strcmp(key, "setup_threads") && (value == 0 || value == 256 || value == 512)) { g_eng.setup_threads = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
@@ -469,7 +471,7 @@ static int priors_fill(nfa_priors *p, const nfa_prior_desc *priors, int n_prior,
             for (int f = 0; f < 6; ++f)
                 if (need[d][f] && n < MAXSTAGE) { g.stage[n++] = StageItem{d, f, g.ds[d].size, off}; off += g.ds[d].size; }
         g.n_stage = n; g.stage_doubles = off;
-        if (off * sizeof(double) > 72 * 1024) { g.n_stage = 0; g.stage_doubles = 0; }     // too big: stay in global memory
+        if (off * sizeof(double) > 72 * 1024 || !g_eng.prior_stage) { g.n_stage = 0; g.stage_doubles = 0; }     // too big (or option prior_stage 0): stay in global memory
         // one contiguous image of the staged tables, in LDS order: staging is a flat copy (every load of a
         // workgroup in flight at once) instead of a walk over the table list
         g.stage_image = nullptr;
