@@ -87,6 +87,39 @@ def read_fits(path):
     return header, data
 
 
+def _format_card(key, value):
+    """One 80-character header card `KEYWORD = value` (fixed format: logicals and numbers right-justified
+    to column 30, strings quoted from column 11)."""
+    if isinstance(value, (bool, np.bool_)):
+        txt = f'{"T" if value else "F":>20}'
+    elif isinstance(value, (int, np.integer)):
+        txt = f'{int(value):>20d}'
+    elif isinstance(value, (float, np.floating)):
+        txt = f'{float(value):>20.13E}' if np.isfinite(value) else f"{'':>20}"
+    else:
+        txt = "'" + f'{str(value).replace(chr(39), chr(39) * 2):<8}' + "'"
+    return f'{key[:8].upper():<8}= {txt}'[:80].ljust(80)
+
+
+def write_fits(path, header, data):
+    """A primary HDU: `data` (numpy array in FITS axis order [NAXISn, ..., NAXIS1], written as float32 or
+    float64 big-endian) under `header` (a dict; SIMPLE / BITPIX / NAXIS* are set from the array, everything
+    else is written as given).  The counterpart of `read_fits` for the map products of a fit."""
+    data = np.asarray(data)
+    bitpix = -32 if data.dtype == np.float32 else -64
+    cards = [_format_card('SIMPLE', True), _format_card('BITPIX', bitpix), _format_card('NAXIS', data.ndim)]
+    cards += [_format_card(f'NAXIS{k + 1}', n) for k, n in enumerate(data.shape[::-1])]
+    skip = {'SIMPLE', 'BITPIX', 'NAXIS', 'EXTEND', 'END'} | {f'NAXIS{k}' for k in range(1, 10)}
+    cards += [_format_card(k, v) for k, v in header.items() if k.upper() not in skip and v is not None]
+    cards.append('END'.ljust(80))
+    head = ''.join(cards).encode('ascii', 'replace')
+    head += b' ' * (-len(head) % _BLOCK)
+    body = np.ascontiguousarray(data, dtype=_DTYPES[bitpix]).tobytes()
+    body += b'\0' * (-len(body) % _BLOCK)
+    with open(path, 'wb') as f:
+        f.write(head + body)
+
+
 class SimpleCube:
     """The slice of ``spectral_cube.SpectralCube`` that ``DataCube`` needs: header, data in
     (spectral, lat, lon) order, brightness unit, spectral axis in Hz and in km/s (radio)."""

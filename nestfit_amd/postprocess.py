@@ -364,6 +364,23 @@ def generate_predicted_profiles(store, stack, runner=None, predict_backend=None)
         store.create_dataset(f'trans{dc.trans_id}', cube, group=f'{store.dpath}/model_spec')
 
 
+def create_fits_from_store(store, prefix='source'):
+    """The deblended cubes as FITS files, one per transition, the components added up, on the velocity grid of
+    the PDF bins: `<prefix>_hf_deblended_trans<t>.fits` (main.py:1196-1237; peak / integrated intensity and the
+    PDF products are a TODO there as well).  Returns the paths written."""
+    from .cubeio import write_fits
+    header = dict(store.read_header(full=True))
+    vaxis = _product(store, 'pdf_bins')[store.model.IX_VCEN]
+    cube = _product(store, 'hf_deblended')                 # (t, m, S, b, l)
+    header.update(BUNIT='K', CRPIX3=1, CDELT3=float(vaxis[1] - vaxis[0]), CUNIT3='km/s', CTYPE3='VRAD',
+                  CRVAL3=float(vaxis[0]), SPECSYS='LSRK')
+    paths = []
+    for t in range(cube.shape[0]):
+        paths.append(f'{prefix}_hf_deblended_trans{t}.fits')
+        write_fits(paths[-1], header, np.nansum(cube[t], axis=0).astype(np.float32))      # (S, b, l)
+    return paths
+
+
 def postprocess_run(store, stack, runner=None, par_bins=None, evid_kernel=None, post_kernel=None,
                     evid_weight=True, predict_backend=None):
     """All steps in the reference's order (main.py:1240-1276)."""

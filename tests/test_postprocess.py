@@ -149,6 +149,15 @@ def test_hot_path_steps_against_per_pixel_predictions(fitted):
                 if vaxis.min() < th[0] - 4 * th[4] and vaxis.max() > th[0] + 4 * th[4]:
                     assert hfdb[t, m, :, b, l].sum() == pytest.approx(integ[t, m, b, l], rel=2e-2)
         assert seen >= 2
+        # FITS export of the deblended cubes: read back with the package's own reader
+        from nestfit_amd.cubeio import read_fits
+        paths = pp.create_fits_from_store(store, prefix=str(path) + '_out')
+        assert len(paths) == 2
+        hdr, data = read_fits(paths[1])
+        assert data.shape == (pp.N_PDF_BINS - 1, 2, 4) and hdr['CTYPE3'] == 'VRAD' and hdr['BITPIX'] == -32
+        vaxis = prod['pdf_bins'][...][0]
+        assert hdr['CRVAL3'] == pytest.approx(vaxis[0]) and hdr['CDELT3'] == pytest.approx(vaxis[1] - vaxis[0])
+        np.testing.assert_array_equal(data, np.nansum(hfdb[1], axis=0).astype(np.float32).astype(np.float64))
 
 
 @pytest.mark.gpu
