@@ -23,13 +23,13 @@ def main():
     store_name = sys.argv[1] if len(sys.argv) > 1 else '/tmp/nestfit_amd_dist'
     same_gpu = len(sys.argv) > 2 and sys.argv[2] == 'same_gpu'
     import nestfit_amd as na
-    from nestfit_amd.comm import RcclComm, TcpComm
+    from nestfit_amd.comm import TcpComm, comm_from_env
     from nestfit_amd.cubeio import CubeStack, DataCube, SimpleCube
     from nestfit_amd.fitter import CubeFitter
     from nestfit_amd.store import HdfStore
     na.set_device(0 if same_gpu else local)
-    # only a barrier is needed: RCCL between the ranks' GPUs, plain sockets when they share one
-    comm = TcpComm.from_env() if same_gpu else RcclComm.from_env()
+    # only a barrier is needed: RCCL between the ranks' GPUs (sockets if RCCL cannot start), plain sockets when they share one
+    comm = TcpComm.from_env() if same_gpu else comm_from_env()[0]
     stack = CubeStack([
         DataCube(SimpleCube.read(ROOT / 'tests' / 'golden' / f'ammonia_{t}{t}_cutout.fits')[:-1], 0.35, trans_id=t)
         for t in (1, 2)])
