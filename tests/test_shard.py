@@ -146,3 +146,19 @@ def test_comm_from_env_falls_back_to_sockets_together():
     for p in procs:
         p.join(timeout=60)
     assert [g[1] for g in got] == ['tcp', 'tcp'] and [g[2] for g in got] == [3.0, 3.0]
+
+
+@pytest.mark.gpu
+def test_comm_from_env_two_ranks_on_one_gpu_agree_on_sockets():
+    """Two ranks on the one GPU of the box: RCCL itself refuses the second rank on a device (or its rendezvous
+    times out); both ranks must come out with the socket communicator and a working collective."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_from_env_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert [g[1] for g in got] == ['tcp', 'tcp'] and [g[2] for g in got] == [3.0, 3.0]
