@@ -331,7 +331,7 @@ def main():
         from nestfit_amd._model import _RunnerHandle
         _ffi.set_option('streams', 1)
         solo = _RunnerHandle(cube._ss, ut, ncomp, False, False)
-        _ffi.set_option('streams', args.streams if args.streams else 4)
+        _ffi.set_option('streams', args.streams if args.streams else 0)
         n = min(60, n_steps)
         reset_inputs()
         for k in range(min(5, n)):
@@ -348,6 +348,9 @@ def main():
         _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 0))
         return sp[1] / sc.value * 1e3, sp[0] / sc.value * 1e3, int(sc.value)
 
+    # lanes the engine rotates the steps over (its automatic choice: six for launches of about one wave per wave slot)
+    units, slots = B * len(trans), 256 * 32
+    lanes_used = args.streams or (6 if 4 * units >= 3 * slots and 2 * units <= 3 * slots else 4)
     modes = list(MODES) if args.modes == 'all' else [args.exp_mode]
     per_mode = {}
     evals_per_block = args.steps * B * world
@@ -448,7 +451,7 @@ def main():
                             f'get_irdc_priors(size=500); pixels = rank stripe (i_lon % {world}) of the C3 cube '
                             f'{args.side}x{args.side}, one pixel per '
                             + ('ROW (one evaluation per pixel)' if per_row else 'step'),
-                'exp_mode': args.exp_mode, 'stream_lanes': args.streams or 4, 'pixels_per_gpu': int(n_pix),
+                'exp_mode': args.exp_mode, 'stream_lanes': lanes_used, 'pixels_per_gpu': int(n_pix),
                 'sharding': 'pixel stripes i_lon % world (nestfit/main.py:565-571), no data-path collective; '
                             'barrier / max-time / record gather over '
                             + {'rccl': 'RCCL (nfa_comm_*)', 'tcp': 'TCP sockets (ranks share a GPU, or RCCL did not start)',

@@ -62,8 +62,9 @@ int nfa_get_exp_mode(void);
  *                   of this option and of the batch an evaluation travels in;
  *   "lnl_cap"       workgroups of the likelihood kernel resident per CU at most (fast and poly mode,
  *                   0 = no cap, the default; 1..8): A/B knob, see DESIGN.md;
- *   "streams"       number of HIP streams ("lanes", 1..8, default 4) that runners created
- *                   afterwards spread consecutive nfa_runner_loglike_batch_dev calls over;
+ *   "streams"       number of HIP streams ("lanes", 1..8) that runners created afterwards spread consecutive
+ *                   nfa_runner_loglike_batch_dev calls over; 0 (default) = six streams of which a batch of
+ *                   about one wavefront per wave slot of the GPU uses all six and any other batch four;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
  *   "prior_stage"   1 / 0: the set-up kernel stages the prior tables in LDS (default) or reads them from global
  *                   memory; taken over by priors created afterwards (A/B knob: no measurable difference in the

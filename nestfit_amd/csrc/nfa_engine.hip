@@ -56,7 +56,7 @@ struct Engine {
                                      // kernels of the next batch paid off (+7 %) until those kernels got a raised wave
                                      // priority of their own; with it the cap only costs occupancy (-6 %).
     int    ablate = 0;
-    int    streams = 4;              // stream lanes of new runners
+    int    streams = 0;              // stream lanes of new runners; 0 = six, of which a batch uses four or six (run_batch)
     int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
     int    graph = -1;               // single-point graph replay: -1 = decide at first use, 0 off, 1 on
     int    prior_stage = 1;          // prior tables staged in LDS by the set-up kernel (priors created afterwards)
@@ -173,6 +173,7 @@ struct nfa_runner {
     // next; inside a lane the set-up kernel and the likelihood kernel run in order and own
     // the lane's derived-parameter records.
     int         n_lanes = 1;
+    bool        lanes_auto = false;      // n_lanes = 6: batches of about one wave per slot rotate over all six, others over four
     hipStream_t lanes[NFA_MAX_LANES] = {};
     double     *d_D[NFA_MAX_LANES] = {};
     double     *d_part[NFA_MAX_LANES] = {};  // per (item, spectrum) log-likelihood terms
@@ -251,7 +252,7 @@ int nfa_set_option(const char *key, int value) {
 #ifdef NFA_ABLATE
     if (key && !strcmp(key, "ablate") && value >= 0 && value <= 127) { g_eng.ablate = value; return NFA_OK; }
 #endif
-    if (key && !strcmp(key, "streams") && value >= 1 && value <= NFA_MAX_LANES) { g_eng.streams = value; return NFA_OK; }
+    if (key && !strcmp(key, "streams") && value >= 0 && value <= NFA_MAX_LANES) { g_eng.streams = value; return NFA_OK; }
     return fail(NFA_ERR_ARG, "unknown option, or value out of range");
 }
 
@@ -565,7 +566,8 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors, int
     nfa_runner *r = new nfa_runner();
     r->ss = ss; r->pr = priors; r->ncomp = ncomp; r->cold = cold ? 1 : 0; r->lte = lte ? 1 : 0;
     r->ndim = ss->dev.npar * ncomp;
-    r->n_lanes = std::max(1, std::min(g_eng.streams, NFA_MAX_LANES));
+    r->lanes_auto = g_eng.streams == 0;
+    r->n_lanes = r->lanes_auto ? 6 : std::max(1, std::min(g_eng.streams, NFA_MAX_LANES));
     r->wpb = g_eng.wpb; r->wpb_table = g_eng.wpb_table; r->lnl_cap = g_eng.lnl_cap; r->lnl_split = g_eng.lnl_split;
     for (int k = 0; k < r->n_lanes; ++k) HIP_TRY(hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking));
     r->stream = r->lanes[0];
@@ -784,7 +786,15 @@ static int run_batch(nfa_runner *r, const int *d_pix, double *d_U, double *d_lnL
                      int64_t B, bool has_prior, int force_lane, int *lane_out) {
     int rc0 = engine_init(); if (rc0) return rc0;            // binds the calling thread to the device
     if (!g_eng.have_t0) return fail(NFA_ERR_STATE, "nfa_set_iemtex_table has not been called");
-    const int slot = force_lane >= 0 ? force_lane : (int)(r->n_calls % (uint64_t)r->n_lanes);
+    // Lanes a sequence of batches rotates over.  Four overlap the draining tail of one batch with the next;
+    // a batch of about one wave per wave slot (the metric's 4096 rows x 2 spectra) leaves the longest tail and
+    // gains another 3 % from six, smaller and larger ones lose with more than four (profiles/r02/sweep_lanes.txt).
+    int n_use = r->n_lanes;
+    if (r->lanes_auto) {
+        const int64_t units = B * r->ss->dev.n_spec, slots = (int64_t)g_eng.n_cu * 32;
+        n_use = (4 * units >= 3 * slots && 2 * units <= 3 * slots) ? 6 : 4;
+    }
+    const int slot = force_lane >= 0 ? force_lane : (int)(r->n_calls % (uint64_t)n_use);
     hipStream_t st = r->lanes[slot];
     hipEvent_t *e = nullptr;
     if (r->profiling) {
@@ -1049,7 +1059,7 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
     // Large batches go through the stream lanes in chunks: the kernels of chunk c run while the
     // host copies chunk c+1 in, and the results of chunk c come back while c+1 computes.  (Every
     // per-item result is independent of the batch it travels in.)
-    const int n_chunks = (B >= 16384 && r->n_lanes > 1) ? (int)std::min<int64_t>(r->n_lanes, B / 4096) : 1;
+    const int n_chunks = (B >= 16384 && r->n_lanes > 1) ? (int)std::min<int64_t>(r->lanes_auto ? 4 : r->n_lanes, B / 4096) : 1;
     const int64_t per = ((B + n_chunks - 1) / n_chunks + 63) / 64 * 64;
     const int ndim = r->ndim;
     for (int c = 0; c < n_chunks; ++c) {
