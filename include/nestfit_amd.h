@@ -51,7 +51,7 @@ int nfa_device_name(char *buf, int buflen);
 int nfa_set_exp_mode(int mode);
 int nfa_get_exp_mode(void);
 /* Engine tuning knobs for A/B measurements (key, value):
- *   "wpb"           waves per workgroup of the likelihood kernel (1..16, default 4), and
+ *   "wpb"           waves per workgroup of the likelihood kernel (1..16, default 1), and
  *   "wpb_table"     the same in table mode (0 = chosen per spectra set, the default): both are
  *                   taken over by runners created afterwards;
  *   "lnl_split"     waves that share one (item, spectrum) unit of the likelihood kernel: 1, 2, 4, or 0 = chosen per

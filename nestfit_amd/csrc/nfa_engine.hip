@@ -45,7 +45,8 @@ struct Engine {
     int    device = 0;
     int    n_cu = 256;
     int    exp_mode = 2;             // "fast": see include/nestfit_amd.h, nfa_set_exp_mode
-    int    wpb = 4;                  // waves per workgroup of the likelihood kernel
+    int    wpb = 1;                  // waves per workgroup of the likelihood kernel (fast / poly mode): one -- a workgroup
+                                     // retires, and its slot is refilled, wave by wave (4: -1.5 %, 8: -9 %, profiles/r02/sweep_lanes.txt)
     int    wpb_table = 0;            // the same in table mode; 0 = chosen per spectra set (launch_lnl_t)
     int    lnl_split = 0;            // waves per (item, spectrum) unit of the likelihood kernel: 1, 2, 4, or
                                      // 0 = by launch size (resolve_split).  The chi^2 of a unit is a sum of LNL_PARTS
@@ -167,7 +168,7 @@ struct nfa_runner {
     // numerical mode: -1 = the process default at call time (nfa_set_exp_mode), 0..2 = pinned to
     // this runner (nfa_runner_set_exp_mode): runners of different modes may then work side by side
     int exp_mode = -1;
-    int wpb = 4, wpb_table = 0, lnl_cap = 0, lnl_split = 0;   // launch geometry, taken from the process options at creation
+    int wpb = 1, wpb_table = 0, lnl_cap = 0, lnl_split = 0;   // launch geometry, taken from the process options at creation
     // Stream lanes: consecutive batches go to different HIP streams (round robin), so the
     // tail of one batch (few workgroups left, SIMDs draining) overlaps the start of the
     // next; inside a lane the set-up kernel and the likelihood kernel run in order and own
