@@ -150,7 +150,7 @@ def bench_c5(args):
     from nestfit_amd.cube import CubeRunner
     from nestfit_amd.synth import freq_axis
     na.set_exp_mode(args.exp_mode)
-    for key, val in (('setup_ti', args.setup_ti), ('setup_threads', args.setup_threads)):
+    for key, val in (('setup_ti', args.setup_ti), ('setup_threads', args.setup_threads), ('wpb', args.wpb), ('streams', args.streams)):
         if val:
             _ffi.set_option(key, val)
     if args.prior_stage >= 0:

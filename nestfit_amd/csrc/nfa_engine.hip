@@ -174,7 +174,7 @@ struct nfa_runner {
     // next; inside a lane the set-up kernel and the likelihood kernel run in order and own
     // the lane's derived-parameter records.
     int         n_lanes = 1;
-    bool        lanes_auto = false;      // n_lanes = 6: batches of about one wave per slot rotate over all six, others over four
+    bool        lanes_auto = false;      // four lanes, six once batches of about one wave per slot have come by (run_batch)
     hipStream_t lanes[NFA_MAX_LANES] = {};
     double     *d_D[NFA_MAX_LANES] = {};
     double     *d_part[NFA_MAX_LANES] = {};  // per (item, spectrum) log-likelihood terms
@@ -568,7 +568,7 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors, int
     r->ss = ss; r->pr = priors; r->ncomp = ncomp; r->cold = cold ? 1 : 0; r->lte = lte ? 1 : 0;
     r->ndim = ss->dev.npar * ncomp;
     r->lanes_auto = g_eng.streams == 0;
-    r->n_lanes = r->lanes_auto ? 6 : std::max(1, std::min(g_eng.streams, NFA_MAX_LANES));
+    r->n_lanes = r->lanes_auto ? 4 : std::max(1, std::min(g_eng.streams, NFA_MAX_LANES));     // automatic: two more on demand (run_batch)
     r->wpb = g_eng.wpb; r->wpb_table = g_eng.wpb_table; r->lnl_cap = g_eng.lnl_cap; r->lnl_split = g_eng.lnl_split;
     for (int k = 0; k < r->n_lanes; ++k) HIP_TRY(hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking));
     r->stream = r->lanes[0];
@@ -794,6 +794,14 @@ static int run_batch(nfa_runner *r, const int *d_pix, double *d_U, double *d_lnL
     if (r->lanes_auto) {
         const int64_t units = B * r->ss->dev.n_spec, slots = (int64_t)g_eng.n_cu * 32;
         n_use = (4 * units >= 3 * slots && 2 * units <= 3 * slots) ? 6 : 4;
+        // The fifth and sixth stream exist only once a batch of that size has come by: idle streams are not free --
+        // with six streams mapped the small launches of a sampler round trip 25 % slower even on the three they use
+        // (config 5, one component: 1.25 -> 1.56 s).
+        while (r->n_lanes < n_use && force_lane < 0) {
+            HIP_TRY(hipStreamCreateWithFlags(&r->lanes[r->n_lanes], hipStreamNonBlocking));
+            r->n_lanes += 1;
+        }
+        n_use = std::min(n_use, r->n_lanes);
     }
     const int slot = force_lane >= 0 ? force_lane : (int)(r->n_calls % (uint64_t)n_use);
     hipStream_t st = r->lanes[slot];
