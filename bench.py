@@ -150,7 +150,8 @@ def bench_c5(args):
     from nestfit_amd.cube import CubeRunner
     from nestfit_amd.synth import freq_axis
     na.set_exp_mode(args.exp_mode)
-    for key, val in (('setup_ti', args.setup_ti), ('setup_threads', args.setup_threads), ('wpb', args.wpb), ('streams', args.streams)):
+    for key, val in (('setup_ti', args.setup_ti), ('setup_threads', args.setup_threads), ('wpb', args.wpb), ('streams', args.streams),
+                     ('sampler_parts', args.sampler_parts)):
         if val:
             _ffi.set_option(key, val)
     if args.prior_stage >= 0:
@@ -223,6 +224,7 @@ def main():
     ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
     ap.add_argument('--lnl-split', type=int, default=-1, help='engine A/B knob: waves per (item, spectrum) unit (0 = by launch size)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
+    ap.add_argument('--sampler-parts', type=int, default=0, help='engine A/B knob (C5): groups of pixels pipelined over the lanes')
     ap.add_argument('--prior-stage', type=int, default=-1, help='engine A/B knob: prior tables staged in LDS (1) or left in global memory (0)')
     ap.add_argument('--setup-ti', type=int, default=0, help='engine A/B knob: items per set-up workgroup (0 = default)')
     ap.add_argument('--setup-threads', type=int, default=0, help='engine A/B knob: threads per set-up workgroup (0 = default)')
