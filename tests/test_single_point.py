@@ -135,3 +135,41 @@ def test_every_prior_kind_through_the_fused_stage_and_the_point_kernel(engine):
             one = U[11].copy()
             assert run.loglikelihood(one) == lnl[11] or np.isnan(lnl[11])
             assert np.array_equal(one, want[11], equal_nan=True), (name, ncomp)
+
+
+def test_random_shapes_point_kernel_batch_kernels_oracle(engine, nfo):
+    """Twenty random spectra sets -- 1 .. 4 transitions out of (1,1) .. (6,6), ragged channel counts from 40 to
+    1500, 1 .. 3 components, cold / lte flags, fast and table mode: the point kernel gives the bits of the batch
+    kernels, and both the oracle's log-likelihood within the mode's tolerance."""
+    from nestfit_amd import _ffi
+    rng = np.random.default_rng(2024)
+    try:
+        for case in range(20):
+            mode = ('fast', 'table')[case % 2]
+            engine.set_exp_mode(mode)
+            n_spec = int(rng.integers(1, 5))
+            trans = [int(t) for t in rng.choice(np.arange(1, 7), size=n_spec, replace=False)]
+            sizes = [int(rng.integers(40, 1500)) for _ in trans]
+            ncomp = int(rng.integers(1, 4))
+            cold, lte = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            spec_data = [[freq_axis(t, n), rng.normal(0, 0.3, n), float(rng.uniform(0.1, 0.5)), t] for t, n in zip(trans, sizes)]
+            ut = engine.get_irdc_priors(size=200, vsys=0.0)
+            run = engine.AmmoniaRunner.from_data(spec_data, ut, ncomp=ncomp, cold=cold, lte=lte)
+            cpu = nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(*sd) for sd in spec_data], nfo.PriorSet(ut.lower()), ncomp=ncomp,
+                                    cold=cold, lte=lte)
+            U = rng.uniform(size=(33, 6 * ncomp))
+            _ffi.set_option('point', 0)
+            Ub = U.copy()
+            want = run.loglikelihood_batch(Ub)
+            _ffi.set_option('point', 1)
+            Up = U.copy()
+            got = run.loglikelihood_batch(Up)                        # 33 workgroups of the point kernel
+            assert np.array_equal(got, want, equal_nan=True) and np.array_equal(Up, Ub), (case, trans, sizes, ncomp, cold, lte)
+            one = U[5].copy()
+            assert run.loglikelihood(one) == want[5]
+            Uc = U.copy()
+            np.testing.assert_allclose(want, cpu.loglikelihood_batch(Uc), rtol=LNL_RTOL[mode], err_msg=str((case, trans, sizes, ncomp)))
+            np.testing.assert_allclose(Ub, Uc, rtol=1e-9, atol=1e-10)
+    finally:
+        _ffi.set_option('point', 1)
+        engine.set_exp_mode('fast')
