@@ -614,12 +614,20 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             // one component: the lines in `mask` add their optical depths, then the Tb pass
             auto component = [&](int c, unsigned long long mask, double kind, double a0x, double b0x) {
                 const LineRec *lrec = w_line + c * G.nhf_max;
+                // the component's table base as a per-lane value: a line's record address is then ONE vector
+                // shift-add of the scalar line index (left to itself the compiler forms it with two scalar
+                // instructions and a move; the scalar unit is the shared resource, see the header)
+                typedef const __attribute__((address_space(3))) char *lds_char_p;
+                unsigned lbase = (unsigned)(uintptr_t)(lds_char_p)lrec;
+                asm volatile("" : "+v"(lbase));
                 tau_t tau = 0;
                 double td = 0.0;                                      // WIDE: fp64 running sum
                 auto line = [&](int i) {
-                    const char *q = (const char *)lrec + (i << 5);
-                    const double2 ab = *(const double2 *)q;           // nucen, idenom
-                    const int4 hw = *(const int4 *)(q + 16);          // htau (8 bytes), lo, len
+                    const lds_char_p q = (lds_char_p)(uintptr_t)(lbase + ((unsigned)i << 5));
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    const v2d ab = *(const __attribute__((address_space(3))) v2d *)q;                   // nucen, idenom
+                    const v4i hw = *(const __attribute__((address_space(3))) v4i *)(q + 16);            // htau (8 bytes), lo, len
                     if constexpr (MODE == 2 && !WIDE) {
                         line_step_fast(tau, j, xj, ab.x, ab.y, __int_as_float(hw.x), hw.z, hw.w);
                     } else {
@@ -644,7 +652,11 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                 if (ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); }
                 else if (nhf <= 32) {                                 // every NH3 transition: 32-bit mask arithmetic
                     unsigned m = (unsigned)mask;
-                    do { const int i = __builtin_ctz(m); m &= m - 1; line(i); } while (m);
+                    do {
+                        const int i = __builtin_ctz(m);
+                        asm("s_bitset0_b32 %0, %1" : "+s"(m) : "s"(i));      // m &= ~(1 << i) in one scalar instruction
+                        line(i);
+                    } while (m);
                 } else {
                     do { const int i = __builtin_ctzll(mask); mask &= mask - 1; line(i); } while (mask);
                 }
