@@ -415,8 +415,9 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
 //  multiplied by zero.  Per line x row: thirteen vector instructions -- the LDS address, two
 //  for the window test, three fp64 operations for the float-narrowed FastExp argument
 //  (math.pxd:17), the conversion, five fp32 operations for exp, one multiply-add -- and six
-//  scalar ones (find the line, clear its bit, compare, restore EXEC, branch, wait; the scalar unit is shared by the four SIMDs of a CU: a scalar instruction
-//  costs the wave as much as an fp64 one, scripts/ubench_lineloop.hip).
+//  scalar ones (find the line, clear its bit, compare, restore EXEC, branch, wait; the scalar unit is
+//  shared by the four SIMDs of a CU: a scalar instruction costs the wave as much as an fp64 one,
+//  scripts/ubench_lineloop.hip).
 //  Rows without any line window (about 40 % at the metric shape) cost two compares per
 //  component: their chi^2 term is the precomputed sum of data^2 of the row (SpecDev.rowsq).
 //  NCOMP > 0: the number of components is a compile-time constant, the component loop is
