@@ -544,6 +544,11 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // it fails `hi > r0` for every row), and the component's constants of the Tb pass
     int wlo[NC], whi[NC];
     double ck_kind[NC], ck_a0x[NC], ck_b0x[NC];
+    // the LDS address of each component's line table as a per-lane value, formed once: a line's record address
+    // is then ONE vector shift-add of the scalar line index (left to itself the compiler forms it with two
+    // scalar instructions and a move per step; the scalar unit is the shared resource, see the header)
+    typedef const __attribute__((address_space(3))) char *lds_char_p;
+    unsigned lbase_c[NC];
     bool need_t0 = MODE != 2;      // T0 and tbg per channel: exact modes always; fast mode only where
                                    // y(T0) is not the single table cell (kind != 1)
     if (NCOMP > 0) {
@@ -554,6 +559,8 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             wlo[c] = lane < G.nhf_max ? lo : 0;
             whi[c] = lane < G.nhf_max ? lo + len : 0;
             if (ablate & 8) { wlo[c] = 0; whi[c] = 0; }
+            lbase_c[c] = (unsigned)(uintptr_t)(lds_char_p)(w_line + c * G.nhf_max);
+            asm volatile("" : "+v"(lbase_c[c]));
             const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
             ck_kind[c] = Dk[dko + DK_KIND]; ck_a0x[c] = Dk[dko + DK_A0X]; ck_b0x[c] = Dk[dko + DK_B0X];
             if (MODE == 2 && S.model != NFA_MODEL_GAUSSIAN) need_t0 = need_t0 || ck_kind[c] != 1.0;
@@ -614,13 +621,13 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             double pred = 0.0;
             // one component: the lines in `mask` add their optical depths, then the Tb pass
             auto component = [&](int c, unsigned long long mask, double kind, double a0x, double b0x) {
-                const LineRec *lrec = w_line + c * G.nhf_max;
-                // the component's table base as a per-lane value: a line's record address is then ONE vector
-                // shift-add of the scalar line index (left to itself the compiler forms it with two scalar
-                // instructions and a move; the scalar unit is the shared resource, see the header)
-                typedef const __attribute__((address_space(3))) char *lds_char_p;
-                unsigned lbase = (unsigned)(uintptr_t)(lds_char_p)lrec;
-                asm volatile("" : "+v"(lbase));
+                unsigned lbase;
+                if (NCOMP > 0) {
+                    lbase = lbase_c[c];
+                } else {
+                    lbase = (unsigned)(uintptr_t)(lds_char_p)(w_line + c * G.nhf_max);
+                    asm volatile("" : "+v"(lbase));
+                }
                 tau_t tau = 0;
                 double td = 0.0;                                      // WIDE: fp64 running sum
                 auto line = [&](int i) {
