@@ -14,7 +14,9 @@ def test_row_split_matches_one_wave_per_unit(engine, nfo, mode):
     from nestfit_amd import _ffi
     engine.set_exp_mode(mode)
     try:
-        for trans, n, ncomp, truth in (((1, 2), 1024, 2, TRUTH_2COMP), ((1, 2, 3), 200, 3, TRUTH_3COMP), ((9,), 70, 1, None)):
+        # (5000 channels = 79 rows: more than one group of 64 rows for the signal-free-row bookkeeping)
+        for trans, n, ncomp, truth in (((1, 2), 1024, 2, TRUTH_2COMP), ((1, 2, 3), 200, 3, TRUTH_3COMP), ((9,), 70, 1, None),
+                                       ((2, 1), 5000, 2, None)):
             rng = np.random.default_rng(5)
             axes = [freq_axis(t, n) for t in trans]
             spec_data = [[x, rng.normal(0, 0.2, n), 0.2, t] for x, t in zip(axes, trans)]
