@@ -321,8 +321,11 @@ def main():
             t0 = time.perf_counter()
             for k in range(args.warmup, n_steps):
                 step(handle, k)
+            t_enq = time.perf_counter() - t0         # host time to enqueue the K steps (diagnostic, NFA_BENCH_HOST=1)
             sync(handle)
             out.append(time.perf_counter() - t0)     # this rank's K steps; the block is the slowest rank's
+            if os.environ.get('NFA_BENCH_HOST') and rank == 0:
+                print(f'host enqueue {t_enq / args.steps * 1e6:.1f} us/step of {out[-1] / args.steps * 1e6:.1f}', file=sys.stderr)
             comm.barrier()
         mine = np.array(out)
         return comm.allreduce(mine, 'max'), comm.allreduce(mine, 'min')
