@@ -631,6 +631,25 @@ static SpecDev runner_specdev(const nfa_runner *r) {
 
 // Set-up stage of a batch on stream lane `slot`: [unit cube -> theta in place] -> partition sums ->
 // derived records r->d_D[slot], one launch (setup_kernel, nfa_setup.h)
+// A kernel that wants more than 64 KB of dynamic LDS has to be told so -- once per kernel and size, not on every
+// launch (the attribute call is a trip into the runtime: 1-2 us of the ~10 the host spends on enqueueing a step).
+static int ensure_dynamic_lds(const void *kernel, size_t lds) {
+    if (lds <= 64 * 1024) return NFA_OK;
+    static std::mutex m;
+    static std::vector<std::pair<const void *, size_t>> granted;
+    std::lock_guard<std::mutex> lk(m);
+    for (auto &g : granted)
+        if (g.first == kernel) {
+            if (g.second >= lds) return NFA_OK;
+            HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            g.second = lds;
+            return NFA_OK;
+        }
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    granted.emplace_back(kernel, lds);
+    return NFA_OK;
+}
+
 // derived records and chi^2 parts of stream lane `slot` for B items
 static int reserve_lane(nfa_runner *r, int slot, int64_t B) {
     if (B <= r->cap_D[slot]) return NFA_OK;  // grown outside any timed loop
@@ -668,8 +687,7 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     const size_t lds = setup_lds_bytes(r, mode, has_prior);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "too many parameters for the set-up kernel");
     auto kern = tables ? setup_kernel<0> : setup_kernel<1>;
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc2 = ensure_dynamic_lds((const void *)kern, lds); if (rc2) return rc2; }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, prog, S, d_U, r->d_D[slot], (long)B,
                        has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti);
     HIP_TRY(hipGetLastError());
@@ -732,8 +750,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     if (MODE != 0 && r->lnl_cap > 0 && waves * r->lnl_cap < 32)      // residency cap: see Engine::lnl_cap
         lds = std::max(lds, (size_t)((160 * 1024) / r->lnl_cap) & ~(size_t)15);
     auto kern = lnl_kernel<MODE, WS, WIDE, NCOMP>;
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc2 = ensure_dynamic_lds((const void *)kern, lds); if (rc2) return rc2; }
     const int64_t units = B * S.n_spec;
     const int64_t upw = waves / split;
     const int64_t blocks = (units + upw - 1) / upw;
@@ -911,7 +928,7 @@ int nfa_runner_synchronize(nfa_runner *r) {
 template <int MODE, int NCOMP>
 static void launch_point_t(nfa_runner *r, const SpecDev &S, const PointIn &in, const LnlGeom &G, size_t lds) {
     auto kern = point_kernel<MODE, NCOMP>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)ensure_dynamic_lds((const void *)kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)in.n), dim3(POINT_THREADS), lds, r->lanes[0], (const PriorProg *)r->pr->d_prog, S, in,
                        r->d_pix, r->d_U, r->d_D[0], r->d_part[0], r->d_point, r->d_point_done, G,
                        (const double *)g_eng.d_tabs);
