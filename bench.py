@@ -475,7 +475,12 @@ def main():
     lib.nfa_free(d_lnL)
     lib.nfa_free(d_pix)
     comm.barrier()
+    stuck = getattr(comm, 'stuck_thread', None)
     comm.close()
+    if stuck is not None and stuck.is_alive():     # an RCCL rendezvous that never returned: do not wait for its teardown
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':

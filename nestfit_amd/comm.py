@@ -221,6 +221,7 @@ def comm_from_env(rccl_timeout=90.0):
             print(f'nestfit_amd.comm: no RCCL unique id ({exc}); using the socket communicator', flush=True)
     uid = tcp.allgather(uid).reshape(world, 17)[0]
     state = {}
+    t = None
 
     def attempt():
         try:
@@ -239,6 +240,9 @@ def comm_from_env(rccl_timeout=90.0):
     if rank == 0:
         print(f'nestfit_amd.comm: RCCL communicator not available on every rank '
               f'({state.get("error", "timed out" if uid[16] == 1.0 else "no unique id")}); using the socket communicator', flush=True)
+    # a rendezvous that timed out may still sit in its (daemon) thread: callers that are about to exit can look at
+    # `stuck_thread` and leave through os._exit instead of waiting for the library's teardown
+    tcp.stuck_thread = t if (uid[16] == 1.0 and t.is_alive()) else None
     return tcp, 'tcp'
 
 
