@@ -504,14 +504,15 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
 // points of pixel p (one copy off the device instead of three per pixel)
 __global__ void ns_pack_dead_kernel(NsDev S, const long *__restrict__ off, double *__restrict__ outT,
                                     double *__restrict__ outL, double *__restrict__ outW) {
-    const long p = blockIdx.y;
-    const long n = off[p + 1] - off[p];
     const int DT = S.DT;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n * DT; e += (long)gridDim.x * blockDim.x)
-        outT[off[p] * DT + e] = S.deadT[p * S.cap * DT + e];
-    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
-        outL[off[p] + r] = S.deadL[p * S.cap + r];
-        outW[off[p] + r] = S.deadlnw[p * S.cap + r];
+    for (long p = blockIdx.y; p < S.P; p += gridDim.y) {       // (the grid's second dimension ends at 65535)
+        const long n = off[p + 1] - off[p];
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n * DT; e += (long)gridDim.x * blockDim.x)
+            outT[off[p] * DT + e] = S.deadT[p * S.cap * DT + e];
+        for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
+            outL[off[p] + r] = S.deadL[p * S.cap + r];
+            outW[off[p] + r] = S.deadlnw[p * S.cap + r];
+        }
     }
 }
 
@@ -783,7 +784,7 @@ int nfa_sampler_dead_packed(nfa_sampler *s, const int64_t *offsets, double *thet
     static_assert(sizeof(long) == sizeof(int64_t), "LP64");
     hipStream_t st = s->r->lanes[0];
     bool ok = hipMemcpyAsync(d_off, offsets, sizeof(long) * (P + 1), hipMemcpyHostToDevice, st) == hipSuccess;
-    hipLaunchKernelGGL(ns_pack_dead_kernel, dim3(16, (unsigned)P), dim3(256), 0, st, d, (const long *)d_off, d_T, d_L, d_W);
+    hipLaunchKernelGGL(ns_pack_dead_kernel, dim3(16, (unsigned)std::min(P, 32768)), dim3(256), 0, st, d, (const long *)d_off, d_T, d_L, d_W);
     ok = ok && hipGetLastError() == hipSuccess;
     ok = ok && hipMemcpyAsync(theta, d_T, sizeof(double) * total * d.DT, hipMemcpyDeviceToHost, st) == hipSuccess;
     ok = ok && hipMemcpyAsync(lnL, d_L, sizeof(double) * total, hipMemcpyDeviceToHost, st) == hipSuccess;
