@@ -635,18 +635,19 @@ static SpecDev runner_specdev(const nfa_runner *r) {
 // launch (the attribute call is a trip into the runtime: 1-2 us of the ~10 the host spends on enqueueing a step).
 static int ensure_dynamic_lds(const void *kernel, size_t lds) {
     if (lds <= 64 * 1024) return NFA_OK;
+    struct Grant { const void *kernel; int device; size_t lds; };        // the attribute belongs to a kernel on a device
     static std::mutex m;
-    static std::vector<std::pair<const void *, size_t>> granted;
+    static std::vector<Grant> granted;
     std::lock_guard<std::mutex> lk(m);
     for (auto &g : granted)
-        if (g.first == kernel) {
-            if (g.second >= lds) return NFA_OK;
+        if (g.kernel == kernel && g.device == g_eng.device) {
+            if (g.lds >= lds) return NFA_OK;
             HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            g.second = lds;
+            g.lds = lds;
             return NFA_OK;
         }
     HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    granted.emplace_back(kernel, lds);
+    granted.push_back(Grant{kernel, g_eng.device, lds});
     return NFA_OK;
 }
 
