@@ -181,3 +181,56 @@ def test_postprocess_on_device(engine, nfo, fitted, tmp_path):
             np.testing.assert_allclose(v, prod[k][...], rtol=1e-6 if k == 'hf_deblended' else 1e-11, equal_nan=True)
         for t in range(2):
             np.testing.assert_allclose(dev_spec[t], prod['model_spec'][f'trans{t + 1}'][...], rtol=2e-7, atol=1e-30, equal_nan=True)
+
+
+def test_smooth_map_against_a_direct_sum():
+    """The two convolution flavours against their definition evaluated pixel by pixel: weights of the valid
+    neighbours only, border repeated ('nearest') or empty ('constant'), scaled back by the kernel's sum where the
+    kernel is not to be normalised."""
+    rng = np.random.default_rng(9)
+    img = rng.normal(size=(7, 9))
+    img[rng.uniform(size=img.shape) < 0.2] = np.nan
+    k = rng.uniform(0.1, 1.0, size=(3, 5))
+    ky, kx = k.shape[0] // 2, k.shape[1] // 2
+
+    def direct(edge, normalise):
+        out = np.full(img.shape, np.nan)
+        for b in range(img.shape[0]):
+            for l in range(img.shape[1]):
+                num = den = 0.0
+                for dy in range(-ky, ky + 1):
+                    for dx in range(-kx, kx + 1):
+                        yy, xx = b - dy, l - dx                      # convolution: the kernel is flipped
+                        if edge == 'nearest':
+                            yy, xx = min(max(yy, 0), img.shape[0] - 1), min(max(xx, 0), img.shape[1] - 1)
+                        elif not (0 <= yy < img.shape[0] and 0 <= xx < img.shape[1]):
+                            continue
+                        v = img[yy, xx]
+                        if np.isfinite(v):
+                            w = k[dy + ky, dx + kx]
+                            num += w * v
+                            den += w
+                if den > 0:
+                    out[b, l] = num / den * (1.0 if normalise else k.sum())
+        return out
+    for edge, normalise in (('nearest', True), ('constant', False), ('constant', True)):
+        np.testing.assert_allclose(pp.smooth_map(img, k, edge=edge, normalise=normalise), direct(edge, normalise),
+                                   rtol=1e-12, equal_nan=True)
+
+
+def test_fits_writer_round_trip(tmp_path):
+    from nestfit_amd.cubeio import read_fits, write_fits
+    rng = np.random.default_rng(3)
+    for dtype in (np.float32, np.float64):
+        data = rng.normal(size=(5, 4, 3)).astype(dtype)
+        hdr = {'BUNIT': 'K', 'CRVAL3': -12.5, 'CDELT3': 0.25, 'CRPIX3': 1, 'CTYPE3': 'VRAD', 'OBJECT': "it's a test",
+               'FLAG': True, 'NAXIS': 99, 'SIMPLE': False}         # structural keywords come from the array, not from here
+        path = tmp_path / f'cube_{np.dtype(dtype).name}.fits'
+        write_fits(path, hdr, data)
+        assert path.stat().st_size % 2880 == 0
+        back_hdr, back = read_fits(path)
+        assert np.array_equal(back, data.astype(np.float64))
+        assert back_hdr['NAXIS'] == 3 and [back_hdr[f'NAXIS{k}'] for k in (1, 2, 3)] == [3, 4, 5]
+        assert back_hdr['BITPIX'] == (-32 if dtype == np.float32 else -64) and back_hdr['SIMPLE'] is True
+        assert back_hdr['CRVAL3'] == -12.5 and back_hdr['CDELT3'] == 0.25 and back_hdr['CTYPE3'] == 'VRAD'
+        assert back_hdr['OBJECT'] == "it's a test" and back_hdr['FLAG'] is True
