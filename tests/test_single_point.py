@@ -173,3 +173,25 @@ def test_random_shapes_point_kernel_batch_kernels_oracle(engine, nfo):
     finally:
         _ffi.set_option('point', 1)
         engine.set_exp_mode('fast')
+
+
+@pytest.mark.parametrize('mode', ['fast', 'table'])
+def test_long_spectrum_many_row_groups(engine, nfo, mode):
+    """20,000 channels = 313 rows of 64: five groups of 64 rows for the signal-free-row bookkeeping in each of the
+    four row parts, a window test far from the origin; batch kernels, point kernel and oracle."""
+    engine.set_exp_mode(mode)
+    try:
+        rng = np.random.default_rng(8)
+        n = 20000
+        spec_data = [[freq_axis(1, n, 400.0), rng.normal(0, 0.3, n), 0.3, 1], [freq_axis(2, 777, 60.0), rng.normal(0, 0.2, 777), 0.2, 2]]
+        ut = engine.get_irdc_priors(size=200, vsys=0.0)
+        run = engine.AmmoniaRunner.from_data(spec_data, ut, ncomp=2)
+        cpu = nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(*sd) for sd in spec_data], nfo.PriorSet(ut.lower()), ncomp=2)
+        U = rng.uniform(size=(200, 12))
+        Ub, Uc = U.copy(), U.copy()
+        want = run.loglikelihood_batch(Ub)                          # 200 rows: the batch kernels
+        np.testing.assert_allclose(want, cpu.loglikelihood_batch(Uc), rtol=LNL_RTOL[mode])
+        few = U[:6].copy()
+        assert np.array_equal(run.loglikelihood_batch(few), want[:6]) and np.array_equal(few, Ub[:6])     # point kernel
+    finally:
+        engine.set_exp_mode('fast')
