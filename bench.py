@@ -224,6 +224,7 @@ def main():
     ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
     ap.add_argument('--lnl-split', type=int, default=-1, help='engine A/B knob: waves per (item, spectrum) unit (0 = by launch size)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
+    ap.add_argument('--coalesce', type=int, default=0, help='engine A/B knob: device-pointer batches launched together at most (1 = none; 0 = default 4)')
     ap.add_argument('--sampler-parts', type=int, default=0, help='engine A/B knob (C5): groups of pixels pipelined over the lanes')
     ap.add_argument('--prior-stage', type=int, default=-1, help='engine A/B knob: prior tables staged in LDS (1) or left in global memory (0)')
     ap.add_argument('--setup-ti', type=int, default=0, help='engine A/B knob: items per set-up workgroup (0 = default)')
@@ -250,7 +251,7 @@ def main():
     na.set_device(0 if same_gpu else local_rank)      # one process per GPU, before any other call
     if args.ablate and 'NFA_ENGINE_LIB' not in os.environ:
         raise SystemExit('--ablate needs the test library: NFA_ENGINE_LIB=nestfit_amd/lib/libnestfit_amd_test.so')
-    for key, val in (('wpb', args.wpb), ('streams', args.streams), ('ablate', args.ablate), ('setup_ti', args.setup_ti),
+    for key, val in (('wpb', args.wpb), ('streams', args.streams), ('ablate', args.ablate), ('setup_ti', args.setup_ti), ('coalesce', args.coalesce),
                      ('setup_threads', args.setup_threads)):
         if val:
             _ffi.set_option(key, val)
@@ -353,9 +354,16 @@ def main():
         _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 0))
         return sp[1] / sc.value * 1e3, sp[0] / sc.value * 1e3, int(sc.value)
 
-    # lanes the engine rotates the steps over (its automatic choice: six for launches of about one wave per wave slot)
+    # What the engine makes of the steps: device-pointer batches of one shape that arrive back to back are launched
+    # together (option coalesce: up to four, a group below four waves per wave slot), and a sequence of launches
+    # rotates over four stream lanes (six for launches of about one wave per wave slot).
     units, slots = B * len(trans), 256 * 32
-    lanes_used = args.streams or (6 if 4 * units >= 3 * slots and 2 * units <= 3 * slots else 4)
+    group = args.coalesce or 4
+    steps_per_launch = 1
+    if group > 1 and B % 64 == 0 and 2 * units <= 4 * slots:
+        steps_per_launch = int(max(1, min(group, (4 * slots) // units)))
+    launch_units = units * steps_per_launch
+    lanes_used = args.streams or (6 if 4 * launch_units >= 3 * slots and 2 * launch_units <= 3 * slots else 4)
     modes = list(MODES) if args.modes == 'all' else [args.exp_mode]
     per_mode = {}
     evals_per_block = args.steps * B * world
@@ -372,6 +380,13 @@ def main():
             k_med = int(np.argsort(t)[len(t) // 2])
             entry['rank_ms_per_step'] = {'slowest': float(t[k_med]) / args.steps * 1e3,
                                          'fastest': float(t_fastest[k_med]) / args.steps * 1e3}
+        if mode == args.exp_mode and steps_per_launch > 1:
+            # the same blocks with every step launched on its own
+            _ffi.set_option('coalesce', 1)
+            ta, _ = timed_blocks(rh, max(3, args.blocks // 3))
+            _ffi.set_option('coalesce', group)
+            entry['one_step_per_launch'] = {'value': evals_per_block / float(np.median(ta)),
+                                            'ms_per_step': float(np.median(ta)) / args.steps * 1e3}
         if rank == 0 and world == 1 and not per_row:
             lnl_us, setup_us, n_l = one_lane_kernel_times()
             entry.update({'lnl_kernel_us': lnl_us, 'setup_kernel_us': setup_us, 'one_lane_launches': n_l,
@@ -405,8 +420,9 @@ def main():
                                     'python bench.py --streams 1 --modes one --no-cpu-baseline)'})
         pipe = bytes_eval * B * world / step_s / 1e9
         roof['pipeline'] = {'us_per_step': step_s * 1e6, 'achieved': pipe, 'frac': pipe / (HBM_PEAK_GBS * world),
-                            'note': 'the same bytes / the time per step of the timed blocks (stream lanes overlap the '
-                                    'launches): the rate the job sustains, a hard bound on the kernel'}
+                            'note': 'the same bytes / the time per step of the timed blocks (the engine launches '
+                                    f'{steps_per_launch} step(s) together and overlaps launches on its stream lanes): '
+                                    'the rate the job sustains, a hard bound on the kernel'}
         # figures that need their own profiler passes come from the committed summaries of the round
         try:
             pmc = json.loads((PROFILE_DIR / 'pmc_lnl_fast.json').read_text())
@@ -456,7 +472,7 @@ def main():
                             f'get_irdc_priors(size=500); pixels = rank stripe (i_lon % {world}) of the C3 cube '
                             f'{args.side}x{args.side}, one pixel per '
                             + ('ROW (one evaluation per pixel)' if per_row else 'step'),
-                'exp_mode': args.exp_mode, 'stream_lanes': lanes_used, 'pixels_per_gpu': int(n_pix),
+                'exp_mode': args.exp_mode, 'stream_lanes': lanes_used, 'steps_per_launch': steps_per_launch, 'pixels_per_gpu': int(n_pix),
                 'sharding': 'pixel stripes i_lon % world (nestfit/main.py:565-571), no data-path collective; '
                             'barrier / max-time / record gather over '
                             + {'rccl': 'RCCL (nfa_comm_*)', 'tcp': 'TCP sockets (ranks share a GPU, or RCCL did not start)',

@@ -66,6 +66,12 @@ int nfa_get_exp_mode(void);
  *                   nfa_runner_loglike_batch_dev calls over; 0 (default) = six streams of which a batch of
  *                   about one wavefront per wave slot of the GPU uses all six and any other batch four;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
+ *   "coalesce"      1..4 (default 4): nfa_runner_loglike_batch_dev calls of one shape (same number of rows, a
+ *                   multiple of 64; pixels given or not) that follow each other are held and launched together,
+ *                   at most this many (1 = every call its own launches).  Results are bitwise the same; anything
+ *                   that looks at them or changes the way launches are made (nfa_runner_synchronize,
+ *                   nfa_device_synchronize, the host-pointer calls, a mode change, the sampler) launches what is
+ *                   held first.  Read at every call;
  *   "prior_stage"   1 / 0: the set-up kernel stages the prior tables in LDS (default) or reads them from global
  *                   memory; taken over by priors created afterwards (A/B knob: no measurable difference in the
  *                   pipelined rates, the staged form is 5 us shorter when the stage runs alone);
@@ -197,9 +203,11 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
 
 /* Same as nfa_runner_loglike_batch with every buffer already resident in device
  * memory (from nfa_malloc); enqueued, returns without synchronising.  d_pix may be
- * NULL.  Consecutive calls go to different HIP streams of the runner (round
- * robin) and may overlap on the device: the buffers of calls that are in flight
- * together must not alias.  nfa_runner_synchronize waits for all of them. */
+ * NULL.  Consecutive calls of one shape may be launched together (option "coalesce");
+ * consecutive launches go to different HIP streams of the runner (round robin) and may
+ * overlap on the device: the buffers of calls that are in flight together must not
+ * alias, and the caller's buffers must stay valid until nfa_runner_synchronize (or
+ * nfa_device_synchronize), which launches what is still held and waits for all of it. */
 int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_U,
                                  double *d_lnL, int64_t B);
 int nfa_runner_synchronize(nfa_runner *r);

@@ -117,6 +117,21 @@ struct SpecDev {
 #define DK_YLO 14
 __host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncomp + ncomp * nspec * DREC_CS; }
 
+// Up to NFA_GROUP_MAX batches of `each` rows that a caller enqueues one after the other travel as ONE launch (the
+// engine coalesces them, nfa_engine.hip): item b of the launch is row b - c * each of batch c = b / each, and every
+// batch keeps its own pixel, unit-cube and result arrays.
+#define NFA_GROUP_MAX 4
+struct BatchGroup {
+    const int *pix[NFA_GROUP_MAX];
+    double    *U[NFA_GROUP_MAX];
+    double    *lnL[NFA_GROUP_MAX];
+    long       each;
+    int        n;
+};
+__device__ __forceinline__ int group_of(const BatchGroup &g, long b) {
+    return g.n > 1 ? (int)(b >= g.each) + (int)(b >= 2 * g.each) + (int)(b >= 3 * g.each) : 0;
+}
+
 #define LNL_PARTS 4      // row parts of a unit: the fixed shape of its chi^2 sum
 struct LnlGeom {
     int nhf_max;       // lines per component slot in the LDS line table
@@ -459,7 +474,8 @@ template <int MODE, bool WRITE_SPEC, bool WIDE, int NCOMP>
 __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict__ pix, const double *__restrict__ D,
                                          double *__restrict__ part, double *__restrict__ spec_out, long B,
                                          const LnlGeom &G, const double *__restrict__ g_tabs, double *smem,
-                                         const double *sm, int n_shared, unsigned block_id) {
+                                         const double *sm, int n_shared, unsigned block_id,
+                                         const BatchGroup *grp = nullptr) {
     typedef typename std::conditional<MODE == 2, float, double>::type tau_t;
     constexpr int NC = NCOMP > 0 ? NCOMP : 1;
     const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
@@ -504,7 +520,14 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const int s = (int)(unit - bu * (unsigned)nspec);
     const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
     const int nhf = __builtin_amdgcn_readfirstlane(c_nhf[t]);
-    const long p_ix = pix ? (long)__builtin_amdgcn_readfirstlane(pix[b]) : 0;
+    long p_ix = 0;
+    if (grp) {                                                    // batch kernels: the item's batch of the group has the pixels
+        const int c = group_of(*grp, b);
+        const int *pp = grp->pix[c];
+        if (pp) p_ix = (long)__builtin_amdgcn_readfirstlane(pp[b - c * grp->each]);
+    } else if (pix) {
+        p_ix = (long)__builtin_amdgcn_readfirstlane(pix[b]);
+    }
     const double nu0 = S.rest[s];
     const double *xs = S.xarr + off;
     const k_dbl_p Dk = (k_dbl_p)(D + b * drec);                    // the item's record: scalar loads
@@ -750,13 +773,13 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
 // WIDE (fast mode only): the spectra set holds a transition with more than 26 lines (N2H+)
 template <int MODE, bool WRITE_SPEC, bool WIDE, int NCOMP>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))
-lnl_kernel(SpecDev S, const int *__restrict__ pix, const double *__restrict__ D, double *__restrict__ part,
+lnl_kernel(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__restrict__ part,
            double *__restrict__ spec_out, long B, LnlGeom G, const double *__restrict__ g_tabs) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int n_shared = 0;
     const double *sm = smem;
     if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);   // fast: no tables
-    lnl_body<MODE, WRITE_SPEC, WIDE, NCOMP>(S, pix, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x);
+    lnl_body<MODE, WRITE_SPEC, WIDE, NCOMP>(S, nullptr, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x, &grp);
 }
 
 // chi^2 parts of one item -> its log-likelihood: the sum over the spectra, in order (ammonia.pyx:425-432), of
@@ -773,11 +796,14 @@ __device__ __forceinline__ double lnl_of_item(const double *__restrict__ part, c
 
 // lnL of the items of a batch, lanes = items (the division happens here instead of once per likelihood wave)
 __global__ void lnl_sum_kernel(const double *__restrict__ part, const double *__restrict__ noise,
-                               const int *__restrict__ pix, double *__restrict__ lnL, long B, int nspec) {
+                               BatchGroup grp, long B, int nspec) {
     __builtin_amdgcn_s_setprio(3);
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    lnL[b] = lnl_of_item(part, noise, pix ? (long)pix[b] : 0, b, nspec);
+    const int c = group_of(grp, b);
+    const long row = b - c * grp.each;
+    const int *pix = grp.pix[c];
+    grp.lnL[c][row] = lnl_of_item(part, noise, pix ? (long)pix[row] : 0, b, nspec);
 }
 
 #include "nfa_setup.h"

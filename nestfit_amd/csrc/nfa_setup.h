@@ -503,10 +503,14 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
 
 template <int MODE>
 __global__ void __launch_bounds__(512) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
-                                                    double *__restrict__ U, double *__restrict__ D,
+                                                    BatchGroup grp, double *__restrict__ D,
                                                     long B, int has_prior,
                                                     const double *__restrict__ g_tabs, int ablate_in, int ti) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    // the workgroup's items belong to one batch of the group (the host sees to it that `each` is a multiple of ti):
+    // its unit-cube array, shifted so that the body can go on indexing it with the item's number in the launch
+    const int c = group_of(grp, (long)blockIdx.x * ti);
+    double *U = grp.U[c] - (long)c * grp.each * (S.npar * S.ncomp);
     __builtin_amdgcn_s_setprio(3);
     int n_shared;
     const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);

@@ -1,0 +1,133 @@
+"""The device-pointer entry point (nfa_runner_loglike_batch_dev: what bench.py and a GPU-resident caller use) and
+the engine's coalescing of batches that arrive back to back: every batch must come out bit for bit as the host
+-pointer call gives it, whatever company it travelled in -- groups of four, a rest, shapes that change mid-stream,
+batches that cannot be coalesced, a mode switch between two batches, cube runners with pixel arrays and single
+-pixel runners without."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nestfit_amd.synth import freq_axis
+
+pytestmark = pytest.mark.gpu
+
+
+class _DeviceArrays:
+    def __init__(self, lib, check):
+        self.lib, self.check, self.ptrs = lib, check, []
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        self.check(self.lib.nfa_malloc(C.byref(p), a.nbytes))
+        self.check(self.lib.nfa_memcpy_h2d(p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        self.ptrs.append(p)
+        return p
+
+    def empty(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.nfa_malloc(C.byref(p), nbytes))
+        self.ptrs.append(p)
+        return p
+
+    def download(self, p, like):
+        out = np.empty_like(like)
+        self.check(self.lib.nfa_memcpy_d2h(out.ctypes.data_as(C.c_void_p), p, out.nbytes))
+        return out
+
+    def free(self):
+        for p in self.ptrs:
+            self.lib.nfa_free(p)
+
+
+def _run_on_device(_ffi, handle, batches, sync_after=()):
+    """batches: list of (pix or None, U[B, ndim]); returns [(theta, lnL)] after one synchronise at the end (and
+    after the batches whose index is in `sync_after`)."""
+    lib = _ffi.load()
+    dev = _DeviceArrays(lib, _ffi.check)
+    try:
+        slots = []
+        for pix, U in batches:
+            d_u = dev.upload(U)
+            d_l = dev.empty(8 * U.shape[0])
+            d_p = dev.upload(np.ascontiguousarray(pix, dtype=np.int32)) if pix is not None else None
+            slots.append((d_p, d_u, d_l, U))
+        for k, (d_p, d_u, d_l, U) in enumerate(slots):
+            _ffi.check(lib.nfa_runner_loglike_batch_dev(handle, d_p, d_u, d_l, U.shape[0]))
+            if k in sync_after:
+                _ffi.check(lib.nfa_runner_synchronize(handle))
+        _ffi.check(lib.nfa_runner_synchronize(handle))
+        return [(dev.download(d_u, U), dev.download(d_l, np.empty(U.shape[0]))) for d_p, d_u, d_l, U in slots]
+    finally:
+        dev.free()
+
+
+@pytest.mark.parametrize('mode', ['fast', 'table'])
+def test_device_batches_coalesced_or_not_give_the_host_call_bits(engine, mode):
+    from nestfit_amd import _ffi
+    from nestfit_amd.cube import CubeRunner
+    engine.set_exp_mode(mode)
+    try:
+        rng = np.random.default_rng(12)
+        n, n_pix = 192, 6
+        axes = [freq_axis(1, n), freq_axis(2, n)]
+        data = rng.normal(0, 0.2, (n_pix, 2 * n))
+        noise = rng.uniform(0.1, 0.3, (n_pix, 2))
+        ut = engine.get_irdc_priors(size=200, vsys=0.0)
+        # seven batches of 256 (a group of four and a rest of three), then the shape changes, then a batch whose size
+        # is no multiple of 64 (never coalesced), then two more of the first shape
+        sizes = [256] * 7 + [320] * 3 + [200] + [256] * 2
+        batches = []
+        for k, B in enumerate(sizes):
+            pix = np.full(B, k % n_pix, dtype=np.int32) if k % 3 else rng.integers(0, n_pix, B).astype(np.int32)
+            batches.append((pix, rng.uniform(size=(B, 12))))
+        for coalesce in (4, 1, 3):
+            _ffi.set_option('coalesce', coalesce)
+            rc = CubeRunner(axes, (1, 2), data, noise, ut, ncomp=2)
+            want = []
+            for pix, U in batches:
+                Uh = U.copy()
+                want.append((Uh, rc.loglikelihood_batch(pix, Uh)))          # host-pointer call: theta in place, lnL
+            for sync_after in ((), (1, 5)):
+                got = _run_on_device(_ffi, rc._run.handle, batches, sync_after)
+                for k, ((th, ln), (wt, wl)) in enumerate(zip(got, want)):
+                    assert np.array_equal(th, wt) and np.array_equal(ln, wl, equal_nan=True), (mode, coalesce, sync_after, k)
+    finally:
+        _ffi.set_option('coalesce', 4)
+        engine.set_exp_mode('fast')
+
+
+def test_single_pixel_runner_and_mode_switch_between_batches(engine):
+    """No pixel array (an AmmoniaRunner); the runner's mode changes while two batches are held: they run in the
+    mode they were enqueued under."""
+    from nestfit_amd import _ffi
+    rng = np.random.default_rng(4)
+    spec_data = [[freq_axis(t, 256), rng.normal(0, 0.2, 256), 0.2, t] for t in (1, 2)]
+    ut = engine.get_irdc_priors(size=200, vsys=0.0)
+    run = engine.AmmoniaRunner.from_data(spec_data, ut, ncomp=1)
+    U = [rng.uniform(size=(128, 6)) for _ in range(4)]
+    want = {}
+    for mode in ('fast', 'table'):
+        run.set_exp_mode(mode)
+        want[mode] = []
+        for u in U:
+            uh = u.copy()
+            want[mode].append((uh, run.loglikelihood_batch(uh)))
+    lib = _ffi.load()
+    dev = _DeviceArrays(lib, _ffi.check)
+    try:
+        run.set_exp_mode('fast')
+        bufs = [(dev.upload(u), dev.empty(8 * 128)) for u in U]
+        for k, (d_u, d_l) in enumerate(bufs):
+            if k == 2:
+                run.set_exp_mode('table')                   # two batches are held at this point
+            _ffi.check(lib.nfa_runner_loglike_batch_dev(run._run.handle, None, d_u, d_l, 128))
+        _ffi.check(lib.nfa_device_synchronize())            # flushes what is held, too
+        for k, (d_u, d_l) in enumerate(bufs):
+            mode = 'fast' if k < 2 else 'table'
+            assert np.array_equal(dev.download(d_u, U[k]), want[mode][k][0]), k
+            assert np.array_equal(dev.download(d_l, np.empty(128)), want[mode][k][1]), k
+    finally:
+        dev.free()
+        run.set_exp_mode(None)
