@@ -417,7 +417,7 @@ def main():
             roof.update({'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'avg_launch_us': head['lnl_kernel_us'],
                          'setup_kernel_us': head['setup_kernel_us'],
                          'rocprof': 'profiles/r02/onelane_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- '
-                                    'python bench.py --streams 1 --modes one --no-cpu-baseline)'})
+                                    'python bench.py --streams 1 --coalesce 1 --modes one --no-cpu-baseline)'})
         pipe = bytes_eval * B * world / step_s / 1e9
         roof['pipeline'] = {'us_per_step': step_s * 1e6, 'achieved': pipe, 'frac': pipe / (HBM_PEAK_GBS * world),
                             'note': 'the same bytes / the time per step of the timed blocks (the engine launches '
@@ -429,7 +429,7 @@ def main():
             roof['valu'] = {'busy_frac_one_lane': pmc.get('valu_busy_frac'),
                             'valu_instructions_per_eval': pmc['instructions_per_eval'].get('valu'),
                             'salu_instructions_per_eval': pmc['instructions_per_eval'].get('salu'),
-                            'source': 'profiles/r02/pmc_lnl_fast.json (rocprofv3 --pmc passes of bench.py --streams 1)'}
+                            'source': 'profiles/r02/pmc_lnl_fast.json (rocprofv3 --pmc passes of bench.py --streams 1 --coalesce 1)'}
         except Exception:
             pass
         try:

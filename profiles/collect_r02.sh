@@ -8,7 +8,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r02; mkdir -p $out
-ONE="--streams 1 --modes one --no-cpu-baseline --blocks 3 --steps 60 --warmup 10"
+ONE="--streams 1 --coalesce 1 --modes one --no-cpu-baseline --blocks 3 --steps 60 --warmup 10"     # one lane, one step per launch
 case "$1" in
 bench)
   python bench.py > $out/bench_default.json 2> $out/bench_default.err || exit 1
