@@ -231,6 +231,8 @@ def main():
     ap.add_argument('--setup-threads', type=int, default=0, help='engine A/B knob: threads per set-up workgroup (0 = default)')
     ap.add_argument('--ablate', type=int, default=0, help='timing experiment with the -DNFA_ABLATE build (INVALID results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--skip-single-step', action='store_true',
+                    help='do not also time the launch of a single step (profiler runs: one launch shape per kernel name)')
     args = ap.parse_args()
 
     if args.workload == 'C5':
@@ -331,22 +333,28 @@ def main():
         mine = np.array(out)
         return comm.allreduce(mine, 'max'), comm.allreduce(mine, 'min')
 
-    def one_lane_kernel_times():
+    def one_lane_kernel_times(spl=1):
         """(lnl_kernel us, set-up kernel us, launches) on a one-lane runner: launches do not overlap, a
-        HIP-event interval is the execution time (what rocprofv3 shows for such a launch)."""
+        HIP-event interval is the execution time (what rocprofv3 shows for such a launch).  `spl` steps per
+        launch: the launch the engine makes of `spl` coalesced steps, here as one call over their (contiguous) rows."""
         from nestfit_amd._model import _RunnerHandle
         _ffi.set_option('streams', 1)
         solo = _RunnerHandle(cube._ss, ut, ncomp, False, False)
         _ffi.set_option('streams', args.streams if args.streams else 0)
-        n = min(60, n_steps)
+        n = max(1, min(60, n_steps) // spl)
+
+        def launch(k):
+            _ffi.check(lib.nfa_runner_loglike_batch_dev(solo.handle, C.c_void_p(d_pix.value + k * spl * B * 4),
+                                                        C.c_void_p(d_U.value + k * spl * B * ndim * 8),
+                                                        C.c_void_p(d_lnL.value + k * spl * B * 8), spl * B))
         reset_inputs()
         for k in range(min(5, n)):
-            step(solo.handle, k)
+            launch(k)
         sync(solo.handle)
         reset_inputs()
         _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 1))
         for k in range(n):
-            step(solo.handle, k)
+            launch(k)
         sync(solo.handle)
         sp = (C.c_double * 4)(0, 0, 0, 0)
         sc = C.c_int64(0)
@@ -380,7 +388,7 @@ def main():
             k_med = int(np.argsort(t)[len(t) // 2])
             entry['rank_ms_per_step'] = {'slowest': float(t[k_med]) / args.steps * 1e3,
                                          'fastest': float(t_fastest[k_med]) / args.steps * 1e3}
-        if mode == args.exp_mode and steps_per_launch > 1:
+        if mode == args.exp_mode and steps_per_launch > 1 and not args.skip_single_step:
             # the same blocks with every step launched on its own
             _ffi.set_option('coalesce', 1)
             ta, _ = timed_blocks(rh, max(3, args.blocks // 3))
@@ -388,9 +396,15 @@ def main():
             entry['one_step_per_launch'] = {'value': evals_per_block / float(np.median(ta)),
                                             'ms_per_step': float(np.median(ta)) / args.steps * 1e3}
         if rank == 0 and world == 1 and not per_row:
-            lnl_us, setup_us, n_l = one_lane_kernel_times()
+            # the launch as the engine makes it (steps_per_launch steps together), alone on one lane ...
+            lnl_us, setup_us, n_l = one_lane_kernel_times(steps_per_launch)
             entry.update({'lnl_kernel_us': lnl_us, 'setup_kernel_us': setup_us, 'one_lane_launches': n_l,
-                          'roofline_frac': bytes_eval * B / (lnl_us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                          'evals_per_launch': B * steps_per_launch,
+                          'roofline_frac': bytes_eval * B * steps_per_launch / (lnl_us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+            if steps_per_launch > 1 and not args.skip_single_step:                      # ... and the launch of a single step
+                l1, s1, n1 = one_lane_kernel_times(1)
+                entry['single_step_launch'] = {'lnl_kernel_us': l1, 'setup_kernel_us': s1, 'one_lane_launches': n1,
+                                               'roofline_frac': bytes_eval * B / (l1 * 1e-6) / 1e9 / HBM_PEAK_GBS}
         per_mode[mode] = entry
 
     # results of the last step, for the end-of-run gather and a sanity check
@@ -411,13 +425,16 @@ def main():
         value = head['value']
         step_s = head['ms_per_step'] * 1e-3
         roof = {'bound': 'valu', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
-                'kernel': 'lnl_kernel', 'algorithmic_bytes_per_eval': bytes_eval, 'evals_per_launch': B}
+                'kernel': 'lnl_kernel', 'algorithmic_bytes_per_eval': bytes_eval, 'evals_per_launch': B * steps_per_launch,
+                'steps_per_launch': steps_per_launch}
         if 'lnl_kernel_us' in head:
-            ach = bytes_eval * B / (head['lnl_kernel_us'] * 1e-6) / 1e9
+            ach = bytes_eval * B * steps_per_launch / (head['lnl_kernel_us'] * 1e-6) / 1e9
             roof.update({'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'avg_launch_us': head['lnl_kernel_us'],
                          'setup_kernel_us': head['setup_kernel_us'],
                          'rocprof': 'profiles/r02/onelane_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- '
-                                    'python bench.py --streams 1 --coalesce 1 --modes one --no-cpu-baseline)'})
+                                    'python bench.py --streams 1 --modes one --no-cpu-baseline)'})
+            if 'single_step_launch' in head:
+                roof['single_step_launch'] = head['single_step_launch']
         pipe = bytes_eval * B * world / step_s / 1e9
         roof['pipeline'] = {'us_per_step': step_s * 1e6, 'achieved': pipe, 'frac': pipe / (HBM_PEAK_GBS * world),
                             'note': 'the same bytes / the time per step of the timed blocks (the engine launches '
@@ -446,12 +463,13 @@ def main():
                     if row['Name'].startswith('void lnl_kernel<2, false, false, 2>') and args.workload == 'C2' and B == 4096:
                         us = float(row['AverageNs']) * 1e-3
                         roof['rocprof_avg_launch_us'] = us
-                        roof['rocprof_frac'] = bytes_eval * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                        roof['rocprof_frac'] = bytes_eval * B * steps_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
         except Exception:
             pass
-        roof['note'] = ('achieved / frac: algorithmic bytes (SURVEY 8d) per launch / lnl_kernel time per launch, HIP events on a '
-                        'one-lane runner after the timed blocks; `rocprof` names the committed summary of the one-lane command '
-                        'whose average agrees. The kernel is VALU bound: `valu` = busy fraction of the vector ALUs from '
+        roof['note'] = ('achieved / frac: algorithmic bytes (SURVEY 8d) per launch / lnl_kernel time per launch -- the launch the '
+                        'engine makes of `steps_per_launch` steps that arrive back to back -- HIP events on a one-lane runner after '
+                        'the timed blocks; `single_step_launch` = the same for the launch of one step; `rocprof` names the '
+                        'committed summary of the one-lane command whose average agrees. The kernel is VALU bound: `valu` = busy fraction of the vector ALUs from '
                         'SQ_ACTIVE_INST_VALU and instructions per evaluation (separate --pmc passes); with --pixels-per-step 1 '
                         'the pixel stays in L2 (traffic << algorithmic bytes), see DESIGN.md')
         cpu = None

@@ -8,7 +8,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r02; mkdir -p $out
-ONE="--streams 1 --coalesce 1 --modes one --no-cpu-baseline --blocks 3 --steps 60 --warmup 10"     # one lane, one step per launch
+ONE="--streams 1 --modes one --no-cpu-baseline --skip-single-step --blocks 3 --steps 60 --warmup 12"     # one lane; 72 steps = 18 launches of four steps: one launch shape
 case "$1" in
 bench)
   python bench.py > $out/bench_default.json 2> $out/bench_default.err || exit 1
@@ -33,8 +33,8 @@ pmc)
     i=$((i+1))
     timeout -k 10 200 rocprofv3 --pmc $p --output-format csv -d $out/pmc_$i -- python bench.py $ONE > $out/pmc_$i.log 2>&1 || echo "pmc pass $i failed"
   done
-  python profiles/pmc_to_json.py "lnl_kernel<2, false" 4096 $out/pmc_lnl_fast.json $out/pmc_*/*/*counter_collection.csv > $out/pmc_lnl_fast.txt
-  python profiles/pmc_to_json.py "setup_kernel" 4096 $out/pmc_setup.json $out/pmc_*/*/*counter_collection.csv > $out/pmc_setup.txt
+  python profiles/pmc_to_json.py "lnl_kernel<2, false" 16384 $out/pmc_lnl_fast.json $out/pmc_*/*/*counter_collection.csv > $out/pmc_lnl_fast.txt
+  python profiles/pmc_to_json.py "setup_kernel" 16384 $out/pmc_setup.json $out/pmc_*/*/*counter_collection.csv > $out/pmc_setup.txt
   ;;
 pmc_table)
   # table mode: is the likelihood kernel bound by its LDS gathers (three product-table reads per line x row step)?
@@ -44,7 +44,7 @@ pmc_table)
     i=$((i+1))
     timeout -k 10 200 rocprofv3 --pmc $p --output-format csv -d $out/pmct_$i -- python bench.py $ONE --exp-mode table > $out/pmct_$i.log 2>&1 || echo "pmc_table pass $i failed"
   done
-  python profiles/pmc_to_json.py "lnl_kernel<0, false" 4096 $out/pmc_lnl_table.json $out/pmct_*/*/*counter_collection.csv > $out/pmc_lnl_table.txt
+  python profiles/pmc_to_json.py "lnl_kernel<0, false" 16384 $out/pmc_lnl_table.json $out/pmct_*/*/*counter_collection.csv > $out/pmc_lnl_table.txt
   ;;
 traffic)
   for c in FETCH_SIZE WRITE_SIZE; do
