@@ -452,8 +452,9 @@ def main():
         try:
             tr = json.loads((PROFILE_DIR / 'pmc_traffic.json').read_text())
             key = 'pixel_per_item' if per_row else 'one_pixel'
-            roof['traffic'] = tr['detail'][args.exp_mode][key]['total_bytes'] if args.workload == 'C2' and B == 4096 else None
-            roof['traffic_source'] = 'profiles/r02/pmc_traffic.json (FETCH_SIZE x calibration + WRITE_SIZE, separate passes)'
+            # measured per 4096-row batch; a launch of coalesced steps moves that once per step
+            roof['traffic'] = tr['detail'][args.exp_mode][key]['total_bytes'] * steps_per_launch if args.workload == 'C2' and B == 4096 else None
+            roof['traffic_source'] = 'profiles/r02/pmc_traffic.json (FETCH_SIZE x calibration + WRITE_SIZE, separate passes, per 4096-row batch) x steps_per_launch'
         except Exception:
             pass
         try:
