@@ -572,8 +572,6 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // scalar instructions and a move per step; the scalar unit is the shared resource, see the header)
     typedef const __attribute__((address_space(3))) char *lds_char_p;
     unsigned lbase_c[NC];
-    bool need_t0 = MODE != 2;      // T0 and tbg per channel: exact modes always; fast mode only where
-                                   // y(T0) is not the single table cell (kind != 1)
     if (NCOMP > 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -586,10 +584,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             asm volatile("" : "+v"(lbase_c[c]));
             const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
             ck_kind[c] = Dk[dko + DK_KIND]; ck_a0x[c] = Dk[dko + DK_A0X]; ck_b0x[c] = Dk[dko + DK_B0X];
-            if (MODE == 2 && S.model != NFA_MODEL_GAUSSIAN) need_t0 = need_t0 || ck_kind[c] != 1.0;
         }
-    } else if (MODE == 2 && S.model != NFA_MODEL_GAUSSIAN) {
-        for (int c = 0; c < ncomp; ++c) need_t0 = need_t0 || Dk[4 * ncomp + (c * nspec + s) * DREC_CS + DK_KIND] != 1.0;
     }
     // --- rows of 64 channels: tau profile, Tb, chi^2 (hyperfine.pyx:93-113, core.pyx:522-530)
     const double *t0s = S.t0 + off, *tbgs = S.tbg + off, *p3s = S.t0tbg + off;
@@ -640,7 +635,10 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             const double dj = *(const double *)((const char *)ds + jo);
             double p3, x2, T0, tbg;                    // read only where the branches below have set them
             if (MODE == 2) { p3 = *(const double *)((const char *)p3s + jo); x2 = xj * xj; }
-            if (need_t0) { T0 = *(const double *)((const char *)t0s + jo); tbg = *(const double *)((const char *)tbgs + jo); }
+            // exact modes: T0 and tbg of the channel for every Tb pass; the fast mode reads them inside the rare pass
+            // that needs them (y(T0) not a single table cell): carried through the row as "maybe loaded" values they
+            // cost two register copies per row
+            if (MODE != 2) { T0 = *(const double *)((const char *)t0s + jo); tbg = *(const double *)((const char *)tbgs + jo); }
             double pred = 0.0;
             // one component: the lines in `mask` add their optical depths, then the Tb pass
             auto component = [&](int c, unsigned long long mask, double kind, double a0x, double b0x) {
@@ -710,6 +708,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         // y = A0 + B0 T0 and T0 = kappa x:  g = B0x x^2 + A0x x - T0 tbg
                         g = __builtin_fma(b0x, x2, __builtin_fma(a0x, xj, -p3));
                     } else if (kind != 0.0) {
+                        const double T0 = *(const double *)((const char *)t0s + jo), tbg = *(const double *)((const char *)tbgs + jo);
                         const bool up = !(T0 < Dk[dko + DK_SPLIT]);
                         const double dT = T0 - Dk[dko + DK_M];
                         const double ya = up ? Dk[dko + DK_A1] : Dk[dko + DK_A0];
@@ -717,6 +716,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         const double y = __builtin_fma(__builtin_fma(Dk[dko + DK_Q], dT, yb), dT, ya);
                         g = T0 * (y - tbg);
                     } else {
+                        const double T0 = *(const double *)((const char *)t0s + jo), tbg = *(const double *)((const char *)tbgs + jo);
                         const double y = nf_iemtex(T0 / Dk[c * 4], g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
                         g = T0 * (y - tbg);
                     }
