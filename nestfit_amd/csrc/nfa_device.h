@@ -75,6 +75,7 @@ struct SpecDev {
     const double *xarr, *t0, *tbg, *data, *noise;
     const double *t0tbg;                 // T0 * tbg per channel (fast mode: g = B0x x^2 + A0x x - T0 tbg)
     const double *rowsq;                 // [n_pix][rows_tot]: sum of data^2 over each row of 64 channels
+    const double *totsq;                 // [n_pix][n_spec]: sum of data^2 over a spectrum (its rows added in order)
     int     row_off[MAXSPEC];            // first row of spectrum s inside a pixel's rowsq slice
     int64_t rows_tot;                    // sum over the spectra of ceil(size / 64)
     double  t0_xmin, t0_xmax, t0_inv_dx;
@@ -589,27 +590,17 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // --- rows of 64 channels: tau profile, Tb, chi^2 (hyperfine.pyx:93-113, core.pyx:522-530)
     const double *t0s = S.t0 + off, *tbgs = S.tbg + off, *p3s = S.t0tbg + off;
     const double *ds = S.data + p_ix * S.chan_tot + off;
-    const double *rsq = S.rowsq + p_ix * S.rows_tot + S.row_off[s];
+    // chi^2 = sum (d - pred)^2 = sum d^2 + sum pred (pred - 2 d): the first sum is a constant of the (pixel,
+    // spectrum), formed once (SpecDev.totsq); the second has a term only where the model is not zero -- rows no
+    // line window touches are never read, and a lane outside every window adds pred (...) = 0 to its row's sum
     double acc = 0.0;
-    unsigned long long empt = 0ull;                              // signal-free rows of this block of 64 rows
-    // chi^2 of the signal-free rows of a block of 64 rows: their precomputed sums of data^2
-    auto flush_empty = [&](int block_row0) {
-        if (empt) {
-            const bool mine = (empt >> lane) & 1ull;
-            const double q = rsq[mine ? block_row0 + lane : 0];
-            acc += mine ? q : 0.0;
-        }
-        empt = 0ull;
-    };
     const int n_rows = (ablate & 4) ? 0 : (N + 63) >> 6;
     const int parts_per_wave = LNL_PARTS / split;
     double tot = 0.0;
     for (int hp = 0; hp < parts_per_wave; ++hp) {
     const int h = rpart * parts_per_wave + hp;                 // part h = rows h, h + LNL_PARTS, h + 2 LNL_PARTS, ...
     acc = 0.0;
-    int row_last = 0;
     for (int row = h; row < n_rows; row += LNL_PARTS) {
-        row_last = row;
         const int r0 = row << 6;
         const int j = r0 + lane;
         // lines of each component that touch this row
@@ -748,16 +739,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                 }
             }
             if (WRITE_SPEC) { if (valid) spec_out[b * S.chan_tot + off + j] = pred; }
-            if (any) {
-                const double dev = dj - pred;
-                if (r0 + 64 <= N) acc = __builtin_fma(dev, dev, acc);      // full row: no lane select
-                else if (valid) acc = __builtin_fma(dev, dev, acc);
-            }
+            if (any) acc = __builtin_fma(pred, __builtin_fma(-2.0, dj, pred), acc);       // lanes beyond N: pred = 0
         }
-        if (!any) empt |= 1ull << (row & 63);
-        if (((row + LNL_PARTS) >> 6) != (row >> 6)) flush_empty(row & ~63);      // the part's last row of this group of 64
     }
-    flush_empty(row_last & ~63);
     if (split == 1) tot += acc; else w_part[h * 64 + lane] = acc;
     }
     if (split > 1) {
@@ -767,7 +751,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     }
     tot = wave_sum(tot);
     // sum of squared deviations of the unit; lnl_sum_kernel scales and adds
-    if (lane == 0 && part) part[unit] = tot;
+    if (lane == 0 && part) part[unit] = S.totsq[p_ix * nspec + s] + tot;
 }
 
 // WIDE (fast mode only): the spectra set holds a transition with more than 26 lines (N2H+)
@@ -837,6 +821,19 @@ __global__ void rowsq_kernel(SpecDev S, long pix0, long n_pix, double *__restric
     if (j < S.size[s]) { const double d = S.data[p * S.chan_tot + S.off[s] + j]; v = d * d; }
     v = wave_sum(v);
     if (lane == 0) out[p * S.rows_tot + rr] = v;
+}
+
+// totsq[pix][spec] = sum over the rows of the spectrum, in order, of rowsq: the constant part of chi^2
+__global__ void totsq_kernel(SpecDev S, long pix0, long n_pix, const double *__restrict__ rowsq, double *__restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix * S.n_spec) return;
+    const long p = pix0 + i / S.n_spec;
+    const int s = (int)(i % S.n_spec);
+    const int n_rows = (S.size[s] + 63) >> 6;
+    const double *r = rowsq + p * S.rows_tot + S.row_off[s];
+    double v = 0.0;
+    for (int k = 0; k < n_rows; ++k) v += r[k];
+    out[p * S.n_spec + s] = v;
 }
 
 // null_lnZ[pix][spec] = -sum(data^2)/(2 noise^2): Spectrum.c_loglikelihood with

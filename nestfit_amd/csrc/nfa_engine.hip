@@ -158,7 +158,7 @@ struct nfa_specset {
     int64_t n_pix = 0;
     int     nhf_max = 0;
     double *d_xarr = nullptr, *d_t0 = nullptr, *d_tbg = nullptr, *d_data = nullptr, *d_noise = nullptr;
-    double *d_t0tbg = nullptr, *d_rowsq = nullptr;
+    double *d_t0tbg = nullptr, *d_rowsq = nullptr, *d_totsq = nullptr;
 };
 
 struct nfa_priors {
@@ -298,6 +298,8 @@ static int launch_rowsq(nfa_specset *ss, int64_t pix0, int64_t n) {
     const int64_t waves = n * ss->dev.rows_tot;
     hipLaunchKernelGGL(rowsq_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, 0, ss->dev,
                        (long)pix0, (long)n, ss->d_rowsq);
+    hipLaunchKernelGGL(totsq_kernel, dim3((unsigned)((n * ss->dev.n_spec + 255) / 256)), dim3(256), 0, 0, ss->dev,
+                       (long)pix0, (long)n, (const double *)ss->d_rowsq, ss->d_totsq);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return NFA_OK;
@@ -357,6 +359,7 @@ static int specset_fill(nfa_specset *ss, int model, int n_spec, const int64_t *s
     HIP_TRY(hipMalloc(&ss->d_data, sizeof(double) * tot * n_pix));
     HIP_TRY(hipMalloc(&ss->d_noise, sizeof(double) * n_spec * n_pix));
     HIP_TRY(hipMalloc(&ss->d_rowsq, sizeof(double) * rows * n_pix));
+    HIP_TRY(hipMalloc(&ss->d_totsq, sizeof(double) * n_spec * n_pix));
     HIP_TRY(hipMemcpy(ss->d_xarr, xcat.data(), sizeof(double) * tot, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ss->d_data, data, sizeof(double) * tot * n_pix, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ss->d_noise, noise, sizeof(double) * n_spec * n_pix, hipMemcpyHostToDevice));
@@ -364,7 +367,7 @@ static int specset_fill(nfa_specset *ss, int model, int n_spec, const int64_t *s
                        ss->d_xarr, ss->d_t0, ss->d_tbg, ss->d_t0tbg, (long)tot);
     HIP_TRY(hipGetLastError());
     d.xarr = ss->d_xarr; d.t0 = ss->d_t0; d.tbg = ss->d_tbg; d.data = ss->d_data; d.noise = ss->d_noise;
-    d.t0tbg = ss->d_t0tbg; d.rowsq = ss->d_rowsq;
+    d.t0tbg = ss->d_t0tbg; d.rowsq = ss->d_rowsq; d.totsq = ss->d_totsq;
     return launch_rowsq(ss, 0, n_pix);
 }
 
@@ -390,7 +393,7 @@ int nfa_specset_create_model(nfa_specset **out, int model, int n_spec, const int
 int nfa_specset_destroy(nfa_specset *ss) {
     if (!ss) return NFA_OK;
     (void)hipFree(ss->d_xarr); (void)hipFree(ss->d_t0); (void)hipFree(ss->d_tbg); (void)hipFree(ss->d_data); (void)hipFree(ss->d_noise);
-    (void)hipFree(ss->d_t0tbg); (void)hipFree(ss->d_rowsq);
+    (void)hipFree(ss->d_t0tbg); (void)hipFree(ss->d_rowsq); (void)hipFree(ss->d_totsq);
     delete ss;
     return NFA_OK;
 }
