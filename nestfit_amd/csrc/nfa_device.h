@@ -415,7 +415,7 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t) {
     const bool tiny = t < 1e-8f;
     if (__builtin_amdgcn_fcmpf(t, 1e-8f, NF_FCMP_OLT) != 0ull) {
         asm volatile("" ::: "memory");            // keep the rare path a branch (no if-conversion)
-        const double r1 = 1.0 - (double)(t * pc);
+        const double r1 = 1.0 - w;                 // (a tiny lane is below 2^-5: its w is the cubic t * pc)
         w = tiny ? 1.0 - r1 : w;
     }
     return w;
