@@ -137,12 +137,14 @@ class CubeFitter:
         for p in range(lon.size):
             hdf[f'/pix/{lon[p]}/{lat[p]}'].attrs.update(i_lon=int(lon[p]), i_lat=int(lat[p]), nbest=int(nbest[p]))
 
-    def fit_cube(self, store_name='run/test_cube', nproc=1, rank=None):
+    def fit_cube(self, store_name='run/test_cube', nproc=1, rank=None, file_format=None):
         """Creates the store, fits every pixel and links the chunk files (main.py:476-526).
         `nproc` = number of stripes / chunk files (the reference's process count: one per GPU
         here).  With `rank` given (one process per GPU, e.g. under torch.distributed.run) this
         process fits only stripe `rank`; the caller links the files once all ranks are done
-        (`HdfStore(store_name).link_files()`).  Without it all stripes are fitted in turn."""
+        (`HdfStore(store_name).link_files()`).  Without it all stripes are fitted in turn.
+        `file_format`: 'hdf5' or 'npz' for a new store (default: HDF5 wherever libhdf5 loads,
+        `store.store_format`); every rank has to pass the same."""
         n_lon = self.stack.spatial_shape[0]
         if nproc > n_lon:
             raise ValueError(
@@ -151,12 +153,13 @@ class CubeFitter:
         indices = get_multiproc_indices(self.stack.spatial_shape, nproc)
         if rank is not None and rank != 0:           # only rank 0 touches the table file
             from pathlib import Path
-            from .store import check_ext
+            from .store import FILE_SUFFIXES, check_ext, store_format
             store_dir = Path(check_ext(str(store_name), ext='store'))
             store_dir.mkdir(parents=True, exist_ok=True)
-            self.fit(indices[rank], store_dir / f'{HdfStore.chunk_prefix}{rank}.npz')
+            suffix = FILE_SUFFIXES[file_format or store_format()]
+            self.fit(indices[rank], store_dir / f'{HdfStore.chunk_prefix}{rank}{suffix}')
             return
-        store = HdfStore(store_name, nchunks=nproc)
+        store = HdfStore(store_name, nchunks=nproc, file_format=file_format)
         if 'simple_header' not in store.hdf:
             store.insert_header(self.stack)
         store.insert_fitter_pars(self)

@@ -8,17 +8,32 @@ nestfit/core/core.pyx:627-687):
                                     /pix/<i_lon>/<i_lat>/<ncomp>  attrs + datasets of one run
                                         (posteriors, marginals, bestfit_params, map_params)
 
-h5py is not available in this image, so the container is a loss-free twin: a tree of groups
-(attrs + datasets, the slice of the h5py API the reference uses) saved as one ``.npz`` per file
-(arrays under their full path, attributes as one JSON document).  With h5py importable the same
-tree can be exported with `Group.to_hdf5`.
+Every file is a tree of groups (attrs + datasets, the slice of the h5py API the reference uses)
+held in memory and saved whole.  Two file formats, chosen by the suffix: real HDF5 (``.hdf``) written
+and read through the HDF5 C library (`nestfit_amd/hdf5.py`: h5py is not in this image, libhdf5 is) --
+the table's pixel groups are then external links into the chunk files, like the reference's -- and a
+loss-free ``.npz`` twin (arrays under their full path, attributes as one JSON document) for hosts
+without libhdf5.  `store_format()` says which one a new store gets.
 """
 import inspect
 import json
+import os
 import warnings
 from pathlib import Path
 
 import numpy as np
+
+from . import hdf5
+
+HDF5_SUFFIXES = ('.hdf', '.h5', '.hdf5')
+
+
+def store_format():
+    """'hdf5' or 'npz' for a new store: `NFA_STORE_FORMAT` when set, else HDF5 wherever libhdf5 loads."""
+    want = os.environ.get('NFA_STORE_FORMAT', '').lower()
+    if want in ('hdf5', 'npz'):
+        return want
+    return 'hdf5' if hdf5.available() else 'npz'
 
 
 class Group:
@@ -153,14 +168,19 @@ def _unjson(v):
 
 
 class StoreFile(Group):
-    """One file of the store (the table or a chunk): a root group that saves itself as .npz."""
+    """One file of the store (the table or a chunk): a root group that saves itself, as HDF5 when the
+    suffix is one of `HDF5_SUFFIXES`, else as .npz."""
 
     def __init__(self, path, mode='a'):
         super().__init__('/')
         self.path = Path(path)
         self._open = True
         self.mode = mode
-        if self.path.exists() and mode in ('a', 'r'):
+        self.is_hdf5 = self.path.suffix in HDF5_SUFFIXES
+        self._linked_files = {}                         # chunk files behind this file's external links
+        if self.path.exists() and mode in ('a', 'r') and self.is_hdf5:
+            hdf5.read_tree(self.path, self, self._resolve_external)
+        elif self.path.exists() and mode in ('a', 'r'):
             with np.load(self.path, allow_pickle=False) as z:
                 attrs = json.loads(str(z['__attrs__']))
                 for name in attrs:
@@ -172,8 +192,34 @@ class StoreFile(Group):
         elif mode == 'r':
             raise FileNotFoundError(str(self.path))
 
+    def _resolve_external(self, parent, name, file_name, obj_path):
+        """An external link read from the file: the object of the linked file takes the link's place (a link
+        whose file or object is gone is dropped, like a dangling link that cannot be opened)."""
+        target = Path(file_name)
+        if not target.is_absolute():
+            target = self.path.parent / target
+        try:
+            if target not in self._linked_files:
+                self._linked_files[target] = StoreFile(target, 'r')
+            parent._children[name] = self._linked_files[target][obj_path]
+        except (FileNotFoundError, KeyError, hdf5.Hdf5Error):
+            pass
+
+    def _external_of(self, child):
+        """(file name, object path) of a child that lives in another file, None for this file's own."""
+        if child._root is self._root:
+            return None
+        other = child._root.path
+        same_dir = other.parent.resolve() == self.path.parent.resolve()
+        return (other.name if same_dir else str(other.resolve())), child.name
+
     def _flush(self):
         if self.mode == 'r':
+            return
+        if self.is_hdf5:
+            tmp = self.path.with_name(self.path.name + '.tmp')
+            hdf5.write_tree(tmp, self, self._external_of)
+            tmp.replace(self.path)
             return
         arrays, attrs = {}, {}
         self._collect(arrays, attrs)
@@ -207,7 +253,7 @@ class StoreFile(Group):
 STORE_SUFFIX = '.store'
 TABLE_NAME = 'table'
 CHUNK_STEM = 'chunk'
-FILE_SUFFIX = '.npz'               # '.hdf' in the reference; the npz twin keeps the same tree
+FILE_SUFFIXES = {'hdf5': '.hdf', 'npz': '.npz'}       # '.hdf' is the reference's (main.py:236)
 PRODUCTS_GROUP = '/products'
 
 # root attribute of the table file  <-  attribute of the CubeFitter          (store_spec.rst:60-63)
@@ -240,13 +286,18 @@ class HdfStore:
     entry points (nestfit/main.py:233-377).  `hdf` is the open table (a `StoreFile`)."""
     dpath = PRODUCTS_GROUP
     chunk_prefix = CHUNK_STEM
-    linked_table = Path(TABLE_NAME + FILE_SUFFIX)
 
-    def __init__(self, store_name, nchunks=1):
+    def __init__(self, store_name, nchunks=1, file_format=None):
         from . import MODELS
         self.store_name = str(store_name)
         self.store_dir = Path(check_ext(self.store_name, ext=STORE_SUFFIX.lstrip('.')))
         self.store_dir.mkdir(parents=True, exist_ok=True)
+        # an existing store keeps the format it was written in; a new one takes `file_format` ('hdf5' / 'npz')
+        # or what `store_format()` finds
+        found = [f for f, sfx in FILE_SUFFIXES.items() if (self.store_dir / (TABLE_NAME + sfx)).exists()]
+        self.file_format = found[0] if found else (file_format or store_format())
+        self.file_suffix = FILE_SUFFIXES[self.file_format]
+        self.linked_table = Path(TABLE_NAME + self.file_suffix)
         self.hdf = StoreFile(self.store_dir / self.linked_table, 'a')
         root = self.hdf.attrs
         root.setdefault('nchunks', nchunks)          # an existing store keeps its own number of chunks
@@ -269,7 +320,7 @@ class HdfStore:
 
     @property
     def chunk_paths(self):
-        return [self.store_dir / f'{self.chunk_prefix}{k}{FILE_SUFFIX}' for k in range(self.nchunks)]
+        return [self.store_dir / f'{self.chunk_prefix}{k}{self.file_suffix}' for k in range(self.nchunks)]
 
     def close(self):
         if not self.is_open:
@@ -298,8 +349,8 @@ class HdfStore:
         raise ValueError('No valid pix groups found.')
 
     def link_files(self):
-        """Hang the pixel groups of every chunk file under the table's /pix (h5py external links in the
-        reference; object references here)."""
+        """Hang the pixel groups of every chunk file under the table's /pix: object references in memory,
+        external links (`chunk<i>.hdf:/pix/<i_lon>/<i_lat>`, main.py:286-296) in the table's HDF5 file."""
         assert self.is_open
         for path in self.chunk_paths:
             if not path.exists():

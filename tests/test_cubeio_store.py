@@ -164,8 +164,14 @@ def test_noise_map_from_pbimg_and_nan_pixels():
 
 
 # ---- store -------------------------------------------------------------------------------------
-def test_group_tree_and_npz_round_trip(tmp_path):
-    f = StoreFile(tmp_path / 'chunk0.npz')
+_HAVE_HDF5 = __import__('nestfit_amd.hdf5', fromlist=['available']).available()
+_SUFFIXES = ['.npz', pytest.param('.hdf', marks=pytest.mark.skipif(not _HAVE_HDF5, reason='no libhdf5'))]
+_FORMATS = ['npz', pytest.param('hdf5', marks=pytest.mark.skipif(not _HAVE_HDF5, reason='no libhdf5'))]
+
+
+@pytest.mark.parametrize('suffix', _SUFFIXES)
+def test_group_tree_and_file_round_trip(tmp_path, suffix):
+    f = StoreFile(tmp_path / f'chunk0{suffix}')
     g = f.require_group('/pix/3/4')
     sub = g.create_group('1')
     sub.attrs['global_lnZ'] = -12.5
@@ -179,24 +185,27 @@ def test_group_tree_and_npz_round_trip(tmp_path):
     f.close()
     with pytest.raises(ValueError):
         f.flush()
-    r = StoreFile(tmp_path / 'chunk0.npz', 'r')
+    r = StoreFile(tmp_path / f'chunk0{suffix}', 'r')
     sub = r['/pix/3/4/1']
     assert sub.attrs['global_lnZ'] == -12.5 and sub.attrs['marg_cols'] == ['min', 'max']
     np.testing.assert_array_equal(sub.attrs['marg_quantiles'], [0.0, 1.0])
     assert sub['posteriors'].dtype == np.float32 and sub['posteriors'].shape == (3, 4)
     assert r['/pix/3/4'].attrs['nbest'] == 1
     with pytest.raises(FileNotFoundError):
-        StoreFile(tmp_path / 'nope.npz', 'r')
+        StoreFile(tmp_path / f'nope{suffix}', 'r')
 
 
-def test_hdfstore_layout(tmp_path, stack):
+@pytest.mark.parametrize('fmt', _FORMATS)
+def test_hdfstore_layout(tmp_path, stack, fmt, monkeypatch):
     import nestfit_amd as na
+    monkeypatch.setenv('NFA_STORE_FORMAT', fmt)
+    sfx = {'npz': '.npz', 'hdf5': '.hdf'}[fmt]
 
     class _Fitter:
         lnZ_thresh, ncomp_max, mn_kwargs = 11, 2, {'nlive': 100}
     with HdfStore(str(tmp_path / 'run'), nchunks=2) as store:
         assert store.store_dir.name == 'run.store' and store.nchunks == 2 and store.model is None
-        assert [p.name for p in store.chunk_paths] == ['chunk0.npz', 'chunk1.npz']
+        assert [p.name for p in store.chunk_paths] == [f'chunk0{sfx}', f'chunk1{sfx}'] and store.file_format == fmt
         store.insert_header(stack)
         store.insert_fitter_pars(_Fitter())
         store.insert_model_metadata(na.AmmoniaRunner)
@@ -210,7 +219,9 @@ def test_hdfstore_layout(tmp_path, stack):
         with pytest.warns(RuntimeWarning, match='Deleting dataset'):
             store.create_dataset('nbest', np.ones((20, 20)), group=store.dpath)
         assert store.hdf['/products/nbest'].sum() == 400
+    monkeypatch.setenv('NFA_STORE_FORMAT', 'npz')               # an existing store keeps its own format
     again = HdfStore(str(tmp_path / 'run'))
+    assert again.file_format == fmt and (tmp_path / 'run.store' / f'table{sfx}').exists()
     assert again.nchunks == 2 and again.model is na.MODELS['ammonia']
     assert again.hdf.attrs['par_names'] == ['voff', 'trot', 'tex', 'ntot', 'sigm', 'orth']
     assert again.hdf.attrs['lnZ_threshold'] == 11 and again.hdf.attrs['naxis1'] == 20

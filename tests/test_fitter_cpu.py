@@ -116,7 +116,9 @@ def test_fit_cube_one_process_per_stripe_gloo(tmp_path):
     store_name = str(tmp_path / 'run')
     mp.spawn(_worker, args=(2, _free_port(), store_name), nprocs=2, join=True)
     _check_store(store_name, 4)
-    assert sorted(p.name for p in (tmp_path / 'run.store').iterdir()) == ['chunk0.npz', 'chunk1.npz', 'table.npz']
+    from nestfit_amd.store import FILE_SUFFIXES, store_format
+    sfx = FILE_SUFFIXES[store_format()]
+    assert sorted(p.name for p in (tmp_path / 'run.store').iterdir()) == [f'chunk0{sfx}', f'chunk1{sfx}', f'table{sfx}']
     # same seed, same pixels, same slots within their stripe -> the two-process run equals the
     # one-process run stripe by stripe
     one = str(tmp_path / 'one')
