@@ -247,6 +247,39 @@ int  nfa_broker_loglike(nfa_broker *b, int32_t pix, double *cube, double *lnew);
 void nfa_broker_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx);
 /* out[0] batches launched, out[1] evaluations served, out[2] largest batch */
 int  nfa_broker_stats(nfa_broker *b, int64_t *out);
+
+/* ---- cross-process transport for the broker --------------------
+ * The reference runs one process per stripe (nestfit/main.py:516-523), each with its own
+ * MultiNest (one instance per process) calling LogLike point by point
+ * (cmultinest.pxd:27-28).  With a ring those processes never touch the GPU: each attaches to a
+ * POSIX shared-memory ring (`name`), owns one slot, and nfa_ring_loglike / nfa_ring_callback
+ * (MultiNest's LogLike signature; context = nfa_ring_client) post the point there and sleep
+ * until the ONE serving process has evaluated it together with the other processes' points:
+ * nfa_ring_serve = nfa_ring_poll -> nfa_runner_loglike_batch (up to 128 points: one launch)
+ * -> nfa_ring_complete, until nfa_ring_stop, max_batches (> 0) or idle_ms without a post.
+ * Results are bitwise those of nfa_runner_loglike_batch.  poll / complete are public so that a
+ * server can put its own evaluator between them.  All entry points except nfa_ring_serve are
+ * also exported by libnestfit_amd_ring.so, which has no HIP in it: the one library a sampler
+ * process loads. */
+typedef struct nfa_ring nfa_ring;
+typedef struct { nfa_ring *ring; int32_t pix; } nfa_ring_client;
+int  nfa_ring_create(nfa_ring **out, const char *name, int n_slots, int ndim);      /* server */
+int  nfa_ring_attach(nfa_ring **out, const char *name, int wait_ms);                /* client: takes a slot */
+int  nfa_ring_close(nfa_ring *r);            /* client: gives the slot back; server: removes the ring */
+int  nfa_ring_stop(nfa_ring *r);             /* everybody leaves: blocked clients get NFA_ERR_STATE */
+int  nfa_ring_ndim(const nfa_ring *r);
+int  nfa_ring_slot(const nfa_ring *r);
+int  nfa_ring_loglike(nfa_ring *r, int32_t pix, double *cube, double *lnew);
+void nfa_ring_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx);
+/* slots[k], pix[k], U[k*ndim..]: request k of the *n gathered (at most max_batch); returns when every
+ * attached client has posted, or max_wait_us after the first post; *n = 0 after idle_ms without a
+ * post or when the ring was stopped (*stopped). */
+int  nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, int32_t *slots,
+                   int32_t *pix, double *U, int *n, int *stopped);
+int  nfa_ring_complete(nfa_ring *r, int n, const int32_t *slots, const double *U, const double *lnL, int rc);
+int  nfa_ring_serve(nfa_ring *r, nfa_runner *run, int64_t max_wait_us, int64_t max_batches, int idle_ms);
+/* out[0] batches served, out[1] evaluations served, out[2] largest batch, out[3] clients attached */
+int  nfa_ring_stats(nfa_ring *r, int64_t *out);
 /* ---- device-resident batched nested sampler --------------------
  * Stand-in for one serial MultiNest run per pixel (run_multinest, nestfit/core/core.pyx:727-823,
  * pixel loop nestfit/main.py:452-469) when libmultinest is absent: all pixels' runs advance in

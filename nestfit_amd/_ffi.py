@@ -79,6 +79,19 @@ SIGNATURES = {
     'nfa_broker_loglike': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
     'nfa_broker_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
     'nfa_broker_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'nfa_ring_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int]),
+    'nfa_ring_attach': (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
+    'nfa_ring_close': (C.c_int, [C.c_void_p]),
+    'nfa_ring_stop': (C.c_int, [C.c_void_p]),
+    'nfa_ring_ndim': (C.c_int, [C.c_void_p]),
+    'nfa_ring_slot': (C.c_int, [C.c_void_p]),
+    'nfa_ring_loglike': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+    'nfa_ring_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
+    'nfa_ring_poll': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, _ip, _ip, _dp, C.POINTER(C.c_int),
+                                C.POINTER(C.c_int)]),
+    'nfa_ring_complete': (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, _dp, C.c_int]),
+    'nfa_ring_serve': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
+    'nfa_ring_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'nfa_sampler_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, _ip, C.c_int64, C.c_int, C.c_int,
                                      C.c_int64, C.c_int64, _ip]),
     'nfa_sampler_destroy': (C.c_int, [C.c_void_p]),

@@ -10,12 +10,15 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 SRC = HERE / 'csrc' / 'nfa_engine.hip'
-DEPS = sorted((HERE / 'csrc').glob('*.h*')) + [HERE.parent / 'include' / 'nestfit_amd.h']
+DEPS = sorted((HERE / 'csrc').glob('*.h*')) + [HERE / 'csrc' / 'nfa_ring.cpp'] + [HERE.parent / 'include' / 'nestfit_amd.h']
 OUT = HERE / 'lib' / 'libnestfit_amd.so'
 # the same engine with the unit-test hooks and the "ablate" timing option compiled in: tests and
 # measurement scripts only (include/nestfit_amd_test.h); the product library has neither
 OUT_TEST = HERE / 'lib' / 'libnestfit_amd_test.so'
 TEST_FLAGS = ['-DNFA_TEST_HOOKS', '-DNFA_ABLATE']
+# the shared-memory ring alone (csrc/nfa_ring.h), host code without HIP: what a sampler process loads
+OUT_RING = HERE / 'lib' / 'libnestfit_amd_ring.so'
+SRC_RING = HERE / 'csrc' / 'nfa_ring.cpp'
 
 FLAGS = [
     '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared',
@@ -50,10 +53,16 @@ def build(force=False, verbose=False, extra=(), test_lib=True):
         jobs.append((OUT, _compile(OUT, extra, verbose)))
     if test_lib and (force or needs_build(OUT_TEST)):
         jobs.append((OUT_TEST, _compile(OUT_TEST, list(extra) + TEST_FLAGS, verbose)))
+    if force or needs_build(OUT_RING):
+        cxx = os.environ.get('CXX', 'g++')
+        cmd = [cxx, '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', '-o', str(OUT_RING), str(SRC_RING), '-lrt', '-pthread']
+        if verbose:
+            print(' '.join(cmd))
+        jobs.append((OUT_RING, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for out, proc in jobs:
         text, _ = proc.communicate()
         if proc.returncode != 0:
-            raise RuntimeError(f'hipcc failed for {out.name}:\n' + text)
+            raise RuntimeError(f'compiling {out.name} failed:\n' + text)
         if verbose and text:
             print(text)
     return OUT

@@ -1,0 +1,345 @@
+// nfa_ring.h -- cross-process transport for the callback broker, host code only.
+//
+// The reference fits a cube with one process per stripe (nestfit/main.py:516-523), each with its own
+// MultiNest instance (Fortran, global state: one per process) that hands LogLike one point at a time
+// (nestfit/core/cmultinest.pxd:27-28).  Processes that each own a runner time-slice the GPU (two of
+// them overlap, no more).  Here the sampler processes do not touch the GPU at all: each one owns a slot
+// of a POSIX shared-memory ring, writes its point there and sleeps on the slot; ONE process serves the
+// ring, gathers the posted slots into a batch for the engine and writes the results back.
+//
+//   /dev/shm/<name>:  Header | Slot 0 | Slot 1 | ...      (slot stride: 64-byte multiple)
+//   slot state: FREE -> (client) POSTED -> (server) DONE -> (client) FREE
+//
+// Waiting is a short spin, then a futex on the word that changes (the slot's state for a client, the
+// header's post counter for the server): no busy process per sampler.  This file is compiled twice:
+// into the engine library (which adds nfa_ring_serve, the loop around nfa_runner_loglike_batch) and,
+// alone, into libnestfit_amd_ring.so -- the only library a sampler process loads (no HIP in it).
+#pragma once
+#include <atomic>
+#include <cerrno>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fcntl.h>
+#include <linux/futex.h>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <signal.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#define NFA_RING_MAGIC   0x4e46524eu       // "NFRN"
+#define NFA_RING_VERSION 1u
+#define NFA_RING_MAXBATCH 128              // what one point-kernel launch takes (nestfit_amd.h)
+
+enum { RING_FREE = 0, RING_POSTED = 1, RING_DONE = 2 };
+
+struct RingHeader {
+    uint32_t magic, version;
+    int32_t  n_slots, ndim;
+    uint64_t slot_stride, total_bytes;
+    int32_t  server_pid, pad0;             // the creator: a ring whose creator is gone is stale
+    std::atomic<uint32_t> stop;            // set by nfa_ring_stop: everybody leaves
+    std::atomic<uint32_t> posts;           // bumped by every post: the word the server sleeps on
+    std::atomic<uint32_t> n_attached;      // clients holding a slot
+    std::atomic<uint32_t> serving;         // a server is inside poll/serve (clients may wait for it)
+    std::atomic<uint64_t> n_batches, n_evals, max_batch_seen;
+    uint8_t  pad[64];
+};
+
+struct RingSlot {
+    std::atomic<uint32_t> state;
+    std::atomic<uint32_t> owner;           // 0 = nobody, else the pid of the client holding the slot
+    int32_t  pix, rc;
+    double   lnl;
+    double   cube[1];                      // ndim doubles
+};
+
+struct nfa_ring {
+    RingHeader *hdr = nullptr;
+    uint8_t    *base = nullptr;
+    size_t      bytes = 0;
+    std::string name;
+    bool        creator = false;
+    int         slot = -1;                 // client: the slot it holds
+    uint32_t    seen_posts = 0;            // server: header post counter at the last scan
+};
+
+#ifndef NFA_RING_STANDALONE
+// inside the engine library fail() and the error codes come from nfa_engine.hip
+#else
+#define NFA_OK 0
+#define NFA_ERR_ARG 1
+#define NFA_ERR_STATE 3
+static thread_local char g_ring_err[256];
+static int fail(int code, const char *msg) { snprintf(g_ring_err, sizeof g_ring_err, "%s", msg); return code; }
+extern "C" const char *nfa_ring_last_error(void) { return g_ring_err; }
+#endif
+
+static inline RingSlot *ring_slot(const nfa_ring *r, int k) {
+    return (RingSlot *)(r->base + sizeof(RingHeader) + (size_t)k * r->hdr->slot_stride);
+}
+
+static inline long ring_futex(std::atomic<uint32_t> *word, int op, uint32_t val, const timespec *ts) {
+    return syscall(SYS_futex, (uint32_t *)word, op, val, ts, nullptr, 0);      // shared (not _PRIVATE): across processes
+}
+
+static inline int64_t ring_now_us() {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (int64_t)t.tv_sec * 1000000 + t.tv_nsec / 1000;
+}
+
+static inline void ring_pause() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
+static std::string ring_shm_name(const char *name) {
+    std::string s = name && name[0] == '/' ? name : std::string("/") + (name ? name : "");
+    return s;
+}
+
+extern "C" {
+
+// Server side: create the ring `name` (a POSIX shared-memory object) with n_slots slots of ndim doubles.
+int nfa_ring_create(nfa_ring **out, const char *name, int n_slots, int ndim) {
+    if (!out || !name || !name[0]) return fail(NFA_ERR_ARG, "null argument");
+    if (n_slots < 1 || n_slots > 4096 || ndim < 1 || ndim > 4096) return fail(NFA_ERR_ARG, "bad ring shape");
+    const std::string shm = ring_shm_name(name);
+    const size_t stride = (offsetof(RingSlot, cube) + sizeof(double) * (size_t)ndim + 63) / 64 * 64;
+    const size_t bytes = sizeof(RingHeader) + stride * (size_t)n_slots;
+    shm_unlink(shm.c_str());                                   // a stale ring of a crashed server
+    const int fd = shm_open(shm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return fail(NFA_ERR_STATE, "shm_open failed");
+    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(shm.c_str()); return fail(NFA_ERR_STATE, "ftruncate failed"); }
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { shm_unlink(shm.c_str()); return fail(NFA_ERR_STATE, "mmap failed"); }
+    memset(p, 0, bytes);
+    nfa_ring *r = new nfa_ring();
+    r->base = (uint8_t *)p; r->hdr = (RingHeader *)p; r->bytes = bytes; r->name = shm; r->creator = true;
+    r->hdr->version = NFA_RING_VERSION; r->hdr->n_slots = n_slots; r->hdr->ndim = ndim;
+    r->hdr->slot_stride = stride; r->hdr->total_bytes = bytes; r->hdr->server_pid = (int32_t)getpid();
+    std::atomic_thread_fence(std::memory_order_release);
+    r->hdr->magic = NFA_RING_MAGIC;                            // last: an attaching client waits for it
+    *out = r;
+    return NFA_OK;
+}
+
+// Client side: map the ring `name` and take a free slot (wait_ms: how long to wait for the ring to appear).
+int nfa_ring_attach(nfa_ring **out, const char *name, int wait_ms) {
+    if (!out || !name || !name[0]) return fail(NFA_ERR_ARG, "null argument");
+    const std::string shm = ring_shm_name(name);
+    const int64_t t_end = ring_now_us() + (int64_t)wait_ms * 1000;
+    struct stat st;
+    void *p = nullptr;
+    RingHeader *h = nullptr;
+    // until the deadline: no object yet, an object still being set up, or one left behind by a server that
+    // died (its successor unlinks and recreates it) all mean "look again in a millisecond"
+    for (const char *why = "no such ring";; usleep(1000)) {
+        if (p) { munmap(p, (size_t)st.st_size); p = nullptr; }
+        if (ring_now_us() >= t_end && why) return fail(NFA_ERR_STATE, why);
+        const int fd = shm_open(shm.c_str(), O_RDWR, 0600);
+        if (fd < 0) { why = "no such ring"; continue; }
+        if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(RingHeader)) { close(fd); why = "ring never initialised"; continue; }
+        p = mmap(nullptr, (size_t)st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) { p = nullptr; return fail(NFA_ERR_STATE, "mmap failed"); }
+        h = (RingHeader *)p;
+        if (*(volatile uint32_t *)&h->magic != NFA_RING_MAGIC) { why = "ring never initialised"; continue; }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (kill((pid_t)h->server_pid, 0) != 0 && errno == ESRCH) { why = "stale ring (its server is gone)"; continue; }
+        break;
+    }
+    if (h->version != NFA_RING_VERSION || h->total_bytes != (uint64_t)st.st_size) {
+        munmap(p, (size_t)st.st_size);
+        return fail(NFA_ERR_STATE, "ring layout mismatch");
+    }
+    nfa_ring *r = new nfa_ring();
+    r->base = (uint8_t *)p; r->hdr = h; r->bytes = (size_t)st.st_size; r->name = shm;
+    const uint32_t me = (uint32_t)getpid();
+    for (int k = 0; k < h->n_slots && r->slot < 0; ++k) {
+        uint32_t nobody = 0;
+        if (ring_slot(r, k)->owner.compare_exchange_strong(nobody, me, std::memory_order_acq_rel)) r->slot = k;
+    }
+    if (r->slot < 0) { munmap(p, r->bytes); delete r; return fail(NFA_ERR_STATE, "no free slot in the ring"); }
+    ring_slot(r, r->slot)->state.store(RING_FREE, std::memory_order_release);
+    h->n_attached.fetch_add(1, std::memory_order_acq_rel);
+    ring_futex(&h->posts, FUTEX_WAKE, 1, nullptr);             // a waiting server re-evaluates its target
+    *out = r;
+    return NFA_OK;
+}
+
+int nfa_ring_ndim(const nfa_ring *r) { return r && r->hdr ? r->hdr->ndim : -1; }
+int nfa_ring_slot(const nfa_ring *r) { return r ? r->slot : -1; }
+
+// Client: give the slot back and unmap.  Server (creator): unmap and remove the shared-memory object.
+int nfa_ring_close(nfa_ring *r) {
+    if (!r) return NFA_OK;
+    if (r->slot >= 0) {
+        ring_slot(r, r->slot)->owner.store(0, std::memory_order_release);
+        r->hdr->n_attached.fetch_sub(1, std::memory_order_acq_rel);
+        ring_futex(&r->hdr->posts, FUTEX_WAKE, 1, nullptr);
+    }
+    munmap(r->base, r->bytes);
+    if (r->creator) shm_unlink(r->name.c_str());
+    delete r;
+    return NFA_OK;
+}
+
+// Everybody leaves: blocked clients return NFA_ERR_STATE, a serving loop returns.
+int nfa_ring_stop(nfa_ring *r) {
+    if (!r) return fail(NFA_ERR_ARG, "null argument");
+    r->hdr->stop.store(1, std::memory_order_release);
+    r->hdr->posts.fetch_add(1, std::memory_order_acq_rel);
+    ring_futex(&r->hdr->posts, FUTEX_WAKE, INT32_MAX, nullptr);
+    for (int k = 0; k < r->hdr->n_slots; ++k) ring_futex(&ring_slot(r, k)->state, FUTEX_WAKE, INT32_MAX, nullptr);
+    return NFA_OK;
+}
+
+// Client: blocking LogLike through the ring.  `cube` (ndim doubles, unit cube) is overwritten with the
+// physical parameters like AmmoniaRunner.c_loglikelihood (ammonia.pyx:423-432); pix < 0 = the runner's
+// single pixel.
+int nfa_ring_loglike(nfa_ring *r, int32_t pix, double *cube, double *lnew) {
+    if (!r || !cube || !lnew || r->slot < 0) return fail(NFA_ERR_ARG, "not an attached ring client");
+    RingHeader *h = r->hdr;
+    RingSlot *s = ring_slot(r, r->slot);
+    if (h->stop.load(std::memory_order_acquire)) return fail(NFA_ERR_STATE, "ring stopped");
+    memcpy(s->cube, cube, sizeof(double) * (size_t)h->ndim);
+    s->pix = pix;
+    s->state.store(RING_POSTED, std::memory_order_release);
+    h->posts.fetch_add(1, std::memory_order_acq_rel);
+    ring_futex(&h->posts, FUTEX_WAKE, 1, nullptr);
+    for (int spin = 0;; ++spin) {
+        if (s->state.load(std::memory_order_acquire) == RING_DONE) break;
+        if (h->stop.load(std::memory_order_acquire)) return fail(NFA_ERR_STATE, "ring stopped");
+        if (spin < 4000) { ring_pause(); continue; }           // a launch takes tens of microseconds: spin first
+        const timespec ts = {0, 2000000};                      // then sleep on the slot (2 ms: re-check `stop`)
+        ring_futex(&s->state, FUTEX_WAIT, RING_POSTED, &ts);
+    }
+    const int rc = s->rc;
+    if (rc == NFA_OK) memcpy(cube, s->cube, sizeof(double) * (size_t)h->ndim);
+    *lnew = rc == NFA_OK ? s->lnl : NAN;
+    s->state.store(RING_FREE, std::memory_order_release);
+    return rc == NFA_OK ? NFA_OK : fail(rc, "the served batch failed");
+}
+
+// MultiNest's LogLike signature (cmultinest.pxd:27-28); context = nfa_ring_client*.  No error channel: NaN.
+#ifdef NFA_RING_STANDALONE
+typedef struct { nfa_ring *ring; int32_t pix; } nfa_ring_client;       // the engine build takes it from nestfit_amd.h
+#endif
+void nfa_ring_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx) {
+    (void)npars;
+    nfa_ring_client *c = (nfa_ring_client *)ctx;
+    if (!c || !c->ring || !Cube || !lnew || !ndim || *ndim != c->ring->hdr->ndim) {
+        if (lnew) *lnew = NAN;
+        return;
+    }
+    if (nfa_ring_loglike(c->ring, c->pix, Cube, lnew) != NFA_OK) *lnew = NAN;
+}
+
+// Server: gather posted slots.  Returns as soon as every attached client (at most max_batch) has a point
+// posted, or -- once at least one is posted -- after max_wait_us; with nothing posted it sleeps until a post,
+// `stop`, or idle_ms have passed.  slots[k] / pix[k] / U[k * ndim ...] describe request k; *n = how many
+// (0: nothing arrived in idle_ms, or the ring was stopped: *stopped says which).
+int nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, int32_t *slots, int32_t *pix,
+                  double *U, int *n, int *stopped) {
+    if (!r || !slots || !pix || !U || !n) return fail(NFA_ERR_ARG, "null argument");
+    RingHeader *h = r->hdr;
+    if (max_batch < 1) max_batch = 1;
+    const int64_t t_idle = ring_now_us() + (int64_t)idle_ms * 1000;
+    int64_t t_first = -1;
+    *n = 0;
+    if (stopped) *stopped = 0;
+    h->serving.store(1, std::memory_order_release);
+    for (int spin = 0;; ++spin) {
+        if (h->stop.load(std::memory_order_acquire)) { if (stopped) *stopped = 1; return NFA_OK; }
+        const uint32_t posts = h->posts.load(std::memory_order_acquire);
+        int count = 0;
+        for (int k = 0; k < h->n_slots && count < max_batch; ++k)
+            if (ring_slot(r, k)->state.load(std::memory_order_acquire) == RING_POSTED) slots[count++] = k;
+        const int64_t now = ring_now_us();
+        if (count > 0) {
+            if (t_first < 0) t_first = now;
+            const int attached = (int)h->n_attached.load(std::memory_order_acquire);
+            const int target = attached > 0 ? (attached < max_batch ? attached : max_batch) : max_batch;
+            if (count >= target || now - t_first >= max_wait_us) {
+                for (int k = 0; k < count; ++k) {
+                    const RingSlot *s = ring_slot(r, slots[k]);
+                    memcpy(U + (size_t)k * h->ndim, s->cube, sizeof(double) * (size_t)h->ndim);
+                    pix[k] = s->pix;
+                }
+                *n = count;
+                return NFA_OK;
+            }
+            ring_pause();                                      // company is microseconds away: spin
+            continue;
+        }
+        if (now >= t_idle) return NFA_OK;
+        if (spin < 2000) { ring_pause(); continue; }
+        const timespec ts = {0, 1000000};
+        ring_futex(&h->posts, FUTEX_WAIT, posts, &ts);         // sleeps only if nothing was posted since the scan
+    }
+}
+
+// Server: results of the requests nfa_ring_poll handed out (rc != 0: the batch failed, the clients get NaN).
+int nfa_ring_complete(nfa_ring *r, int n, const int32_t *slots, const double *U, const double *lnL, int rc) {
+    if (!r || n < 0 || (n > 0 && (!slots || !U || !lnL))) return fail(NFA_ERR_ARG, "null argument");
+    RingHeader *h = r->hdr;
+    for (int k = 0; k < n; ++k) {
+        RingSlot *s = ring_slot(r, slots[k]);
+        if (rc == NFA_OK) memcpy(s->cube, U + (size_t)k * h->ndim, sizeof(double) * (size_t)h->ndim);
+        s->lnl = rc == NFA_OK ? lnL[k] : NAN;
+        s->rc = rc;
+        s->state.store(RING_DONE, std::memory_order_release);
+        ring_futex(&s->state, FUTEX_WAKE, 1, nullptr);
+    }
+    if (n > 0) {
+        h->n_batches.fetch_add(1, std::memory_order_relaxed);
+        h->n_evals.fetch_add((uint64_t)n, std::memory_order_relaxed);
+        if ((uint64_t)n > h->max_batch_seen.load(std::memory_order_relaxed)) h->max_batch_seen.store((uint64_t)n, std::memory_order_relaxed);
+    }
+    return NFA_OK;
+}
+
+// out[0] batches served, out[1] evaluations served, out[2] largest batch, out[3] clients attached
+int nfa_ring_stats(nfa_ring *r, int64_t *out) {
+    if (!r || !out) return fail(NFA_ERR_ARG, "null argument");
+    out[0] = (int64_t)r->hdr->n_batches.load(); out[1] = (int64_t)r->hdr->n_evals.load();
+    out[2] = (int64_t)r->hdr->max_batch_seen.load(); out[3] = (int64_t)r->hdr->n_attached.load();
+    return NFA_OK;
+}
+
+#ifndef NFA_RING_STANDALONE
+// Server loop of the engine: poll -> nfa_runner_loglike_batch (up to 128 points: one point-kernel launch)
+// -> complete, until the ring is stopped, max_batches (> 0) have been served or nothing has arrived for
+// idle_ms.  The runner must not be used by anyone else meanwhile.
+int nfa_ring_serve(nfa_ring *r, nfa_runner *run, int64_t max_wait_us, int64_t max_batches, int idle_ms) {
+    if (!r || !run) return fail(NFA_ERR_ARG, "null argument");
+    if (run->ndim != r->hdr->ndim) return fail(NFA_ERR_ARG, "ring and runner disagree on ndim");
+    const int ndim = run->ndim;
+    std::vector<int32_t> slots(NFA_RING_MAXBATCH), pix(NFA_RING_MAXBATCH);
+    std::vector<double> U((size_t)NFA_RING_MAXBATCH * ndim), lnL(NFA_RING_MAXBATCH);
+    for (int64_t served = 0; max_batches <= 0 || served < max_batches;) {
+        int n = 0, stopped = 0;
+        int rc = nfa_ring_poll(r, NFA_RING_MAXBATCH, max_wait_us, idle_ms, slots.data(), pix.data(), U.data(), &n, &stopped);
+        if (rc != NFA_OK) return rc;
+        if (stopped || n == 0) break;
+        bool any_pix = false;
+        for (int k = 0; k < n; ++k) { any_pix |= pix[k] >= 0; if (pix[k] < 0) pix[k] = 0; }
+        rc = nfa_runner_loglike_batch(run, any_pix ? pix.data() : nullptr, U.data(), lnL.data(), n);
+        nfa_ring_complete(r, n, slots.data(), U.data(), lnL.data(), rc);
+        if (rc != NFA_OK) return rc;
+        ++served;
+    }
+    r->hdr->serving.store(0, std::memory_order_release);
+    return NFA_OK;
+}
+#endif
+
+}  // extern "C"

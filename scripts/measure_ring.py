@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Sampler processes behind the shared-memory ring (nestfit_amd/ring.py, csrc/nfa_ring.h): N processes
+that never touch the GPU post their LogLike points (one at a time each, like MultiNest:
+nestfit/core/cmultinest.pxd:27-28, one process per stripe: nestfit/main.py:516-523), ONE process with the
+runner serves them, every round of posted points one point-kernel launch.  Prints the aggregate rate, the
+time a client waits per call and the mean batch; beside it profiles/r02/multiproc_points.txt has the same
+processes with a runner each (no ring)."""
+import multiprocessing as mp
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def client(name, rank, n_calls, start, out):
+    from nestfit_amd.ring import RingClient
+    c = RingClient(name, wait_ms=60000)
+    rng = np.random.default_rng(rank)
+    U = rng.uniform(size=(n_calls + 200, c.ndim))
+    for k in range(200):
+        c.loglikelihood(U[k])
+    start.wait(120)
+    t0 = time.perf_counter()
+    for k in range(200, n_calls + 200):
+        c.loglikelihood(U[k])
+    t1 = time.perf_counter()
+    c.close()
+    out.put((rank, t0, t1))
+
+
+def main():
+    import nestfit_amd as na
+    from nestfit_amd.ring import RingServer
+    from nestfit_amd.synth import TRUTH_2COMP, freq_axis
+    rng = np.random.default_rng(0)
+    args = []
+    for t in (1, 2):
+        x = freq_axis(t, 1024)
+        s = na.AmmoniaSpectrum(x, np.zeros(1024), 0.2, t)
+        na.amm_predict(s, TRUTH_2COMP)
+        args.append([x, s.get_spec() + rng.normal(0, 0.2, 1024), 0.2, t])
+    run = na.AmmoniaRunner.from_data(args, na.get_irdc_priors(size=500, vsys=0.0), ncomp=2)
+    ctx = mp.get_context('spawn')
+    counts = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 14]
+    for n_proc in counts:
+        n_calls = 20000
+        name = f'nfa_measure_ring_{n_proc}'
+        with RingServer(name, n_slots=n_proc, runner=run) as server:
+            t = threading.Thread(target=server.serve, kwargs=dict(max_wait_us=30, idle_ms=120000))
+            t.start()
+            start, out = ctx.Barrier(n_proc), ctx.Queue()
+            procs = [ctx.Process(target=client, args=(name, k, n_calls, start, out)) for k in range(n_proc)]
+            for p in procs:
+                p.start()
+            res = [out.get(timeout=600) for _ in procs]
+            for p in procs:
+                p.join()
+            server.stop()
+            t.join()
+            st = server.stats
+        wall = max(r[2] for r in res) - min(r[1] for r in res)
+        per_call = np.mean([r[2] - r[1] for r in res]) / n_calls
+        print(f'{n_proc:2d} processes: {n_proc * n_calls / wall / 1e3:7.1f} k evals/s in all, {per_call * 1e6:6.1f} us per call '
+              f'in each, {st["evals"] / st["batches"]:5.2f} points per launch (largest {st["largest_batch"]})', flush=True)
+
+
+if __name__ == '__main__':
+    main()

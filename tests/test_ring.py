@@ -1,0 +1,185 @@
+"""The shared-memory ring between sampler processes and the one serving process (csrc/nfa_ring.h,
+nestfit_amd/ring.py; reference pattern: one process per stripe, nestfit/main.py:516-523, each calling
+LogLike point by point, cmultinest.pxd:27-28).  CPU: the transport with a numpy evaluator between poll and
+complete, real processes on the client side.  GPU: the engine's native serving loop against direct calls."""
+import ctypes as C
+import multiprocessing as mp
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from nestfit_amd import _ffi
+from nestfit_amd.ring import RingClient, RingServer, ring_library
+
+NDIM = 5
+
+
+def _evaluate(pix, U):
+    """Stand-in for the engine: theta and lnL as exact functions of the request."""
+    theta = 2.0 * U + pix[:, None]
+    return theta, -np.sum(U * U, axis=1) + pix
+
+
+def _client(name, rank, n_points, out, start):
+    # a sampler process: only the ring library, no engine, no GPU
+    client = RingClient(name, wait_ms=20000)
+    start.wait(60)                                             # all processes attached: they run side by side
+    rng = np.random.default_rng(100 + rank)
+    rows = []
+    for i in range(n_points):
+        u = rng.random(NDIM)
+        theta = u.copy()
+        lnl = client.loglikelihood(theta, pix=rank if i % 2 else -1)
+        rows.append((u, theta, lnl, rank if i % 2 else -1))
+    client.close()
+    out.put((rank, rows))
+
+
+def _serve_with(server, evaluate, n_total):
+    served = 0
+    while served < n_total:
+        slots, pix, U, stopped = server.poll(max_wait_us=5000, idle_ms=20000)
+        assert not stopped and slots.size > 0, 'clients went silent'
+        theta, lnl = evaluate(pix.copy(), U.copy())
+        server.complete(slots, theta, lnl)
+        served += slots.size
+    return served
+
+
+def test_ring_between_processes():
+    name = f'nfa_test_ring_{os.getpid()}'
+    n_clients, n_points = 3, 200
+    ctx = mp.get_context('spawn')
+    out, start = ctx.Queue(), ctx.Barrier(n_clients)
+    with RingServer(name, n_slots=4, ndim=NDIM) as server:
+        procs = [ctx.Process(target=_client, args=(name, r, n_points, out, start)) for r in range(n_clients)]
+        for p in procs:
+            p.start()
+        _serve_with(server, _evaluate, n_clients * n_points)
+        got = dict(out.get(timeout=60) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        stats = server.stats
+    assert stats['evals'] == n_clients * n_points and stats['largest_batch'] >= 2 and stats['clients'] == 0
+    assert stats['batches'] < stats['evals']                   # points of different processes shared batches
+    for rank, rows in got.items():
+        for u, theta, lnl, pix in rows:
+            t, l = _evaluate(np.array([pix]), u[None, :])
+            assert np.array_equal(theta, t[0]) and lnl == l[0]
+    assert not os.path.exists(f'/dev/shm/{name}')              # the server's close removes the object
+
+
+def test_ring_callback_signature_stop_and_errors():
+    lib = ring_library()
+    name = f'nfa_test_ring_cb_{os.getpid()}'
+    with pytest.raises(_ffi.EngineError, match='no such ring'):
+        RingClient(name + '_absent', wait_ms=30)
+    server = RingServer(name, n_slots=1, ndim=NDIM)
+    client = RingClient(name)
+    assert client.ndim == NDIM and client.slot == 0
+    with pytest.raises(_ffi.EngineError, match='no free slot'):
+        RingClient(name, wait_ms=30)
+    with pytest.raises(ValueError, match='Invalid shape'):
+        client.loglikelihood(np.zeros(NDIM + 1))
+
+    def serve_two():
+        for k in range(2):
+            slots, pix, U, _stopped = server.poll(idle_ms=20000)
+            theta, lnl = _evaluate(pix.copy(), U.copy())
+            server.complete(slots, theta, lnl, rc=0 if k == 0 else 3)
+    t = threading.Thread(target=serve_two)
+    t.start()
+    # MultiNest's LogLike: void (*)(double *Cube, int *ndim, int *npars, double *lnew, void *context)
+    proto = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p)
+    fn, ctx = client.callback(pix=7)
+    loglike = C.cast(fn, proto)
+    cube = np.linspace(0.1, 0.5, NDIM)
+    u0 = cube.copy()
+    nd, lnew = C.c_int(NDIM), C.c_double()
+    loglike(cube.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nd), C.byref(nd), C.byref(lnew), C.cast(ctx, C.c_void_p))
+    assert np.array_equal(cube, 2 * u0 + 7) and lnew.value == -np.sum(u0 * u0) + 7
+    # a failed batch: NaN through the callback (no error channel), the cube left alone
+    cube = u0.copy()
+    loglike(cube.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nd), C.byref(nd), C.byref(lnew), C.cast(ctx, C.c_void_p))
+    assert np.isnan(lnew.value) and np.array_equal(cube, u0)
+    t.join()
+    # a wrong ndim never reaches the ring
+    bad = C.c_int(NDIM - 1)
+    loglike(cube.ctypes.data_as(C.POINTER(C.c_double)), C.byref(bad), C.byref(bad), C.byref(lnew), C.cast(ctx, C.c_void_p))
+    assert np.isnan(lnew.value)
+    # a client blocked in a call leaves when the ring is stopped
+    result = {}
+
+    def blocked():
+        try:
+            client.loglikelihood(u0.copy())
+        except _ffi.EngineError as e:
+            result['err'] = str(e)
+    t = threading.Thread(target=blocked)
+    t.start()
+    slots, _, _, stopped = server.poll(idle_ms=20000)         # the point has arrived ...
+    assert slots.size == 1 and not stopped
+    server.stop()                                              # ... and is never answered
+    t.join(timeout=30)
+    assert 'stopped' in result['err']
+    assert server.poll(idle_ms=10)[3] is True
+    client.close()
+    server.close()
+    assert lib.nfa_ring_close(None) == 0
+
+
+@pytest.mark.gpu
+def test_ring_serves_processes_from_the_engine(engine, nfo):
+    """Four sampler processes (no GPU context) against the native serving loop: bitwise what the runner gives
+    directly, several processes' points per launch."""
+    from nestfit_amd.synth import TRUTH_2COMP, freq_axis
+    rng = np.random.default_rng(3)
+    axes = [freq_axis(t, 512) for t in (1, 2)]
+    data = []
+    for t, x in zip((1, 2), axes):
+        s = nfo.AmmoniaSpectrum(x, np.zeros(512), 0.2, t)
+        nfo.amm_predict(s, TRUTH_2COMP)
+        data.append(s.get_spec() + rng.normal(0, 0.2, 512))
+    ut = engine.get_irdc_priors(size=500)
+    runner = engine.AmmoniaRunner.from_data([[x, d, 0.2, t] for x, d, t in zip(axes, data, (1, 2))], ut, ncomp=2)
+    name = f'nfa_test_ring_gpu_{os.getpid()}'
+    n_clients, n_points = 4, 150
+    ctx = mp.get_context('spawn')
+    out, start = ctx.Queue(), ctx.Barrier(n_clients)
+    with RingServer(name, n_slots=n_clients, runner=runner) as server:
+        assert server.ndim == 12
+        procs = [ctx.Process(target=_gpu_client, args=(name, r, n_points, out, start)) for r in range(n_clients)]
+        for p in procs:
+            p.start()
+        t = threading.Thread(target=server.serve, kwargs=dict(max_wait_us=200, idle_ms=60000))
+        t.start()
+        got = dict(out.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        server.stop()
+        t.join(timeout=30)
+        stats = server.stats
+    assert stats['evals'] == n_clients * n_points and stats['largest_batch'] >= 2
+    for rank, rows in got.items():
+        U = np.array([r[0] for r in rows])
+        direct_theta = U.copy()
+        direct = runner.loglikelihood_batch(direct_theta)
+        assert np.array_equal(np.array([r[1] for r in rows]), direct_theta)
+        assert np.array_equal(np.array([r[2] for r in rows]), direct)
+
+
+def _gpu_client(name, rank, n_points, out, start):
+    client = RingClient(name, wait_ms=30000)
+    start.wait(60)
+    rng = np.random.default_rng(200 + rank)
+    rows = []
+    for _ in range(n_points):
+        u = rng.random(client.ndim)
+        theta = u.copy()
+        rows.append((u, theta, client.loglikelihood(theta)))
+    client.close()
+    out.put((rank, rows))
