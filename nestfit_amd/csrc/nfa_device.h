@@ -389,31 +389,50 @@ __device__ __forceinline__ unsigned long long lanes_gt(int a, int b) { return __
 // Below 1e-8 the reference's own evaluation 1 - (1 - q) is quantised in steps of 2^-53 (it
 // even returns exactly 0 below 1.1e-16, which decides the zero pattern of faint channels):
 // those lanes repeat that rounding in fp64, under a wave-uniform branch that is rarely taken.
-__device__ __forceinline__ double one_minus_fastexp_f32(float t) {
+// The two upper ranges are one instruction block in which the range IS the EXEC mask (v_cmpx: the lanes
+// of a range compute and write, the others idle; a range no lane is in is jumped over): a select per
+// range costs a compare and a v_cndmask, four cycles each against 2.3 for an fp32 multiply-add
+// (profiles/r02/ubench_valu.txt).  EXEC must be all ones on entry (every branch around a call is
+// wave-uniform) and is all ones on exit.
+// `live`: the lanes whose tau is not zero (a lane outside every window of its row holds an exact 0: without the
+// mask such a lane alone would send most passes through the sub-1e-8 branch, which leaves its 0 a 0).
+__device__ __forceinline__ double one_minus_fastexp_f32(float t, unsigned long long live = ~0ull) {
     float pc = __builtin_fmaf(t, 1.0f / 6.0f, -0.5f);            // 1 - t/2 + t^2/6: the reference's cubic / t
     pc = __builtin_fmaf(t, pc, 1.0f);
     float wf = t * pc;
-    // Most rows lie in the line wings where every lane is below 2^-5 and the cubic is all there is;
-    // the other two ranges are evaluated only when some lane of the wave needs them.
-    if (__builtin_amdgcn_fcmpf(t, 0.03125f, NF_FCMP_UGE) != 0ull) {
-        asm volatile("" ::: "memory");
-        // (1 - e^-t)/t on [2^-5, 1/4]: degree-4 interpolant at the Chebyshev nodes of the interval
-        // (1.2e-7 relative in fp32 arithmetic, the rounding floor; the degree-6 Taylor sum was no better)
-        float p = 0.00741590978577733f;
-        p = __builtin_fmaf(p, t, -0.04143298789858818f);
-        p = __builtin_fmaf(p, t, 0.16663944721221924f);
-        p = __builtin_fmaf(p, t, -0.4999985992908478f);
-        p = __builtin_fmaf(p, t, 1.0f);
-        wf = (t < 0.03125f) ? wf : t * p;
-        if (__builtin_amdgcn_fcmpf(t, 0.25f, NF_FCMP_UGE) != 0ull) {
-            asm volatile("" ::: "memory");
-            const float w_big = 1.0f - exp_neg_f32(t);
-            wf = (t < 0.25f) ? wf : w_big;
-        }
-    }
+    // Most rows lie in the line wings where every lane is below 2^-5 and the cubic is all there is.
+    float p, q, e, r;
+    asm volatile("v_cmpx_ngt_f32 0x3d000000, %[t]\n\t"                  // lanes at or above 2^-5 (and NaN)
+                 "s_cbranch_execz 1f\n\t"
+                 // (1 - e^-t)/t on [2^-5, 1/4]: degree-4 interpolant at the Chebyshev nodes of the interval
+                 // (1.2e-7 relative in fp32 arithmetic, the rounding floor; the degree-6 Taylor sum was no better)
+                 "v_fmamk_f32 %[p], %[t], 0x3bf30129, %[c3]\n\t"         //   0.00741590978577733 t - 0.04143298789858818
+                 "v_fmaak_f32 %[p], %[p], %[t], 0x3e2aa388\n\t"          //   ... t + 0.16663944721221924
+                 "v_fmaak_f32 %[p], %[p], %[t], 0xbeffffd1\n\t"          //   ... t - 0.4999985992908478
+                 "v_fma_f32 %[p], %[p], %[t], 1.0\n\t"
+                 "v_mul_f32 %[wf], %[t], %[p]\n\t"
+                 "v_cmpx_ngt_f32 0x3e800000, %[t]\n\t"                  // of those, the lanes at or above 1/4
+                 "s_cbranch_execz 1f\n\t"
+                 // 1 - exp(-t) like exp_neg_f32; t capped at 64: from 32 on (and for NaN, which v_min drops)
+                 // 2^yh is below 2^-46 and the difference is exactly 1
+                 "v_min_f32 %[p], 0x42800000, %[t]\n\t"
+                 "v_mul_f32 %[e], 0xbfb8aa3b, %[p]\n\t"                  // yh = -x log2(e)_hi
+                 // (the result of a transcendental instruction must not be read by the next vector instruction on
+                 // gfx940+: the compiler pads its own code, nobody pads this block -- two instructions lie between)
+                 "v_exp_f32 %[r], %[e]\n\t"
+                 "v_fma_f32 %[q], %[p], %[l2e], -%[e]\n\t"               // yl = (-x log2(e)_hi - yh)
+                 "v_fmac_f32 %[q], 0xb2a57060, %[p]\n\t"                 //      - x log2(e)_lo
+                 "v_mul_f32 %[p], 0x3f317218, %[r]\n\t"                  // 2^yh ln 2
+                 "v_fmac_f32 %[r], %[p], %[q]\n\t"                       // 2^yh (1 + yl ln 2)
+                 "v_sub_f32 %[wf], 1.0, %[r]\n\t"
+                 "1:\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [wf] "+v"(wf), [p] "=&v"(p), [q] "=&v"(q), [e] "=&v"(e), [r] "=&v"(r)
+                 : [t] "v"(t), [c3] "v"(-0.04143298789858818f), [l2e] "s"(-1.44269502162933349609375f)
+                 : "vcc");
     double w = (double)wf;
     const bool tiny = t < 1e-8f;
-    if (__builtin_amdgcn_fcmpf(t, 1e-8f, NF_FCMP_OLT) != 0ull) {
+    if ((__builtin_amdgcn_fcmpf(t, 1e-8f, NF_FCMP_OLT) & live) != 0ull) {
         asm volatile("" ::: "memory");            // keep the rare path a branch (no if-conversion)
         const double r1 = 1.0 - w;                 // (a tiny lane is below 2^-5: its w is the cubic t * pc)
         w = tiny ? 1.0 - r1 : w;
@@ -567,6 +586,11 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // windows [lo, hi) of the lines of each component, lane = line (an empty window is [0, 0):
     // it fails `hi > r0` for every row), and the component's constants of the Tb pass
     int wlo[NC], whi[NC];
+    // fast mode, two components (at most 26 lines each): both components' windows in one register pair, lanes
+    // 0..31 the first component's lines, lanes 32..63 the second's -- two compares per row instead of four
+    // (a compare costs as much as an fp64 operation, profiles/r02/ubench_valu.txt)
+        constexpr bool PACK2 = MODE == 2 && !WIDE && NCOMP == 2;
+    int wlo2 = 0, whi2 = 0;
     double ck_kind[NC], ck_a0x[NC], ck_b0x[NC];
     // the LDS address of each component's line table as a per-lane value, formed once: a line's record address
     // is then ONE vector shift-add of the scalar line index (left to itself the compiler forms it with two
@@ -577,15 +601,25 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const LineRec *q = w_line + c * G.nhf_max + (lane < G.nhf_max ? lane : 0);
-            const int lo = q->lo, len = q->len;
-            wlo[c] = lane < G.nhf_max ? lo : 0;
-            whi[c] = lane < G.nhf_max ? lo + len : 0;
-            if (ablate & 8) { wlo[c] = 0; whi[c] = 0; }
+            if (!PACK2) {
+                const int lo = q->lo, len = q->len;
+                wlo[c] = lane < G.nhf_max ? lo : 0;
+                whi[c] = lane < G.nhf_max ? lo + len : 0;
+                if (ablate & 8) { wlo[c] = 0; whi[c] = 0; }
+            }
             lbase_c[c] = (unsigned)(uintptr_t)(lds_char_p)(w_line + c * G.nhf_max);
             asm volatile("" : "+v"(lbase_c[c]));
             const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
             ck_kind[c] = Dk[dko + DK_KIND]; ck_a0x[c] = Dk[dko + DK_A0X]; ck_b0x[c] = Dk[dko + DK_B0X];
         }
+    }
+    if (PACK2) {
+        const int l = lane & 31;
+        const LineRec *q = w_line + (lane >> 5) * G.nhf_max + (l < G.nhf_max ? l : 0);
+        const int lo = q->lo, len = q->len;
+        wlo2 = l < G.nhf_max ? lo : 0;
+        whi2 = l < G.nhf_max ? lo + len : 0;
+        if (ablate & 8) { wlo2 = 0; whi2 = 0; }
     }
     // --- rows of 64 channels: tau profile, Tb, chi^2 (hyperfine.pyx:93-113, core.pyx:522-530)
     const double *t0s = S.t0 + off, *tbgs = S.tbg + off, *p3s = S.t0tbg + off;
@@ -606,7 +640,12 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
         // lines of each component that touch this row
         unsigned long long hitm[NC];
         bool any = false;
-        if (NCOMP > 0) {
+        if (PACK2) {
+            const unsigned long long hit = lanes_lt(wlo2, r0 + 64) & lanes_gt(whi2, r0);
+            hitm[0] = hit & 0xffffffffull;
+            hitm[NC - 1] = hit >> 32;
+            any = hit != 0ull;
+        } else if (NCOMP > 0) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 hitm[c] = lanes_lt(wlo[c], r0 + 64) & lanes_gt(whi[c], r0);
@@ -670,7 +709,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     }
                 };
                 if (ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); }
-                else if (nhf <= 32) {                                 // every NH3 transition: 32-bit mask arithmetic
+                                else if ((MODE == 2 && !WIDE) || nhf <= 32) {         // every NH3 transition (the fast mode's narrow form holds at most 26 lines: no test): 32-bit mask arithmetic
                     unsigned m = (unsigned)mask;
                     do {
                         const int i = __builtin_ctz(m);
@@ -699,7 +738,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         // y = A0 + B0 T0 and T0 = kappa x:  g = B0x x^2 + A0x x - T0 tbg
                         g = __builtin_fma(b0x, x2, __builtin_fma(a0x, xj, -p3));
                     } else if (kind != 0.0) {
-                        const double T0 = *(const double *)((const char *)t0s + jo), tbg = *(const double *)((const char *)tbgs + jo);
+                        unsigned jr = jo;
+                        asm volatile("" : "+v"(jr));                  // the two addresses are formed here, not in every row's head
+                        const double T0 = *(const double *)((const char *)t0s + jr), tbg = *(const double *)((const char *)tbgs + jr);
                         const bool up = !(T0 < Dk[dko + DK_SPLIT]);
                         const double dT = T0 - Dk[dko + DK_M];
                         const double ya = up ? Dk[dko + DK_A1] : Dk[dko + DK_A0];
@@ -707,11 +748,13 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         const double y = __builtin_fma(__builtin_fma(Dk[dko + DK_Q], dT, yb), dT, ya);
                         g = T0 * (y - tbg);
                     } else {
-                        const double T0 = *(const double *)((const char *)t0s + jo), tbg = *(const double *)((const char *)tbgs + jo);
+                        unsigned jr = jo;
+                        asm volatile("" : "+v"(jr));
+                        const double T0 = *(const double *)((const char *)t0s + jr), tbg = *(const double *)((const char *)tbgs + jr);
                         const double y = nf_iemtex(T0 / Dk[c * 4], g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
                         g = T0 * (y - tbg);
                     }
-                    pred = __builtin_fma(g, one_minus_fastexp_f32((float)tau), pred);
+                    pred = __builtin_fma(g, one_minus_fastexp_f32((float)tau, livem), pred);
                 } else {
                     const double x = T0 / Dk[c * 4];
                     double y;

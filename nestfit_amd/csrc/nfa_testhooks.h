@@ -27,8 +27,11 @@ __global__ void test_fastexp_kernel(const double *x, double *out, long n, const 
 
 // 1 - FastExp(tau) as the fast mode evaluates it
 __global__ void test_one_minus_fastexp_kernel(const double *x, double *out, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = one_minus_fastexp_f32((float)x[i]);
+    // whole waves walk the array (the function sets the EXEC mask itself and wants it full on entry)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ((n + 63) & ~63L); i += (long)gridDim.x * blockDim.x) {
+        const double v = one_minus_fastexp_f32((float)(i < n ? x[i] : 1.0));
+        if (i < n) out[i] = v;
+    }
 }
 
 __global__ void test_iemtex_kernel(const double *x, double *out, long n, const double *g_tabs,
