@@ -70,6 +70,24 @@ def test_fastexp_table_mode_is_bit_identical(engine, nfo):
     np.testing.assert_allclose(got[neg], want[neg], rtol=1e-15)
 
 
+def test_fastexp_golden_set_g1_on_device(engine):
+    """The device against the reference's own outputs (tests/golden/g1_fastexp.npz, recorded from fastexp.c):
+    table mode bit for bit, polynomial mode to 1e-15, fast mode to 2e-7; exact zeros (x >= 32) in all three."""
+    from pathlib import Path
+    g = np.load(Path(__file__).parent / 'golden' / 'g1_fastexp.npz')
+    x, want = g['x'].astype(np.float64), g['y']
+    pos = ~(x < 0) | np.signbit(x) & (x == 0)     # FastExp(x < 0) = libm exp(|x|): device exp() vs glibc
+    got = _test_fastexp(engine, x, 'table')
+    assert np.array_equal(got[pos].view(np.uint64), want[pos].view(np.uint64))
+    np.testing.assert_allclose(got[~pos], want[~pos], rtol=1e-15)
+    for mode, tol in (('poly', 1e-15), ('fast', 2e-7)):
+        got = _test_fastexp(engine, x[pos], mode)
+        w = want[pos]
+        assert np.array_equal(got == 0, w == 0)
+        ok = w != 0
+        assert np.max(np.abs(got[ok] - w[ok]) / w[ok]) < tol
+
+
 def test_fastexp_poly_mode(engine, nfo):
     x = _fastexp_inputs()
     got = _test_fastexp(engine, x, 'poly')

@@ -36,6 +36,20 @@ def test_fastexp_matches_reference_source_bit_for_bit(nfo):
     assert np.array_equal(mine.view(np.uint64), theirs.view(np.uint64))
 
 
+def test_fastexp_golden_set_g1(nfo):
+    """4096 FastExp values recorded from the reference's own fastexp.c
+    (tests/golden/make_g1_fastexp.py); needs no reference tree, so it also pins the oracle on the GPU box."""
+    from pathlib import Path
+    g = np.load(Path(__file__).parent / 'golden' / 'g1_fastexp.npz')
+    x, y = g['x'], g['y']
+    assert x.dtype == np.float32 and x.size == 4096 and (y == 0).sum() > 100 and (x < 2.0**-5).sum() > 10
+    assert np.array_equal(nfo.fastexp(x).view(np.uint64), y.view(np.uint64))
+    ref = nfo.ref_fastexp_lib()
+    if ref is not None:                           # where the reference is present the fixture is re-derived
+        again = np.array([ref.FastExp(C.c_float(float(v))) for v in x])
+        assert np.array_equal(again.view(np.uint64), y.view(np.uint64))
+
+
 def test_fastexp_index_fields_match_reference_layout(nfo):
     # x = (128+j0) 2^(l-12) + j1 2^(l-20) + j2 2^(l-28)  (fastexp.c:239-283)
     rng = np.random.default_rng(2)
