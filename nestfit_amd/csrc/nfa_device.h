@@ -138,6 +138,7 @@ struct LnlGeom {
     int nhf_max;       // lines per component slot in the LDS line table
     int wave_doubles;  // LDS doubles per wave
     unsigned inv_nspec; // floor(2^32 / nspec) + 1: unit / nspec = mulhi(unit, inv_nspec) for unit < 2^28; 0: nspec == 1
+    unsigned inv_nhf;   // floor(2^32 / nhf_max) + 1: p / nhf_max = mulhi(p, inv_nhf) for the few hundred (component, line) slots; 0: nhf_max == 1
     int split;          // waves that share one (item, spectrum) unit (1, 2, 4), each taking LNL_PARTS / split row parts
     int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 4 skip rows, 8 skip line set-up
 };
@@ -523,10 +524,13 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const unsigned units = (unsigned)B * (unsigned)nspec;
     const unsigned rot = __builtin_amdgcn_readfirstlane((block_id * 0x9E3779B1u) >> 28);
     const unsigned wsel0 = (unsigned)wave + rot;
-    const unsigned wsel = waves == 4 ? (wsel0 & 3u) : wsel0 % (unsigned)waves;
-    const unsigned upw = (unsigned)(waves / split);                 // units per workgroup
-    const unsigned ulocal = split == 1 ? wsel : wsel / (unsigned)split;
-    const int rpart = split == 1 ? 0 : (int)(wsel - ulocal * (unsigned)split);
+    // (no integer division in here: the compiler builds one from two dozen vector instructions, and a wave
+    // of the metric shape is only ~2200 long; split is 1, 2 or 4, the waves of a workgroup mostly a power of two)
+    const unsigned wsel = (waves & (waves - 1)) == 0 ? (wsel0 & (unsigned)(waves - 1)) : wsel0 % (unsigned)waves;
+    const int split_log2 = split >> 1;                              // 1, 2, 4 -> 0, 1, 2
+    const unsigned upw = (unsigned)waves >> split_log2;             // units per workgroup
+    const unsigned ulocal = wsel >> split_log2;
+    const int rpart = (int)(wsel & (unsigned)(split - 1));
     const unsigned unit = block_id * upw + ulocal;
     LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)ulocal * G.wave_doubles);
     // split > 1: the parts' per-lane sums meet here, [unit of the workgroup][part][lane]
@@ -553,7 +557,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const k_dbl_p Dk = (k_dbl_p)(D + b * drec);                    // the item's record: scalar loads
     // --- line constants + windows, lanes = (component, line) pairs (hyperfine.pyx:68-91)
     for (int p = lane; p < ncomp * G.nhf_max && !(ablate & 8) && rpart == 0; p += 64) {
-        const int c = p / G.nhf_max, i = p - c * G.nhf_max;
+        const int c = G.inv_nhf ? (int)__umulhi((unsigned)p, G.inv_nhf) : p, i = p - c * G.nhf_max;     // inv_nhf == 0: one line per component
         LineRec rec;
         rec.nucen = 0.0; rec.idenom = 0.0; rec.htau = 0.0; rec.lo = 0; rec.len = 0;   // slots beyond the last line
         if (i < nhf) {
@@ -629,7 +633,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // line window touches are never read, and a lane outside every window adds pred (...) = 0 to its row's sum
     double acc = 0.0;
     const int n_rows = (ablate & 4) ? 0 : (N + 63) >> 6;
-    const int parts_per_wave = LNL_PARTS / split;
+    const int parts_per_wave = LNL_PARTS >> split_log2;
     double tot = 0.0;
     for (int hp = 0; hp < parts_per_wave; ++hp) {
     const int h = rpart * parts_per_wave + hp;                 // part h = rows h, h + LNL_PARTS, h + 2 LNL_PARTS, ...

@@ -740,6 +740,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     G.ablate = g_eng.ablate;
     G.nhf_max = r->ss->nhf_max;
     G.inv_nspec = S.n_spec == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)S.n_spec) + 1u;
+    G.inv_nhf = G.nhf_max == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)G.nhf_max) + 1u;
     if (B * S.n_spec * 8 >= (1LL << 28)) return fail(NFA_ERR_ARG, "batch too large for one launch");
     // Waves per unit.  A launch with fewer units than a few per wave slot is latency bound: its waves are
     // placed once and every SIMD waits for its own longest; splitting the rows of a unit over 2 or 4 waves
@@ -1020,6 +1021,7 @@ static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, doubl
     G.ablate = 0;
     G.nhf_max = r->ss->nhf_max;
     G.inv_nspec = S.n_spec == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)S.n_spec) + 1u;
+    G.inv_nhf = G.nhf_max == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)G.nhf_max) + 1u;
     G.split = resolve_split(r, S, 1);
     if (G.split > POINT_WAVES) return 0;
     G.wave_doubles = r->ncomp * G.nhf_max * (int)(sizeof(LineRec) / sizeof(double));
