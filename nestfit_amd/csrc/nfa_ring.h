@@ -65,7 +65,6 @@ struct nfa_ring {
     std::string name;
     bool        creator = false;
     int         slot = -1;                 // client: the slot it holds
-    uint32_t    seen_posts = 0;            // server: header post counter at the last scan
 };
 
 #ifndef NFA_RING_STANDALONE
@@ -163,13 +162,22 @@ int nfa_ring_attach(nfa_ring **out, const char *name, int wait_ms) {
     nfa_ring *r = new nfa_ring();
     r->base = (uint8_t *)p; r->hdr = h; r->bytes = (size_t)st.st_size; r->name = shm;
     const uint32_t me = (uint32_t)getpid();
+    bool inherited = false;                        // the slot of a client that died without closing: still counted
     for (int k = 0; k < h->n_slots && r->slot < 0; ++k) {
         uint32_t nobody = 0;
         if (ring_slot(r, k)->owner.compare_exchange_strong(nobody, me, std::memory_order_acq_rel)) r->slot = k;
     }
+    for (int k = 0; k < h->n_slots && r->slot < 0; ++k) {
+        uint32_t owner = ring_slot(r, k)->owner.load(std::memory_order_acquire);
+        if (owner != 0 && owner != me && kill((pid_t)owner, 0) != 0 && errno == ESRCH &&
+            ring_slot(r, k)->owner.compare_exchange_strong(owner, me, std::memory_order_acq_rel)) {
+            r->slot = k;
+            inherited = true;
+        }
+    }
     if (r->slot < 0) { munmap(p, r->bytes); delete r; return fail(NFA_ERR_STATE, "no free slot in the ring"); }
     ring_slot(r, r->slot)->state.store(RING_FREE, std::memory_order_release);
-    h->n_attached.fetch_add(1, std::memory_order_acq_rel);
+    if (!inherited) h->n_attached.fetch_add(1, std::memory_order_acq_rel);
     ring_futex(&h->posts, FUTEX_WAKE, 1, nullptr);             // a waiting server re-evaluates its target
     *out = r;
     return NFA_OK;
@@ -334,7 +342,7 @@ int nfa_ring_serve(nfa_ring *r, nfa_runner *run, int64_t max_wait_us, int64_t ma
         for (int k = 0; k < n; ++k) { any_pix |= pix[k] >= 0; if (pix[k] < 0) pix[k] = 0; }
         rc = nfa_runner_loglike_batch(run, any_pix ? pix.data() : nullptr, U.data(), lnL.data(), n);
         nfa_ring_complete(r, n, slots.data(), U.data(), lnL.data(), rc);
-        if (rc != NFA_OK) return rc;
+        if (rc != NFA_OK) { r->hdr->serving.store(0, std::memory_order_release); return rc; }
         ++served;
     }
     r->hdr->serving.store(0, std::memory_order_release);

@@ -131,6 +131,23 @@ def test_ring_callback_signature_stop_and_errors():
     assert lib.nfa_ring_close(None) == 0
 
 
+def _dies_holding_a_slot(name):
+    RingClient(name, wait_ms=20000)
+    os._exit(0)                                                # no close: the slot stays marked with a dead pid
+
+
+def test_slot_of_a_dead_client_is_inherited():
+    name = f'nfa_test_ring_dead_{os.getpid()}'
+    with RingServer(name, n_slots=1, ndim=NDIM) as server:
+        p = mp.get_context('spawn').Process(target=_dies_holding_a_slot, args=(name,))
+        p.start()
+        p.join(timeout=60)
+        assert p.exitcode == 0 and server.stats['clients'] == 1
+        with RingClient(name, wait_ms=100) as client:          # the only slot: taken over from the dead process
+            assert client.slot == 0 and server.stats['clients'] == 1
+        assert server.stats['clients'] == 0
+
+
 @pytest.mark.gpu
 def test_ring_serves_processes_from_the_engine(engine, nfo):
     """Four sampler processes (no GPU context) against the native serving loop: bitwise what the runner gives
