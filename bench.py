@@ -446,7 +446,7 @@ def main():
             roof['valu'] = {'busy_frac_one_lane': pmc.get('valu_busy_frac'),
                             'valu_instructions_per_eval': pmc['instructions_per_eval'].get('valu'),
                             'salu_instructions_per_eval': pmc['instructions_per_eval'].get('salu'),
-                            'source': 'profiles/r02/pmc_lnl_fast.json (rocprofv3 --pmc passes of bench.py --streams 1 --coalesce 1)'}
+                            'source': 'profiles/r02/pmc_lnl_fast.json (rocprofv3 --pmc passes of the one-lane command, profiles/collect_r02.sh pmc)'}
         except Exception:
             pass
         try:
