@@ -221,6 +221,7 @@ def main():
                     help='the mode `value` is quoted in (all three are timed)')
     ap.add_argument('--modes', default='all', choices=['all', 'one'], help='time all three numerical modes or only --exp-mode')
     ap.add_argument('--wpb', type=int, default=0, help='engine A/B knob: waves per workgroup (0 = default)')
+    ap.add_argument('--wpb-table', type=int, default=0, help='engine A/B knob: waves per workgroup in table mode (0 = chosen per spectra set)')
     ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
     ap.add_argument('--lnl-split', type=int, default=-1, help='engine A/B knob: waves per (item, spectrum) unit (0 = by launch size)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
@@ -254,7 +255,7 @@ def main():
     if args.ablate and 'NFA_ENGINE_LIB' not in os.environ:
         raise SystemExit('--ablate needs the test library: NFA_ENGINE_LIB=nestfit_amd/lib/libnestfit_amd_test.so')
     for key, val in (('wpb', args.wpb), ('streams', args.streams), ('ablate', args.ablate), ('setup_ti', args.setup_ti), ('coalesce', args.coalesce),
-                     ('setup_threads', args.setup_threads)):
+                     ('setup_threads', args.setup_threads), ('wpb_table', args.wpb_table)):
         if val:
             _ffi.set_option(key, val)
     if args.lnl_cap >= 0:
