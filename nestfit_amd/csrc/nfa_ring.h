@@ -8,7 +8,7 @@
 // ring, gathers the posted slots into a batch for the engine and writes the results back.
 //
 //   /dev/shm/<name>:  Header | Slot 0 | Slot 1 | ...      (slot stride: 64-byte multiple)
-//   slot state: FREE -> (client) POSTED -> (server) DONE -> (client) FREE
+//   slot state: FREE -> (client) POSTED -> (a server's poll) CLAIMED -> (its complete) DONE -> (client) FREE
 //
 // Waiting is a short spin, then a futex on the word that changes (the slot's state for a client, the
 // header's post counter for the server): no busy process per sampler.  This file is compiled twice:
@@ -35,7 +35,7 @@
 #define NFA_RING_VERSION 1u
 #define NFA_RING_MAXBATCH 128              // what one point-kernel launch takes (nestfit_amd.h)
 
-enum { RING_FREE = 0, RING_POSTED = 1, RING_DONE = 2 };
+enum { RING_FREE = 0, RING_POSTED = 1, RING_DONE = 2, RING_CLAIMED = 3 };
 
 struct RingHeader {
     uint32_t magic, version;
@@ -45,7 +45,7 @@ struct RingHeader {
     std::atomic<uint32_t> stop;            // set by nfa_ring_stop: everybody leaves
     std::atomic<uint32_t> posts;           // bumped by every post: the word the server sleeps on
     std::atomic<uint32_t> n_attached;      // clients holding a slot
-    std::atomic<uint32_t> serving;         // a server is inside poll/serve (clients may wait for it)
+    std::atomic<uint32_t> n_servers;       // serving loops at work (each with a runner of its own): they share the clients
     std::atomic<uint64_t> n_batches, n_evals, max_batch_seen;
     uint8_t  pad[64];
 };
@@ -222,13 +222,18 @@ int nfa_ring_loglike(nfa_ring *r, int32_t pix, double *cube, double *lnew) {
     s->pix = pix;
     s->state.store(RING_POSTED, std::memory_order_release);
     h->posts.fetch_add(1, std::memory_order_acq_rel);
-    ring_futex(&h->posts, FUTEX_WAKE, 1, nullptr);
+    ring_futex(&h->posts, FUTEX_WAKE, INT32_MAX, nullptr);     // every sleeping server looks
+    // a launch takes tens of microseconds: spin first -- unless there are more sampler processes than cores,
+    // where a spinning process only keeps another one from posting
+    static const long n_cpu = sysconf(_SC_NPROCESSORS_ONLN);
+    const int spin_limit = (long)h->n_attached.load(std::memory_order_relaxed) + 2 <= n_cpu ? 4000 : 50;
     for (int spin = 0;; ++spin) {
-        if (s->state.load(std::memory_order_acquire) == RING_DONE) break;
+        const uint32_t cur = s->state.load(std::memory_order_acquire);
+        if (cur == RING_DONE) break;
         if (h->stop.load(std::memory_order_acquire)) return fail(NFA_ERR_STATE, "ring stopped");
-        if (spin < 4000) { ring_pause(); continue; }           // a launch takes tens of microseconds: spin first
+        if (spin < spin_limit) { ring_pause(); continue; }
         const timespec ts = {0, 2000000};                      // then sleep on the slot (2 ms: re-check `stop`)
-        ring_futex(&s->state, FUTEX_WAIT, RING_POSTED, &ts);
+        ring_futex(&s->state, FUTEX_WAIT, cur, &ts);
     }
     const int rc = s->rc;
     if (rc == NFA_OK) memcpy(cube, s->cube, sizeof(double) * (size_t)h->ndim);
@@ -251,9 +256,10 @@ void nfa_ring_callback(double *Cube, int *ndim, int *npars, double *lnew, void *
     if (nfa_ring_loglike(c->ring, c->pix, Cube, lnew) != NFA_OK) *lnew = NAN;
 }
 
-// Server: gather posted slots.  Returns as soon as every attached client (at most max_batch) has a point
-// posted, or -- once at least one is posted -- after max_wait_us; with nothing posted it sleeps until a post,
-// `stop`, or idle_ms have passed.  slots[k] / pix[k] / U[k * ndim ...] describe request k; *n = how many
+// Server: gather posted slots (each one claimed with a compare-and-swap: several serving loops, each with a
+// runner of its own, may poll one ring).  Returns as soon as this server holds its share of the attached clients'
+// points (all of them for a lone server, at most max_batch), or -- once it holds at least one -- after
+// max_wait_us; with nothing posted it sleeps until a post, `stop`, or idle_ms have passed.  slots[k] / pix[k] / U[k * ndim ...] describe request k; *n = how many
 // (0: nothing arrived in idle_ms, or the ring was stopped: *stopped says which).
 int nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, int32_t *slots, int32_t *pix,
                   double *U, int *n, int *stopped) {
@@ -264,18 +270,24 @@ int nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, 
     int64_t t_first = -1;
     *n = 0;
     if (stopped) *stopped = 0;
-    h->serving.store(1, std::memory_order_release);
+    int count = 0;                                             // slots this call has claimed so far
     for (int spin = 0;; ++spin) {
         if (h->stop.load(std::memory_order_acquire)) { if (stopped) *stopped = 1; return NFA_OK; }
         const uint32_t posts = h->posts.load(std::memory_order_acquire);
-        int count = 0;
-        for (int k = 0; k < h->n_slots && count < max_batch; ++k)
-            if (ring_slot(r, k)->state.load(std::memory_order_acquire) == RING_POSTED) slots[count++] = k;
+        for (int k = 0; k < h->n_slots && count < max_batch; ++k) {
+            uint32_t posted = RING_POSTED;
+            RingSlot *s = ring_slot(r, k);
+            if (s->state.load(std::memory_order_acquire) == RING_POSTED &&
+                s->state.compare_exchange_strong(posted, RING_CLAIMED, std::memory_order_acq_rel))
+                slots[count++] = k;
+        }
         const int64_t now = ring_now_us();
         if (count > 0) {
             if (t_first < 0) t_first = now;
             const int attached = (int)h->n_attached.load(std::memory_order_acquire);
-            const int target = attached > 0 ? (attached < max_batch ? attached : max_batch) : max_batch;
+            const int servers = (int)h->n_servers.load(std::memory_order_acquire);
+            const int share = servers > 1 ? (attached + servers - 1) / servers : attached;
+            const int target = share > 0 ? (share < max_batch ? share : max_batch) : max_batch;
             if (count >= target || now - t_first >= max_wait_us) {
                 for (int k = 0; k < count; ++k) {
                     const RingSlot *s = ring_slot(r, slots[k]);
@@ -331,21 +343,22 @@ int nfa_ring_serve(nfa_ring *r, nfa_runner *run, int64_t max_wait_us, int64_t ma
     if (!r || !run) return fail(NFA_ERR_ARG, "null argument");
     if (run->ndim != r->hdr->ndim) return fail(NFA_ERR_ARG, "ring and runner disagree on ndim");
     const int ndim = run->ndim;
+    r->hdr->n_servers.fetch_add(1, std::memory_order_acq_rel);
     std::vector<int32_t> slots(NFA_RING_MAXBATCH), pix(NFA_RING_MAXBATCH);
     std::vector<double> U((size_t)NFA_RING_MAXBATCH * ndim), lnL(NFA_RING_MAXBATCH);
     for (int64_t served = 0; max_batches <= 0 || served < max_batches;) {
         int n = 0, stopped = 0;
         int rc = nfa_ring_poll(r, NFA_RING_MAXBATCH, max_wait_us, idle_ms, slots.data(), pix.data(), U.data(), &n, &stopped);
-        if (rc != NFA_OK) return rc;
+        if (rc != NFA_OK) { r->hdr->n_servers.fetch_sub(1, std::memory_order_acq_rel); return rc; }
         if (stopped || n == 0) break;
         bool any_pix = false;
         for (int k = 0; k < n; ++k) { any_pix |= pix[k] >= 0; if (pix[k] < 0) pix[k] = 0; }
         rc = nfa_runner_loglike_batch(run, any_pix ? pix.data() : nullptr, U.data(), lnL.data(), n);
         nfa_ring_complete(r, n, slots.data(), U.data(), lnL.data(), rc);
-        if (rc != NFA_OK) { r->hdr->serving.store(0, std::memory_order_release); return rc; }
+        if (rc != NFA_OK) { r->hdr->n_servers.fetch_sub(1, std::memory_order_acq_rel); return rc; }
         ++served;
     }
-    r->hdr->serving.store(0, std::memory_order_release);
+    r->hdr->n_servers.fetch_sub(1, std::memory_order_acq_rel);
     return NFA_OK;
 }
 #endif

@@ -107,13 +107,25 @@ class RingServer:
         self._pix = np.zeros(cap, dtype=np.int32)
         self._U = np.zeros((cap, self.ndim))
 
-    def serve(self, max_wait_us=50, max_batches=0, idle_ms=1000):
+    def serve(self, max_wait_us=50, max_batches=0, idle_ms=1000, runner=None):
         """Serve until `stop`, `max_batches` (> 0) batches, or `idle_ms` without a request.  ctypes releases the
-        GIL for the call: run it in a thread to keep the interpreter free."""
-        if self.runner is None:
+        GIL for the call: run it in a thread to keep the interpreter free.  Several threads may serve one ring,
+        each with a `runner` of its own (same spectra and priors): the loops claim the posted points between
+        them and their launches overlap on the GPU -- more sampler processes than one launch per round feeds."""
+        runner = runner if runner is not None else self.runner
+        if runner is None:
             raise ValueError('serve needs a runner; use poll / complete with your own evaluator')
-        _ffi.check(self._lib.nfa_ring_serve(self.handle, self.runner._run.handle, int(max_wait_us), int(max_batches),
+        _ffi.check(self._lib.nfa_ring_serve(self.handle, runner._run.handle, int(max_wait_us), int(max_batches),
                                             int(idle_ms)))
+
+    def serve_in_threads(self, runners, max_wait_us=50, idle_ms=1000):
+        """One serving thread per runner; returns the started threads (join them after `stop`)."""
+        import threading
+        threads = [threading.Thread(target=self.serve, kwargs=dict(max_wait_us=max_wait_us, idle_ms=idle_ms, runner=r))
+                   for r in runners]
+        for t in threads:
+            t.start()
+        return threads
 
     def poll(self, max_batch=128, max_wait_us=50, idle_ms=1000):
         """(slots, pix, U, stopped) of the requests gathered; U is a view valid until the next poll."""

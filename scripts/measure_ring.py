@@ -34,6 +34,7 @@ def client(name, rank, n_calls, start, out):
 
 
 def main():
+    """measure_ring.py [processes[:serving threads] ...]"""
     import nestfit_amd as na
     from nestfit_amd.ring import RingServer
     from nestfit_amd.synth import TRUTH_2COMP, freq_axis
@@ -44,29 +45,33 @@ def main():
         s = na.AmmoniaSpectrum(x, np.zeros(1024), 0.2, t)
         na.amm_predict(s, TRUTH_2COMP)
         args.append([x, s.get_spec() + rng.normal(0, 0.2, 1024), 0.2, t])
-    run = na.AmmoniaRunner.from_data(args, na.get_irdc_priors(size=500, vsys=0.0), ncomp=2)
+    priors = na.get_irdc_priors(size=500, vsys=0.0)
+    runners = []
     ctx = mp.get_context('spawn')
-    counts = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 14]
-    for n_proc in counts:
-        n_calls = 20000
-        name = f'nfa_measure_ring_{n_proc}'
-        with RingServer(name, n_slots=n_proc, runner=run) as server:
-            t = threading.Thread(target=server.serve, kwargs=dict(max_wait_us=30, idle_ms=120000))
-            t.start()
+    cases = [tuple(int(v) for v in (a + ':1').split(':')[:2]) for a in sys.argv[1:]] or [(1, 1), (2, 1), (4, 1), (8, 1), (14, 1)]
+    for n_proc, n_serv in cases:
+        while len(runners) < n_serv:                   # one runner (its own streams) per serving thread
+            runners.append(na.AmmoniaRunner.from_data(args, priors, ncomp=2))
+        n_calls = 20000 if n_proc <= 16 else 8000
+        name = f'nfa_measure_ring_{n_proc}_{n_serv}'
+        with RingServer(name, n_slots=n_proc, runner=runners[0]) as server:
+            threads = server.serve_in_threads(runners[:n_serv], max_wait_us=30, idle_ms=120000)
             start, out = ctx.Barrier(n_proc), ctx.Queue()
             procs = [ctx.Process(target=client, args=(name, k, n_calls, start, out)) for k in range(n_proc)]
             for p in procs:
                 p.start()
-            res = [out.get(timeout=600) for _ in procs]
+            res = [out.get(timeout=900) for _ in procs]
             for p in procs:
                 p.join()
             server.stop()
-            t.join()
+            for t in threads:
+                t.join()
             st = server.stats
         wall = max(r[2] for r in res) - min(r[1] for r in res)
         per_call = np.mean([r[2] - r[1] for r in res]) / n_calls
-        print(f'{n_proc:2d} processes: {n_proc * n_calls / wall / 1e3:7.1f} k evals/s in all, {per_call * 1e6:6.1f} us per call '
-              f'in each, {st["evals"] / st["batches"]:5.2f} points per launch (largest {st["largest_batch"]})', flush=True)
+        print(f'{n_proc:2d} processes, {n_serv} serving thread(s): {n_proc * n_calls / wall / 1e3:7.1f} k evals/s in all, '
+              f'{per_call * 1e6:6.1f} us per call in each, {st["evals"] / st["batches"]:5.2f} points per launch '
+              f'(largest {st["largest_batch"]})', flush=True)
 
 
 if __name__ == '__main__':

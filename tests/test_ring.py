@@ -131,6 +131,49 @@ def test_ring_callback_signature_stop_and_errors():
     assert lib.nfa_ring_close(None) == 0
 
 
+def test_two_servers_share_one_ring():
+    """Two serving loops on one ring (each would have a runner of its own): every point is claimed by exactly
+    one of them."""
+    name = f'nfa_test_ring_two_{os.getpid()}'
+    n_clients, n_points = 4, 150
+    ctx = mp.get_context('spawn')
+    out, start = ctx.Queue(), ctx.Barrier(n_clients)
+    served = [0, 0]
+    with RingServer(name, n_slots=n_clients, ndim=NDIM) as server:
+        def loop(which):
+            srv = server if which == 0 else other        # the second loop: same ring, buffers of its own
+            while True:
+                slots, pix, U, stopped = srv.poll(max_wait_us=200, idle_ms=200)
+                if stopped:
+                    return
+                if slots.size == 0:
+                    continue
+                theta, lnl = _evaluate(pix.copy(), U.copy())
+                srv.complete(slots, theta, lnl)
+                served[which] += int(slots.size)
+        other = RingServer.__new__(RingServer)
+        other.__dict__.update(server.__dict__)
+        other._slots, other._pix, other._U = np.zeros(128, np.int32), np.zeros(128, np.int32), np.zeros((128, NDIM))
+        threads = [threading.Thread(target=loop, args=(w,)) for w in (0, 1)]
+        for t in threads:
+            t.start()
+        procs = [ctx.Process(target=_client, args=(name, r, n_points, out, start)) for r in range(n_clients)]
+        for p in procs:
+            p.start()
+        got = dict(out.get(timeout=60) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        server.stop()
+        for t in threads:
+            t.join(timeout=30)
+        assert sum(served) == n_clients * n_points == server.stats['evals'] and min(served) > 0
+    for rank, rows in got.items():
+        for u, theta, lnl, pix in rows:
+            t, l = _evaluate(np.array([pix]), u[None, :])
+            assert np.array_equal(theta, t[0]) and lnl == l[0]
+
+
 def _dies_holding_a_slot(name):
     RingClient(name, wait_ms=20000)
     os._exit(0)                                                # no close: the slot stays marked with a dead pid
