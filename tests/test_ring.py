@@ -209,19 +209,21 @@ def test_ring_serves_processes_from_the_engine(engine, nfo):
     n_clients, n_points = 4, 150
     ctx = mp.get_context('spawn')
     out, start = ctx.Queue(), ctx.Barrier(n_clients)
+    # two serving threads, each with a runner of its own over the same spectra: they share the clients
+    second = engine.AmmoniaRunner.from_data([[x, d, 0.2, t] for x, d, t in zip(axes, data, (1, 2))], ut, ncomp=2)
     with RingServer(name, n_slots=n_clients, runner=runner) as server:
         assert server.ndim == 12
         procs = [ctx.Process(target=_gpu_client, args=(name, r, n_points, out, start)) for r in range(n_clients)]
         for p in procs:
             p.start()
-        t = threading.Thread(target=server.serve, kwargs=dict(max_wait_us=200, idle_ms=60000))
-        t.start()
+        threads = server.serve_in_threads([runner, second], max_wait_us=200, idle_ms=60000)
         got = dict(out.get(timeout=120) for _ in procs)
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
         server.stop()
-        t.join(timeout=30)
+        for t in threads:
+            t.join(timeout=30)
         stats = server.stats
     assert stats['evals'] == n_clients * n_points and stats['largest_batch'] >= 2
     for rank, rows in got.items():
