@@ -174,6 +174,64 @@ def test_two_servers_share_one_ring():
             assert np.array_equal(theta, t[0]) and lnl == l[0]
 
 
+_C_SAMPLER = r"""
+/* a serial sampler in plain C: links libnestfit_amd_ring.so only and hands the ring's callback to its
+   sampling loop exactly where MultiNest takes LogLike (cmultinest.pxd:27-28) */
+#include <stdio.h>
+#include <stdlib.h>
+#include "nestfit_amd.h"
+typedef void (*loglike_fn)(double *Cube, int *ndim, int *npars, double *lnew, void *context);
+static void sample(loglike_fn loglike, void *context, int ndim, int n_points) {
+    double cube[64], lnew;
+    for (int k = 0; k < n_points; ++k) {
+        for (int j = 0; j < ndim; ++j) cube[j] = (double)((k * 7 + j * 3) % 101) / 101.0;
+        loglike(cube, &ndim, &ndim, &lnew, context);
+        printf("%d %a", k, lnew);
+        for (int j = 0; j < ndim; ++j) printf(" %a", cube[j]);
+        printf("\n");
+    }
+}
+int main(int argc, char **argv) {
+    nfa_ring *ring = NULL;
+    if (argc < 3 || nfa_ring_attach(&ring, argv[1], 20000) != NFA_OK) return 2;
+    nfa_ring_client ctx = { ring, 5 };
+    sample(nfa_ring_callback, &ctx, nfa_ring_ndim(ring), atoi(argv[2]));
+    return nfa_ring_close(ring);
+}
+"""
+
+
+def test_a_c_sampler_process_through_the_ring(tmp_path):
+    """The boundary as a compiled host program sees it: C99, the public header, the ring library alone."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    from nestfit_amd.build import OUT_RING
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if cc is None:
+        pytest.skip('no C compiler')
+    root = Path(__file__).resolve().parents[1]
+    (tmp_path / 'sampler.c').write_text(_C_SAMPLER)
+    exe = tmp_path / 'sampler'
+    subprocess.run([cc, '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', str(root / 'include'), '-o', str(exe),
+                    str(tmp_path / 'sampler.c'), str(OUT_RING), f'-Wl,-rpath,{OUT_RING.parent}'], check=True)
+    ldd = subprocess.run(['ldd', str(exe)], capture_output=True, text=True).stdout
+    assert 'libnestfit_amd_ring' in ldd and 'amdhip' not in ldd and 'libnestfit_amd.so' not in ldd
+    name, n_points = f'nfa_test_ring_c_{os.getpid()}', 120
+    with RingServer(name, n_slots=1, ndim=NDIM) as server:
+        proc = subprocess.Popen([str(exe), name, str(n_points)], stdout=subprocess.PIPE, text=True)
+        _serve_with(server, _evaluate, n_points)
+        out, _ = proc.communicate(timeout=60)
+        assert proc.returncode == 0
+    rows = [line.split() for line in out.strip().split('\n')]
+    assert len(rows) == n_points
+    for k, row in enumerate(rows):
+        u = np.array([((k * 7 + j * 3) % 101) / 101.0 for j in range(NDIM)])
+        theta, lnl = _evaluate(np.array([5]), u[None, :])
+        assert int(row[0]) == k and float.fromhex(row[1]) == lnl[0]
+        assert np.array_equal([float.fromhex(v) for v in row[2:]], theta[0])
+
+
 def _dies_holding_a_slot(name):
     RingClient(name, wait_ms=20000)
     os._exit(0)                                                # no close: the slot stays marked with a dead pid
