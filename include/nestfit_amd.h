@@ -15,6 +15,7 @@
 #ifndef NESTFIT_AMD_H
 #define NESTFIT_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -194,6 +195,12 @@ int nfa_runner_get_exp_mode(const nfa_runner *r);
  * the batch kernels with copies in and out; the values do not depend on the route. */
 int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U,
                              double *lnL, int64_t B);
+/* Host buffers the device can address (pinned and mapped).  A U / lnL / pix buffer of
+ * nfa_runner_loglike_batch that lies in such memory (from here, or registered with the HIP runtime by the
+ * caller) is not copied: the kernels read the unit cube over the bus and write theta and lnL in place
+ * (no reference counterpart: the reference's arrays never leave the host). */
+int nfa_host_alloc(void **out, size_t bytes);
+int nfa_host_free(void *p);
 
 /* AmmoniaRunner.predict / amm_predict (ammonia.pyx:437-447, 364-366) for B
  * parameter rows theta[B][ndim] (no priors).  spectra_out[B][chan_tot] and/or

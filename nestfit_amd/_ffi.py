@@ -73,6 +73,8 @@ SIGNATURES = {
     'nfa_runner_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'nfa_runner_get_profile': (C.c_int, [C.c_void_p, _dp, _lp]),
     'nfa_loglike_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
+    'nfa_host_alloc': (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    'nfa_host_free': (C.c_int, [C.c_void_p]),
     'nfa_broker_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int64, C.c_int]),
     'nfa_broker_destroy': (C.c_int, [C.c_void_p]),
     'nfa_broker_set_clients': (C.c_int, [C.c_void_p, C.c_int]),
@@ -192,6 +194,21 @@ def broker_loglike_address():
 def loglike_callback_address():
     """Address of the product library's nfa_loglike_callback (MultiNest's LogLike), for nfa_test_callback_latency."""
     return C.cast(load().nfa_loglike_callback, C.c_void_p)
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """An uninitialised numpy array in pinned, device-addressable host memory (nfa_host_alloc): passed to
+    `loglikelihood_batch` it is read and written by the kernels directly, without the copies in and out."""
+    import weakref
+    dtype = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    nbytes = max(int(np.prod(shape)) * dtype.itemsize, 1)
+    lib = load()
+    p = C.c_void_p()
+    check(lib.nfa_host_alloc(C.byref(p), nbytes))
+    raw = (C.c_char * nbytes).from_address(p.value)
+    weakref.finalize(raw, lib.nfa_host_free, C.c_void_p(p.value))
+    return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 def dptr(a):

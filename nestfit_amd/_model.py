@@ -183,12 +183,15 @@ class EngineRunner(Runner):
             raise ValueError(f'Invalid shape for ncomp={self.ncomp}: {utheta.shape[0]}')
         return float(self.loglikelihood_batch(utheta.reshape(1, -1))[0])
 
-    def loglikelihood_batch(self, U):
-        """lnL[B] for unit-cube rows U[B, ndim] (overwritten with parameters)."""
+    def loglikelihood_batch(self, U, out=None):
+        """lnL[B] for unit-cube rows U[B, ndim] (overwritten with parameters).  `out`: where lnL goes; with `U`
+        and `out` from `nestfit_amd.pinned_empty` the kernels work on the caller's arrays directly (no copies)."""
         U = _as_inplace_matrix(U)
         if U.shape[1] != self.ndim:
             raise ValueError(f'Invalid shape for ncomp={self.ncomp}: {U.shape[1]}')
-        lnL = np.empty(U.shape[0])
+        lnL = np.empty(U.shape[0]) if out is None else out
+        if lnL.shape != (U.shape[0],) or lnL.dtype != np.float64 or not lnL.flags.c_contiguous:
+            raise ValueError('out must be a contiguous float64 array of one value per row')
         _ffi.check(_ffi.load().nfa_runner_loglike_batch(self._run.handle, None, _ffi.dptr(U),
                                                         _ffi.dptr(lnL), U.shape[0]))
         return lnL

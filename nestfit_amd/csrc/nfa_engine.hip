@@ -1140,6 +1140,28 @@ static int single_point_graph(nfa_runner *r, double *U, double *lnL) {
 
 extern "C" {
 
+// The device's view of host memory it can address (pinned and mapped: nfa_host_alloc, hipHostMalloc,
+// hipHostRegister), nullptr for ordinary pageable memory.
+static void *mapped_view(const void *host) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    return a.devicePointer;
+}
+
+// Pinned, device-addressable host memory for the buffers of the host-pointer entry points.
+int nfa_host_alloc(void **out, size_t bytes) {
+    if (!out || bytes == 0) return fail(NFA_ERR_ARG, "null argument");
+    int rc = engine_init(); if (rc) return rc;
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocMapped | hipHostMallocPortable));
+    return NFA_OK;
+}
+int nfa_host_free(void *p) {
+    if (!p) return NFA_OK;
+    HIP_TRY(hipHostFree(p));
+    return NFA_OK;
+}
+
 int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, double *lnL, int64_t B) {
     if (!r || !U || !lnL) return fail(NFA_ERR_ARG, "null argument");
     if (B <= 0) return NFA_OK;
@@ -1159,6 +1181,11 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
     // Large batches go through the stream lanes in chunks: the kernels of chunk c run while the
     // host copies chunk c+1 in, and the results of chunk c come back while c+1 computes.  (Every
     // per-item result is independent of the batch it travels in.)
+    // A buffer the device can address itself (nfa_host_alloc, or memory the caller registered with the
+    // runtime) is not copied at all: the set-up kernel reads the unit cube over the bus and writes theta back
+    // in place, the sum kernel writes lnL there.
+    double *vU = (double *)mapped_view(U), *vL = (double *)mapped_view(lnL);
+    const int32_t *vP = pix ? (const int32_t *)mapped_view(pix) : nullptr;
     const int n_chunks = (B >= 16384 && r->n_lanes > 1) ? (int)std::min<int64_t>(r->lanes_auto ? 4 : r->n_lanes, B / 4096) : 1;
     const int64_t per = ((B + n_chunks - 1) / n_chunks + 63) / 64 * 64;
     const int ndim = r->ndim;
@@ -1166,17 +1193,18 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
         const int64_t b0 = c * per, nb = std::min<int64_t>(per, B - b0);
         if (nb <= 0) break;
         hipStream_t st = r->lanes[c];
-        HIP_TRY(hipMemcpyAsync(r->d_U + b0 * ndim, U + b0 * ndim, sizeof(double) * nb * ndim, hipMemcpyHostToDevice, st));
-        if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix + b0, pix + b0, sizeof(int) * nb, hipMemcpyHostToDevice, st));
-        rc = run_batch(r, pix ? r->d_pix + b0 : nullptr, r->d_U + b0 * ndim, r->d_lnL + b0, nullptr, nb, true, c, nullptr);
+        if (!vU) HIP_TRY(hipMemcpyAsync(r->d_U + b0 * ndim, U + b0 * ndim, sizeof(double) * nb * ndim, hipMemcpyHostToDevice, st));
+        if (pix && !vP) HIP_TRY(hipMemcpyAsync(r->d_pix + b0, pix + b0, sizeof(int) * nb, hipMemcpyHostToDevice, st));
+        rc = run_batch(r, pix ? (vP ? vP + b0 : r->d_pix + b0) : nullptr, vU ? vU + b0 * ndim : r->d_U + b0 * ndim,
+                       vL ? vL + b0 : r->d_lnL + b0, nullptr, nb, true, c, nullptr);
         if (rc) return rc;
     }
     for (int c = 0; c < n_chunks; ++c) {
         const int64_t b0 = c * per, nb = std::min<int64_t>(per, B - b0);
         if (nb <= 0) break;
         hipStream_t st = r->lanes[c];
-        HIP_TRY(hipMemcpyAsync(U + b0 * ndim, r->d_U + b0 * ndim, sizeof(double) * nb * ndim, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(lnL + b0, r->d_lnL + b0, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+        if (!vU) HIP_TRY(hipMemcpyAsync(U + b0 * ndim, r->d_U + b0 * ndim, sizeof(double) * nb * ndim, hipMemcpyDeviceToHost, st));
+        if (!vL) HIP_TRY(hipMemcpyAsync(lnL + b0, r->d_lnL + b0, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
     }
     for (int c = 0; c < n_chunks; ++c) HIP_TRY(hipStreamSynchronize(r->lanes[c]));
     r->lane_busy &= ~((1u << n_chunks) - 1u);

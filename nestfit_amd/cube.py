@@ -62,16 +62,19 @@ class CubeRunner:
         """Numerical mode of this runner alone (None: the process default again)."""
         self._run.set_exp_mode(mode)
 
-    def loglikelihood_batch(self, pix, U):
+    def loglikelihood_batch(self, pix, U, out=None):
         """lnL[B] of unit-cube rows U[B, ndim] against pixels pix[B]; U is overwritten
-        with the physical parameters (like Runner.loglikelihood, core.pyx:558-561)."""
+        with the physical parameters (like Runner.loglikelihood, core.pyx:558-561).  `out`: where lnL goes;
+        arrays from `nestfit_amd.pinned_empty` are used by the kernels in place (no copies)."""
         U = _as_inplace_matrix(U)
         if U.shape[1] != self.ndim:
             raise ValueError(f'Invalid shape for ncomp={self.ncomp}: {U.shape[1]}')
         pix = np.ascontiguousarray(pix, dtype=np.int32)
         if pix.shape != (U.shape[0],):
             raise ValueError('one pixel index per row is required')
-        lnL = np.empty(U.shape[0])
+        lnL = np.empty(U.shape[0]) if out is None else out
+        if lnL.shape != (U.shape[0],) or lnL.dtype != np.float64 or not lnL.flags.c_contiguous:
+            raise ValueError('out must be a contiguous float64 array of one value per row')
         _ffi.check(_ffi.load().nfa_runner_loglike_batch(self._run.handle, pix.ctypes.data_as(_ffi._ip),
                                                         _ffi.dptr(U), _ffi.dptr(lnL), U.shape[0]))
         return lnL

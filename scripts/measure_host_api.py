@@ -50,3 +50,22 @@ for B in (1, 16, 64, 128, 129, 400, 4096, 65536):
         run.loglikelihood_batch(b)
     dt = (time.perf_counter() - t0) / reps
     print(f'host API B={B}: {dt*1e6:.1f} us per call, {B/dt/1e6:.3f} M evals/s (PCIe + sync inclusive)')
+# the same calls with buffers the device addresses itself (nestfit_amd.pinned_empty): no copies in or out
+import nestfit_amd as _na
+for B in (400, 4096, 16384, 65536):
+    U = rng.uniform(size=(B, 12))
+    pu, pl = _na.pinned_empty((B, 12)), _na.pinned_empty(B)
+    reps = 200 if B <= 4096 else 20
+    pu[...] = U
+    run.loglikelihood_batch(pu, out=pl)
+    t_fill = time.perf_counter()
+    for _ in range(reps):
+        pu[...] = U
+    t_fill = (time.perf_counter() - t_fill) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pu[...] = U                                  # (the caller's own write of the unit cube: timed and subtracted)
+        run.loglikelihood_batch(pu, out=pl)
+    dt = (time.perf_counter() - t0) / reps - t_fill
+    print(f'host API, pinned buffers, B={B}: {dt*1e6:.1f} us per call, {B/dt/1e6:.3f} M evals/s (sync inclusive)')
+

@@ -131,3 +131,31 @@ def test_single_pixel_runner_and_mode_switch_between_batches(engine):
     finally:
         dev.free()
         run.set_exp_mode(None)
+
+
+@pytest.mark.parametrize('rows', [200, 4096, 20000])
+def test_pinned_host_buffers_are_used_in_place(engine, rows):
+    """Host buffers the device can address (nestfit_amd.pinned_empty -> nfa_host_alloc): the kernels read the unit
+    cube and write theta and lnL there, no copies; bit for bit what pageable buffers give -- one chunk, several
+    chunks over the lanes, pixels given or not, only some of the buffers pinned."""
+    rng = np.random.default_rng(rows)
+    spec_data = [[freq_axis(t, 256), rng.normal(0, 0.2, 256), 0.2, t] for t in (1, 2)]
+    ut = engine.get_irdc_priors(size=200, vsys=0.0)
+    run = engine.AmmoniaRunner.from_data(spec_data, ut, ncomp=2)
+    U = rng.uniform(size=(rows, run.ndim))
+    want_theta = U.copy()
+    want = run.loglikelihood_batch(want_theta)
+    pu, pl = engine.pinned_empty((rows, run.ndim)), engine.pinned_empty(rows)
+    pu[...] = U
+    pl[...] = np.nan
+    got = run.loglikelihood_batch(pu, out=pl)
+    assert got is pl and np.array_equal(pl, want) and np.array_equal(pu, want_theta)
+    pu[...] = U                                            # pinned U, pageable lnL
+    assert np.array_equal(run.loglikelihood_batch(pu), want) and np.array_equal(pu, want_theta)
+    theta = U.copy()                                       # pageable U, pinned lnL
+    pl[...] = np.nan
+    run.loglikelihood_batch(theta, out=pl)
+    assert np.array_equal(pl, want) and np.array_equal(theta, want_theta)
+    with pytest.raises(ValueError, match='out must be'):
+        run.loglikelihood_batch(U.copy(), out=np.empty(rows + 1))
+    del pu, pl                                             # frees the pinned memory (weakref finaliser)
