@@ -204,7 +204,7 @@ int nfa_host_free(void *p);
 
 /* AmmoniaRunner.predict / amm_predict (ammonia.pyx:437-447, 364-366) for B
  * parameter rows theta[B][ndim] (no priors).  spectra_out[B][chan_tot] and/or
- * lnL_out[B] may be NULL. */
+ * lnL_out[B] may be NULL; output buffers from nfa_host_alloc are written by the kernels themselves. */
 int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *theta,
                              int64_t B, double *spectra_out, double *lnL_out);
 

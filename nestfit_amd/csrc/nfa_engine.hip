@@ -1217,17 +1217,21 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
     if (B <= 0) return NFA_OK;
     int rc = check_pix(r, pix, B); if (rc) return rc;
     rc = sync_all_lanes(r); if (rc) return rc;
-    rc = runner_reserve(r, B, spectra_out != nullptr); if (rc) return rc;
+    // output buffers the device can address (nfa_host_alloc) are written by the kernels themselves: the spectra
+    // -- B x chan_tot doubles, the bulk of this call's traffic -- then cross the bus once, without a staging copy
+    double *vS = spectra_out ? (double *)mapped_view(spectra_out) : nullptr;
+    double *vL = lnL_out ? (double *)mapped_view(lnL_out) : nullptr;
+    rc = runner_reserve(r, B, spectra_out != nullptr && !vS); if (rc) return rc;
     hipStream_t st = r->lanes[0];
     HIP_TRY(hipMemcpyAsync(r->d_U, theta, sizeof(double) * B * r->ndim, hipMemcpyHostToDevice, st));
     if (pix) HIP_TRY(hipMemcpyAsync(r->d_pix, pix, sizeof(int) * B, hipMemcpyHostToDevice, st));
-    rc = run_batch(r, pix ? r->d_pix : nullptr, r->d_U, r->d_lnL, spectra_out ? r->d_spec : nullptr, B,
+    rc = run_batch(r, pix ? r->d_pix : nullptr, r->d_U, vL ? vL : r->d_lnL, spectra_out ? (vS ? vS : r->d_spec) : nullptr, B,
                    false, 0, nullptr);
     if (rc) return rc;
-    if (spectra_out)
+    if (spectra_out && !vS)
         HIP_TRY(hipMemcpyAsync(spectra_out, r->d_spec, sizeof(double) * B * r->ss->dev.chan_tot,
                                hipMemcpyDeviceToHost, st));
-    if (lnL_out)
+    if (lnL_out && !vL)
         HIP_TRY(hipMemcpyAsync(lnL_out, r->d_lnL, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     r->lane_busy &= ~1u;

@@ -80,10 +80,11 @@ class CubeRunner:
         return lnL
 
 
-    def predict_batch(self, pix, theta, want_spectra=True):
+    def predict_batch(self, pix, theta, want_spectra=True, out=None):
         """Model spectra [B, n_chan_tot] and lnL[B] of physical parameter rows theta[B, ndim]
         against pixels pix[B]: `runner.predict` for many pixels at once (the spectra-out mode of
-        the post-processing, nestfit/main.py:1106-1113, 1186)."""
+        the post-processing, nestfit/main.py:1106-1113, 1186).  `out`: where the spectra go; an array from
+        `nestfit_amd.pinned_empty` is written by the kernel itself (no staging copy of B x n_chan_tot doubles)."""
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         if theta.ndim != 2 or theta.shape[1] != self.ndim:
             raise ValueError(f'Invalid shape for ncomp={self.ncomp}: {theta.shape}')
@@ -91,7 +92,9 @@ class CubeRunner:
         if pix.shape != (theta.shape[0],):
             raise ValueError('one pixel index per row is required')
         B = theta.shape[0]
-        spec = np.empty((B, self.n_chan_tot)) if want_spectra else None
+        spec = (np.empty((B, self.n_chan_tot)) if out is None else out) if want_spectra else None
+        if spec is not None and (spec.shape != (B, self.n_chan_tot) or spec.dtype != np.float64 or not spec.flags.c_contiguous):
+            raise ValueError('out must be a contiguous float64 array [B, n_chan_tot]')
         lnl = np.empty(B)
         _ffi.check(_ffi.load().nfa_runner_predict_batch(
             self._run.handle, pix.ctypes.data_as(_ffi._ip), _ffi.dptr(theta), B,
@@ -101,7 +104,9 @@ class CubeRunner:
     def peak_and_integrated(self, pix, theta):
         """max_spec and sum_spec of every spectrum for parameter rows (core.pyx:532-539 as
         `deblend_hf_intensity` uses them, main.py:1110-1113): two arrays [B, n_spec]."""
-        spec, _ = self.predict_batch(pix, theta)
+        if getattr(self, '_scratch_spec', None) is None or self._scratch_spec.shape[0] < theta.shape[0]:
+            self._scratch_spec = _ffi.pinned_empty((max(theta.shape[0], 1), self.n_chan_tot))
+        spec, _ = self.predict_batch(pix, theta, out=self._scratch_spec[:theta.shape[0]])
         off = self._ss.offsets
         peak = np.stack([np.nanmax(spec[:, off[k]:off[k + 1]], axis=1) for k in range(self.n_spec)], axis=1)
         tot = np.stack([np.nansum(spec[:, off[k]:off[k + 1]], axis=1) for k in range(self.n_spec)], axis=1)

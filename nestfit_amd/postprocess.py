@@ -292,10 +292,17 @@ def _device_predictor(store, stack):
                         model=model_id, **extra)
     runner.set_exp_mode('table')                         # map products in the reference's own arithmetic: a one-off, not a rate
 
+    scratch = {}
+
     def predict(lon, lat, theta, want_spectra):
         pix = np.zeros(theta.shape[0], dtype=np.int32)
         if want_spectra:
-            spec, _ = runner.predict_batch(pix, theta)
+            # (one buffer the device addresses itself serves every batch: the callers use a batch's spectra before
+            # they ask for the next)
+            if scratch.get('rows', 0) < theta.shape[0]:
+                from ._ffi import pinned_empty
+                scratch['buf'], scratch['rows'] = pinned_empty((theta.shape[0], chan_tot)), theta.shape[0]
+            spec, _ = runner.predict_batch(pix, theta, out=scratch['buf'][:theta.shape[0]])
             return spec, None, None
         peak, tot = runner.peak_and_integrated(pix, theta)
         return None, peak, tot

@@ -159,3 +159,24 @@ def test_pinned_host_buffers_are_used_in_place(engine, rows):
     with pytest.raises(ValueError, match='out must be'):
         run.loglikelihood_batch(U.copy(), out=np.empty(rows + 1))
     del pu, pl                                             # frees the pinned memory (weakref finaliser)
+
+
+def test_predict_batch_writes_pinned_spectra_in_place(engine):
+    """The spectra-out mode with an output buffer the device addresses itself: same spectra, same lnL."""
+    from nestfit_amd.cube import CubeRunner
+    rng = np.random.default_rng(12)
+    xarrs = [freq_axis(t, 384) for t in (1, 2)]
+    data = rng.normal(0, 0.2, (3, 768))
+    run = CubeRunner(xarrs, [1, 2], data, np.full((3, 2), 0.2), None, ncomp=2)
+    theta = np.column_stack([rng.uniform(-2, 2, 300), rng.uniform(-2, 2, 300), rng.uniform(8, 20, 300), rng.uniform(8, 20, 300),
+                             rng.uniform(3, 8, 300), rng.uniform(3, 8, 300), rng.uniform(13.5, 15, 300), rng.uniform(13.5, 15, 300),
+                             rng.uniform(0.2, 1, 300), rng.uniform(0.2, 1, 300), rng.uniform(0, 0.5, 300), rng.uniform(0, 0.5, 300)])
+    pix = rng.integers(0, 3, 300).astype(np.int32)
+    want_spec, want_lnl = run.predict_batch(pix, theta)
+    out = engine.pinned_empty((300, 768))
+    out[...] = np.nan
+    spec, lnl = run.predict_batch(pix, theta, out=out)
+    assert spec is out and np.array_equal(out, want_spec) and np.array_equal(lnl, want_lnl)
+    peak, tot = run.peak_and_integrated(pix, theta)          # goes through a pinned scratch buffer of its own
+    assert np.array_equal(peak[:, 0], np.nanmax(want_spec[:, :384], axis=1))
+    np.testing.assert_allclose(tot[:, 1], np.nansum(want_spec[:, 384:], axis=1), rtol=1e-13)
