@@ -32,7 +32,7 @@
 #include <unistd.h>
 
 #define NFA_RING_MAGIC   0x4e46524eu       // "NFRN"
-#define NFA_RING_VERSION 1u
+#define NFA_RING_VERSION 2u
 #define NFA_RING_MAXBATCH 128              // what one point-kernel launch takes (nestfit_amd.h)
 
 enum { RING_FREE = 0, RING_POSTED = 1, RING_DONE = 2, RING_CLAIMED = 3 };
@@ -46,6 +46,7 @@ struct RingHeader {
     std::atomic<uint32_t> posts;           // bumped by every post: the word the server sleeps on
     std::atomic<uint32_t> n_attached;      // clients holding a slot
     std::atomic<uint32_t> n_servers;       // serving loops at work (each with a runner of its own): they share the clients
+    std::atomic<uint32_t> servers_asleep;  // serving loops inside a futex wait on `posts`: only then does a post pay for a wake call
     std::atomic<uint64_t> n_batches, n_evals, max_batch_seen;
     uint8_t  pad[64];
 };
@@ -53,7 +54,8 @@ struct RingHeader {
 struct RingSlot {
     std::atomic<uint32_t> state;
     std::atomic<uint32_t> owner;           // 0 = nobody, else the pid of the client holding the slot
-    int32_t  pix, rc;
+    std::atomic<uint32_t> asleep;          // the client is inside a futex wait on `state` (a spinning one needs no wake call)
+    int32_t  pix, rc, pad;
     double   lnl;
     double   cube[1];                      // ndim doubles
 };
@@ -221,8 +223,8 @@ int nfa_ring_loglike(nfa_ring *r, int32_t pix, double *cube, double *lnew) {
     memcpy(s->cube, cube, sizeof(double) * (size_t)h->ndim);
     s->pix = pix;
     s->state.store(RING_POSTED, std::memory_order_release);
-    h->posts.fetch_add(1, std::memory_order_acq_rel);
-    ring_futex(&h->posts, FUTEX_WAKE, INT32_MAX, nullptr);     // every sleeping server looks
+    h->posts.fetch_add(1);                                     // (sequentially consistent with the servers' flag)
+    if (h->servers_asleep.load() != 0) ring_futex(&h->posts, FUTEX_WAKE, INT32_MAX, nullptr);     // every sleeping server looks
     // a launch takes tens of microseconds: spin first -- unless there are more sampler processes than cores,
     // where a spinning process only keeps another one from posting
     static const long n_cpu = sysconf(_SC_NPROCESSORS_ONLN);
@@ -233,7 +235,9 @@ int nfa_ring_loglike(nfa_ring *r, int32_t pix, double *cube, double *lnew) {
         if (h->stop.load(std::memory_order_acquire)) return fail(NFA_ERR_STATE, "ring stopped");
         if (spin < spin_limit) { ring_pause(); continue; }
         const timespec ts = {0, 2000000};                      // then sleep on the slot (2 ms: re-check `stop`)
-        ring_futex(&s->state, FUTEX_WAIT, cur, &ts);
+        s->asleep.store(1);                                    // before the kernel re-reads `state`: the server either
+        ring_futex(&s->state, FUTEX_WAIT, cur, &ts);           // sees the flag or has changed `state` already
+        s->asleep.store(0);
     }
     const int rc = s->rc;
     if (rc == NFA_OK) memcpy(cube, s->cube, sizeof(double) * (size_t)h->ndim);
@@ -303,7 +307,9 @@ int nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, 
         if (now >= t_idle) return NFA_OK;
         if (spin < 2000) { ring_pause(); continue; }
         const timespec ts = {0, 1000000};
+        h->servers_asleep.fetch_add(1);
         ring_futex(&h->posts, FUTEX_WAIT, posts, &ts);         // sleeps only if nothing was posted since the scan
+        h->servers_asleep.fetch_sub(1);
     }
 }
 
@@ -316,8 +322,8 @@ int nfa_ring_complete(nfa_ring *r, int n, const int32_t *slots, const double *U,
         if (rc == NFA_OK) memcpy(s->cube, U + (size_t)k * h->ndim, sizeof(double) * (size_t)h->ndim);
         s->lnl = rc == NFA_OK ? lnL[k] : NAN;
         s->rc = rc;
-        s->state.store(RING_DONE, std::memory_order_release);
-        ring_futex(&s->state, FUTEX_WAKE, 1, nullptr);
+        s->state.store(RING_DONE);
+        if (s->asleep.load() != 0) ring_futex(&s->state, FUTEX_WAKE, 1, nullptr);
     }
     if (n > 0) {
         h->n_batches.fetch_add(1, std::memory_order_relaxed);

@@ -33,8 +33,58 @@ def client(name, rank, n_calls, start, out):
     out.put((rank, t0, t1))
 
 
+C_CLIENT = r"""
+/* a compiled serial sampler (what MultiNest is to the ring): attach, warm up, wait for the start time, call */
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+#include "nestfit_amd.h"
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+int main(int argc, char **argv) {
+    nfa_ring *ring = NULL;
+    if (argc < 5 || nfa_ring_attach(&ring, argv[1], 60000) != NFA_OK) return 2;
+    const int rank = atoi(argv[2]), n_calls = atoi(argv[3]), ndim = nfa_ring_ndim(ring);
+    const double t_start = atof(argv[4]);
+    nfa_ring_client ctx = { ring, -1 };
+    double cube[64], lnew;
+    unsigned long long state = 88172645463325252ull + (unsigned long long)rank * 7919ull;
+    for (int k = -200; k < n_calls; ++k) {
+        if (k == 0) while (now() < t_start) ;
+        for (int j = 0; j < ndim; ++j) {                     /* xorshift: a fresh unit-cube point per call */
+            state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+            cube[j] = (double)(state >> 11) / 9007199254740992.0;
+        }
+        nfa_ring_callback(cube, (int *)&ndim, (int *)&ndim, &lnew, &ctx);
+    }
+    printf("%.9f %.9f\n", t_start, now());
+    return nfa_ring_close(ring);
+}
+"""
+
+
+def native_clients(name, n_proc, n_calls):
+    """N compiled clients as subprocesses; returns [(t_start, t_end)] on the monotonic clock."""
+    import subprocess
+    import tempfile
+    from nestfit_amd.build import OUT_RING
+    tmp = Path(tempfile.mkdtemp())
+    (tmp / 'client.c').write_text(C_CLIENT)
+    exe = tmp / 'client'
+    subprocess.run(['gcc', '-O2', '-std=gnu99', '-I', str(ROOT / 'include'), '-o', str(exe), str(tmp / 'client.c'),
+                    str(OUT_RING), f'-Wl,-rpath,{OUT_RING.parent}'], check=True)
+    t_start = time.clock_gettime(time.CLOCK_MONOTONIC) + 1.0 + 0.02 * n_proc
+    procs = [subprocess.Popen([str(exe), name, str(k), str(n_calls), f'{t_start:.9f}'], stdout=subprocess.PIPE, text=True)
+             for k in range(n_proc)]
+    out = []
+    for p in procs:
+        text, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, p.returncode
+        out.append(tuple(float(v) for v in text.split()))
+    return out
+
+
 def main():
-    """measure_ring.py [processes[:serving threads] ...]"""
+    """measure_ring.py [native] [processes[:serving threads] ...]   (native: compiled C clients instead of Python ones)"""
     import nestfit_amd as na
     from nestfit_amd.ring import RingServer
     from nestfit_amd.synth import TRUTH_2COMP, freq_axis
@@ -48,7 +98,9 @@ def main():
     priors = na.get_irdc_priors(size=500, vsys=0.0)
     runners = []
     ctx = mp.get_context('spawn')
-    cases = [tuple(int(v) for v in (a + ':1').split(':')[:2]) for a in sys.argv[1:]] or [(1, 1), (2, 1), (4, 1), (8, 1), (14, 1)]
+    argv = [a for a in sys.argv[1:] if a != 'native']
+    native = 'native' in sys.argv[1:]
+    cases = [tuple(int(v) for v in (a + ':1').split(':')[:2]) for a in argv] or [(1, 1), (2, 1), (4, 1), (8, 1), (14, 1)]
     for n_proc, n_serv in cases:
         while len(runners) < n_serv:                   # one runner (its own streams) per serving thread
             runners.append(na.AmmoniaRunner.from_data(args, priors, ncomp=2))
@@ -56,20 +108,23 @@ def main():
         name = f'nfa_measure_ring_{n_proc}_{n_serv}'
         with RingServer(name, n_slots=n_proc, runner=runners[0]) as server:
             threads = server.serve_in_threads(runners[:n_serv], max_wait_us=30, idle_ms=120000)
-            start, out = ctx.Barrier(n_proc), ctx.Queue()
-            procs = [ctx.Process(target=client, args=(name, k, n_calls, start, out)) for k in range(n_proc)]
-            for p in procs:
-                p.start()
-            res = [out.get(timeout=900) for _ in procs]
-            for p in procs:
-                p.join()
+            if native:
+                res = [(k, a, b) for k, (a, b) in enumerate(native_clients(name, n_proc, n_calls))]
+            else:
+                start, out = ctx.Barrier(n_proc), ctx.Queue()
+                procs = [ctx.Process(target=client, args=(name, k, n_calls, start, out)) for k in range(n_proc)]
+                for p in procs:
+                    p.start()
+                res = [out.get(timeout=900) for _ in procs]
+                for p in procs:
+                    p.join()
             server.stop()
             for t in threads:
                 t.join()
             st = server.stats
         wall = max(r[2] for r in res) - min(r[1] for r in res)
         per_call = np.mean([r[2] - r[1] for r in res]) / n_calls
-        print(f'{n_proc:2d} processes, {n_serv} serving thread(s): {n_proc * n_calls / wall / 1e3:7.1f} k evals/s in all, '
+        print(f'{n_proc:2d} {"compiled" if native else "Python"} processes, {n_serv} serving thread(s): {n_proc * n_calls / wall / 1e3:7.1f} k evals/s in all, '
               f'{per_call * 1e6:6.1f} us per call in each, {st["evals"] / st["batches"]:5.2f} points per launch '
               f'(largest {st["largest_batch"]})', flush=True)
 
