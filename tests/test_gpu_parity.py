@@ -119,6 +119,13 @@ def test_fastexp_fast_mode(engine, nfo):
     got = _test_fastexp(engine, tau, '1m')
     want = 1.0 - nfo.fast_expn(tau)
     assert np.max(np.abs(got - want) / want) < 3e-7
+    # the corners of the instruction block: not a number and infinity give exactly 1 (FastExp returns 0 there,
+    # fastexp.c:272-273), zero and a denormal exactly 0, the range borders sit on the right side
+    edge = np.array([np.nan, np.inf, 0.0, 1e-45, 32.0, 64.0, 1e30, 0.25, np.nextafter(np.float32(0.25), np.float32(0))],
+                    dtype=np.float32).astype(np.float64)
+    got = _test_fastexp(engine, edge, '1m')
+    assert list(got[:4]) == [1.0, 1.0, 0.0, 0.0] and list(got[4:7]) == [1.0, 1.0, 1.0]
+    np.testing.assert_allclose(got[7:], 1.0 - nfo.fast_expn(edge[7:]), rtol=3e-7)
 
 
 def test_iemtex_and_partition(engine, nfo):
