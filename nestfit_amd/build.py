@@ -19,6 +19,9 @@ TEST_FLAGS = ['-DNFA_TEST_HOOKS', '-DNFA_ABLATE']
 # the shared-memory ring alone (csrc/nfa_ring.h), host code without HIP: what a sampler process loads
 OUT_RING = HERE / 'lib' / 'libnestfit_amd_ring.so'
 SRC_RING = HERE / 'csrc' / 'nfa_ring.cpp'
+# host helper of hdf5.py (batches of HDF5 calls per native call; dlopens the HDF5 library itself)
+OUT_H5 = HERE / 'lib' / 'libnestfit_amd_h5.so'
+SRC_H5 = HERE / 'csrc' / 'nfa_h5.cpp'
 
 FLAGS = [
     '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared',
@@ -59,6 +62,12 @@ def build(force=False, verbose=False, extra=(), test_lib=True):
         if verbose:
             print(' '.join(cmd))
         jobs.append((OUT_RING, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    if force or not OUT_H5.exists() or OUT_H5.stat().st_mtime < SRC_H5.stat().st_mtime:
+        cxx = os.environ.get('CXX', 'g++')
+        cmd = [cxx, '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', '-o', str(OUT_H5), str(SRC_H5), '-ldl']
+        if verbose:
+            print(' '.join(cmd))
+        jobs.append((OUT_H5, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for out, proc in jobs:
         text, _ = proc.communicate()
         if proc.returncode != 0:

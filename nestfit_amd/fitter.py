@@ -86,8 +86,8 @@ class CubeFitter:
             for nl in np.unique(nlive):
                 sel = np.flatnonzero(nlive == nl)
                 self._fit_group(hdf, lon[sel], lat[sel], int(nl), kw)
-        hdf.flush()
-        hdf.close()
+        hdf.close()                                  # saves the file (once)
+        return hdf
 
     def _fit_on_device(self, lon, lat, ncomp, nlive, kw):
         runner, rlon, rlat = self.stack.to_device(self.utrans, ncomp=ncomp, lon=lon, lat=lat,
@@ -165,8 +165,9 @@ class CubeFitter:
         store.insert_fitter_pars(self)
         store.insert_model_metadata(self.runner_cls)
         todo = range(store.nchunks) if rank is None else [0]
+        written = {}
         for k in todo:
-            self.fit(indices[k], store.chunk_paths[k])
+            written[store.chunk_paths[k]] = self.fit(indices[k], store.chunk_paths[k])
         if rank is None:
-            store.link_files()
+            store.link_files(loaded=written)           # the trees just written need not be read back
         store.close()

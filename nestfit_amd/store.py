@@ -348,14 +348,14 @@ class HdfStore:
                 return group['1']
         raise ValueError('No valid pix groups found.')
 
-    def link_files(self):
+    def link_files(self, loaded=None):
         """Hang the pixel groups of every chunk file under the table's /pix: object references in memory,
         external links (`chunk<i>.hdf:/pix/<i_lon>/<i_lat>`, main.py:286-296) in the table's HDF5 file."""
         assert self.is_open
         for path in self.chunk_paths:
             if not path.exists():
                 continue
-            chunk = StoreFile(path, 'r')
+            chunk = (loaded or {}).get(path) or StoreFile(path, 'r')     # `loaded`: {path: StoreFile} already in memory
             if '/pix' not in chunk:
                 continue
             for lon_name in chunk['/pix']:

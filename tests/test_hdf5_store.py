@@ -178,3 +178,42 @@ def test_post_processing_products_land_in_the_table(tmp_path, monkeypatch):
     for dset in ('nbest', 'evidence', 'evidence_err', 'AIC', 'AICc', 'BIC', 'conv_evidence', 'conv_nbest',
                  'marg_quantiles', 'nbest_MAP', 'nbest_bestfit', 'nbest_marginals'):
         assert f'DATASET "{dset}"' in head, dset
+
+
+def test_native_helper_and_plain_ctypes_paths_agree(tmp_path, monkeypatch):
+    """csrc/nfa_h5.cpp (the attributes / datasets of an object in one native call) against the call-by-call
+    ctypes path: files written by either are read identically by both."""
+    if hdf5._fast() is None:
+        pytest.skip('helper library not built')
+    def tree(path):
+        rng = np.random.default_rng(5)
+        f = StoreFile(path)
+        g = f.require_group('/pix/1/2')
+        g.attrs.update(i_lon=1, i_lat=2, nbest=2, ok=True, label='µ', cols=['a', 'b'], q=np.linspace(0, 1, 5),
+                       six=rng.normal(size=(2, 1, 3, 1, 2, 2)), empty=np.zeros(0), u=np.uint16(7))
+        g.create_dataset('posteriors', data=rng.normal(size=(9, 8)).astype('f4'))
+        g.create_dataset('six', data=rng.normal(size=(2, 1, 3, 1, 2, 2)))
+        g.create_dataset('none', data=np.zeros((0, 4)))
+        return f
+
+    def same(a, b):
+        assert set(a.attrs) == set(b.attrs) and set(a._datasets) == set(b._datasets)
+        for k, v in a.attrs.items():
+            w = b.attrs[k]
+            assert type(v) is type(w), k
+            assert np.array_equal(v, w) and getattr(v, 'dtype', None) == getattr(w, 'dtype', None), k
+        for k, v in a._datasets.items():
+            assert np.array_equal(v, b._datasets[k]) and v.dtype == b._datasets[k].dtype
+    tree(tmp_path / 'fast.hdf').close()
+    fast_by_fast = StoreFile(tmp_path / 'fast.hdf', 'r')
+    monkeypatch.setattr(hdf5, '_helper', None)               # the plain path from here on
+    assert hdf5._fast() is None
+    tree(tmp_path / 'plain.hdf').close()
+    fast_by_plain = StoreFile(tmp_path / 'fast.hdf', 'r')
+    plain_by_plain = StoreFile(tmp_path / 'plain.hdf', 'r')
+    monkeypatch.undo()
+    assert hdf5._fast() is not None
+    plain_by_fast = StoreFile(tmp_path / 'plain.hdf', 'r')
+    for other in (fast_by_plain, plain_by_plain, plain_by_fast):
+        same(fast_by_fast['/pix/1/2'], other['/pix/1/2'])
+    assert _dump('-H', tmp_path / 'fast.hdf').replace('fast.hdf', 'X') == _dump('-H', tmp_path / 'plain.hdf').replace('plain.hdf', 'X')
