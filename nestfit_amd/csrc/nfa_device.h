@@ -667,8 +667,8 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             const unsigned jo = (unsigned)(valid ? j : N - 1) * 8u;           // byte offset of the lane's channel
             const double xj = *(const double *)((const char *)xs + jo);
             const double dj = *(const double *)((const char *)ds + jo);
-            double p3, x2, T0, tbg;                    // read only where the branches below have set them
-            if (MODE == 2) { p3 = *(const double *)((const char *)p3s + jo); x2 = xj * xj; }
+            double p3, T0, tbg;                        // read only where the branches below have set them
+            if (MODE == 2) p3 = *(const double *)((const char *)p3s + jo);
             // exact modes: T0 and tbg of the channel for every Tb pass; the fast mode reads them inside the rare pass
             // that needs them (y(T0) not a single table cell): carried through the row as "maybe loaded" values they
             // cost two register copies per row
@@ -740,7 +740,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     double g;                                         // T0 (y(T0) - tbg)
                     if (kind == 1.0) {                                // one table cell over the band (usual):
                         // y = A0 + B0 T0 and T0 = kappa x:  g = B0x x^2 + A0x x - T0 tbg
-                        g = __builtin_fma(b0x, x2, __builtin_fma(a0x, xj, -p3));
+                        g = __builtin_fma(xj, __builtin_fma(b0x, xj, a0x), -p3);      // (Horner: no x^2 per row)
                     } else if (kind != 0.0) {
                         unsigned jr = jo;
                         asm volatile("" : "+v"(jr));                  // the two addresses are formed here, not in every row's head
