@@ -933,10 +933,6 @@ int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_
         int rc = flush_pending(r); if (rc) return rc;
     }
     if (!fits) return run_batch(r, d_pix, d_U, d_lnL, nullptr, B, true, -1, nullptr);
-    // Nothing in flight (the first batch since the last synchronisation): launch it now -- holding it would leave
-    // the device idle while the caller enqueues its next three (10 us of host time each); the batches that arrive
-    // while this one runs are the ones that travel together
-    if (p.n == 0 && r->lane_busy == 0) return run_batch(r, d_pix, d_U, d_lnL, nullptr, B, true, -1, nullptr);
     p.pix[p.n] = d_pix; p.U[p.n] = d_U; p.lnL[p.n] = d_lnL; p.each = (long)B; p.n += 1;
     if (p.n >= group || (int64_t)(p.n + 1) * units > 4 * slots) return flush_pending(r);
     return NFA_OK;
