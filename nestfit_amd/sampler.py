@@ -574,9 +574,27 @@ class Dumper:
         self.marginal_cols, self.quantiles = marginal_quantile_table()
 
     def calc_marginals(self, posteriors):
-        """Quantiles of every parameter column (the two trailing columns are -2 lnL and the weights)."""
+        """Quantiles of every parameter column (the two trailing columns are -2 lnL and the weights):
+        `np.quantile(columns, quantiles, axis=0)` of the reference's Dumper (core.pyx:596-598), bit for bit, from
+        one sort of the columns and numpy's own interpolation rule (a + (b - a) t, from the upper side for
+        t >= 1/2) -- a map has tens of thousands of runs and the general routine costs six times as much per run."""
         n_par = posteriors.shape[1] - 2
-        return np.quantile(posteriors[:, :n_par], self.quantiles, axis=0)
+        a = np.asarray(posteriors[:, :n_par], dtype=np.float64)
+        n = a.shape[0]
+        if n == 0 or np.isnan(a).any():
+            return np.quantile(a, self.quantiles, axis=0)
+        q = np.asarray(self.quantiles, dtype=np.float64)
+        s = np.sort(a, axis=0)
+        virtual = (n - 1) * q
+        below = np.floor(virtual).astype(np.intp)
+        above = np.minimum(below + 1, n - 1)
+        t = (virtual - below)[:, None]
+        lo, hi = s[below], s[above]
+        step = hi - lo
+        out = lo + step * t
+        upper = (t >= 0.5)[:, 0]
+        out[upper] = hi[upper] - step[upper] * (1 - t[upper])
+        return out
 
     def flush(self):
         self.group.file.flush()

@@ -358,3 +358,24 @@ def test_sampler_on_sibling_models(engine, nfo):
     for p, r in enumerate(res):
         assert r.lnZ - cube.null_lnZ[p] > 11
         np.testing.assert_allclose(r.param_constr[0], [-2.0, 1.2, 1.5], atol=0.15)
+
+
+def test_marginals_are_numpy_quantiles_bit_for_bit():
+    """Dumper.calc_marginals sorts once and interpolates like numpy's default method: the values np.quantile gives
+    (what the reference stores, core.pyx:596-598), to the last bit -- ties, tiny and odd sample counts, NaN columns."""
+    from nestfit_amd import sampler
+    d = sampler.Dumper(sampler.MemoryGroup())
+    rng = np.random.default_rng(17)
+    for n in (1, 2, 3, 16, 401, 2999, 3000):
+        for n_par in (3, 6, 12):
+            post = rng.normal(size=(n, n_par + 2))
+            if n > 3:
+                post[rng.integers(0, n, 7)] = post[0]
+            want = np.quantile(post[:, :n_par], d.quantiles, axis=0)
+            got = d.calc_marginals(post)
+            assert got.shape == (15, n_par) and np.array_equal(got, want), (n, n_par)
+            got32 = d.calc_marginals(post.astype(np.float32))
+            assert np.array_equal(got32, np.quantile(post.astype(np.float32)[:, :n_par].astype(np.float64), d.quantiles, axis=0))
+    post = rng.normal(size=(50, 8))
+    post[3, 2] = np.nan
+    assert np.array_equal(d.calc_marginals(post), np.quantile(post[:, :6], d.quantiles, axis=0), equal_nan=True)
