@@ -114,7 +114,18 @@ int nfa_ring_create(nfa_ring **out, const char *name, int n_slots, int ndim) {
     const std::string shm = ring_shm_name(name);
     const size_t stride = (offsetof(RingSlot, cube) + sizeof(double) * (size_t)ndim + 63) / 64 * 64;
     const size_t bytes = sizeof(RingHeader) + stride * (size_t)n_slots;
-    shm_unlink(shm.c_str());                                   // a stale ring of a crashed server
+    {   // a ring of that name whose server is alive is somebody's: refuse; one left by a crashed server goes
+        const int old = shm_open(shm.c_str(), O_RDWR, 0600);
+        if (old >= 0) {
+            RingHeader h0;
+            const bool whole = pread(old, &h0, sizeof h0, 0) == (ssize_t)sizeof h0;
+            close(old);
+            if (whole && h0.magic == NFA_RING_MAGIC && h0.server_pid > 0 &&
+                !(kill((pid_t)h0.server_pid, 0) != 0 && errno == ESRCH) && !h0.stop.load())
+                return fail(NFA_ERR_STATE, "a ring of that name is being served");
+            shm_unlink(shm.c_str());
+        }
+    }
     const int fd = shm_open(shm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0) return fail(NFA_ERR_STATE, "shm_open failed");
     if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(shm.c_str()); return fail(NFA_ERR_STATE, "ftruncate failed"); }

@@ -78,6 +78,8 @@ def test_ring_callback_signature_stop_and_errors():
     with pytest.raises(_ffi.EngineError, match='no such ring'):
         RingClient(name + '_absent', wait_ms=30)
     server = RingServer(name, n_slots=1, ndim=NDIM)
+    with pytest.raises(_ffi.EngineError, match='being served'):
+        RingServer(name, n_slots=1, ndim=NDIM)             # the name belongs to a live server
     client = RingClient(name)
     assert client.ndim == NDIM and client.slot == 0
     with pytest.raises(_ffi.EngineError, match='no free slot'):
