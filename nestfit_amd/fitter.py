@@ -7,6 +7,8 @@ the pixels whose evidence gained at least `lnZ_thresh` with two, and so on -- th
 rule per pixel (main.py:452-469), the same groups and attributes in the store.
 """
 import inspect
+import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -28,6 +30,9 @@ class _RunInfo:
 # run_multinest keywords a CubeFitter passes unless told otherwise (the reference's choice for cube fits:
 # fewer live points and a looser tolerance than run_multinest's own defaults, main.py:381-387)
 MN_CUBE_DEFAULTS = dict(nlive=100, tol=1.0, efr=0.3, updInt=2000)
+# groups of pixels (one per number of live points) sampled side by side: a group of a few hundred pixels is bound by
+# the latency of its rounds, not by the device, and the groups' rounds interleave (1 = one group after the other)
+GROUP_WORKERS = 3
 # device memory the sampler state of one lock-step group may take (dead points dominate: cap x (ndim + 2) doubles
 # per pixel); larger groups are fitted in several passes
 SAMPLER_MEMORY_BUDGET = 24 << 30
@@ -54,6 +59,8 @@ class CubeFitter:
         self.lnZ_thresh, self.ncomp_max, self.nlive_snr_fact = lnZ_thresh, ncomp_max, nlive_snr_fact
         self.nlive_quantum = max(1, int(nlive_quantum))
         self.fit_backend = fit_backend
+        self.group_workers = GROUP_WORKERS
+        self._tree_lock = threading.Lock()           # the store tree and runner creation: one thread at a time
 
     def _nlive(self, lon, lat):
         base = int(self.mn_kwargs['nlive'])
@@ -83,15 +90,25 @@ class CubeFitter:
         if lon.size:
             nlive = self._nlive(lon, lat)
             kw = {k: self.mn_kwargs[k] for k in ('tol', 'efr', 'seed', 'maxiter') if k in self.mn_kwargs}
-            for nl in np.unique(nlive):
-                sel = np.flatnonzero(nlive == nl)
-                self._fit_group(hdf, lon[sel], lat[sel], int(nl), kw)
+            groups = [(np.flatnonzero(nlive == nl), int(nl)) for nl in np.unique(nlive)]
+            workers = min(len(groups), self.group_workers) if self.fit_backend is None else 1
+            if workers > 1:
+                # largest groups first; results do not depend on the company (the random streams are keyed by the
+                # seed, the pixel's slot in its group and the candidate index)
+                groups.sort(key=lambda g: -g[0].size)
+                with ThreadPoolExecutor(max_workers=workers) as pool:
+                    for f in [pool.submit(self._fit_group, hdf, lon[sel], lat[sel], nl, kw) for sel, nl in groups]:
+                        f.result()
+            else:
+                for sel, nl in groups:
+                    self._fit_group(hdf, lon[sel], lat[sel], nl, kw)
         hdf.close()                                  # saves the file (once)
         return hdf
 
     def _fit_on_device(self, lon, lat, ncomp, nlive, kw):
-        runner, rlon, rlat = self.stack.to_device(self.utrans, ncomp=ncomp, lon=lon, lat=lat,
-                                                  model=self.model_id, **self.runner_kwargs)
+        with self._tree_lock:
+            runner, rlon, rlat = self.stack.to_device(self.utrans, ncomp=ncomp, lon=lon, lat=lat,
+                                                      model=self.model_id, **self.runner_kwargs)
         assert np.array_equal(rlon, lon) and np.array_equal(rlat, lat)
         # the sampler keeps every dead point of every pixel on the device: fit the group in passes that fit
         # the memory budget (a pass's pixels keep their slot numbers' random streams; the seed moves on)
@@ -122,20 +139,22 @@ class CubeFitter:
                 old_lnZ = np.array(null_lnZ, dtype=np.float64)
                 assert np.isfinite(old_lnZ).all()
             gain = np.empty(alive.size)
-            for k, (p, r) in enumerate(zip(alive, res)):
-                group = hdf.require_group(f'/pix/{lon[p]}/{lat[p]}')
-                sub_group = group.create_group(f'{ncomp}')
-                info = _RunInfo(ncomp, float(null_lnZ[k]), n_chan_tot, self.n_model * ncomp)
-                sampler.Dumper(sub_group).dump(info, r)
-                assert np.isfinite(info.run_lnZ)
-                gain[k] = info.run_lnZ - old_lnZ[p]
+            with self._tree_lock:
+                for k, (p, r) in enumerate(zip(alive, res)):
+                    group = hdf.require_group(f'/pix/{lon[p]}/{lat[p]}')
+                    sub_group = group.create_group(f'{ncomp}')
+                    info = _RunInfo(ncomp, float(null_lnZ[k]), n_chan_tot, self.n_model * ncomp)
+                    sampler.Dumper(sub_group).dump(info, r)
+                    assert np.isfinite(info.run_lnZ)
+                    gain[k] = info.run_lnZ - old_lnZ[p]
             keep = gain >= self.lnZ_thresh               # main.py:464-469
             nbest[alive[keep]] = ncomp
             old_lnZ[alive[keep]] = np.array([r.lnZ for r in res])[keep]
             alive = alive[keep]
             ncomp += 1
-        for p in range(lon.size):
-            hdf[f'/pix/{lon[p]}/{lat[p]}'].attrs.update(i_lon=int(lon[p]), i_lat=int(lat[p]), nbest=int(nbest[p]))
+        with self._tree_lock:
+            for p in range(lon.size):
+                hdf[f'/pix/{lon[p]}/{lat[p]}'].attrs.update(i_lon=int(lon[p]), i_lat=int(lat[p]), nbest=int(nbest[p]))
 
     def fit_cube(self, store_name='run/test_cube', nproc=1, rank=None, file_format=None):
         """Creates the store, fits every pixel and links the chunk files (main.py:476-526).

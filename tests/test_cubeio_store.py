@@ -269,6 +269,16 @@ def test_real_cube_likelihood_and_fit(engine, nfo, stack, tmp_path):
             one = g['1']
             assert one.attrs['ncomp'] == 1 and one.attrs['n_params'] == 6 and one.attrs['n_chan_tot'] == 758
             assert one['posteriors'].shape == (one.attrs['n_samples'], 8)
+        first = {g.name: (g.attrs['nbest'], g['1'].attrs['global_lnZ'], g['1']['posteriors'].copy()) for g in groups}
+    # the groups of pixels (one per number of live points) are sampled side by side by default: one after the other
+    # the store comes out the same to the last bit
+    assert fitter.group_workers > 1
+    fitter.group_workers = 1
+    fitter.fit_cube(str(tmp_path / 'cutout_serial'), nproc=2)
+    with HdfStore(str(tmp_path / 'cutout_serial')) as store:
+        for g in store.iter_pix_groups():
+            nbest, lnz, post = first[g.name]
+            assert g.attrs['nbest'] == nbest and g['1'].attrs['global_lnZ'] == lnz and np.array_equal(g['1']['posteriors'], post)
             assert one['marginals'].shape == (15, 6) and one['bestfit_params'].shape == (6,)
             assert np.isfinite(one.attrs['global_lnZ'])
             if g.attrs['nbest'] >= 1:
