@@ -212,7 +212,8 @@ def _write_items_fast(h, loc, items, is_dataset, what):
             raise TypeError('more than eight axes')
         for j, d in enumerate(shape):
             dims[8 * i + j] = d
-        data[i] = _ptr(buf)
+        # (the address without a ctypes object per item: there are some fifty items per fitted pixel)
+        data[i] = buf.__array_interface__['data'][0] if isinstance(buf, np.ndarray) else C.addressof(buf)
     rc = h.nfa_h5_write_items(loc, int(is_dataset), n, names, types, ndims, dims, data)
     if rc != 0:
         raise Hdf5Error(f'HDF5: writing {what} {items[rc - 1][0] if rc > 0 else ""} failed')

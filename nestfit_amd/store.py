@@ -178,6 +178,7 @@ class StoreFile(Group):
         self.mode = mode
         self.is_hdf5 = self.path.suffix in HDF5_SUFFIXES
         self._linked_files = {}                         # chunk files behind this file's external links
+        self._link_names = {}                           # file name to store in a link, per linked file
         if self.path.exists() and mode in ('a', 'r') and self.is_hdf5:
             hdf5.read_tree(self.path, self, self._resolve_external)
         elif self.path.exists() and mode in ('a', 'r'):
@@ -210,8 +211,11 @@ class StoreFile(Group):
         if child._root is self._root:
             return None
         other = child._root.path
-        same_dir = other.parent.resolve() == self.path.parent.resolve()
-        return (other.name if same_dir else str(other.resolve())), child.name
+        known = self._link_names.get(other)             # (one answer per linked file, not per pixel)
+        if known is None:
+            same_dir = other.parent.resolve() == self.path.parent.resolve()
+            known = self._link_names[other] = other.name if same_dir else str(other.resolve())
+        return known, child.name
 
     def _flush(self):
         if self.mode == 'r':
