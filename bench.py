@@ -14,9 +14,12 @@ data-path collective: the ranks only meet in the barrier / max-time reduction ar
 and in the end-of-run gather of per-pixel records (RCCL through the engine's C ABI, no torch).
 
 Every input of a timed block (the unit-cube rows of all its steps, the stripe, the prior tables) is
-resident in HBM before the clock starts.  A block is exactly K steps between barrier + device
-synchronisation on both sides; its time is the maximum over ranks.  `--blocks` R blocks are timed;
-`value` is the median block (whole-job evaluations / block time), `spread` holds min / max.
+resident in HBM before the clock starts.  A timed block is the K-step sequence of `--steps`, repeated back to
+back `repeats_per_block` times (chosen so that a block lasts >= 20 ms whatever K is: K = 20 steps alone are
+0.6 ms, of which the fill and drain of the launch pipeline are 12 %; every repeat works on unit-cube rows of its own)
+between barrier + device synchronisation on both sides; its time is the maximum over ranks and `ms_per_step` =
+block time / (K x repeats).  `--blocks` blocks are timed; `value` is the median block (whole-job evaluations /
+block time), `spread` holds min / max; `k_steps_alone` is the same for blocks of exactly K steps.
 The three numerical modes are timed in the same run (`modes`); `value` is the fast mode, whose
 arithmetic `dtype` states.  `roofline`: algorithmic bytes per launch / the average duration of
 lnl_kernel, measured live with HIP events on a one-lane runner (launches do not overlap there, so
@@ -52,7 +55,17 @@ WORKLOADS = {
     'C4': ((1, 2, 3), 2048, 40.0, 3, 'TRUTH_3COMP', 4096),
     'C1': ((1,), 256, 30.0, 1, 'TRUTH_1COMP', 4096),
 }
-PROFILE_DIR = ROOT / 'profiles' / 'r02'
+PROFILE_DIRS = [ROOT / 'profiles' / 'r03', ROOT / 'profiles' / 'r02']
+MIN_BLOCK_S = 0.020            # a timed block lasts at least this long (the K-step sequence is repeated)
+MAX_BLOCK_STEPS = 4096
+
+
+def profile_file(name):
+    """The committed profiler summary `name` of the latest round that has one (or None)."""
+    for d in PROFILE_DIRS:
+        if (d / name).exists():
+            return d / name
+    return None
 
 
 def algorithmic_bytes(trans, n_chan, ncomp):
@@ -192,15 +205,33 @@ def bench_c5(args):
 
 
 def relaunch_one_rank_per_gpu(args):
-    """`python bench.py --gpus N` without a launcher: start one rank per GPU as child processes (this
-    process has not touched the GPU yet and never will) and pass their output through."""
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as child processes with the
+    launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT).  This process has not
+    touched the GPU and never will; the children are plain `python bench.py ...` processes (no exec from a
+    process with a GPU context, no torch)."""
     import socket
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-           '--master-addr', '127.0.0.1', '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:                # one rank failed: the others would wait for it in a barrier forever
+                    q.terminate()
+    raise SystemExit(rc)
 
 
 def main():
@@ -277,7 +308,6 @@ def main():
         B = args.batch
     ndim = 6 * ncomp
     noise = 0.2
-    n_steps = args.warmup + args.steps
     per_row = args.pixels_per_step == 'B'
     if per_row and args.side * args.side // world < B:
         raise SystemExit('--pixels-per-step B needs a stripe of at least B pixels')
@@ -286,53 +316,77 @@ def main():
     n_pix = cube.n_pix
     rh = cube._run.handle
 
-    # inputs of all steps of a block resident in HBM before the clock starts
-    U_host = np.random.default_rng(7 + rank).uniform(size=(B, ndim))
-    U_all = np.ascontiguousarray(np.broadcast_to(U_host, (n_steps, B, ndim)))
-    if per_row:
-        pix_all = ((np.arange(n_steps)[:, None] * 977 + np.arange(B)[None, :]) % n_pix).astype(np.int32)
-    else:
-        pix_all = np.repeat((np.arange(n_steps) % n_pix).astype(np.int32)[:, None], B, axis=1)
-    pix_all = np.ascontiguousarray(pix_all)
-    d_U, d_lnL, d_pix = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    _ffi.check(lib.nfa_malloc(C.byref(d_U), U_all.nbytes))
-    _ffi.check(lib.nfa_malloc(C.byref(d_lnL), n_steps * B * 8))        # one result vector per step
-    _ffi.check(lib.nfa_malloc(C.byref(d_pix), pix_all.nbytes))
-    _ffi.check(lib.nfa_memcpy_h2d(d_pix, pix_all.ctypes.data_as(C.c_void_p), pix_all.nbytes))
+    # inputs of all steps of a block resident in HBM before the clock starts: unit-cube rows of its own for every
+    # step (a pass overwrites them with theta in place), the pixel index of every row, one result vector per step
+    U_host = np.ascontiguousarray(np.random.default_rng(7 + rank).uniform(size=(B, ndim)))
+    step_bytes = U_host.nbytes
+    buf = {'cap': 0, 'U': C.c_void_p(), 'lnL': C.c_void_p(), 'pix': C.c_void_p()}
 
-    def reset_inputs():       # a pass overwrites U with theta in place: fresh unit-cube rows for the next block
-        _ffi.check(lib.nfa_memcpy_h2d(d_U, U_all.ctypes.data_as(C.c_void_p), U_all.nbytes))
+    def alloc_inputs(n_cap):
+        for key in ('U', 'lnL', 'pix'):
+            if buf[key].value:
+                _ffi.check(lib.nfa_free(buf[key]))
+                buf[key] = C.c_void_p()
+        if per_row:
+            pix_all = (np.arange(n_cap)[:, None] * 977 + np.arange(B)[None, :]) % n_pix
+        else:
+            pix_all = np.repeat((np.arange(n_cap) % n_pix)[:, None], B, axis=1)
+        pix_all = np.ascontiguousarray(pix_all.astype(np.int32))
+        _ffi.check(lib.nfa_malloc(C.byref(buf['U']), n_cap * step_bytes))
+        _ffi.check(lib.nfa_malloc(C.byref(buf['lnL']), n_cap * B * 8))
+        _ffi.check(lib.nfa_malloc(C.byref(buf['pix']), pix_all.nbytes))
+        _ffi.check(lib.nfa_memcpy_h2d(buf['pix'], pix_all.ctypes.data_as(C.c_void_p), pix_all.nbytes))
+        buf['cap'] = n_cap
+
+    def reset_inputs(n):
+        """Fresh unit-cube rows for steps 0 .. n-1 (every step gets the same B rows): one upload, then copies on the
+        device that double the filled part."""
+        assert n <= buf['cap']
+        _ffi.check(lib.nfa_memcpy_h2d(buf['U'], U_host.ctypes.data_as(C.c_void_p), step_bytes))
+        have = 1
+        while have < n:
+            m = min(have, n - have)
+            _ffi.check(lib.nfa_memcpy_d2d(C.c_void_p(buf['U'].value + have * step_bytes), buf['U'], m * step_bytes))
+            have += m
 
     def step(handle, k):
         # consecutive steps may overlap on the device (stream lanes): no buffer is shared
-        _ffi.check(lib.nfa_runner_loglike_batch_dev(handle, C.c_void_p(d_pix.value + k * B * 4),
-                                                    C.c_void_p(d_U.value + k * B * ndim * 8),
-                                                    C.c_void_p(d_lnL.value + k * B * 8), B))
+        _ffi.check(lib.nfa_runner_loglike_batch_dev(handle, C.c_void_p(buf['pix'].value + k * B * 4),
+                                                    C.c_void_p(buf['U'].value + k * step_bytes),
+                                                    C.c_void_p(buf['lnL'].value + k * B * 8), B))
 
     def sync(handle):
         _ffi.check(lib.nfa_runner_synchronize(handle))
         _ffi.check(lib.nfa_device_synchronize())
 
-    def timed_blocks(handle, n_blocks):
-        """[seconds of each block]: exactly --steps steps between barrier + synchronise, max over ranks."""
+    def timed_blocks(handle, n_blocks, repeats):
+        """[seconds of each block]: `repeats` x --steps steps between barrier + synchronise, max (and min) over ranks."""
         out = []
+        n_timed = args.steps * repeats
         for _ in range(n_blocks):
-            reset_inputs()
+            reset_inputs(args.warmup + n_timed)
             for k in range(args.warmup):
                 step(handle, k)
             sync(handle)
             comm.barrier()
             t0 = time.perf_counter()
-            for k in range(args.warmup, n_steps):
+            for k in range(args.warmup, args.warmup + n_timed):
                 step(handle, k)
-            t_enq = time.perf_counter() - t0         # host time to enqueue the K steps (diagnostic, NFA_BENCH_HOST=1)
+            t_enq = time.perf_counter() - t0         # host time to enqueue the steps (diagnostic, NFA_BENCH_HOST=1)
             sync(handle)
-            out.append(time.perf_counter() - t0)     # this rank's K steps; the block is the slowest rank's
+            out.append(time.perf_counter() - t0)     # this rank's steps; the block is the slowest rank's
             if os.environ.get('NFA_BENCH_HOST') and rank == 0:
-                print(f'host enqueue {t_enq / args.steps * 1e6:.1f} us/step of {out[-1] / args.steps * 1e6:.1f}', file=sys.stderr)
+                print(f'host enqueue {t_enq / n_timed * 1e6:.1f} us/step of {out[-1] / n_timed * 1e6:.1f}', file=sys.stderr)
             comm.barrier()
         mine = np.array(out)
         return comm.allreduce(mine, 'max'), comm.allreduce(mine, 'min')
+
+    def repeats_for(handle):
+        """How often the K-step sequence is repeated inside a timed block so that the block lasts MIN_BLOCK_S: from
+        two probe blocks of K steps (the slowest rank's time, so that every rank repeats alike)."""
+        t, _ = timed_blocks(handle, 2, 1)
+        r = int(np.ceil(MIN_BLOCK_S / float(t.min())))
+        return max(1, min(r, MAX_BLOCK_STEPS // args.steps if args.steps <= MAX_BLOCK_STEPS else 1))
 
     def one_lane_kernel_times(spl=1):
         """(lnl_kernel us, set-up kernel us, launches) on a one-lane runner: launches do not overlap, a
@@ -342,17 +396,18 @@ def main():
         _ffi.set_option('streams', 1)
         solo = _RunnerHandle(cube._ss, ut, ncomp, False, False)
         _ffi.set_option('streams', args.streams if args.streams else 0)
-        n = max(1, min(60, n_steps) // spl)
+        n_have = min(60, buf['cap'])
+        n = max(1, n_have // spl)
 
         def launch(k):
-            _ffi.check(lib.nfa_runner_loglike_batch_dev(solo.handle, C.c_void_p(d_pix.value + k * spl * B * 4),
-                                                        C.c_void_p(d_U.value + k * spl * B * ndim * 8),
-                                                        C.c_void_p(d_lnL.value + k * spl * B * 8), spl * B))
-        reset_inputs()
+            _ffi.check(lib.nfa_runner_loglike_batch_dev(solo.handle, C.c_void_p(buf['pix'].value + k * spl * B * 4),
+                                                        C.c_void_p(buf['U'].value + k * spl * step_bytes),
+                                                        C.c_void_p(buf['lnL'].value + k * spl * B * 8), spl * B))
+        reset_inputs(n_have)
         for k in range(min(5, n)):
             launch(k)
         sync(solo.handle)
-        reset_inputs()
+        reset_inputs(n_have)
         _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 1))
         for k in range(n):
             launch(k)
@@ -375,27 +430,40 @@ def main():
     lanes_used = args.streams or (6 if 4 * launch_units >= 3 * slots and 2 * launch_units <= 3 * slots else 4)
     modes = list(MODES) if args.modes == 'all' else [args.exp_mode]
     per_mode = {}
-    evals_per_block = args.steps * B * world
     bytes_eval = algorithmic_bytes(trans, n_chan, ncomp)
+    # buffers for the longest block any mode will run: sized from a probe in the fastest mode of the run
+    alloc_inputs(args.warmup + args.steps)
+    na.set_exp_mode('fast' if 'fast' in modes else modes[0])
+    r_cap = repeats_for(rh) + 1
+    alloc_inputs(args.warmup + max(args.steps * r_cap, min(60, args.warmup + args.steps)))
     for mode in modes:
         na.set_exp_mode(mode)
         n_blocks = args.blocks if mode == args.exp_mode else max(3, args.blocks // 3)
-        t, t_fastest = timed_blocks(rh, n_blocks)
+        repeats = min(r_cap, repeats_for(rh))
+        steps_block = args.steps * repeats
+        evals_per_block = steps_block * B * world
+        t, t_fastest = timed_blocks(rh, n_blocks, repeats)
         med = float(np.median(t))
-        entry = {'value': evals_per_block / med, 'ms_per_step': med / args.steps * 1e3, 'blocks': int(n_blocks),
+        entry = {'value': evals_per_block / med, 'ms_per_step': med / steps_block * 1e3, 'blocks': int(n_blocks),
+                 'repeats_per_block': repeats, 'block_ms': med * 1e3,
                  'min': evals_per_block / float(t.max()), 'max': evals_per_block / float(t.min()), 'dtype': DTYPES[mode]}
         if world > 1:
             # the slowest and the fastest rank of the median block: their ratio - 1 is the imbalance of the stripes
             k_med = int(np.argsort(t)[len(t) // 2])
-            entry['rank_ms_per_step'] = {'slowest': float(t[k_med]) / args.steps * 1e3,
-                                         'fastest': float(t_fastest[k_med]) / args.steps * 1e3}
+            entry['rank_ms_per_step'] = {'slowest': float(t[k_med]) / steps_block * 1e3,
+                                         'fastest': float(t_fastest[k_med]) / steps_block * 1e3}
+        if mode == args.exp_mode and repeats > 1:
+            # blocks of exactly K steps, nothing repeated: what the fill and drain of the launch pipeline cost a short block
+            tk, _ = timed_blocks(rh, max(3, args.blocks // 3), 1)
+            entry['k_steps_alone'] = {'value': args.steps * B * world / float(np.median(tk)),
+                                      'ms_per_step': float(np.median(tk)) / args.steps * 1e3, 'block_ms': float(np.median(tk)) * 1e3}
         if mode == args.exp_mode and steps_per_launch > 1 and not args.skip_single_step:
             # the same blocks with every step launched on its own
             _ffi.set_option('coalesce', 1)
-            ta, _ = timed_blocks(rh, max(3, args.blocks // 3))
+            ta, _ = timed_blocks(rh, max(3, args.blocks // 3), repeats)
             _ffi.set_option('coalesce', group)
             entry['one_step_per_launch'] = {'value': evals_per_block / float(np.median(ta)),
-                                            'ms_per_step': float(np.median(ta)) / args.steps * 1e3}
+                                            'ms_per_step': float(np.median(ta)) / steps_block * 1e3}
         if rank == 0 and world == 1 and not per_row:
             # the launch as the engine makes it (steps_per_launch steps together), alone on one lane ...
             lnl_us, setup_us, n_l = one_lane_kernel_times(steps_per_launch)
@@ -410,8 +478,9 @@ def main():
 
     # results of the last step, for the end-of-run gather and a sanity check
     lnL = np.empty(B)
+    n_steps = args.warmup + args.steps
     _ffi.check(lib.nfa_memcpy_d2h(lnL.ctypes.data_as(C.c_void_p),
-                                  C.c_void_p(d_lnL.value + (n_steps - 1) * B * 8), B * 8))
+                                  C.c_void_p(buf['lnL'].value + (n_steps - 1) * B * 8), B * 8))
     if not np.isfinite(lnL).all():
         raise SystemExit('non-finite log-likelihood in the benchmark batch')
     # end-of-run gather of fixed-size per-pixel records: here (i_lon, i_lat, rank, best lnL
@@ -420,6 +489,12 @@ def main():
     rec = np.array([[lon[k_last], lat[k_last], rank, float(lnL.max()), float(args.steps * B)]])
     allrec = nfcomm.gather_pixel_records(rec, comm)
     assert allrec.shape == (world, 5) and (allrec[:, 0] % world == allrec[:, 2]).all()
+
+    # which device every rank computes on (two ranks on one GPU, or a silent fallback, show on the line)
+    ubuf = C.create_string_buffer(40)
+    _ffi.check(lib.nfa_device_uuid(ubuf, 40))
+    mine = np.frombuffer(bytes.fromhex(ubuf.value.decode()), dtype=np.uint8).astype(np.float64)
+    uuids = [bytes(row.astype(np.uint8)).hex() for row in comm.allgather(mine).reshape(world, 16)]
 
     if rank == 0:
         head = per_mode[args.exp_mode]
@@ -431,9 +506,7 @@ def main():
         if 'lnl_kernel_us' in head:
             ach = bytes_eval * B * steps_per_launch / (head['lnl_kernel_us'] * 1e-6) / 1e9
             roof.update({'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'avg_launch_us': head['lnl_kernel_us'],
-                         'setup_kernel_us': head['setup_kernel_us'],
-                         'rocprof': 'profiles/r02/onelane_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- '
-                                    'python bench.py --streams 1 --modes one --no-cpu-baseline)'})
+                         'setup_kernel_us': head['setup_kernel_us']})
             if 'single_step_launch' in head:
                 roof['single_step_launch'] = head['single_step_launch']
         pipe = bytes_eval * B * world / step_s / 1e9
@@ -441,31 +514,38 @@ def main():
                             'note': 'the same bytes / the time per step of the timed blocks (the engine launches '
                                     f'{steps_per_launch} step(s) together and overlaps launches on its stream lanes): '
                                     'the rate the job sustains, a hard bound on the kernel'}
-        # figures that need their own profiler passes come from the committed summaries of the round
+        # figures that need their own profiler passes come from the committed summaries of the latest round that has them
+        def rel(path):
+            return str(path.relative_to(ROOT))
         try:
-            pmc = json.loads((PROFILE_DIR / 'pmc_lnl_fast.json').read_text())
+            f = profile_file('pmc_lnl_fast.json')
+            pmc = json.loads(f.read_text())
             roof['valu'] = {'busy_frac_one_lane': pmc.get('valu_busy_frac'),
                             'valu_instructions_per_eval': pmc['instructions_per_eval'].get('valu'),
                             'salu_instructions_per_eval': pmc['instructions_per_eval'].get('salu'),
-                            'source': 'profiles/r02/pmc_lnl_fast.json (rocprofv3 --pmc passes of the one-lane command, profiles/collect_r02.sh pmc)'}
+                            'source': f'{rel(f)} (rocprofv3 --pmc passes of the one-lane command, profiles/collect_round.sh pmc)'}
         except Exception:
             pass
         try:
-            tr = json.loads((PROFILE_DIR / 'pmc_traffic.json').read_text())
+            f = profile_file('pmc_traffic.json')
+            tr = json.loads(f.read_text())
             key = 'pixel_per_item' if per_row else 'one_pixel'
             # measured per 4096-row batch; a launch of coalesced steps moves that once per step
             roof['traffic'] = tr['detail'][args.exp_mode][key]['total_bytes'] * steps_per_launch if args.workload == 'C2' and B == 4096 else None
-            roof['traffic_source'] = 'profiles/r02/pmc_traffic.json (FETCH_SIZE x calibration + WRITE_SIZE, separate passes, per 4096-row batch) x steps_per_launch'
+            roof['traffic_source'] = f'{rel(f)} (FETCH_SIZE x calibration + WRITE_SIZE, separate passes, per 4096-row batch) x steps_per_launch'
         except Exception:
             pass
         try:
             import csv
-            with open(PROFILE_DIR / 'onelane_kernel_stats.csv') as f:
-                for row in csv.DictReader(f):
+            f = profile_file('onelane_kernel_stats.csv')
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
                     if row['Name'].startswith('void lnl_kernel<2, false, false, 2>') and args.workload == 'C2' and B == 4096:
                         us = float(row['AverageNs']) * 1e-3
                         roof['rocprof_avg_launch_us'] = us
                         roof['rocprof_frac'] = bytes_eval * B * steps_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                        roof['rocprof'] = (f'{rel(f)} (rocprofv3 --kernel-trace --stats -- python bench.py --streams 1 '
+                                           '--modes one --no-cpu-baseline --skip-single-step)')
         except Exception:
             pass
         roof['note'] = ('achieved / frac: algorithmic bytes (SURVEY 8d) per launch / lnl_kernel time per launch -- the launch the '
@@ -477,6 +557,17 @@ def main():
         cpu = None
         if args.gpus == 1 and not args.no_cpu_baseline and not per_row:
             cpu = cpu_baseline(spec0, ut.lower(), ncomp, U_host)
+            # the port beside the real reference.  The reference cannot travel; its rate at this shape
+            # was measured in the build container and the port was timed on the same CPU there
+            # (scripts/measure_port_vs_reference.py): ratio_to_reference = port / reference, per core.
+            f = profile_file('port_vs_reference.json')
+            if f is not None and args.workload == 'C2':
+                pv = json.loads(f.read_text())
+                ratio = pv['ratio_to_reference']
+                cpu['ratio_to_reference'] = ratio
+                cpu['reference_equivalent'] = cpu['value'] / ratio
+                cpu['ratio_source'] = f'{f.relative_to(ROOT)}: port {pv["port_evals_per_s_one_core"]:.0f} evals/s against the ' \
+                                      f'reference\'s {pv["reference_evals_per_s_one_core"]:.0f} on one core of the same CPU'
         name = C.create_string_buffer(128)
         lib.nfa_device_name(name, 128)
         metric = 'loglikelihood evals/sec, 1024-ch 2-comp NH3(1,1)+(2,2); HBM GB/s vs peak'
@@ -493,6 +584,11 @@ def main():
                             f'{args.side}x{args.side}, one pixel per '
                             + ('ROW (one evaluation per pixel)' if per_row else 'step'),
                 'exp_mode': args.exp_mode, 'stream_lanes': lanes_used, 'steps_per_launch': steps_per_launch, 'pixels_per_gpu': int(n_pix),
+                'repeats_per_block': head['repeats_per_block'], 'block_ms': head['block_ms'],
+                'comm': comm_kind, 'devices': uuids,
+                **({'rccl_fallback': 'RCCL did not come up on every rank: barrier / max-time / record gather went over TCP sockets'}
+                   if comm_kind == 'tcp' and not same_gpu else {}),
+                **({'ranks_share_a_device': True} if len(set(uuids)) < world else {}),
                 'sharding': 'pixel stripes i_lon % world (nestfit/main.py:565-571), no data-path collective; '
                             'barrier / max-time / record gather over '
                             + {'rccl': 'RCCL (nfa_comm_*)', 'tcp': 'TCP sockets (ranks share a GPU, or RCCL did not start)',
@@ -505,11 +601,12 @@ def main():
         }
         if cpu:
             line['speedup_vs_cpu_all_cores'] = value / cpu['value']
+            if 'reference_equivalent' in cpu:       # against what the reference itself would deliver on these cores
+                line['speedup_vs_reference_all_cores'] = value / cpu['reference_equivalent']
         print(json.dumps(line), flush=True)
 
-    lib.nfa_free(d_U)
-    lib.nfa_free(d_lnL)
-    lib.nfa_free(d_pix)
+    for key in ('U', 'lnL', 'pix'):
+        lib.nfa_free(buf[key])
     comm.barrier()
     stuck = getattr(comm, 'stuck_thread', None)
     comm.close()

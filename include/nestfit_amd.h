@@ -38,6 +38,8 @@ int nfa_device_count(int *count);
 int nfa_set_device(int device);              /* one process per GPU: call first */
 int nfa_device_synchronize(void);
 int nfa_device_name(char *buf, int buflen);
+/* the 16-byte UUID of the engine's device as 32 hex digits (two ranks that report the same one share a GPU) */
+int nfa_device_uuid(char *buf, int buflen);
 
 /* Numerical mode of the FastExp replacement (process default, 2 unless set; a runner can pin
  * its own with nfa_runner_set_exp_mode):
@@ -356,6 +358,7 @@ int nfa_malloc(void **dptr, int64_t bytes);
 int nfa_free(void *dptr);
 int nfa_memcpy_h2d(void *dst, const void *src, int64_t bytes);
 int nfa_memcpy_d2h(void *dst, const void *src, int64_t bytes);
+int nfa_memcpy_d2d(void *dst, const void *src, int64_t bytes);
 int nfa_event_create(void **ev);
 int nfa_event_destroy(void *ev);
 int nfa_event_record(void *ev, nfa_runner *r);       /* on the runner's stream */

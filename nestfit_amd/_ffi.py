@@ -42,6 +42,7 @@ SIGNATURES = {
     'nfa_set_device': (C.c_int, [C.c_int]),
     'nfa_device_synchronize': (C.c_int, []),
     'nfa_device_name': (C.c_int, [C.c_char_p, C.c_int]),
+    'nfa_device_uuid': (C.c_int, [C.c_char_p, C.c_int]),
     'nfa_set_exp_mode': (C.c_int, [C.c_int]),
     'nfa_get_exp_mode': (C.c_int, []),
     'nfa_set_option': (C.c_int, [C.c_char_p, C.c_int]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     'nfa_free': (C.c_int, [C.c_void_p]),
     'nfa_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     'nfa_memcpy_d2h': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'nfa_memcpy_d2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     'nfa_event_create': (C.c_int, [C.POINTER(C.c_void_p)]),
     'nfa_event_destroy': (C.c_int, [C.c_void_p]),
     'nfa_event_record': (C.c_int, [C.c_void_p, C.c_void_p]),

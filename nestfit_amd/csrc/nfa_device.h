@@ -64,6 +64,9 @@ __constant__ double c_ea[NFA_N_LEVELS];
 __constant__ double c_voff[NFA_T_ALL][NFA_MAX_HF_N];
 __constant__ double c_hfreq[NFA_T_ALL][NFA_MAX_HF_N];       // (1 - voff / CKMS) * nu of every line
 __constant__ double c_tauw[NFA_T_ALL][NFA_MAX_HF_N];
+// position of line i of transition t when the lines are ordered by their velocity offset (stable): in that order
+// the lines whose windows touch a row of channels form ONE run of neighbours (fast mode's line table, lnl_body)
+__constant__ unsigned char c_rank[NFA_T_ALL][NFA_MAX_HF_N];
 
 struct SpecDev {
     int     n_spec, ncomp, cold, lte;
@@ -488,6 +491,43 @@ __device__ __forceinline__ void line_step_fast(float &tau, int j, double xj, dou
                  : "vcc");
 }
 
+// Fast mode's line record (32 bytes, two 16-byte broadcast reads) and its line x row step.
+//   * the Gaussian argument as ((x - nucen) sq)^2 with sq = sqrt(0.5) / width: two fp64 multiplications
+//     instead of three.  The reference forms (x - nucen)^2 * idenom (hyperfine.pyx:94) before it narrows the
+//     argument to float (math.pxd:17); the two forms differ by a few 2^-53 relative, so the narrowed float is
+//     the reference's except where the exact value lies that close to a rounding boundary of the float grid:
+//     about one (line, channel) pair in 2e8, and then by one ulp of the float (<= 7.5e-7 of that one term).
+//   * the window [lo, lo + len) as |j - mid| < half in fp32 (mid = lo + (len - 1) / 2, half = len / 2: exact
+//     for spectra below 2^22 channels): an fp32 subtraction runs at twice the rate of an integer one.
+//   * exp as 2^yh (1 + r), r = -x - yh ln2 in ONE fused step (the exact product with the float nearest ln 2;
+//     what is dropped, yh (ln 2 - fl(ln 2)), is below 3.5e-8 relative inside a window, x <= 12.5).
+struct __attribute__((aligned(16))) FastRec {
+    double nucen, sq;
+    float htau, mid, half;
+    int pad;
+};
+__device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj, double nucen, double sq,
+                                                float htau, float mid, float half) {
+    double d;
+    float t0, t1, t2;
+    asm volatile("v_sub_f32 %[t0], %[jf], %[mid]\n\t"
+                 "v_cmpx_lt_f32_e64 vcc, |%[t0]|, %[half]\n\t"
+                 "v_add_f64 %[d], %[xj], -%[nucen]\n\t"
+                 "v_mul_f64 %[d], %[d], %[sq]\n\t"
+                 "v_mul_f64 %[d], %[d], %[d]\n\t"
+                 "v_cvt_f32_f64 %[t0], %[d]\n\t"                       // math.pxd:17 narrowing
+                 "v_mul_f32 %[t1], 0xbfb8aa3b, %[t0]\n\t"               // yh = -x log2(e)
+                 "v_exp_f32 %[t2], %[t1]\n\t"
+                 "v_fma_f32 %[t0], %[t1], %[kln2], -%[t0]\n\t"          // r = -x - yh ln2 (also the wait state behind v_exp)
+                 "v_fmac_f32 %[t2], %[t2], %[t0]\n\t"                   // e = 2^yh (1 + r)
+                 "v_fmac_f32 %[tau], %[htau], %[t2]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [tau] "+v"(tau), [d] "=&v"(d), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                 : [jf] "v"(jf), [mid] "v"(mid), [half] "v"(half), [xj] "v"(xj), [nucen] "v"(nucen),
+                   [sq] "v"(sq), [htau] "v"(htau), [kln2] "s"(-0.693147182464599609375f)
+                 : "vcc");
+}
+
 // The body of the likelihood kernel for workgroup `block_id` of a launch (lnl_kernel: the hardware's
 // workgroup; point_kernel: the one workgroup walks the few of a single point).  `sm` = the staged
 // exponential tables (n_shared doubles at the start of smem), the line tables follow them.
@@ -499,6 +539,12 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                                          const BatchGroup *grp = nullptr) {
     typedef typename std::conditional<MODE == 2, float, double>::type tau_t;
     constexpr int NC = NCOMP > 0 ? NCOMP : 1;
+    // fast mode, at most 26 lines per transition: FastRec records in velocity order, windows in an array of their own
+#ifdef NFA_LEGACY_STEP          // A/B builds only: round 2's line step (LineRec records, integer window test, three fp64 products)
+    constexpr bool FASTN = false;
+#else
+    constexpr bool FASTN = MODE == 2 && !WIDE;
+#endif
     const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
 
 #ifdef NFA_ABLATE
@@ -533,6 +579,8 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const int rpart = (int)(wsel & (unsigned)(split - 1));
     const unsigned unit = block_id * upw + ulocal;
     LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)ulocal * G.wave_doubles);
+    FastRec *f_line = (FastRec *)w_line;                                   // FASTN: the same slots hold FastRec records ...
+    int2 *w_win = (int2 *)(w_line + (NCOMP > 0 ? NCOMP : S.ncomp) * G.nhf_max);   // ... and their windows [lo, hi) follow
     // split > 1: the parts' per-lane sums meet here, [unit of the workgroup][part][lane]
     double *w_part = smem + n_shared + (size_t)upw * G.wave_doubles + (size_t)ulocal * (LNL_PARTS * 64);
     if (unit >= units) {
@@ -558,8 +606,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // --- line constants + windows, lanes = (component, line) pairs (hyperfine.pyx:68-91)
     for (int p = lane; p < ncomp * G.nhf_max && !(ablate & 8) && rpart == 0; p += 64) {
         const int c = G.inv_nhf ? (int)__umulhi((unsigned)p, G.inv_nhf) : p, i = p - c * G.nhf_max;     // inv_nhf == 0: one line per component
-        LineRec rec;
-        rec.nucen = 0.0; rec.idenom = 0.0; rec.htau = 0.0; rec.lo = 0; rec.len = 0;   // slots beyond the last line
+        // slots beyond the last line: empty windows
+        double r_nucen = 0.0, r_idenom = 0.0, r_htau = 0.0;
+        int r_lo = 0, r_len = 0, slot = p;
         if (i < nhf) {
             const LineConst lc = nf_line(t, i, D[b * drec + c * 4 + 2], D[b * drec + c * 4 + 1], nu0, S.nu_min[s],
                                          S.nu_chan[s], N);
@@ -576,15 +625,31 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             // a centre or a width that is not a finite number gives FastExp NaN or inf at every channel: 0 each
             // time (fastexp.c:272-273), i.e. a line that adds nothing -- an empty window says the same
             if (!(fabs(lc.nucen) < INFINITY) || !(lc.idenom < INFINITY)) lo = hi;
-            rec.nucen = lc.nucen;
-            rec.idenom = lc.idenom;
-            const double htau = D[b * drec + 4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
-            // fast mode keeps the weight as a float in the low word (no union store: that goes through scratch)
-            rec.htau = MODE == 2 ? __longlong_as_double((long long)__float_as_uint((float)htau)) : htau;
-            rec.lo = lo;
-            rec.len = hi > lo ? hi - lo : 0;
+            r_nucen = lc.nucen;
+            r_idenom = lc.idenom;
+            r_htau = D[b * drec + 4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
+            r_lo = lo;
+            r_len = hi > lo ? hi - lo : 0;
+            if (FASTN) slot = c * G.nhf_max + c_rank[t][i];        // velocity order: the lines of a row are neighbours
         }
-        w_line[p] = rec;
+        if constexpr (FASTN) {
+            FastRec fr;
+            fr.nucen = r_nucen;
+            fr.sq = sqrt(r_idenom);                              // correctly rounded (no fast-math)
+            fr.htau = (float)r_htau;
+            fr.mid = (float)r_lo + 0.5f * (float)(r_len - 1);
+            fr.half = 0.5f * (float)r_len;                       // an empty window: half = 0, no channel passes
+            fr.pad = 0;
+            f_line[slot] = fr;
+            w_win[slot] = make_int2(r_lo, r_lo + r_len);
+        } else {
+            LineRec rec;
+            rec.nucen = r_nucen; rec.idenom = r_idenom;
+            // fast mode keeps the weight as a float in the low word (no union store: that goes through scratch)
+            rec.htau = MODE == 2 ? __longlong_as_double((long long)__float_as_uint((float)r_htau)) : r_htau;
+            rec.lo = r_lo; rec.len = r_len;
+            w_line[p] = rec;
+        }
     }
     if (split > 1) __syncthreads(); else wave_lds_sync();
     // windows [lo, hi) of the lines of each component, lane = line (an empty window is [0, 0):
@@ -593,7 +658,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // fast mode, two components (at most 26 lines each): both components' windows in one register pair, lanes
     // 0..31 the first component's lines, lanes 32..63 the second's -- two compares per row instead of four
     // (a compare costs as much as an fp64 operation, profiles/r02/ubench_valu.txt)
-        constexpr bool PACK2 = MODE == 2 && !WIDE && NCOMP == 2;
+    constexpr bool PACK2 = MODE == 2 && !WIDE && NCOMP == 2;
     int wlo2 = 0, whi2 = 0;
     double ck_kind[NC], ck_a0x[NC], ck_b0x[NC];
     // the LDS address of each component's line table as a per-lane value, formed once: a line's record address
@@ -601,30 +666,24 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // scalar instructions and a move per step; the scalar unit is the shared resource, see the header)
     typedef const __attribute__((address_space(3))) char *lds_char_p;
     unsigned lbase_c[NC];
+    // window [lo, hi) of line `l` of component `c` (0, 0 for l beyond the table)
+    auto window_of = [&](int c, int l, int &lo, int &hi) {
+        const int k = c * G.nhf_max + (l < G.nhf_max ? l : 0);
+        if constexpr (FASTN) { const int2 w = w_win[k]; lo = w.x; hi = w.y; }
+        else { const LineRec *q = w_line + k; lo = q->lo; hi = lo + q->len; }
+        if (!(l < G.nhf_max) || (ablate & 8)) { lo = 0; hi = 0; }
+    };
     if (NCOMP > 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const LineRec *q = w_line + c * G.nhf_max + (lane < G.nhf_max ? lane : 0);
-            if (!PACK2) {
-                const int lo = q->lo, len = q->len;
-                wlo[c] = lane < G.nhf_max ? lo : 0;
-                whi[c] = lane < G.nhf_max ? lo + len : 0;
-                if (ablate & 8) { wlo[c] = 0; whi[c] = 0; }
-            }
+            if (!PACK2) window_of(c, lane, wlo[c], whi[c]);
             lbase_c[c] = (unsigned)(uintptr_t)(lds_char_p)(w_line + c * G.nhf_max);
             asm volatile("" : "+v"(lbase_c[c]));
             const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
             ck_kind[c] = Dk[dko + DK_KIND]; ck_a0x[c] = Dk[dko + DK_A0X]; ck_b0x[c] = Dk[dko + DK_B0X];
         }
     }
-    if (PACK2) {
-        const int l = lane & 31;
-        const LineRec *q = w_line + (lane >> 5) * G.nhf_max + (l < G.nhf_max ? l : 0);
-        const int lo = q->lo, len = q->len;
-        wlo2 = l < G.nhf_max ? lo : 0;
-        whi2 = l < G.nhf_max ? lo + len : 0;
-        if (ablate & 8) { wlo2 = 0; whi2 = 0; }
-    }
+    if (PACK2) window_of(lane >> 5, lane & 31, wlo2, whi2);
     // --- rows of 64 channels: tau profile, Tb, chi^2 (hyperfine.pyx:93-113, core.pyx:522-530)
     const double *t0s = S.t0 + off, *tbgs = S.tbg + off, *p3s = S.t0tbg + off;
     const double *ds = S.data + p_ix * S.chan_tot + off;
@@ -641,6 +700,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     for (int row = h; row < n_rows; row += LNL_PARTS) {
         const int r0 = row << 6;
         const int j = r0 + lane;
+        const float jf = (float)j;                                 // FASTN: the window test runs in fp32
         // lines of each component that touch this row
         unsigned long long hitm[NC];
         bool any = false;
@@ -657,9 +717,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             }
         } else {
             for (int c = 0; c < ncomp && !any; ++c) {
-                const LineRec *q = w_line + c * G.nhf_max + (lane < G.nhf_max ? lane : 0);
-                const int lo = q->lo, hi = lo + q->len;
-                any = __builtin_amdgcn_ballot_w64((lane < G.nhf_max) & (lo < r0 + 64) & (hi > r0) & (hi > lo)) != 0ull;
+                int lo, hi;
+                window_of(c, lane, lo, hi);
+                any = __builtin_amdgcn_ballot_w64((lo < r0 + 64) & (hi > r0) & (hi > lo)) != 0ull;
             }
         }
         if (any || WRITE_SPEC) {
@@ -713,7 +773,41 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     }
                 };
                 if (ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); }
-                                else if ((MODE == 2 && !WIDE) || nhf <= 32) {         // every NH3 transition (the fast mode's narrow form holds at most 26 lines: no test): 32-bit mask arithmetic
+                else if constexpr (FASTN) {
+                    // The table is in velocity order, so the lines of this row are the run from the lowest to the highest
+                    // set bit of the mask (a line inside the run whose window misses the row -- widths differ by 1e-4 from
+                    // line to line -- finds no lane in its window and adds nothing).  The run is walked two lines at a
+                    // time: the records of a pair are four reads off one address, which advances once per pair.
+                    const unsigned m = (unsigned)mask;
+                    const int first = __builtin_ctz(m);
+                    int n = 32 - __builtin_clz(m) - first;
+                    unsigned va = lbase + ((unsigned)first << 5);
+                    asm volatile("" : "+v"(va));
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    typedef const __attribute__((address_space(3))) v2d *lds_v2d_p;
+                    typedef const __attribute__((address_space(3))) v4f *lds_v4f_p;
+                    if (n & 1) {
+                        const v2d ab = *(lds_v2d_p)(uintptr_t)va;
+                        const v4f hw = *(lds_v4f_p)(uintptr_t)(va + 16);
+                        line_step_fastz(tau, jf, xj, ab.x, ab.y, hw.x, hw.y, hw.z);
+                        va += 32;
+                        asm volatile("" : "+v"(va));
+                        n -= 1;
+                    }
+                    while (n) {
+                        const v2d ab0 = *(lds_v2d_p)(uintptr_t)va;
+                        const v4f hw0 = *(lds_v4f_p)(uintptr_t)(va + 16);
+                        const v2d ab1 = *(lds_v2d_p)(uintptr_t)(va + 32);
+                        const v4f hw1 = *(lds_v4f_p)(uintptr_t)(va + 48);
+                        line_step_fastz(tau, jf, xj, ab0.x, ab0.y, hw0.x, hw0.y, hw0.z);
+                        line_step_fastz(tau, jf, xj, ab1.x, ab1.y, hw1.x, hw1.y, hw1.z);
+                        va += 64;
+                        asm volatile("" : "+v"(va));
+                        n -= 2;
+                    }
+                }
+                else if ((MODE == 2 && !WIDE) || nhf <= 32) {         // every NH3 transition (the fast mode's narrow form holds at most 26 lines: no test): 32-bit mask arithmetic
                     unsigned m = (unsigned)mask;
                     do {
                         const int i = __builtin_ctz(m);
@@ -776,10 +870,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     if (hitm[c] != 0ull) component(c, hitm[c], ck_kind[c], ck_a0x[c], ck_b0x[c]);
             } else {
                 for (int c = 0; c < ncomp; ++c) {
-                    const LineRec *q = w_line + c * G.nhf_max + (lane < G.nhf_max ? lane : 0);
-                    const int lo = q->lo, hi = lo + q->len;
-                    const unsigned long long mask =
-                        __builtin_amdgcn_ballot_w64((lane < G.nhf_max) & (lo < r0 + 64) & (hi > r0) & (hi > lo));
+                    int lo, hi;
+                    window_of(c, lane, lo, hi);
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64((lo < r0 + 64) & (hi > r0) & (hi > lo));
                     if (mask == 0ull) continue;
                     const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
                     component(c, mask, Dk[dko + DK_KIND], Dk[dko + DK_A0X], Dk[dko + DK_B0X]);

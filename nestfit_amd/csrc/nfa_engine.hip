@@ -128,6 +128,16 @@ static int engine_init_once() {
                 volatile double f = 1.0 - q;
                 h_hfreq[t][i] = f * h_nu[t];
             }
+        // rank of every line when a transition's lines are ordered by velocity offset (stable; nfa_device.h: c_rank)
+        static unsigned char h_rank[NFA_T_ALL][NFA_MAX_HF_N];
+        for (int t = 0; t < NFA_T_ALL; ++t) {
+            std::vector<int> order(h_nhf[t]);
+            for (int i = 0; i < h_nhf[t]; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h_voff[t][a] > h_voff[t][b]; });
+            for (int i = 0; i < NFA_MAX_HF_N; ++i) h_rank[t][i] = (unsigned char)i;
+            for (int k = 0; k < h_nhf[t]; ++k) h_rank[t][order[k]] = (unsigned char)k;
+        }
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_rank), h_rank, sizeof(h_rank)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hfreq), h_hfreq, sizeof(h_hfreq)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_nhf), h_nhf, sizeof(h_nhf)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_nu), h_nu, sizeof(h_nu)));
@@ -242,6 +252,15 @@ int nfa_device_name(char *buf, int buflen) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, g_eng.device));
     snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return NFA_OK;
+}
+
+int nfa_device_uuid(char *buf, int buflen) {
+    if (!buf || buflen < 33) return fail(NFA_ERR_ARG, "buffer too small for a UUID (33 bytes)");
+    int rc = engine_init(); if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g_eng.device));
+    for (int k = 0; k < 16; ++k) snprintf(buf + 2 * k, 3, "%02x", (unsigned)(unsigned char)prop.uuid.bytes[k]);
     return NFA_OK;
 }
 
@@ -413,9 +432,10 @@ int nfa_specset_null_lnz(const nfa_specset *ss, double *out) {
     HIP_TRY(hipMalloc(&d_out, sizeof(double) * n));
     hipLaunchKernelGGL(null_lnz_kernel, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, 0,
                        ss->dev, (long)ss->n_pix, d_out);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);                                     // on every path
+    if (e != hipSuccess) return fail(NFA_ERR_DEVICE, std::string("nfa_specset_null_lnz: ") + hipGetErrorString(e));
     return NFA_OK;
 }
 
@@ -718,6 +738,24 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     return NFA_OK;
 }
 
+// the fast mode's narrow form (FastRec records, fp32 window test): at most 26 lines per transition (a 32-bit line
+// mask per component) and channel indices that fp32 holds to the half (nfa_device.h: FastRec)
+static bool lnl_wide(const nfa_runner *r) {
+    int max_size = 0;
+    for (int k = 0; k < r->ss->dev.n_spec; ++k) max_size = std::max(max_size, r->ss->dev.size[k]);
+    return r->ss->nhf_max > 26 || max_size > (1 << 22);
+}
+// LDS doubles per (item, spectrum) unit: the line table (32-byte records, nhf_max per component), in the fast mode's
+// narrow form followed by the windows (two ints per line)
+static int lnl_wave_doubles(const nfa_runner *r, int mode) {
+#ifdef NFA_LEGACY_STEP
+    const int per_line = (int)(sizeof(LineRec) / sizeof(double));
+#else
+    const int per_line = (int)(sizeof(LineRec) / sizeof(double)) + ((mode == 2 && !lnl_wide(r)) ? 1 : 0);
+#endif
+    return (r->ncomp * r->ss->nhf_max * per_line + 1) & ~1;          // 16-byte records: an even number of doubles
+}
+
 // waves per unit of a launch of B items (runner option lnl_split; 0 = by the size of the launch)
 static int resolve_split(const nfa_runner *r, const SpecDev &S, int64_t B) {
     int split = r->lnl_split;
@@ -747,8 +785,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     // gives the hardware shorter waves to place as slots free up (a single point: 2 units -> 8 waves).
     const int split = resolve_split(r, S, B);
     G.split = split;
-    // LDS per wave: the line table of one spectrum (32-byte records, nhf_max per component)
-    G.wave_doubles = r->ncomp * G.nhf_max * (int)(sizeof(LineRec) / sizeof(double));
+    G.wave_doubles = lnl_wave_doubles(r, MODE);
     const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
     // waves per workgroup.  Table mode stages 51 KB of product tables per workgroup, so the
     // workgroup is made as fat as keeps the most waves resident per CU (ties: more workgroups,
@@ -816,7 +853,7 @@ static int launch_lnl(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, 
         return d_spec ? launch_lnl_n<1, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
                       : launch_lnl_n<1, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
     default:
-        if (r->ss->nhf_max > 26)        // more lines than any NH3 transition: fp64 running sum of tau
+        if (lnl_wide(r))                // more lines than any NH3 transition (or 2^22 channels): fp64 running sum of tau
             return d_spec ? launch_lnl_n<2, true, true>(r, d_pix, slot, d_lnL, d_spec, B)
                           : launch_lnl_n<2, false, true>(r, d_pix, slot, d_lnL, d_spec, B);
         return d_spec ? launch_lnl_n<2, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
@@ -1014,7 +1051,7 @@ static void launch_point_n(nfa_runner *r, const SpecDev &S, const PointIn &in, c
 
 static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, double *lnL, int64_t B) {
     const int ndim = r->ndim;
-    if (!g_eng.point || r->profiling || ndim > NFA_POINT_MAXDIM || r->ss->nhf_max > 26 || B > NFA_POINT_MAXB) return 0;
+    if (!g_eng.point || r->profiling || ndim > NFA_POINT_MAXDIM || lnl_wide(r) || B > NFA_POINT_MAXB) return 0;
     const int mode = r->exp_mode >= 0 ? r->exp_mode : g_eng.exp_mode;
     const SpecDev S = runner_specdev(r);
     LnlGeom G;
@@ -1024,7 +1061,7 @@ static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, doubl
     G.inv_nhf = G.nhf_max == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)G.nhf_max) + 1u;
     G.split = resolve_split(r, S, 1);
     if (G.split > POINT_WAVES) return 0;
-    G.wave_doubles = r->ncomp * G.nhf_max * (int)(sizeof(LineRec) / sizeof(double));
+    G.wave_doubles = lnl_wave_doubles(r, mode);
     const int upw = POINT_WAVES / G.split;                       // units per pass of the workgroup
     const int n_shared = mode == 0 ? (SM_END_TABLE - SM_EXP2) : (mode == 1 ? 32 : 0);
     // the set-up stage and the likelihood waves use the same LDS one after the other, behind the staged tables
@@ -1041,7 +1078,6 @@ static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, doubl
         if (!ok) {
             (void)hipGetLastError();
             if (r->h_point) (void)hipHostFree(r->h_point);
-    if (r->d_point_done) (void)hipFree(r->d_point_done);
             if (r->d_point_done) (void)hipFree(r->d_point_done);
             r->h_point = nullptr; r->d_point_done = nullptr;
             g_eng.point = 0;
@@ -1256,6 +1292,9 @@ int nfa_memcpy_h2d(void *dst, const void *src, int64_t bytes) {
 }
 int nfa_memcpy_d2h(void *dst, const void *src, int64_t bytes) {
     HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost)); return NFA_OK;
+}
+int nfa_memcpy_d2d(void *dst, const void *src, int64_t bytes) {
+    HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice)); return NFA_OK;
 }
 int nfa_event_create(void **ev) {
     int rc = engine_init(); if (rc) return rc;
