@@ -264,25 +264,36 @@ int  nfa_broker_stats(nfa_broker *b, int64_t *out);
  * POSIX shared-memory ring (`name`), owns one slot, and nfa_ring_loglike / nfa_ring_callback
  * (MultiNest's LogLike signature; context = nfa_ring_client) post the point there and sleep
  * until the ONE serving process has evaluated it together with the other processes' points:
- * nfa_ring_serve = nfa_ring_poll -> nfa_runner_loglike_batch (up to 128 points: one launch)
- * -> nfa_ring_complete, until nfa_ring_stop, max_batches (> 0) or idle_ms without a post.
+ * nfa_ring_serve = nfa_ring_poll -> nfa_runner_loglike_batch (up to 128 points: one launch;
+ * up to 1024 through the batch kernels) -> nfa_ring_complete, until nfa_ring_stop, max_batches
+ * (> 0) or idle_ms without a post.  A request that names a pixel the runner does not have fails
+ * alone (NFA_ERR_ARG to its client); a device error stops the ring.
  * Results are bitwise those of nfa_runner_loglike_batch.  poll / complete are public so that a
  * server can put its own evaluator between them.  All entry points except nfa_ring_serve are
  * also exported by libnestfit_amd_ring.so, which has no HIP in it: the one library a sampler
  * process loads. */
 typedef struct nfa_ring nfa_ring;
 typedef struct { nfa_ring *ring; int32_t pix; } nfa_ring_client;
-int  nfa_ring_create(nfa_ring **out, const char *name, int n_slots, int ndim);      /* server */
+int  nfa_ring_create(nfa_ring **out, const char *name, int n_slots, int ndim);      /* server; one point per slot */
+/* slots that hold up to max_points (<= 64) points each: for samplers that post several points per call */
+int  nfa_ring_create_multi(nfa_ring **out, const char *name, int n_slots, int ndim, int max_points);
 int  nfa_ring_attach(nfa_ring **out, const char *name, int wait_ms);                /* client: takes a slot */
 int  nfa_ring_close(nfa_ring *r);            /* client: gives the slot back; server: removes the ring */
 int  nfa_ring_stop(nfa_ring *r);             /* everybody leaves: blocked clients get NFA_ERR_STATE */
 int  nfa_ring_ndim(const nfa_ring *r);
 int  nfa_ring_slot(const nfa_ring *r);
+int  nfa_ring_max_points(const nfa_ring *r);
+/* blocking; NFA_ERR_STATE when the ring was stopped, its creator is gone, or no serving loop has been on it for 5 s */
 int  nfa_ring_loglike(nfa_ring *r, int32_t pix, double *cube, double *lnew);
+/* k points in one call (k <= max_points, all against pixel pix): cubes[k][ndim] in: unit cube, out: theta; lnew[k].
+ * MultiNest asks for one point per call; a sampler whose next k proposals do not depend on each other's
+ * likelihoods (uniform draws from the current bounding ellipsoid) posts them together and uses them in order */
+int  nfa_ring_loglike_many(nfa_ring *r, int32_t pix, double *cubes, double *lnew, int k);
 void nfa_ring_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx);
-/* slots[k], pix[k], U[k*ndim..]: request k of the *n gathered (at most max_batch); returns when every
- * attached client has posted, or max_wait_us after the first post; *n = 0 after idle_ms without a
- * post or when the ring was stopped (*stopped). */
+/* slots[k], pix[k], U[k*ndim..]: row k of the *n gathered points (at most max_batch; the points of one
+ * request are neighbouring rows with the same slot); returns when every attached client has posted, or
+ * max_wait_us after the first post; *n = 0 after idle_ms without a post or when the ring was stopped
+ * (*stopped).  nfa_ring_complete takes whole requests back, in one call or several. */
 int  nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, int32_t *slots,
                    int32_t *pix, double *U, int *n, int *stopped);
 int  nfa_ring_complete(nfa_ring *r, int n, const int32_t *slots, const double *U, const double *lnL, int rc);

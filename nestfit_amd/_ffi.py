@@ -83,12 +83,15 @@ SIGNATURES = {
     'nfa_broker_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
     'nfa_broker_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'nfa_ring_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int]),
+    'nfa_ring_create_multi': (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int, C.c_int]),
     'nfa_ring_attach': (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
     'nfa_ring_close': (C.c_int, [C.c_void_p]),
     'nfa_ring_stop': (C.c_int, [C.c_void_p]),
     'nfa_ring_ndim': (C.c_int, [C.c_void_p]),
     'nfa_ring_slot': (C.c_int, [C.c_void_p]),
+    'nfa_ring_max_points': (C.c_int, [C.c_void_p]),
     'nfa_ring_loglike': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+    'nfa_ring_loglike_many': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, C.c_int]),
     'nfa_ring_callback': (None, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_void_p]),
     'nfa_ring_poll': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, _ip, _ip, _dp, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int)]),

@@ -272,6 +272,27 @@ __device__ __forceinline__ double nf_fastexp(double xd, const double *sm) {
     return r;
 }
 
+// 1 - FastExp(tau) for the Tb pass of the exact modes (hyperfine.pyx:109-113), tau >= +0 or NaN: the same value,
+// bit for bit, as 1.0 - nf_fastexp<MODE, true>(tau, sm).  Most rows lie in the line wings, where every lane is
+// below 2^-5 and FastExp is its Taylor branch (fastexp.c:264-270): that branch is evaluated first, and the table
+// (or polynomial) form with its three gathers only when a lane of the row needs it.
+template <int MODE>
+__device__ __forceinline__ double nf_one_minus_fastexp_row(double tau, const double *sm) {
+    const float x = (float)tau;                               // math.pxd:17 narrowing
+    const double t = (double)x;
+    double r = 1.0 - t * (1.0 / 3.0);                         // x == 0 gives exactly 1
+    r = 1.0 - (t * r) * 0.5;
+    r = 1.0 - (t * r);
+    const uint32_t u = __float_as_uint(x) - (122u << 23);
+    const bool small = (int32_t)u < 0;                        // l < 0
+    if (__builtin_amdgcn_ballot_w64(!small) != 0ull) {
+        asm volatile("" ::: "memory");                        // keep it a branch
+        const double big = nf_fastexp<MODE, true>(tau, sm);   // the general form (rows at a line centre)
+        r = small ? r : big;
+    }
+    return 1.0 - r;
+}
+
 // exp(-x) in fp32 with the exponent split in two floats (MODE 2).  Like FastExp:
 // exactly 0 from x = 32 (and for NaN), exp(|x|) for negative x.
 __device__ __forceinline__ float exp_neg_f32(float x) {
@@ -359,10 +380,19 @@ __device__ __forceinline__ const double *stage_exp_tables(double *smem, const do
 // ---------------------------------------------------------------------------
 //  line records (hyperfine.pyx:68-91) of one (item, spectrum) unit, in the wave's LDS slice
 // ---------------------------------------------------------------------------
+// 32 bytes = two 16-byte broadcast reads.  The table of a component is kept in the order of the lines' velocity
+// offsets (c_rank), so that the lines whose windows touch a row of channels are ONE run of neighbours; the windows
+// themselves, [lo, hi), lie behind the table as an array of their own (the row loop's hit masks).
+//   nucen   line centre (hyperfine.pyx:73)
+//   k       exact modes and the wide form: idenom = 0.5 / width^2 (hyperfine.pyx:75);
+//           fast mode: sqrt(idenom) -- the argument is formed as ((x - nucen) k)^2, see line_step_fastz
+//   w       weight hf_tau (hyperfine.pyx:74): a double in the exact modes, a float in the low word in the fast mode
+//   mid, half   the window [lo, lo + len) as |j - mid| < half, mid = lo + (len - 1) / 2, half = len / 2: exact in
+//           fp32 for spectra below 2^22 channels (longer ones take the wide form, which tests integers)
 struct __attribute__((aligned(16))) LineRec {
-    double nucen, idenom;                        // first 16-B read
-    union { double htau; float htau_f; };        // second 16-B read: weight and window
-    int lo, len;                                 // window [lo, lo+len)
+    double nucen, k;                             // first 16-byte read
+    double w;                                    // second 16-byte read
+    float mid, half;
 };
 typedef const __attribute__((address_space(4))) double *k_dbl_p;     // constant address space: a
                                                                      // uniform index gives an s_load
@@ -465,47 +495,16 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t, unsigned long l
 //  scalar loads).  lnl_sum_kernel adds the terms of an item in spectrum order
 //  (ammonia.pyx:429-432).
 // ---------------------------------------------------------------------------
-// the fast mode's line x row step as one instruction block: window test -> EXEC, float-narrowed
-// Gaussian argument, exp, tau += htau * e; EXEC is all ones on entry (every branch around it is
-// wave-uniform) and on exit
-__device__ __forceinline__ void line_step_fast(float &tau, int j, double xj, double nucen, double idenom,
-                                               float htau, int lo, int len) {
-    double d;
-    float t0, t1, t2;
-    asm volatile("v_sub_u32 %[t0], %[j], %[lo]\n\t"
-                 "v_cmpx_lt_u32 %[t0], %[len]\n\t"
-                 "v_add_f64 %[d], %[xj], -%[nucen]\n\t"
-                 "v_mul_f64 %[d], %[d], %[d]\n\t"
-                 "v_mul_f64 %[d], %[d], %[idenom]\n\t"
-                 "v_cvt_f32_f64 %[t0], %[d]\n\t"                       // math.pxd:17 narrowing
-                 "v_mul_f32 %[t1], 0xbfb8aa3b, %[t0]\n\t"               // yh = -x log2(e)
-                 "v_exp_f32 %[t2], %[t1]\n\t"
-                 "v_fma_f32 %[t0], %[t1], %[kln2], -%[t0]\n\t"          // r = -x - yh ln2_hi
-                 "v_fmac_f32 %[t0], 0x3102e308, %[t1]\n\t"              //       - yh ln2_lo
-                 "v_fmac_f32 %[t2], %[t2], %[t0]\n\t"                   // e = 2^yh (1 + r)
-                 "v_fmac_f32 %[tau], %[htau], %[t2]\n\t"
-                 "s_mov_b64 exec, -1"
-                 : [tau] "+v"(tau), [d] "=&v"(d), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
-                 : [j] "v"(j), [lo] "v"(lo), [len] "v"(len), [xj] "v"(xj), [nucen] "v"(nucen),
-                   [idenom] "v"(idenom), [htau] "v"(htau), [kln2] "s"(-0.693147182464599609375f)
-                 : "vcc");
-}
-
-// Fast mode's line record (32 bytes, two 16-byte broadcast reads) and its line x row step.
-//   * the Gaussian argument as ((x - nucen) sq)^2 with sq = sqrt(0.5) / width: two fp64 multiplications
+// The fast mode's line x row step as one instruction block: window test -> EXEC, float-narrowed Gaussian argument,
+// exp, tau += w e; EXEC is all ones on entry (every branch around it is wave-uniform) and on exit.
+//   * the Gaussian argument as ((x - nucen) k)^2 with k = sqrt(0.5) / width: two fp64 multiplications
 //     instead of three.  The reference forms (x - nucen)^2 * idenom (hyperfine.pyx:94) before it narrows the
 //     argument to float (math.pxd:17); the two forms differ by a few 2^-53 relative, so the narrowed float is
 //     the reference's except where the exact value lies that close to a rounding boundary of the float grid:
 //     about one (line, channel) pair in 2e8, and then by one ulp of the float (<= 7.5e-7 of that one term).
-//   * the window [lo, lo + len) as |j - mid| < half in fp32 (mid = lo + (len - 1) / 2, half = len / 2: exact
-//     for spectra below 2^22 channels): an fp32 subtraction runs at twice the rate of an integer one.
+//   * the window as |j - mid| < half in fp32: an fp32 subtraction runs at twice the rate of an integer one.
 //   * exp as 2^yh (1 + r), r = -x - yh ln2 in ONE fused step (the exact product with the float nearest ln 2;
 //     what is dropped, yh (ln 2 - fl(ln 2)), is below 3.5e-8 relative inside a window, x <= 12.5).
-struct __attribute__((aligned(16))) FastRec {
-    double nucen, sq;
-    float htau, mid, half;
-    int pad;
-};
 __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj, double nucen, double sq,
                                                 float htau, float mid, float half) {
     double d;
@@ -539,12 +538,12 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                                          const BatchGroup *grp = nullptr) {
     typedef typename std::conditional<MODE == 2, float, double>::type tau_t;
     constexpr int NC = NCOMP > 0 ? NCOMP : 1;
-    // fast mode, at most 26 lines per transition: FastRec records in velocity order, windows in an array of their own
-#ifdef NFA_LEGACY_STEP          // A/B builds only: round 2's line step (LineRec records, integer window test, three fp64 products)
-    constexpr bool FASTN = false;
-#else
+    // the fast mode's narrow form: at most 26 lines per transition (32-bit line masks), fp32 optical depth, the
+    // line step as one instruction block (line_step_fastz)
     constexpr bool FASTN = MODE == 2 && !WIDE;
-#endif
+    // the window test in fp32 (LineRec.mid / half); the wide form may hold spectra of 2^22 channels and more and
+    // tests the integers of the window array instead
+    constexpr bool FWIN = !WIDE;
     const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
 
 #ifdef NFA_ABLATE
@@ -579,8 +578,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const int rpart = (int)(wsel & (unsigned)(split - 1));
     const unsigned unit = block_id * upw + ulocal;
     LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)ulocal * G.wave_doubles);
-    FastRec *f_line = (FastRec *)w_line;                                   // FASTN: the same slots hold FastRec records ...
-    int2 *w_win = (int2 *)(w_line + (NCOMP > 0 ? NCOMP : S.ncomp) * G.nhf_max);   // ... and their windows [lo, hi) follow
+    int2 *w_win = (int2 *)(w_line + (NCOMP > 0 ? NCOMP : S.ncomp) * G.nhf_max);   // the windows [lo, hi) follow the table
     // split > 1: the parts' per-lane sums meet here, [unit of the workgroup][part][lane]
     double *w_part = smem + n_shared + (size_t)upw * G.wave_doubles + (size_t)ulocal * (LNL_PARTS * 64);
     if (unit >= units) {
@@ -630,26 +628,17 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             r_htau = D[b * drec + 4 * ncomp + (c * nspec + s) * DREC_CS + DK_TMAIN] * c_tauw[t][i];
             r_lo = lo;
             r_len = hi > lo ? hi - lo : 0;
-            if (FASTN) slot = c * G.nhf_max + c_rank[t][i];        // velocity order: the lines of a row are neighbours
+            slot = c * G.nhf_max + c_rank[t][i];                 // velocity order: the lines of a row are neighbours
         }
-        if constexpr (FASTN) {
-            FastRec fr;
-            fr.nucen = r_nucen;
-            fr.sq = sqrt(r_idenom);                              // correctly rounded (no fast-math)
-            fr.htau = (float)r_htau;
-            fr.mid = (float)r_lo + 0.5f * (float)(r_len - 1);
-            fr.half = 0.5f * (float)r_len;                       // an empty window: half = 0, no channel passes
-            fr.pad = 0;
-            f_line[slot] = fr;
-            w_win[slot] = make_int2(r_lo, r_lo + r_len);
-        } else {
-            LineRec rec;
-            rec.nucen = r_nucen; rec.idenom = r_idenom;
-            // fast mode keeps the weight as a float in the low word (no union store: that goes through scratch)
-            rec.htau = MODE == 2 ? __longlong_as_double((long long)__float_as_uint((float)r_htau)) : r_htau;
-            rec.lo = r_lo; rec.len = r_len;
-            w_line[p] = rec;
-        }
+        LineRec rec;
+        rec.nucen = r_nucen;
+        rec.k = FASTN ? sqrt(r_idenom) : r_idenom;               // (sqrt: correctly rounded, no fast-math)
+        // fast mode keeps the weight as a float in the low word (no union store: that goes through scratch)
+        rec.w = MODE == 2 ? __longlong_as_double((long long)__float_as_uint((float)r_htau)) : r_htau;
+        rec.mid = (float)r_lo + 0.5f * (float)(r_len - 1);
+        rec.half = 0.5f * (float)r_len;                          // an empty window: half = 0, no channel passes
+        w_line[slot] = rec;
+        w_win[slot] = make_int2(r_lo, r_lo + r_len);
     }
     if (split > 1) __syncthreads(); else wave_lds_sync();
     // windows [lo, hi) of the lines of each component, lane = line (an empty window is [0, 0):
@@ -669,8 +658,8 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // window [lo, hi) of line `l` of component `c` (0, 0 for l beyond the table)
     auto window_of = [&](int c, int l, int &lo, int &hi) {
         const int k = c * G.nhf_max + (l < G.nhf_max ? l : 0);
-        if constexpr (FASTN) { const int2 w = w_win[k]; lo = w.x; hi = w.y; }
-        else { const LineRec *q = w_line + k; lo = q->lo; hi = lo + q->len; }
+        const int2 w = w_win[k];
+        lo = w.x; hi = w.y;
         if (!(l < G.nhf_max) || (ablate & 8)) { lo = 0; hi = 0; }
     };
     if (NCOMP > 0) {
@@ -745,77 +734,79 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                 }
                 tau_t tau = 0;
                 double td = 0.0;                                      // WIDE: fp64 running sum
-                auto line = [&](int i) {
-                    const lds_char_p q = (lds_char_p)(uintptr_t)(lbase + ((unsigned)i << 5));
-                    typedef double v2d __attribute__((ext_vector_type(2)));
-                    typedef int v4i __attribute__((ext_vector_type(4)));
-                    const v2d ab = *(const __attribute__((address_space(3))) v2d *)q;                   // nucen, idenom
-                    const v4i hw = *(const __attribute__((address_space(3))) v4i *)(q + 16);            // htau (8 bytes), lo, len
-                    if constexpr (MODE == 2 && !WIDE) {
-                        line_step_fast(tau, j, xj, ab.x, ab.y, __int_as_float(hw.x), hw.z, hw.w);
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(3))) v2d *lds_v2d_p;
+                typedef const __attribute__((address_space(3))) v4i *lds_v4i_p;
+                // one line x row step with the record (nucen, k | w, mid, half) already read; window index `wi` (WIDE)
+                auto step = [&](const v2d ab, const v4i hw, int wi) {
+                    if constexpr (FASTN) {
+                        line_step_fastz(tau, jf, xj, ab.x, ab.y, __int_as_float(hw.x), __int_as_float(hw.z), __int_as_float(hw.w));
                     } else {
-                    // the whole record is read before the window test (left alone the compiler reads lo / len, tests,
-                    // and only then reads the rest: one more trip to LDS in the dependent chain of every step)
-                    double nucen = ab.x, idenom = ab.y;
-                    asm volatile("" : "+v"(nucen), "+v"(idenom));
-                    if ((unsigned)(j - hw.z) < (unsigned)hw.w) {                  // the window is the EXEC mask
-                        asm volatile("" ::: "memory");                // keep it a branch (no if-conversion)
-                        const double nu = xj - nucen;
-                        const double tau_exp = nu * nu * idenom;
-                        if constexpr (MODE == 2) {
-                            const float e = exp_neg_core_f32((float)tau_exp);          // math.pxd:17 narrowing
-                            td = __builtin_fma((double)__int_as_float(hw.x), (double)e, td);
+                        // the whole record is read before the window test (left alone the compiler reads the window, tests,
+                        // and only then reads the rest: one more trip to LDS in the dependent chain of every step)
+                        double nucen = ab.x, idenom = ab.y;
+                        asm volatile("" : "+v"(nucen), "+v"(idenom));
+                        bool inside;
+                        if constexpr (FWIN) {
+                            inside = __builtin_fabsf(jf - __int_as_float(hw.z)) < __int_as_float(hw.w);
                         } else {
-                            const double e = nf_fastexp<MODE, true, true>(tau_exp, sm);
-                            tau = __builtin_fma(__hiloint2double(hw.y, hw.x), e, (double)tau);
+                            const int2 w = w_win[wi];
+                            inside = (unsigned)(j - w.x) < (unsigned)(w.y - w.x);
+                        }
+                        if (inside) {                                     // the window is the EXEC mask
+                            asm volatile("" ::: "memory");                // keep it a branch (no if-conversion)
+                            const double nu = xj - nucen;
+                            const double tau_exp = nu * nu * idenom;      // hyperfine.pyx:94
+                            if constexpr (MODE == 2) {
+                                const float e = exp_neg_core_f32((float)tau_exp);          // math.pxd:17 narrowing
+                                td = __builtin_fma((double)__int_as_float(hw.x), (double)e, td);
+                            } else {
+                                const double e = nf_fastexp<MODE, true, true>(tau_exp, sm);
+                                tau = __builtin_fma(__hiloint2double(hw.y, hw.x), e, (double)tau);
+                            }
                         }
                     }
-                    }
                 };
+                auto rec_ab = [&](unsigned a) { return *(lds_v2d_p)(uintptr_t)a; };
+                auto rec_hw = [&](unsigned a) { return *(lds_v4i_p)(uintptr_t)(a + 16); };
                 if (ablate & 2) { tau = (tau_t)(1e-3 * (lane + 1)); }
-                else if constexpr (FASTN) {
+                else {
                     // The table is in velocity order, so the lines of this row are the run from the lowest to the highest
                     // set bit of the mask (a line inside the run whose window misses the row -- widths differ by 1e-4 from
                     // line to line -- finds no lane in its window and adds nothing).  The run is walked two lines at a
                     // time: the records of a pair are four reads off one address, which advances once per pair.
-                    const unsigned m = (unsigned)mask;
-                    const int first = __builtin_ctz(m);
-                    int n = 32 - __builtin_clz(m) - first;
+                    int first, n;
+                    if (FASTN || nhf <= 32) {                         // every NH3 transition: 32-bit mask arithmetic
+                        const unsigned m = (unsigned)mask;
+                        first = __builtin_ctz(m);
+                        n = 32 - __builtin_clz(m) - first;
+                    } else {
+                        first = __builtin_ctzll(mask);
+                        n = 64 - __builtin_clzll(mask) - first;
+                    }
                     unsigned va = lbase + ((unsigned)first << 5);
                     asm volatile("" : "+v"(va));
-                    typedef double v2d __attribute__((ext_vector_type(2)));
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    typedef const __attribute__((address_space(3))) v2d *lds_v2d_p;
-                    typedef const __attribute__((address_space(3))) v4f *lds_v4f_p;
+                    int wi = c * G.nhf_max + first;
                     if (n & 1) {
-                        const v2d ab = *(lds_v2d_p)(uintptr_t)va;
-                        const v4f hw = *(lds_v4f_p)(uintptr_t)(va + 16);
-                        line_step_fastz(tau, jf, xj, ab.x, ab.y, hw.x, hw.y, hw.z);
+                        const v2d ab = rec_ab(va);
+                        const v4i hw = rec_hw(va);
+                        step(ab, hw, wi);
                         va += 32;
                         asm volatile("" : "+v"(va));
+                        wi += 1;
                         n -= 1;
                     }
-                    while (n) {
-                        const v2d ab0 = *(lds_v2d_p)(uintptr_t)va;
-                        const v4f hw0 = *(lds_v4f_p)(uintptr_t)(va + 16);
-                        const v2d ab1 = *(lds_v2d_p)(uintptr_t)(va + 32);
-                        const v4f hw1 = *(lds_v4f_p)(uintptr_t)(va + 48);
-                        line_step_fastz(tau, jf, xj, ab0.x, ab0.y, hw0.x, hw0.y, hw0.z);
-                        line_step_fastz(tau, jf, xj, ab1.x, ab1.y, hw1.x, hw1.y, hw1.z);
+                    while (n) {                                        // both records of a pair are read before the first step
+                        const v2d ab0 = rec_ab(va), ab1 = rec_ab(va + 32);
+                        const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
+                        step(ab0, hw0, wi);
+                        step(ab1, hw1, wi + 1);
                         va += 64;
                         asm volatile("" : "+v"(va));
+                        wi += 2;
                         n -= 2;
                     }
-                }
-                else if ((MODE == 2 && !WIDE) || nhf <= 32) {         // every NH3 transition (the fast mode's narrow form holds at most 26 lines: no test): 32-bit mask arithmetic
-                    unsigned m = (unsigned)mask;
-                    do {
-                        const int i = __builtin_ctz(m);
-                        asm("s_bitset0_b32 %0, %1" : "+s"(m) : "s"(i));      // m &= ~(1 << i) in one scalar instruction
-                        line(i);
-                    } while (m);
-                } else {
-                    do { const int i = __builtin_ctzll(mask); mask &= mask - 1; line(i); } while (mask);
                 }
                 if (MODE == 2 && WIDE) tau = (tau_t)td;
                 // hyperfine.pyx:104-105: channels with tau == 0 are skipped (lanes beyond the last channel
@@ -854,14 +845,32 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     }
                     pred = __builtin_fma(g, one_minus_fastexp_f32((float)tau, livem), pred);
                 } else {
-                    const double x = T0 / Dk[c * 4];
-                    double y;
-                    if (Dk[dko + DK_XKIND] == 1.0) y = Dk[dko + DK_XS] * (x - Dk[dko + DK_XLO]) + Dk[dko + DK_YLO];
-                    else y = nf_iemtex(x, g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
+                    // x = T0 / tex (hyperfine.pyx:107) without a division per channel: from the correctly rounded
+                    // reciprocal the set-up stage left in the record, q = T0 r, e = T0 - tex q (exact, fused),
+                    // x = q + e r is the correctly rounded quotient (Markstein's final step; the one exception,
+                    // a tex whose mantissa is all ones, has probability 2^-52): the same bits as the division
+                    // (400 M random pairs on the host: 0 differences).  A tex that is not an ordinary positive number
+                    // takes the division.
+                    const double tex = Dk[c * 4], rtex = Dk[c * 4 + 3];
+                    double x;
+                    if (tex > 1e-100 && tex < 1e100) {
+                        const double q = T0 * rtex;
+                        x = __builtin_fma(__builtin_fma(-tex, q, T0), rtex, q);
+                    } else {
+                        x = T0 / tex;
+                    }
                     // the reference's order: pred[i] += T0 * (y - tbg) * (1 - FastExp(tau)), only where tau != 0
                     // (tau is a sum of non-negative terms, or NaN)
-                    const double tb = (T0 * (y - tbg)) * (1.0 - nf_fastexp<MODE, true>((double)tau, sm));
-                    pred += !(tau == 0) ? tb : 0.0;
+                    if (Dk[dko + DK_XKIND] == 1.0) {
+                        // the band's table cell: y is finite, and where tau == 0 the last factor is exactly 1 - 1 = 0 --
+                        // the product adds +0 there and needs no select
+                        const double y = Dk[dko + DK_XS] * (x - Dk[dko + DK_XLO]) + Dk[dko + DK_YLO];
+                        pred += (T0 * (y - tbg)) * nf_one_minus_fastexp_row<MODE>((double)tau, sm);
+                    } else {
+                        const double y = nf_iemtex(x, g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
+                        const double tb = (T0 * (y - tbg)) * nf_one_minus_fastexp_row<MODE>((double)tau, sm);
+                        pred += !(tau == 0) ? tb : 0.0;
+                    }
                 }
             };
             if (NCOMP > 0) {

@@ -219,7 +219,13 @@ struct nfa_runner {
     hipEvent_t ev_after_lnl = nullptr;   // recorded by the next likelihood launch right behind lnl_kernel (profiling)
     BatchGroup  cur_group = {};          // the batches of the launches being enqueued (run_group)
     BatchGroup  pending = {};            // device-pointer batches accepted but not yet launched (coalescing)
+    // One in-flight call per runner is the contract (include/nestfit_amd.h); the process-wide calls
+    // (nfa_device_synchronize, nfa_set_exp_mode) walk every live runner from whatever thread makes them, so the state a
+    // launch touches -- pending, cur_group, n_calls, lane_busy, the lanes themselves -- is guarded: every public entry
+    // point of a runner and the global flush take this lock (recursive: entry points call each other).
+    std::recursive_mutex mu;
 };
+#define RUNNER_LOCK(r) std::lock_guard<std::recursive_mutex> runner_lock_((r)->mu)
 
 extern "C" {
 
@@ -617,8 +623,11 @@ int nfa_runner_create(nfa_runner **out, nfa_specset *ss, nfa_priors *priors, int
 
 int nfa_runner_destroy(nfa_runner *r) {
     if (!r) return NFA_OK;
-    (void)flush_pending(r);
+    // out of the list first: from here on no global call walks this runner
     { std::lock_guard<std::mutex> lk(g_runners_m); g_runners.erase(std::remove(g_runners.begin(), g_runners.end(), r), g_runners.end()); }
+    // batches still held for coalescing are dropped, not launched: their buffers are the caller's, who may have freed
+    // them already (whoever wants the results synchronises, and that launches what is held)
+    { RUNNER_LOCK(r); r->pending.n = 0; }
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamSynchronize(r->lanes[k]);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
     for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_part[k]); }
@@ -636,6 +645,7 @@ int nfa_runner_ndim(const nfa_runner *r) { return r ? r->ndim : 0; }
 
 int nfa_runner_set_exp_mode(nfa_runner *r, int mode) {
     if (!r) return fail(NFA_ERR_ARG, "null runner");
+    RUNNER_LOCK(r);
     if (mode < -1 || mode > 2) return fail(NFA_ERR_ARG, "exp mode must be -1 (process default), 0 (table), 1 (poly) or 2 (fast)");
     { int rc = flush_pending(r); if (rc) return rc; }
     r->exp_mode = mode;
@@ -745,14 +755,10 @@ static bool lnl_wide(const nfa_runner *r) {
     for (int k = 0; k < r->ss->dev.n_spec; ++k) max_size = std::max(max_size, r->ss->dev.size[k]);
     return r->ss->nhf_max > 26 || max_size > (1 << 22);
 }
-// LDS doubles per (item, spectrum) unit: the line table (32-byte records, nhf_max per component), in the fast mode's
-// narrow form followed by the windows (two ints per line)
-static int lnl_wave_doubles(const nfa_runner *r, int mode) {
-#ifdef NFA_LEGACY_STEP
-    const int per_line = (int)(sizeof(LineRec) / sizeof(double));
-#else
-    const int per_line = (int)(sizeof(LineRec) / sizeof(double)) + ((mode == 2 && !lnl_wide(r)) ? 1 : 0);
-#endif
+// LDS doubles per (item, spectrum) unit: the line table (32-byte records, nhf_max per component) followed by the
+// windows (two ints per line)
+static int lnl_wave_doubles(const nfa_runner *r) {
+    const int per_line = (int)(sizeof(LineRec) / sizeof(double)) + 1;
     return (r->ncomp * r->ss->nhf_max * per_line + 1) & ~1;          // 16-byte records: an even number of doubles
 }
 
@@ -785,7 +791,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     // gives the hardware shorter waves to place as slots free up (a single point: 2 units -> 8 waves).
     const int split = resolve_split(r, S, B);
     G.split = split;
-    G.wave_doubles = lnl_wave_doubles(r, MODE);
+    G.wave_doubles = lnl_wave_doubles(r);
     const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
     // waves per workgroup.  Table mode stages 51 KB of product tables per workgroup, so the
     // workgroup is made as fat as keeps the most waves resident per CU (ties: more workgroups,
@@ -932,7 +938,10 @@ static int flush_pending(nfa_runner *r) {
 }
 static int flush_all_runners() {
     std::lock_guard<std::mutex> lk(g_runners_m);
-    for (nfa_runner *r : g_runners) { int rc = flush_pending(r); if (rc) return rc; }
+    for (nfa_runner *r : g_runners) {
+        RUNNER_LOCK(r);
+        int rc = flush_pending(r); if (rc) return rc;
+    }
     return NFA_OK;
 }
 
@@ -960,6 +969,7 @@ int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_
     if (!r || !d_U || !d_lnL) return fail(NFA_ERR_ARG, "null argument");
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     if (B <= 0) return NFA_OK;
+    RUNNER_LOCK(r);
     const int ti = g_eng.setup_ti > 0 ? g_eng.setup_ti : SETUP_TI;
     const int64_t units = B * r->ss->dev.n_spec, slots = (int64_t)g_eng.n_cu * 32;
     BatchGroup &p = r->pending;
@@ -977,6 +987,7 @@ int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_
 
 int nfa_runner_set_profiling(nfa_runner *r, int on) {
     if (!r) return fail(NFA_ERR_ARG, "null runner");
+    RUNNER_LOCK(r);
     int rc = sync_all_lanes(r); if (rc) return rc;
     r->profiling = on != 0;
     r->ev_used = 0;
@@ -999,6 +1010,7 @@ static double union_length(std::vector<std::pair<double, double>> iv) {
 
 int nfa_runner_get_profile(nfa_runner *r, double *out, int64_t *calls) {
     if (!r || !out || !calls) return fail(NFA_ERR_ARG, "null argument");
+    RUNNER_LOCK(r);
     int rc = sync_all_lanes(r); if (rc) return rc;
     double a = 0, b = 0;
     std::vector<std::pair<double, double>> iv_setup, iv_lnl;
@@ -1023,6 +1035,7 @@ int nfa_runner_get_profile(nfa_runner *r, double *out, int64_t *calls) {
 
 int nfa_runner_synchronize(nfa_runner *r) {
     if (!r) return fail(NFA_ERR_ARG, "null runner");
+    RUNNER_LOCK(r);
     return sync_all_lanes(r);
 }
 
@@ -1061,7 +1074,7 @@ static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, doubl
     G.inv_nhf = G.nhf_max == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)G.nhf_max) + 1u;
     G.split = resolve_split(r, S, 1);
     if (G.split > POINT_WAVES) return 0;
-    G.wave_doubles = lnl_wave_doubles(r, mode);
+    G.wave_doubles = lnl_wave_doubles(r);
     const int upw = POINT_WAVES / G.split;                       // units per pass of the workgroup
     const int n_shared = mode == 0 ? (SM_END_TABLE - SM_EXP2) : (mode == 1 ? 32 : 0);
     // the set-up stage and the likelihood waves use the same LDS one after the other, behind the staged tables
@@ -1199,6 +1212,7 @@ int nfa_runner_loglike_batch(nfa_runner *r, const int32_t *pix, double *U, doubl
     if (B <= 0) return NFA_OK;
     int rc = check_pix(r, pix, B); if (rc) return rc;
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
+    RUNNER_LOCK(r);
     rc = sync_all_lanes(r); if (rc) return rc;           // the staging buffers are shared
     rc = runner_reserve(r, B, false); if (rc) return rc;
     if (B <= NFA_POINT_MAXB) {                           // MultiNest-style single points, a broker's handful: one launch, no copies
@@ -1248,6 +1262,7 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
     if (!r || !theta) return fail(NFA_ERR_ARG, "null argument");
     if (B <= 0) return NFA_OK;
     int rc = check_pix(r, pix, B); if (rc) return rc;
+    RUNNER_LOCK(r);
     rc = sync_all_lanes(r); if (rc) return rc;
     // output buffers the device can address (nfa_host_alloc) are written by the kernels themselves: the spectra
     // -- B x chan_tot doubles, the bulk of this call's traffic -- then cross the bus once, without a staging copy
@@ -1302,7 +1317,13 @@ int nfa_event_create(void **ev) {
 }
 int nfa_event_destroy(void *ev) { HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return NFA_OK; }
 int nfa_event_record(void *ev, nfa_runner *r) {
-    HIP_TRY(hipEventRecord((hipEvent_t)ev, r ? r->stream : 0)); return NFA_OK;
+    if (r) {                 // batches held for coalescing are launched first: the event stands behind everything enqueued so far
+        RUNNER_LOCK(r);
+        int rc = flush_pending(r); if (rc) return rc;
+        HIP_TRY(hipEventRecord((hipEvent_t)ev, r->stream));
+        return NFA_OK;
+    }
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, 0)); return NFA_OK;
 }
 int nfa_event_synchronize(void *ev) { HIP_TRY(hipEventSynchronize((hipEvent_t)ev)); return NFA_OK; }
 int nfa_event_elapsed_ms(void *start, void *stop, float *ms) {

@@ -32,8 +32,10 @@
 #include <unistd.h>
 
 #define NFA_RING_MAGIC   0x4e46524eu       // "NFRN"
-#define NFA_RING_VERSION 2u
-#define NFA_RING_MAXBATCH 128              // what one point-kernel launch takes (nestfit_amd.h)
+#define NFA_RING_VERSION 3u
+#define NFA_RING_MAXBATCH 1024             // points one serving round hands the engine at most
+#define NFA_RING_MAXPOINTS 64              // points a client may post in one call (nfa_ring_loglike_many)
+#define NFA_RING_GRACE_MS 5000             // a client gives up after this long without any serving loop on the ring
 
 enum { RING_FREE = 0, RING_POSTED = 1, RING_DONE = 2, RING_CLAIMED = 3 };
 
@@ -41,7 +43,7 @@ struct RingHeader {
     uint32_t magic, version;
     int32_t  n_slots, ndim;
     uint64_t slot_stride, total_bytes;
-    int32_t  server_pid, pad0;             // the creator: a ring whose creator is gone is stale
+    int32_t  server_pid, max_points;       // the creator (a ring whose creator is gone is stale); points per slot
     std::atomic<uint32_t> stop;            // set by nfa_ring_stop: everybody leaves
     std::atomic<uint32_t> posts;           // bumped by every post: the word the server sleeps on
     std::atomic<uint32_t> n_attached;      // clients holding a slot
@@ -55,9 +57,10 @@ struct RingSlot {
     std::atomic<uint32_t> state;
     std::atomic<uint32_t> owner;           // 0 = nobody, else the pid of the client holding the slot
     std::atomic<uint32_t> asleep;          // the client is inside a futex wait on `state` (a spinning one needs no wake call)
-    int32_t  pix, rc, pad;
-    double   lnl;
-    double   cube[1];                      // ndim doubles
+    std::atomic<uint32_t> gen;             // bumped whenever the slot changes hands: a result claimed under an older
+                                           // generation (its client died, the slot was inherited) is dropped, not delivered
+    int32_t  pix, rc, n_points, pad;
+    double   data[1];                      // lnl[max_points], then cube[max_points][ndim]
 };
 
 struct nfa_ring {
@@ -67,6 +70,7 @@ struct nfa_ring {
     std::string name;
     bool        creator = false;
     int         slot = -1;                 // client: the slot it holds
+    uint32_t   *claim_gen = nullptr;       // server: generation of every slot at the time this handle claimed it
 };
 
 #ifndef NFA_RING_STANDALONE
@@ -83,6 +87,9 @@ extern "C" const char *nfa_ring_last_error(void) { return g_ring_err; }
 static inline RingSlot *ring_slot(const nfa_ring *r, int k) {
     return (RingSlot *)(r->base + sizeof(RingHeader) + (size_t)k * r->hdr->slot_stride);
 }
+static inline double *slot_lnl(RingSlot *s) { return s->data; }
+static inline double *slot_cube(const RingHeader *h, RingSlot *s) { return s->data + h->max_points; }
+static inline bool ring_pid_gone(int32_t pid) { return pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH; }
 
 static inline long ring_futex(std::atomic<uint32_t> *word, int op, uint32_t val, const timespec *ts) {
     return syscall(SYS_futex, (uint32_t *)word, op, val, ts, nullptr, 0);      // shared (not _PRIVATE): across processes
@@ -107,12 +114,14 @@ static std::string ring_shm_name(const char *name) {
 
 extern "C" {
 
-// Server side: create the ring `name` (a POSIX shared-memory object) with n_slots slots of ndim doubles.
-int nfa_ring_create(nfa_ring **out, const char *name, int n_slots, int ndim) {
+// Server side: create the ring `name` (a POSIX shared-memory object) with n_slots slots, each for up to max_points
+// points of ndim doubles (nfa_ring_create: one point per slot, MultiNest's one LogLike per call).
+int nfa_ring_create_multi(nfa_ring **out, const char *name, int n_slots, int ndim, int max_points) {
     if (!out || !name || !name[0]) return fail(NFA_ERR_ARG, "null argument");
-    if (n_slots < 1 || n_slots > 4096 || ndim < 1 || ndim > 4096) return fail(NFA_ERR_ARG, "bad ring shape");
+    if (n_slots < 1 || n_slots > 4096 || ndim < 1 || ndim > 4096 || max_points < 1 || max_points > NFA_RING_MAXPOINTS)
+        return fail(NFA_ERR_ARG, "bad ring shape");
     const std::string shm = ring_shm_name(name);
-    const size_t stride = (offsetof(RingSlot, cube) + sizeof(double) * (size_t)ndim + 63) / 64 * 64;
+    const size_t stride = (offsetof(RingSlot, data) + sizeof(double) * (size_t)max_points * (size_t)(ndim + 1) + 63) / 64 * 64;
     const size_t bytes = sizeof(RingHeader) + stride * (size_t)n_slots;
     {   // a ring of that name whose server is alive is somebody's: refuse; one left by a crashed server goes
         const int old = shm_open(shm.c_str(), O_RDWR, 0600);
@@ -120,8 +129,7 @@ int nfa_ring_create(nfa_ring **out, const char *name, int n_slots, int ndim) {
             RingHeader h0;
             const bool whole = pread(old, &h0, sizeof h0, 0) == (ssize_t)sizeof h0;
             close(old);
-            if (whole && h0.magic == NFA_RING_MAGIC && h0.server_pid > 0 &&
-                !(kill((pid_t)h0.server_pid, 0) != 0 && errno == ESRCH) && !h0.stop.load())
+            if (whole && h0.magic == NFA_RING_MAGIC && h0.server_pid > 0 && !ring_pid_gone(h0.server_pid) && !h0.stop.load())
                 return fail(NFA_ERR_STATE, "a ring of that name is being served");
             shm_unlink(shm.c_str());
         }
@@ -135,12 +143,16 @@ int nfa_ring_create(nfa_ring **out, const char *name, int n_slots, int ndim) {
     memset(p, 0, bytes);
     nfa_ring *r = new nfa_ring();
     r->base = (uint8_t *)p; r->hdr = (RingHeader *)p; r->bytes = bytes; r->name = shm; r->creator = true;
-    r->hdr->version = NFA_RING_VERSION; r->hdr->n_slots = n_slots; r->hdr->ndim = ndim;
+    r->claim_gen = new uint32_t[n_slots]();
+    r->hdr->version = NFA_RING_VERSION; r->hdr->n_slots = n_slots; r->hdr->ndim = ndim; r->hdr->max_points = max_points;
     r->hdr->slot_stride = stride; r->hdr->total_bytes = bytes; r->hdr->server_pid = (int32_t)getpid();
     std::atomic_thread_fence(std::memory_order_release);
     r->hdr->magic = NFA_RING_MAGIC;                            // last: an attaching client waits for it
     *out = r;
     return NFA_OK;
+}
+int nfa_ring_create(nfa_ring **out, const char *name, int n_slots, int ndim) {
+    return nfa_ring_create_multi(out, name, n_slots, ndim, 1);
 }
 
 // Client side: map the ring `name` and take a free slot (wait_ms: how long to wait for the ring to appear).
@@ -165,7 +177,7 @@ int nfa_ring_attach(nfa_ring **out, const char *name, int wait_ms) {
         h = (RingHeader *)p;
         if (*(volatile uint32_t *)&h->magic != NFA_RING_MAGIC) { why = "ring never initialised"; continue; }
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (kill((pid_t)h->server_pid, 0) != 0 && errno == ESRCH) { why = "stale ring (its server is gone)"; continue; }
+        if (ring_pid_gone(h->server_pid)) { why = "stale ring (its server is gone)"; continue; }
         break;
     }
     if (h->version != NFA_RING_VERSION || h->total_bytes != (uint64_t)st.st_size) {
@@ -182,13 +194,15 @@ int nfa_ring_attach(nfa_ring **out, const char *name, int wait_ms) {
     }
     for (int k = 0; k < h->n_slots && r->slot < 0; ++k) {
         uint32_t owner = ring_slot(r, k)->owner.load(std::memory_order_acquire);
-        if (owner != 0 && owner != me && kill((pid_t)owner, 0) != 0 && errno == ESRCH &&
+        if (owner != 0 && owner != me && ring_pid_gone((int32_t)owner) &&
             ring_slot(r, k)->owner.compare_exchange_strong(owner, me, std::memory_order_acq_rel)) {
             r->slot = k;
             inherited = true;
         }
     }
     if (r->slot < 0) { munmap(p, r->bytes); delete r; return fail(NFA_ERR_STATE, "no free slot in the ring"); }
+    // a new generation first: whatever a server still holds for the previous owner of this slot is dropped on delivery
+    ring_slot(r, r->slot)->gen.fetch_add(1, std::memory_order_acq_rel);
     ring_slot(r, r->slot)->state.store(RING_FREE, std::memory_order_release);
     if (!inherited) h->n_attached.fetch_add(1, std::memory_order_acq_rel);
     ring_futex(&h->posts, FUTEX_WAKE, 1, nullptr);             // a waiting server re-evaluates its target
@@ -197,6 +211,7 @@ int nfa_ring_attach(nfa_ring **out, const char *name, int wait_ms) {
 }
 
 int nfa_ring_ndim(const nfa_ring *r) { return r && r->hdr ? r->hdr->ndim : -1; }
+int nfa_ring_max_points(const nfa_ring *r) { return r && r->hdr ? r->hdr->max_points : -1; }
 int nfa_ring_slot(const nfa_ring *r) { return r ? r->slot : -1; }
 
 // Client: give the slot back and unmap.  Server (creator): unmap and remove the shared-memory object.
@@ -209,6 +224,7 @@ int nfa_ring_close(nfa_ring *r) {
     }
     munmap(r->base, r->bytes);
     if (r->creator) shm_unlink(r->name.c_str());
+    delete[] r->claim_gen;
     delete r;
     return NFA_OK;
 }
@@ -223,16 +239,23 @@ int nfa_ring_stop(nfa_ring *r) {
     return NFA_OK;
 }
 
-// Client: blocking LogLike through the ring.  `cube` (ndim doubles, unit cube) is overwritten with the
-// physical parameters like AmmoniaRunner.c_loglikelihood (ammonia.pyx:423-432); pix < 0 = the runner's
-// single pixel.
-int nfa_ring_loglike(nfa_ring *r, int32_t pix, double *cube, double *lnew) {
-    if (!r || !cube || !lnew || r->slot < 0) return fail(NFA_ERR_ARG, "not an attached ring client");
+// Client: blocking LogLike through the ring for k points at once (k <= the ring's max_points; all against pixel
+// `pix`, < 0 = the runner's single pixel).  `cubes` (k x ndim doubles, unit cube) is overwritten with the physical
+// parameters like AmmoniaRunner.c_loglikelihood (ammonia.pyx:423-432); lnew[k].  MultiNest asks for one point per
+// call (k = 1: nfa_ring_loglike); a sampler that draws its next proposals independently of each other -- points
+// uniform in the current bounding ellipsoid are -- may post several and use them in order.
+// Returns NFA_ERR_STATE when the ring was stopped, when the process that created the ring is gone, or when no
+// serving loop has been on the ring for NFA_RING_GRACE_MS: a client never waits for a dead server.
+int nfa_ring_loglike_many(nfa_ring *r, int32_t pix, double *cubes, double *lnew, int k) {
+    if (!r || !cubes || !lnew || r->slot < 0) return fail(NFA_ERR_ARG, "not an attached ring client");
     RingHeader *h = r->hdr;
+    if (k < 1 || k > h->max_points) return fail(NFA_ERR_ARG, "more points than the ring's slots hold (nfa_ring_create_multi)");
     RingSlot *s = ring_slot(r, r->slot);
     if (h->stop.load(std::memory_order_acquire)) return fail(NFA_ERR_STATE, "ring stopped");
-    memcpy(s->cube, cube, sizeof(double) * (size_t)h->ndim);
+    const size_t nd = (size_t)h->ndim;
+    memcpy(slot_cube(h, s), cubes, sizeof(double) * nd * (size_t)k);
     s->pix = pix;
+    s->n_points = k;
     s->state.store(RING_POSTED, std::memory_order_release);
     h->posts.fetch_add(1);                                     // (sequentially consistent with the servers' flag)
     if (h->servers_asleep.load() != 0) ring_futex(&h->posts, FUTEX_WAKE, INT32_MAX, nullptr);     // every sleeping server looks
@@ -240,21 +263,40 @@ int nfa_ring_loglike(nfa_ring *r, int32_t pix, double *cube, double *lnew) {
     // where a spinning process only keeps another one from posting
     static const long n_cpu = sysconf(_SC_NPROCESSORS_ONLN);
     const int spin_limit = (long)h->n_attached.load(std::memory_order_relaxed) + 2 <= n_cpu ? 4000 : 50;
+    int64_t unserved_since = -1;                               // first wake-up that found no serving loop
     for (int spin = 0;; ++spin) {
         const uint32_t cur = s->state.load(std::memory_order_acquire);
         if (cur == RING_DONE) break;
         if (h->stop.load(std::memory_order_acquire)) return fail(NFA_ERR_STATE, "ring stopped");
         if (spin < spin_limit) { ring_pause(); continue; }
-        const timespec ts = {0, 2000000};                      // then sleep on the slot (2 ms: re-check `stop`)
+        const timespec ts = {0, 2000000};                      // then sleep on the slot (2 ms: re-check `stop` and the server)
         s->asleep.store(1);                                    // before the kernel re-reads `state`: the server either
         ring_futex(&s->state, FUTEX_WAIT, cur, &ts);           // sees the flag or has changed `state` already
         s->asleep.store(0);
+        // is anybody going to answer?  the creator's death ends the ring; no serving loop for a while does too
+        const char *dead = nullptr;
+        if (ring_pid_gone(h->server_pid)) dead = "the ring's server process is gone";
+        else if (h->n_servers.load(std::memory_order_acquire) == 0) {
+            const int64_t now = ring_now_us();
+            if (unserved_since < 0) unserved_since = now;
+            else if (now - unserved_since > (int64_t)NFA_RING_GRACE_MS * 1000) dead = "no serving loop on the ring";
+        } else unserved_since = -1;
+        if (dead && s->state.load(std::memory_order_acquire) != RING_DONE) {
+            uint32_t posted = RING_POSTED;                     // take the request back unless a server holds it
+            s->state.compare_exchange_strong(posted, RING_FREE, std::memory_order_acq_rel);
+            s->gen.fetch_add(1, std::memory_order_acq_rel);    // a late delivery for it is dropped
+            s->state.store(RING_FREE, std::memory_order_release);
+            return fail(NFA_ERR_STATE, dead);
+        }
     }
     const int rc = s->rc;
-    if (rc == NFA_OK) memcpy(cube, s->cube, sizeof(double) * (size_t)h->ndim);
-    *lnew = rc == NFA_OK ? s->lnl : NAN;
+    if (rc == NFA_OK) memcpy(cubes, slot_cube(h, s), sizeof(double) * nd * (size_t)k);
+    for (int i = 0; i < k; ++i) lnew[i] = rc == NFA_OK ? slot_lnl(s)[i] : NAN;
     s->state.store(RING_FREE, std::memory_order_release);
     return rc == NFA_OK ? NFA_OK : fail(rc, "the served batch failed");
+}
+int nfa_ring_loglike(nfa_ring *r, int32_t pix, double *cube, double *lnew) {
+    return nfa_ring_loglike_many(r, pix, cube, lnew, 1);
 }
 
 // MultiNest's LogLike signature (cmultinest.pxd:27-28); context = nfa_ring_client*.  No error channel: NaN.
@@ -273,43 +315,52 @@ void nfa_ring_callback(double *Cube, int *ndim, int *npars, double *lnew, void *
 
 // Server: gather posted slots (each one claimed with a compare-and-swap: several serving loops, each with a
 // runner of its own, may poll one ring).  Returns as soon as this server holds its share of the attached clients'
-// points (all of them for a lone server, at most max_batch), or -- once it holds at least one -- after
-// max_wait_us; with nothing posted it sleeps until a post, `stop`, or idle_ms have passed.  slots[k] / pix[k] / U[k * ndim ...] describe request k; *n = how many
-// (0: nothing arrived in idle_ms, or the ring was stopped: *stopped says which).
+// requests (all of them for a lone server; at most max_batch POINTS), or -- once it holds at least one -- after
+// max_wait_us; with nothing posted it sleeps until a post, `stop`, or idle_ms have passed.
+// Row k of the *n gathered: slots[k] / pix[k] / U[k * ndim ...]; the points of one request are neighbouring rows
+// with the same slot.  (*n == 0: nothing arrived in idle_ms, or the ring was stopped: *stopped says which.)
 int nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, int32_t *slots, int32_t *pix,
                   double *U, int *n, int *stopped) {
     if (!r || !slots || !pix || !U || !n) return fail(NFA_ERR_ARG, "null argument");
     RingHeader *h = r->hdr;
+    if (!r->claim_gen) r->claim_gen = new uint32_t[h->n_slots]();      // a second serving handle (attached, not created)
     if (max_batch < 1) max_batch = 1;
     const int64_t t_idle = ring_now_us() + (int64_t)idle_ms * 1000;
     int64_t t_first = -1;
     *n = 0;
     if (stopped) *stopped = 0;
-    int count = 0;                                             // slots this call has claimed so far
+    int rows = 0, claimed = 0;                                 // points and requests this call has claimed so far
     for (int spin = 0;; ++spin) {
         if (h->stop.load(std::memory_order_acquire)) { if (stopped) *stopped = 1; return NFA_OK; }
         const uint32_t posts = h->posts.load(std::memory_order_acquire);
-        for (int k = 0; k < h->n_slots && count < max_batch; ++k) {
+        for (int k = 0; k < h->n_slots && rows < max_batch; ++k) {
             uint32_t posted = RING_POSTED;
             RingSlot *s = ring_slot(r, k);
-            if (s->state.load(std::memory_order_acquire) == RING_POSTED &&
-                s->state.compare_exchange_strong(posted, RING_CLAIMED, std::memory_order_acq_rel))
-                slots[count++] = k;
+            if (s->state.load(std::memory_order_acquire) != RING_POSTED) continue;
+            const int np = s->n_points;
+            if (np < 1 || np > h->max_points || rows + np > max_batch) continue;      // (the next round takes it)
+            const uint32_t gen = s->gen.load(std::memory_order_acquire);
+            if (!s->state.compare_exchange_strong(posted, RING_CLAIMED, std::memory_order_acq_rel)) continue;
+            r->claim_gen[k] = gen;
+            for (int i = 0; i < np; ++i) slots[rows + i] = k;
+            rows += np;
+            claimed += 1;
         }
         const int64_t now = ring_now_us();
-        if (count > 0) {
+        if (rows > 0) {
             if (t_first < 0) t_first = now;
             const int attached = (int)h->n_attached.load(std::memory_order_acquire);
             const int servers = (int)h->n_servers.load(std::memory_order_acquire);
             const int share = servers > 1 ? (attached + servers - 1) / servers : attached;
-            const int target = share > 0 ? (share < max_batch ? share : max_batch) : max_batch;
-            if (count >= target || now - t_first >= max_wait_us) {
-                for (int k = 0; k < count; ++k) {
-                    const RingSlot *s = ring_slot(r, slots[k]);
-                    memcpy(U + (size_t)k * h->ndim, s->cube, sizeof(double) * (size_t)h->ndim);
-                    pix[k] = s->pix;
+            if ((share > 0 && claimed >= share) || rows + 1 > max_batch || now - t_first >= max_wait_us) {
+                for (int k = 0; k < rows;) {
+                    RingSlot *s = ring_slot(r, slots[k]);
+                    const int np = s->n_points;
+                    memcpy(U + (size_t)k * h->ndim, slot_cube(h, s), sizeof(double) * (size_t)h->ndim * (size_t)np);
+                    for (int i = 0; i < np; ++i) pix[k + i] = s->pix;
+                    k += np;
                 }
-                *n = count;
+                *n = rows;
                 return NFA_OK;
             }
             ring_pause();                                      // company is microseconds away: spin
@@ -324,17 +375,29 @@ int nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, 
     }
 }
 
-// Server: results of the requests nfa_ring_poll handed out (rc != 0: the batch failed, the clients get NaN).
+// Server: results of rows nfa_ring_poll handed out (whole requests: the neighbouring rows of a slot; rc != 0: those
+// requests failed, their clients get NaN and the code).  A request whose slot changed hands since it was claimed (its
+// client died and another process inherited the slot) is dropped.
 int nfa_ring_complete(nfa_ring *r, int n, const int32_t *slots, const double *U, const double *lnL, int rc) {
     if (!r || n < 0 || (n > 0 && (!slots || !U || !lnL))) return fail(NFA_ERR_ARG, "null argument");
     RingHeader *h = r->hdr;
-    for (int k = 0; k < n; ++k) {
-        RingSlot *s = ring_slot(r, slots[k]);
-        if (rc == NFA_OK) memcpy(s->cube, U + (size_t)k * h->ndim, sizeof(double) * (size_t)h->ndim);
-        s->lnl = rc == NFA_OK ? lnL[k] : NAN;
-        s->rc = rc;
-        s->state.store(RING_DONE);
-        if (s->asleep.load() != 0) ring_futex(&s->state, FUTEX_WAKE, 1, nullptr);
+    for (int k = 0; k < n;) {
+        const int sl = slots[k];
+        int np = 1;
+        while (k + np < n && slots[k + np] == sl) ++np;
+        if (sl < 0 || sl >= h->n_slots) return fail(NFA_ERR_ARG, "slot index out of range");
+        RingSlot *s = ring_slot(r, sl);
+        const bool mine = r->claim_gen && s->gen.load(std::memory_order_acquire) == r->claim_gen[sl] &&
+                          s->state.load(std::memory_order_acquire) == RING_CLAIMED && np == s->n_points;
+        if (mine) {
+            if (rc == NFA_OK) memcpy(slot_cube(h, s), U + (size_t)k * h->ndim, sizeof(double) * (size_t)h->ndim * (size_t)np);
+            for (int i = 0; i < np; ++i) slot_lnl(s)[i] = rc == NFA_OK ? lnL[k + i] : NAN;
+            s->rc = rc;
+            uint32_t held = RING_CLAIMED;
+            if (s->state.compare_exchange_strong(held, RING_DONE) && s->asleep.load() != 0)
+                ring_futex(&s->state, FUTEX_WAKE, 1, nullptr);
+        }
+        k += np;
     }
     if (n > 0) {
         h->n_batches.fetch_add(1, std::memory_order_relaxed);
@@ -353,30 +416,62 @@ int nfa_ring_stats(nfa_ring *r, int64_t *out) {
 }
 
 #ifndef NFA_RING_STANDALONE
-// Server loop of the engine: poll -> nfa_runner_loglike_batch (up to 128 points: one point-kernel launch)
+// Server loop of the engine: poll -> nfa_runner_loglike_batch (up to 128 points: one point-kernel launch; more: the
+// batch kernels reading the unit cubes from, and writing theta and lnL to, buffers the device addresses itself)
 // -> complete, until the ring is stopped, max_batches (> 0) have been served or nothing has arrived for
 // idle_ms.  The runner must not be used by anyone else meanwhile.
+// A request with a pixel index outside the runner's cube fails alone (its client gets NFA_ERR_ARG); the loop goes on.
+// A device error ends the ring: the batch's clients get the code, everybody else NFA_ERR_STATE (nfa_ring_stop).
 int nfa_ring_serve(nfa_ring *r, nfa_runner *run, int64_t max_wait_us, int64_t max_batches, int idle_ms) {
     if (!r || !run) return fail(NFA_ERR_ARG, "null argument");
     if (run->ndim != r->hdr->ndim) return fail(NFA_ERR_ARG, "ring and runner disagree on ndim");
     const int ndim = run->ndim;
+    const int cap = NFA_RING_MAXBATCH;
+    std::vector<int32_t> slots(cap), good_slots(cap);
+    // unit cubes, theta, lnL and pixel indices in memory the device addresses itself: no staging copies for batches
+    // beyond the point kernel's 128 (nfa_runner_loglike_batch recognises such buffers)
+    void *h_buf = nullptr;
+    const size_t n_dbl = (size_t)cap * (ndim + 1);
+    if (nfa_host_alloc(&h_buf, sizeof(double) * n_dbl + sizeof(int32_t) * (size_t)cap) != NFA_OK) return NFA_ERR_DEVICE;
+    double *U = (double *)h_buf, *lnL = U + (size_t)cap * ndim;
+    int32_t *pix = (int32_t *)(lnL + cap);
+    const int64_t n_pix = run->ss->n_pix;
     r->hdr->n_servers.fetch_add(1, std::memory_order_acq_rel);
-    std::vector<int32_t> slots(NFA_RING_MAXBATCH), pix(NFA_RING_MAXBATCH);
-    std::vector<double> U((size_t)NFA_RING_MAXBATCH * ndim), lnL(NFA_RING_MAXBATCH);
+    int rc_out = NFA_OK;
     for (int64_t served = 0; max_batches <= 0 || served < max_batches;) {
         int n = 0, stopped = 0;
-        int rc = nfa_ring_poll(r, NFA_RING_MAXBATCH, max_wait_us, idle_ms, slots.data(), pix.data(), U.data(), &n, &stopped);
-        if (rc != NFA_OK) { r->hdr->n_servers.fetch_sub(1, std::memory_order_acq_rel); return rc; }
+        int rc = nfa_ring_poll(r, cap, max_wait_us, idle_ms, slots.data(), pix, U, &n, &stopped);
+        if (rc != NFA_OK) { rc_out = rc; break; }
         if (stopped || n == 0) break;
+        // requests that name a pixel the runner does not have fail alone; the rest close ranks
+        int m = 0;
         bool any_pix = false;
-        for (int k = 0; k < n; ++k) { any_pix |= pix[k] >= 0; if (pix[k] < 0) pix[k] = 0; }
-        rc = nfa_runner_loglike_batch(run, any_pix ? pix.data() : nullptr, U.data(), lnL.data(), n);
-        nfa_ring_complete(r, n, slots.data(), U.data(), lnL.data(), rc);
-        if (rc != NFA_OK) { r->hdr->n_servers.fetch_sub(1, std::memory_order_acq_rel); return rc; }
+        for (int k = 0; k < n;) {
+            int np = 1;
+            while (k + np < n && slots[k + np] == slots[k]) ++np;
+            if ((int64_t)pix[k] >= n_pix) {
+                nfa_ring_complete(r, np, slots.data() + k, U + (size_t)k * ndim, lnL + k, NFA_ERR_ARG);
+            } else {
+                any_pix |= pix[k] >= 0;
+                if (m != k) {
+                    memmove(U + (size_t)m * ndim, U + (size_t)k * ndim, sizeof(double) * (size_t)ndim * (size_t)np);
+                    for (int i = 0; i < np; ++i) pix[m + i] = pix[k + i];
+                }
+                for (int i = 0; i < np; ++i) { good_slots[m + i] = slots[k]; if (pix[m + i] < 0) pix[m + i] = 0; }
+                m += np;
+            }
+            k += np;
+        }
+        if (m > 0) {
+            rc = nfa_runner_loglike_batch(run, any_pix ? pix : nullptr, U, lnL, m);
+            nfa_ring_complete(r, m, good_slots.data(), U, lnL, rc);
+            if (rc == NFA_ERR_DEVICE) { rc_out = rc; nfa_ring_stop(r); break; }     // nobody will be served any more
+        }
         ++served;
     }
     r->hdr->n_servers.fetch_sub(1, std::memory_order_acq_rel);
-    return NFA_OK;
+    (void)nfa_host_free(h_buf);
+    return rc_out;
 }
 #endif
 

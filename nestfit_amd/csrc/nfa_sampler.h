@@ -615,6 +615,7 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
         method < 0 || method > 2 || n_steps < 1)
         return fail(NFA_ERR_ARG, "bad sampler options");
     nfa_runner *r = s->r;
+    RUNNER_LOCK(r);
     { int rcf = sync_all_lanes(r); if (rcf) return rcf; }    // the lanes are the sampler's from here on
     NsDev &d = s->d;
     const int P = d.P, N = d.N, D = d.D;
@@ -669,6 +670,7 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
 int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_out) {
     if (!s || !s->ran) return fail(NFA_ERR_STATE, "nfa_sampler_begin has not been called");
     nfa_runner *r = s->r;
+    RUNNER_LOCK(r);
     { int rcf = flush_pending(r); if (rcf) return rcf; }
     NsDev &d = s->d;
     const int P = d.P, K = d.K, D = d.D;

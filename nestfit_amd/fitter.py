@@ -42,11 +42,14 @@ class CubeFitter:
     mn_default_kwargs = MN_CUBE_DEFAULTS
 
     def __init__(self, stack, utrans, runner_cls, runner_kwargs=None, lnZ_thresh=11, ncomp_max=2,
-                 mn_kwargs=None, nlive_snr_fact=5, nlive_quantum=20, fit_backend=None):
+                 mn_kwargs=None, nlive_snr_fact=5, nlive_quantum=1, fit_backend=None):
         """Arguments of the reference's CubeFitter (main.py:388-420) plus two of this build:
         `nlive_quantum` -- the reference gives every pixel its own number of live points,
         nlive + int(nlive_snr_fact * snr); pixels are batched by that number rounded up to a multiple
-        of `nlive_quantum` (1 = exactly the reference's value, at the price of smaller batches);
+        of `nlive_quantum`.  The default, 1, is exactly the reference's value (main.py:445-447); a larger quantum
+        (20, say) makes fewer, larger lock-step groups -- a 20 x 20 cube fits several times faster -- at the price of
+        up to quantum - 1 more live points than the reference would give a pixel; a store fitted that way says so
+        in its `nlive_quantum` attribute;
         `fit_backend` -- None = the device sampler, otherwise a callable(fitter, lon, lat, ncomp,
         nlive, kw) -> (results, null_lnZ, n_chan_tot) that fits the given pixels some other way (the
         tests plug in the numpy twin of the sampler fed by the CPU oracle, so that the driver logic

@@ -1,5 +1,5 @@
 """Real HDF5 files for the result store without h5py: a ctypes binding of the
-slice of the HDF5 C library (libhdf5 1.8 / 1.10 / 1.12 API names that all three share) the store
+slice of the HDF5 C library (libhdf5 1.10 / 1.12 / 1.14: the API names they share; 1.8 with its 32-bit hid_t is refused) the store
 needs -- groups, contiguous datasets, attributes, external links -- so that `<name>.store/table.hdf`
 and `chunk<i>.hdf` are what the reference writes through h5py (nestfit/main.py:233-377,
 docs/store_spec.rst:45-110): the table's `/pix/<i_lon>/<i_lat>` are external links into the chunk
@@ -127,6 +127,12 @@ def _bind(lib):
     lib.nf_aiterate.argtypes = [hid_t, C.c_int, C.c_int, C.POINTER(hsize_t), _ATTR_CB, C.c_void_p]
     if lib.H5open() < 0:
         raise OSError('H5open failed')
+    # hid_t is a 64-bit integer from 1.10 on and a 32-bit int before: with the 64-bit binding used here a 1.8
+    # library would hand back garbage for every handle and type constant -- refuse it instead
+    major, minor, rel = C.c_uint(), C.c_uint(), C.c_uint()
+    lib.H5get_libversion(C.byref(major), C.byref(minor), C.byref(rel))
+    if (major.value, minor.value) < (1, 10):
+        raise OSError(f'libhdf5 {major.value}.{minor.value}.{rel.value} is older than 1.10 (32-bit hid_t)')
     lib.H5Eset_auto2(0, None, None)                    # errors come back as return codes, not as stderr text
     g = lambda n: hid_t.in_dll(lib, n).value           # noqa: E731  (type handles are valid after H5open)
     lib.T = {

@@ -17,9 +17,9 @@ import numpy as np
 from . import _ffi
 from .core import _as_inplace_vector
 
-_RING_SIGNATURES = ('nfa_ring_create', 'nfa_ring_attach', 'nfa_ring_close', 'nfa_ring_stop', 'nfa_ring_ndim',
-                    'nfa_ring_slot', 'nfa_ring_loglike', 'nfa_ring_callback', 'nfa_ring_poll',
-                    'nfa_ring_complete', 'nfa_ring_stats')
+_RING_SIGNATURES = ('nfa_ring_create', 'nfa_ring_create_multi', 'nfa_ring_attach', 'nfa_ring_close', 'nfa_ring_stop',
+                    'nfa_ring_ndim', 'nfa_ring_slot', 'nfa_ring_max_points', 'nfa_ring_loglike', 'nfa_ring_loglike_many',
+                    'nfa_ring_callback', 'nfa_ring_poll', 'nfa_ring_complete', 'nfa_ring_stats')
 _ring_lib = None
 
 
@@ -62,6 +62,7 @@ class RingClient:
         self.handle = h
         self.ndim = self._lib.nfa_ring_ndim(h)
         self.slot = self._lib.nfa_ring_slot(h)
+        self.max_points = self._lib.nfa_ring_max_points(h)
 
     def loglikelihood(self, utheta, pix=-1):
         """Blocking lnL of one unit-cube point (overwritten with the physical parameters, core.pyx:558-561)."""
@@ -71,6 +72,18 @@ class RingClient:
         lnl = C.c_double()
         _check(self._lib, self._lib.nfa_ring_loglike(self.handle, int(pix), _ffi.dptr(utheta), C.byref(lnl)), 'ring loglike')
         return lnl.value
+
+    def loglikelihood_many(self, U, pix=-1):
+        """Blocking lnL of k <= `max_points` unit-cube points posted together (rows of U, overwritten with the physical
+        parameters): for samplers whose next proposals do not depend on each other's likelihoods."""
+        if not (isinstance(U, np.ndarray) and U.dtype == np.float64 and U.flags.c_contiguous and U.ndim == 2):
+            raise TypeError('U must be a C-contiguous float64 array of shape (k, ndim): it is overwritten in place')
+        if U.shape[1] != self.ndim:
+            raise ValueError(f'Invalid shape for ndim={self.ndim}: {U.shape[1]}')
+        lnl = np.empty(U.shape[0])
+        _check(self._lib, self._lib.nfa_ring_loglike_many(self.handle, int(pix), _ffi.dptr(U), _ffi.dptr(lnl), int(U.shape[0])),
+               'ring loglike_many')
+        return lnl
 
     def callback(self, pix=-1):
         """(function pointer, context) for a C sampler: MultiNest's `LogLike` and its `context`."""
@@ -95,14 +108,15 @@ class RingServer:
     With a `runner` (AmmoniaRunner, CubeRunner, ...; it must not be used by anyone else meanwhile) `serve`
     runs the engine's native loop; `poll` / `complete` let a server put any evaluator between them."""
 
-    def __init__(self, name, n_slots, runner=None, ndim=None):
+    def __init__(self, name, n_slots, runner=None, ndim=None, max_points=1):
         self.runner = runner
         self.ndim = int(runner.ndim if runner is not None else ndim)
         self._lib = _ffi.load() if runner is not None else ring_library()
         h = C.c_void_p()
-        _check(self._lib, self._lib.nfa_ring_create(C.byref(h), os.fsencode(name), int(n_slots), self.ndim), f'creating ring {name}')
-        self.handle, self.name, self.n_slots = h, name, int(n_slots)
-        cap = 128
+        _check(self._lib, self._lib.nfa_ring_create_multi(C.byref(h), os.fsencode(name), int(n_slots), self.ndim, int(max_points)),
+               f'creating ring {name}')
+        self.handle, self.name, self.n_slots, self.max_points = h, name, int(n_slots), int(max_points)
+        cap = self._cap = 1024
         self._slots = np.zeros(cap, dtype=np.int32)
         self._pix = np.zeros(cap, dtype=np.int32)
         self._U = np.zeros((cap, self.ndim))
@@ -128,10 +142,11 @@ class RingServer:
         return threads
 
     def poll(self, max_batch=128, max_wait_us=50, idle_ms=1000):
-        """(slots, pix, U, stopped) of the requests gathered; U is a view valid until the next poll."""
+        """(slots, pix, U, stopped) of the points gathered (the points of one request are neighbouring rows with the same
+        slot); U is a view valid until the next poll."""
         n, stopped = C.c_int(), C.c_int()
         ip = C.POINTER(C.c_int32)
-        _check(self._lib, self._lib.nfa_ring_poll(self.handle, min(int(max_batch), 128), int(max_wait_us), int(idle_ms),
+        _check(self._lib, self._lib.nfa_ring_poll(self.handle, min(int(max_batch), self._cap), int(max_wait_us), int(idle_ms),
                                                   self._slots.ctypes.data_as(ip), self._pix.ctypes.data_as(ip),
                                                   _ffi.dptr(self._U), C.byref(n), C.byref(stopped)), 'ring poll')
         return self._slots[:n.value], self._pix[:n.value], self._U[:n.value], bool(stopped.value)

@@ -63,6 +63,8 @@ class Group:
         for k, part in enumerate(parts):
             if part in node._children:
                 node = node._children[part]
+                if isinstance(node, BrokenLink):       # what h5py answers for a dangling external link
+                    raise KeyError(f'{path}: broken external link ({node.file_name}:{node.obj_path})')
             elif k == len(parts) - 1 and part in node._datasets:
                 return node._datasets[part]
             elif create:
@@ -139,7 +141,7 @@ class Group:
         for k, d in self._datasets.items():
             arrays[self.name.rstrip('/') + '/' + k] = d
         for c in self._children.values():
-            if c._root is self._root:                  # links into other files are not copied
+            if isinstance(c, Group) and c._root is self._root:      # links into other files are not copied
                 c._collect(arrays, attrs)
 
     def to_hdf5(self, h5group):                         # pragma: no cover (needs h5py)
@@ -165,6 +167,16 @@ def _unjson(v):
     if isinstance(v, dict) and '__ndarray__' in v:
         return np.array(v['__ndarray__'], dtype=v['dtype'])
     return v
+
+
+class BrokenLink:
+    """An external link whose target file or object could not be opened."""
+
+    def __init__(self, file_name, obj_path):
+        self.file_name, self.obj_path = file_name, obj_path
+
+    def __repr__(self):
+        return f'<broken external link {self.file_name}:{self.obj_path}>'
 
 
 class StoreFile(Group):
@@ -194,8 +206,10 @@ class StoreFile(Group):
             raise FileNotFoundError(str(self.path))
 
     def _resolve_external(self, parent, name, file_name, obj_path):
-        """An external link read from the file: the object of the linked file takes the link's place (a link
-        whose file or object is gone is dropped, like a dangling link that cannot be opened)."""
+        """An external link read from the file: the object of the linked file takes the link's place.  A link
+        whose file or object is gone stays in the tree as a `BrokenLink` -- it is written back as the link it was,
+        and whoever walks the pixel groups is told (`HdfStore.iter_pix_groups` raises like the reference's,
+        main.py:296-298); it is never dropped silently."""
         target = Path(file_name)
         if not target.is_absolute():
             target = self.path.parent / target
@@ -204,10 +218,12 @@ class StoreFile(Group):
                 self._linked_files[target] = StoreFile(target, 'r')
             parent._children[name] = self._linked_files[target][obj_path]
         except (FileNotFoundError, KeyError, hdf5.Hdf5Error):
-            pass
+            parent._children[name] = BrokenLink(file_name, obj_path)
 
     def _external_of(self, child):
         """(file name, object path) of a child that lives in another file, None for this file's own."""
+        if isinstance(child, BrokenLink):
+            return child.file_name, child.obj_path
         if child._root is self._root:
             return None
         other = child._root.path
@@ -307,8 +323,11 @@ class HdfStore:
         root.setdefault('nchunks', nchunks)          # an existing store keeps its own number of chunks
         self.nchunks = root['nchunks']
         self.model = MODELS.get(root.get('model_name'))
-        if root.get('linked', False):                # links live in memory only: rebuild them on opening
-            self.link_files()
+        # An HDF5 table keeps its links in the file (external links, resolved while reading it); the .npz twin has no
+        # link objects, so there the links of a linked store are rebuilt on opening -- in memory only: opening a
+        # store to read it never rewrites it.
+        if root.get('linked', False) and self.file_format != 'hdf5':
+            self.link_files(flush=False)
 
     # context manager: `with HdfStore(name) as store`
     def __enter__(self):
@@ -341,7 +360,9 @@ class HdfStore:
         lon_level = self.hdf['/pix']
         for lon_name in lon_level:
             for lat_name in lon_level[lon_name]:
-                node = lon_level[lon_name][lat_name]
+                node = lon_level[lon_name]._children.get(lat_name)
+                if isinstance(node, BrokenLink):     # the chunk file (or the group in it) is gone: main.py:296-298
+                    raise ValueError(f'Broken external HDF link: /pix/{lon_name}/{lat_name} -> {node.file_name}:{node.obj_path}')
                 if isinstance(node, Group):
                     yield node
 
@@ -352,13 +373,17 @@ class HdfStore:
                 return group['1']
         raise ValueError('No valid pix groups found.')
 
-    def link_files(self, loaded=None):
+    def link_files(self, loaded=None, flush=True):
         """Hang the pixel groups of every chunk file under the table's /pix: object references in memory,
-        external links (`chunk<i>.hdf:/pix/<i_lon>/<i_lat>`, main.py:286-296) in the table's HDF5 file."""
+        external links (`chunk<i>.hdf:/pix/<i_lon>/<i_lat>`, main.py:286-296) in the table's HDF5 file.
+        Every one of the `nchunks` chunk files has to be there, like in the reference (its `h5py.File(chunk_path,
+        'r')` raises on a missing one, main.py:315): a stripe whose process has crashed or not finished must not
+        turn into a map with silent holes.  A chunk without pixels (an empty stripe) is fine."""
         assert self.is_open
+        missing = [str(p) for p in self.chunk_paths if p not in (loaded or {}) and not p.exists()]
+        if missing:
+            raise FileNotFoundError(f'chunk file(s) of the store are missing, nothing linked: {", ".join(missing)}')
         for path in self.chunk_paths:
-            if not path.exists():
-                continue
             chunk = (loaded or {}).get(path) or StoreFile(path, 'r')     # `loaded`: {path: StoreFile} already in memory
             if '/pix' not in chunk:
                 continue
@@ -366,8 +391,9 @@ class HdfStore:
                 for lat_name in chunk['/pix'][lon_name]:
                     target = f'/pix/{lon_name}/{lat_name}'
                     self.hdf[target] = chunk[target]
-        self.hdf.attrs['linked'] = True
-        self.hdf.flush()
+        self.hdf.attrs['linked'] = True              # only now: all nchunks files were linked
+        if flush:
+            self.hdf.flush()
 
     def reset_pix_links(self):
         assert self.is_open
@@ -392,6 +418,9 @@ class HdfStore:
     def insert_fitter_pars(self, fitter):
         assert self.is_open
         self.hdf.attrs.update({name: get(fitter) for name, get in FITTER_ATTRS})
+        quantum = getattr(fitter, 'nlive_quantum', 1)
+        if quantum != 1:                 # a deviation from main.py:445-447 is written down where the results are
+            self.hdf.attrs['nlive_quantum'] = int(quantum)
 
     def insert_model_metadata(self, runner_cls):
         assert self.is_open

@@ -18,7 +18,7 @@ import json, sys, glob, statistics as st
 for lib in sys.argv[1:]:
     tag = lib.split('/')[-1][:-3]
     v, k, s = [], [], []
-    for f in sorted(glob.glob(f'gpurun_out/r03/ab/{tag}_*.json')):
+    for f in sorted(glob.glob(f'gpurun_out/r03/ab/{tag}_[0-9].json')):
         d = json.loads(open(f).read().strip().splitlines()[-1])
         m = d['modes'][d['config']['exp_mode']]
         v.append(d['value'] / 1e6); k.append(m.get('lnl_kernel_us', 0)); s.append(m.get('setup_kernel_us', 0))

@@ -2,6 +2,7 @@
 nestfit/main.py:233-377, docs/store_spec.rst:45-110).  Checked three ways: round trips through the
 package's own reader, the HDF5 project's `h5dump` where the tool is installed (an independent reader
 of the same files), and a fit on CPU whose store is walked against the names of the specification."""
+import os
 import re
 import shutil
 import subprocess
@@ -217,3 +218,52 @@ def test_native_helper_and_plain_ctypes_paths_agree(tmp_path, monkeypatch):
     for other in (fast_by_plain, plain_by_plain, plain_by_fast):
         same(fast_by_fast['/pix/1/2'], other['/pix/1/2'])
     assert _dump('-H', tmp_path / 'fast.hdf').replace('fast.hdf', 'X') == _dump('-H', tmp_path / 'plain.hdf').replace('plain.hdf', 'X')
+
+
+def _two_chunk_store(tmp_path, file_format):
+    """A store with two chunk files, one pixel group each, linked."""
+    store = HdfStore(str(tmp_path / 'broken'), nchunks=2, file_format=file_format)
+    for k, path in enumerate(store.chunk_paths):
+        with StoreFile(path, 'a') as chunk:
+            g = chunk.require_group(f'/pix/{k}/0')
+            g.attrs['nbest'] = k + 1
+    store.link_files()
+    store.close()
+    return store.store_dir, [str(p) for p in store.chunk_paths]
+
+
+@pytest.mark.parametrize('file_format', ['hdf5', 'npz'])
+def test_missing_chunks_are_an_error_not_a_hole(tmp_path, file_format):
+    """The reference opens every chunk file (`h5py.File(chunk_path, 'r')`, main.py:315) and raises on a dangling
+    link (main.py:296-298): a stripe that crashed or has not finished must not turn into a map with silent holes."""
+    if file_format == 'hdf5' and not hdf5.available():
+        pytest.skip('libhdf5 not found')
+    store_dir, chunks = _two_chunk_store(tmp_path, file_format)
+    table = store_dir / ('table.hdf' if file_format == 'hdf5' else 'table.npz')
+    before = table.stat().st_mtime_ns
+    with HdfStore(str(store_dir)) as store:                    # opening a linked store to read it ...
+        assert sorted(g.attrs['nbest'] for g in store.iter_pix_groups()) == [1, 2]
+        assert store.hdf.attrs['linked'] is True or store.hdf.attrs['linked'] == 1
+    os.unlink(chunks[1])
+    if file_format == 'hdf5':
+        with HdfStore(str(store_dir)) as store:                # the link is still in the table, its target is gone
+            with pytest.raises(ValueError, match='Broken external HDF link'):
+                list(store.iter_pix_groups())
+            with pytest.raises(KeyError, match='broken external link'):
+                store.hdf['/pix/1/0']
+            assert store.hdf['/pix/0/0'].attrs['nbest'] == 1
+        with HdfStore(str(store_dir)) as store:                # ... and closing it did not drop the dangling link
+            with pytest.raises(ValueError, match='Broken external HDF link'):
+                list(store.iter_pix_groups())
+    else:
+        with pytest.raises(FileNotFoundError, match='chunk1'):
+            HdfStore(str(store_dir))
+    # linking with a chunk missing links nothing and says which file
+    fresh = HdfStore(str(tmp_path / 'fresh'), nchunks=2, file_format=file_format)
+    with StoreFile(fresh.chunk_paths[0], 'a') as chunk:
+        chunk.require_group('/pix/0/0')
+    with pytest.raises(FileNotFoundError, match='chunk1'):
+        fresh.link_files()
+    assert not fresh.hdf.attrs.get('linked', False) and '/pix' not in fresh.hdf
+    fresh.close()
+    assert before > 0

@@ -251,6 +251,145 @@ def test_slot_of_a_dead_client_is_inherited():
         assert server.stats['clients'] == 0
 
 
+def _many_client(name, rank, n_calls, k, out):
+    client = RingClient(name, wait_ms=20000)
+    rng = np.random.default_rng(300 + rank)
+    rows = []
+    for _ in range(n_calls):
+        U = rng.random((k, NDIM))
+        theta = U.copy()
+        lnl = client.loglikelihood_many(theta, pix=rank)
+        rows.append((U, theta, lnl))
+    assert client.max_points == 8
+    client.close()
+    out.put((rank, rows))
+
+
+def test_several_points_per_call():
+    """nfa_ring_loglike_many: a client posts k points in one call (a sampler whose next proposals are independent
+    draws); the points of a request stay together in a batch and come back in order."""
+    name = f'nfa_test_ring_many_{os.getpid()}'
+    n_clients, n_calls, k = 3, 40, 5
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    with RingServer(name, n_slots=n_clients, ndim=NDIM, max_points=8) as server:
+        procs = [ctx.Process(target=_many_client, args=(name, r, n_calls, k, out)) for r in range(n_clients)]
+        for p in procs:
+            p.start()
+        served = 0
+        while served < n_clients * n_calls * k:
+            slots, pix, U, stopped = server.poll(max_batch=12, max_wait_us=5000, idle_ms=20000)    # room for two requests
+            assert not stopped and slots.size in (k, 2 * k)
+            assert all(len(set(slots[a:a + k])) == 1 for a in range(0, slots.size, k))           # whole requests, row by row
+            theta, lnl = _evaluate(pix.copy(), U.copy())
+            server.complete(slots, theta, lnl)
+            served += slots.size
+        got = dict(out.get(timeout=60) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert server.stats['evals'] == n_clients * n_calls * k
+    for rank, rows in got.items():
+        for U, theta, lnl in rows:
+            t, l = _evaluate(np.full(k, rank), U)
+            assert np.array_equal(theta, t) and np.array_equal(lnl, l)
+    with RingServer(name + 'b', n_slots=1, ndim=NDIM) as server:      # one point per slot unless asked otherwise
+        with RingClient(name + 'b') as client:
+            with pytest.raises(_ffi.EngineError, match='more points'):
+                client.loglikelihood_many(np.zeros((2, NDIM)))
+
+
+def _server_that_dies(name, ready):
+    server = RingServer(name, n_slots=2, ndim=NDIM)
+    ready.set()
+    slots, _pix, _U, _stopped = server.poll(idle_ms=30000)     # takes the request ...
+    assert slots.size == 1
+    os._exit(0)                                                # ... and dies with it
+
+
+def test_a_client_does_not_wait_for_a_dead_server():
+    """The process that created the ring dies while a client waits for its answer: the call returns an error within
+    its wake-up period instead of blocking for ever."""
+    import time
+    name = f'nfa_test_ring_orphan_{os.getpid()}'
+    ctx = mp.get_context('spawn')
+    ready = ctx.Event()
+    p = ctx.Process(target=_server_that_dies, args=(name, ready))
+    p.start()
+    assert ready.wait(60)
+    client = RingClient(name, wait_ms=20000)
+    t0 = time.time()
+    with pytest.raises(_ffi.EngineError, match='server process is gone|no serving loop'):
+        client.loglikelihood(np.full(NDIM, 0.25))
+    assert time.time() - t0 < 20
+    p.join(timeout=30)
+    client.close()
+    try:
+        os.unlink(f'/dev/shm/{name}')
+    except OSError:
+        pass
+
+
+def _posts_and_dies(name, posted):
+    import threading as th
+    client = RingClient(name, wait_ms=20000)
+    th.Thread(target=lambda: client.loglikelihood(np.full(NDIM, 0.5), pix=3), daemon=True).start()
+    while RingServerStatsProbe.posts(name) == 0:
+        pass
+    posted.set()
+    import time
+    time.sleep(0.5)                                            # the server claims the request meanwhile
+    os._exit(0)
+
+
+class RingServerStatsProbe:
+    """Reads the post counter of a ring's header straight from the shared-memory object (test helper)."""
+    @staticmethod
+    def posts(name):
+        import struct
+        with open(f'/dev/shm/{name}', 'rb') as f:
+            head = f.read(64)
+        return struct.unpack_from('<I', head, 44)[0]           # RingHeader.posts (csrc/nfa_ring.h)
+
+
+def test_a_late_result_is_not_delivered_to_the_slots_next_owner():
+    """A client dies after a server has claimed its request; another process inherits the slot and posts a request of
+    its own.  The first request's result, completed late, must be dropped (slot generations), the second served."""
+    name = f'nfa_test_ring_gen_{os.getpid()}'
+    ctx = mp.get_context('spawn')
+    posted = ctx.Event()
+    with RingServer(name, n_slots=1, ndim=NDIM) as server:
+        p = ctx.Process(target=_posts_and_dies, args=(name, posted))
+        p.start()
+        assert posted.wait(60)
+        slots, pix, U, _ = server.poll(idle_ms=20000)          # claimed under the dying client's generation
+        old = (slots.copy(), *_evaluate(pix.copy(), U.copy()))
+        p.join(timeout=30)
+        result = {}
+        client = RingClient(name, wait_ms=1000)                # inherits the only slot
+        u = np.full(NDIM, 0.125)
+
+        def call():
+            theta = u.copy()
+            result['lnl'] = client.loglikelihood(theta, pix=1)
+            result['theta'] = theta
+        t = threading.Thread(target=call)
+        t.start()
+        import time
+        while RingServerStatsProbe.posts(name) < 2:
+            time.sleep(0.001)
+        server.complete(*old)                                   # late: must not reach the new owner
+        time.sleep(0.05)
+        assert 'lnl' not in result
+        slots, pix, U, _ = server.poll(idle_ms=20000)
+        assert slots.size == 1 and pix[0] == 1
+        server.complete(slots, *_evaluate(pix.copy(), U.copy()))
+        t.join(timeout=30)
+        want_theta, want_lnl = _evaluate(np.array([1]), u[None, :])
+        assert np.array_equal(result['theta'], want_theta[0]) and result['lnl'] == want_lnl[0]
+        client.close()
+
+
 @pytest.mark.gpu
 def test_ring_serves_processes_from_the_engine(engine, nfo):
     """Four sampler processes (no GPU context) against the native serving loop: bitwise what the runner gives
