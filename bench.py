@@ -56,7 +56,7 @@ WORKLOADS = {
     'C1': ((1,), 256, 30.0, 1, 'TRUTH_1COMP', 4096),
 }
 PROFILE_DIRS = [ROOT / 'profiles' / 'r03', ROOT / 'profiles' / 'r02']
-MIN_BLOCK_S = 0.020            # a timed block lasts at least this long (the K-step sequence is repeated)
+MIN_BLOCK_S = 0.025            # length a timed block is sized for from a lone K-step probe (>= 20 ms in effect)
 MAX_BLOCK_STEPS = 4096
 
 
@@ -385,7 +385,7 @@ def main():
         """How often the K-step sequence is repeated inside a timed block so that the block lasts MIN_BLOCK_S: from
         two probe blocks of K steps (the slowest rank's time, so that every rank repeats alike)."""
         t, _ = timed_blocks(handle, 2, 1)
-        r = int(np.ceil(MIN_BLOCK_S / float(t.min())))
+        r = int(np.ceil(MIN_BLOCK_S / float(t.min())))       # (a lone K-step block pays fill and drain: the repeated block runs faster per step, hence the margin in MIN_BLOCK_S)
         return max(1, min(r, MAX_BLOCK_STEPS // args.steps if args.steps <= MAX_BLOCK_STEPS else 1))
 
     def one_lane_kernel_times(spl=1):
@@ -494,7 +494,11 @@ def main():
     ubuf = C.create_string_buffer(40)
     _ffi.check(lib.nfa_device_uuid(ubuf, 40))
     mine = np.frombuffer(bytes.fromhex(ubuf.value.decode()), dtype=np.uint8).astype(np.float64)
-    uuids = [bytes(row.astype(np.uint8)).hex() for row in comm.allgather(mine).reshape(world, 16)]
+    uuids = []
+    for row in comm.allgather(mine).reshape(world, 16):
+        raw = bytes(row.astype(np.uint8))
+        # HIP reports the UUID as 16 ASCII hex digits on this stack: show those; raw bytes otherwise
+        uuids.append(raw.decode('ascii') if all(32 < b < 127 for b in raw) else raw.hex())
 
     if rank == 0:
         head = per_mode[args.exp_mode]

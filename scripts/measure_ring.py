@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Sampler processes behind the shared-memory ring (nestfit_amd/ring.py, csrc/nfa_ring.h): N processes
 that never touch the GPU post their LogLike points (one at a time each, like MultiNest:
-nestfit/core/cmultinest.pxd:27-28, one process per stripe: nestfit/main.py:516-523), ONE process with the
-runner serves them, every round of posted points one point-kernel launch.  Prints the aggregate rate, the
+nestfit/core/cmultinest.pxd:27-28, one process per stripe: nestfit/main.py:516-523 -- or k at a time through
+nfa_ring_loglike_many: a sampler whose next k proposals are independent draws), ONE process with the
+runner serves them, every round of posted points one launch.  Prints the aggregate rate, the
 time a client waits per call and the mean batch; beside it profiles/r02/multiproc_points.txt has the same
 processes with a runner each (no ring)."""
 import multiprocessing as mp
@@ -17,17 +18,18 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def client(name, rank, n_calls, start, out):
+def client(name, rank, n_calls, start, out, k_pts=1):
     from nestfit_amd.ring import RingClient
     c = RingClient(name, wait_ms=60000)
     rng = np.random.default_rng(rank)
-    U = rng.uniform(size=(n_calls + 200, c.ndim))
+    U = rng.uniform(size=(n_calls + 200, k_pts, c.ndim))
+    call = (lambda u: c.loglikelihood(u[0])) if k_pts == 1 else c.loglikelihood_many
     for k in range(200):
-        c.loglikelihood(U[k])
+        call(U[k])
     start.wait(120)
     t0 = time.perf_counter()
     for k in range(200, n_calls + 200):
-        c.loglikelihood(U[k])
+        call(U[k])
     t1 = time.perf_counter()
     c.close()
     out.put((rank, t0, t1))
@@ -42,19 +44,20 @@ C_CLIENT = r"""
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 int main(int argc, char **argv) {
     nfa_ring *ring = NULL;
-    if (argc < 5 || nfa_ring_attach(&ring, argv[1], 60000) != NFA_OK) return 2;
-    const int rank = atoi(argv[2]), n_calls = atoi(argv[3]), ndim = nfa_ring_ndim(ring);
+    if (argc < 6 || nfa_ring_attach(&ring, argv[1], 60000) != NFA_OK) return 2;
+    const int rank = atoi(argv[2]), n_calls = atoi(argv[3]), ndim = nfa_ring_ndim(ring), k_pts = atoi(argv[5]);
     const double t_start = atof(argv[4]);
     nfa_ring_client ctx = { ring, -1 };
-    double cube[64], lnew;
+    static double cube[64 * 64], lnew[64];
     unsigned long long state = 88172645463325252ull + (unsigned long long)rank * 7919ull;
     for (int k = -200; k < n_calls; ++k) {
         if (k == 0) while (now() < t_start) ;
-        for (int j = 0; j < ndim; ++j) {                     /* xorshift: a fresh unit-cube point per call */
+        for (int j = 0; j < ndim * k_pts; ++j) {             /* xorshift: fresh unit-cube points per call */
             state ^= state << 13; state ^= state >> 7; state ^= state << 17;
             cube[j] = (double)(state >> 11) / 9007199254740992.0;
         }
-        nfa_ring_callback(cube, (int *)&ndim, (int *)&ndim, &lnew, &ctx);
+        if (k_pts == 1) nfa_ring_callback(cube, (int *)&ndim, (int *)&ndim, lnew, &ctx);      /* MultiNest's own call */
+        else if (nfa_ring_loglike_many(ring, -1, cube, lnew, k_pts) != NFA_OK) return 3;
     }
     printf("%.9f %.9f\n", t_start, now());
     return nfa_ring_close(ring);
@@ -62,7 +65,7 @@ int main(int argc, char **argv) {
 """
 
 
-def native_clients(name, n_proc, n_calls):
+def native_clients(name, n_proc, n_calls, k_pts=1):
     """N compiled clients as subprocesses; returns [(t_start, t_end)] on the monotonic clock."""
     import subprocess
     import tempfile
@@ -73,7 +76,7 @@ def native_clients(name, n_proc, n_calls):
     subprocess.run(['gcc', '-O2', '-std=gnu99', '-I', str(ROOT / 'include'), '-o', str(exe), str(tmp / 'client.c'),
                     str(OUT_RING), f'-Wl,-rpath,{OUT_RING.parent}'], check=True)
     t_start = time.clock_gettime(time.CLOCK_MONOTONIC) + 1.0 + 0.02 * n_proc
-    procs = [subprocess.Popen([str(exe), name, str(k), str(n_calls), f'{t_start:.9f}'], stdout=subprocess.PIPE, text=True)
+    procs = [subprocess.Popen([str(exe), name, str(k), str(n_calls), f'{t_start:.9f}', str(k_pts)], stdout=subprocess.PIPE, text=True)
              for k in range(n_proc)]
     out = []
     for p in procs:
@@ -84,7 +87,8 @@ def native_clients(name, n_proc, n_calls):
 
 
 def main():
-    """measure_ring.py [native] [processes[:serving threads] ...]   (native: compiled C clients instead of Python ones)"""
+    """measure_ring.py [native] [processes[:serving threads[:points per call]] ...]
+    (native: compiled C clients instead of Python ones)"""
     import nestfit_amd as na
     from nestfit_amd.ring import RingServer
     from nestfit_amd.synth import TRUTH_2COMP, freq_axis
@@ -100,19 +104,19 @@ def main():
     ctx = mp.get_context('spawn')
     argv = [a for a in sys.argv[1:] if a != 'native']
     native = 'native' in sys.argv[1:]
-    cases = [tuple(int(v) for v in (a + ':1').split(':')[:2]) for a in argv] or [(1, 1), (2, 1), (4, 1), (8, 1), (14, 1)]
-    for n_proc, n_serv in cases:
+    cases = [tuple(int(v) for v in (a + ':1:1').split(':')[:3]) for a in argv] or [(1, 1, 1), (2, 1, 1), (4, 1, 1), (8, 1, 1), (14, 1, 1)]
+    for n_proc, n_serv, k_pts in cases:
         while len(runners) < n_serv:                   # one runner (its own streams) per serving thread
             runners.append(na.AmmoniaRunner.from_data(args, priors, ncomp=2))
-        n_calls = 20000 if n_proc <= 16 else 8000
-        name = f'nfa_measure_ring_{n_proc}_{n_serv}'
-        with RingServer(name, n_slots=n_proc, runner=runners[0]) as server:
+        n_calls = (20000 if n_proc <= 16 else 8000) // max(1, k_pts // 4)
+        name = f'nfa_measure_ring_{n_proc}_{n_serv}_{k_pts}'
+        with RingServer(name, n_slots=n_proc, runner=runners[0], max_points=k_pts) as server:
             threads = server.serve_in_threads(runners[:n_serv], max_wait_us=30, idle_ms=120000)
             if native:
-                res = [(k, a, b) for k, (a, b) in enumerate(native_clients(name, n_proc, n_calls))]
+                res = [(k, a, b) for k, (a, b) in enumerate(native_clients(name, n_proc, n_calls, k_pts))]
             else:
                 start, out = ctx.Barrier(n_proc), ctx.Queue()
-                procs = [ctx.Process(target=client, args=(name, k, n_calls, start, out)) for k in range(n_proc)]
+                procs = [ctx.Process(target=client, args=(name, k, n_calls, start, out, k_pts)) for k in range(n_proc)]
                 for p in procs:
                     p.start()
                 res = [out.get(timeout=900) for _ in procs]
@@ -124,7 +128,8 @@ def main():
             st = server.stats
         wall = max(r[2] for r in res) - min(r[1] for r in res)
         per_call = np.mean([r[2] - r[1] for r in res]) / n_calls
-        print(f'{n_proc:2d} {"compiled" if native else "Python"} processes, {n_serv} serving thread(s): {n_proc * n_calls / wall / 1e3:7.1f} k evals/s in all, '
+        print(f'{n_proc:2d} {"compiled" if native else "Python"} processes x {k_pts} point(s) per call, {n_serv} serving thread(s): '
+              f'{n_proc * n_calls * k_pts / wall / 1e3:7.1f} k evals/s in all, '
               f'{per_call * 1e6:6.1f} us per call in each, {st["evals"] / st["batches"]:5.2f} points per launch '
               f'(largest {st["largest_batch"]})', flush=True)
 

@@ -45,3 +45,43 @@ def test_weights_are_normalised(nfo):
         n = lib.nfo_trans_nhf(t)
         tot = sum(lib.nfo_trans_tau_wt(t, i) for i in range(n))
         assert tot == pytest.approx(1.0, abs=2e-3)
+
+
+def _def_value(text, name, after=None):
+    """The literal of `DEF <name> = <literal>` (the first one behind the marker `after`, if given)."""
+    start = text.index(after) if after else 0
+    m = re.compile(rf'DEF {name}\s*=\s*([-+0-9.eE]+)').search(text, start)
+    assert m, name
+    return float(m.group(1))
+
+
+@pytest.mark.skipif(not REF.exists(), reason='reference tree not present')
+def test_constants_match_reference_text():
+    """The physical and spectroscopic constants of csrc/nh3_data.h (shared by the engine and the oracle: a wrong literal
+    would be common to both) against the reference's own text: model_includes.pxi:27-36, ammonia.pyx:14-30,
+    hyperfine.pyx:10-16, core.pyx:20."""
+    inc = (REF.parents[2] / 'includes' / 'model_includes.pxi').read_text()
+    amm = REF.read_text()
+    hyp = (REF.parent / 'hyperfine.pyx').read_text()
+    core = (REF.parents[1] / 'core' / 'core.pyx').read_text()
+    hdr = (Path(__file__).resolve().parent.parent / 'nestfit_amd' / 'csrc' / 'nh3_data.h').read_text()
+
+    def mine(name, new_const=True):
+        ms = re.findall(rf'#define {name}\s+([-+0-9.eE]+)', hdr)
+        assert ms, name
+        return float(ms[-1] if new_const and len(ms) > 1 else ms[0])
+    assert 'DEF __NEW_CONST = True' in inc and 'DEF __APPROX = True' in inc       # the constant set the reference ships
+    for ref_name, my_name in (('CKMS', 'NFA_CKMS'), ('CCMS', 'NFA_CCMS'), ('H', 'NFA_H'), ('KB', 'NFA_KB')):
+        assert mine(my_name) == _def_value(inc, ref_name)
+    assert mine('NFA_TCMB') == _def_value(inc, 'TCMB', after='IF __NEW_CONST')
+    assert mine('NFA_BROT') == _def_value(amm, 'BROT', after='IF __NEW_CONST')
+    assert mine('NFA_CROT') == _def_value(amm, 'CROT', after='IF __NEW_CONST')
+    assert mine('NFA_NPART') == _def_value(amm, 'NPART') and mine('NFA_N_LEVELS') == _def_value(amm, 'N_LEVELS')
+    assert mine('NFA_N_PARAMS') == _def_value(amm, 'N_PARAMS')
+    assert mine('NFA_MAX_HF_N') == _def_value((REF.parents[2] / 'includes' / 'array_sizes.pxi').read_text(), 'MAX_HF_N')
+    # the 1/(e^x - 1) table: 1000 points between (h 23 GHz / k) / 8 K and (h 28 GHz / k) / 2.7 K
+    assert _def_value(hyp, 'T0_SIZE') == 1000 and 'H * 23.0e9 / KB' in hyp and 'H * 28.0e9 / KB' in hyp
+    assert 'T0_LO / 8.0' in hyp and 'T0_HI / 2.7' in hyp
+    assert _def_value(core, 'FWHM') == 2.3548200450309493
+    # Swift et al. 2005 eq. A6 literals and the (J, K) ladder of the partition sum
+    assert '41.18' in amm and '15.7' in amm and '0.6' in amm
