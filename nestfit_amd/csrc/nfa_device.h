@@ -527,6 +527,71 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
                  : "vcc");
 }
 
+// The fast mode's walk over a run of `n` >= 1 neighbouring line records starting at LDS address `va`: line_step_fastz
+// for each of them, software-pipelined by hand -- the record of the NEXT line is read (two 16-byte broadcast reads
+// into the other of two fixed register sets) before the step of this one, so that the read's latency passes under
+// the step, and the address advances once per two lines.  The compiler will not schedule this (left to it the loop
+// came out with a wait for everything at its head and eight register copies per turn), and inline assembly cannot
+// name the halves of a 128-bit operand: hence fixed registers v48..v63 (record sets A = v48..55, B = v56..63:
+// nucen, k, w, -, mid, half, each its own temporary once read), declared clobbered.  The kernel stays at 64 registers.
+// EXEC is all ones on entry and on exit; nothing else of this wave is in flight on the LDS / scalar-memory counter
+// when the reads start (the wait at the top), so the counted waits below see only these reads.
+#define NF_STEP(S_NUCEN, S_K, S_W, S_T2, S_MID, S_HALF)      /* the record's own registers serve as temporaries once read */ \
+    "v_sub_f32 " S_MID ", %[jf], " S_MID "\n\t"                                                      \
+    "v_cmpx_lt_f32_e64 vcc, |" S_MID "|, " S_HALF "\n\t"                                             \
+    "v_add_f64 " S_NUCEN ", %[xj], -" S_NUCEN "\n\t"                                                 \
+    "v_mul_f64 " S_NUCEN ", " S_NUCEN ", " S_K "\n\t"                                                \
+    "v_mul_f64 " S_NUCEN ", " S_NUCEN ", " S_NUCEN "\n\t"                                            \
+    "v_cvt_f32_f64 " S_MID ", " S_NUCEN "\n\t"              /* math.pxd:17 narrowing */              \
+    "v_mul_f32 " S_HALF ", 0xbfb8aa3b, " S_MID "\n\t"       /* yh = -x log2(e) */                    \
+    "v_exp_f32 " S_T2 ", " S_HALF "\n\t"                                                             \
+    "v_fma_f32 " S_MID ", " S_HALF ", %[kln2], -" S_MID "\n\t"   /* r = -x - yh ln2 (and the wait state) */ \
+    "v_fmac_f32 " S_T2 ", " S_T2 ", " S_MID "\n\t"          /* e = 2^yh (1 + r) */                   \
+    "v_fmac_f32 %[tau], " S_W ", " S_T2 "\n\t"                                                       \
+    "s_mov_b64 exec, -1\n\t"
+#define NF_STEP_A NF_STEP("v[48:49]", "v[50:51]", "v52", "v53", "v54", "v55")
+#define NF_STEP_B NF_STEP("v[56:57]", "v[58:59]", "v60", "v61", "v62", "v63")
+__device__ __forceinline__ void line_run_fast(float &tau, unsigned va, int n, float jf, double xj) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i ra, rb;
+    // the first record's reads go out before the wait for the channel's frequency (a global load the compiler waits
+    // for in front of the block that uses it): two blocks, tied through the register set A
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "ds_read_b128 %[ra], %[va]\n\t"
+                 "ds_read_b128 %[rb], %[va] offset:16"
+                 : [ra] "={v[48:51]}"(ra), [rb] "={v[52:55]}"(rb)
+                 : [va] "v"(va)
+                 : "memory");
+    asm volatile("1:\n\t"
+                 "s_sub_u32 %[n], %[n], 1\n\t"
+                 "s_cmp_eq_u32 %[n], 0\n\t"
+                 "s_cbranch_scc1 3f\n\t"                                  // A is the last line
+                 "ds_read_b128 v[56:59], %[va] offset:32\n\t"
+                 "ds_read_b128 v[60:63], %[va] offset:48\n\t"
+                 "s_waitcnt lgkmcnt(2)\n\t"
+                 NF_STEP_A
+                 "s_sub_u32 %[n], %[n], 1\n\t"
+                 "s_cmp_eq_u32 %[n], 0\n\t"
+                 "s_cbranch_scc1 4f\n\t"                                  // B is the last line
+                 "v_add_u32 %[va], 64, %[va]\n\t"
+                 "ds_read_b128 v[48:51], %[va]\n\t"
+                 "ds_read_b128 v[52:55], %[va] offset:16\n\t"
+                 "s_waitcnt lgkmcnt(2)\n\t"
+                 NF_STEP_B
+                 "s_branch 1b\n\t"
+                 "3:\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 NF_STEP_A
+                 "s_branch 5f\n\t"
+                 "4:\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 NF_STEP_B
+                 "5:"
+                 : [tau] "+v"(tau), [va] "+v"(va), [n] "+s"(n), [ra] "+{v[48:51]}"(ra), [rb] "+{v[52:55]}"(rb)
+                 : [jf] "v"(jf), [xj] "v"(xj), [kln2] "s"(-0.693147182464599609375f)
+                 : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+}
+
 // The body of the likelihood kernel for workgroup `block_id` of a launch (lnl_kernel: the hardware's
 // workgroup; point_kernel: the one workgroup walks the few of a single point).  `sm` = the staged
 // exponential tables (n_shared doubles at the start of smem), the line tables follow them.
@@ -788,24 +853,28 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     unsigned va = lbase + ((unsigned)first << 5);
                     asm volatile("" : "+v"(va));
                     int wi = c * G.nhf_max + first;
-                    if (n & 1) {
-                        const v2d ab = rec_ab(va);
-                        const v4i hw = rec_hw(va);
-                        step(ab, hw, wi);
-                        va += 32;
-                        asm volatile("" : "+v"(va));
-                        wi += 1;
-                        n -= 1;
-                    }
-                    while (n) {                                        // both records of a pair are read before the first step
-                        const v2d ab0 = rec_ab(va), ab1 = rec_ab(va + 32);
-                        const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
-                        step(ab0, hw0, wi);
-                        step(ab1, hw1, wi + 1);
-                        va += 64;
-                        asm volatile("" : "+v"(va));
-                        wi += 2;
-                        n -= 2;
+                    if constexpr (FASTN) {
+                        line_run_fast(tau, va, n, jf, xj);
+                    } else {
+                        if (n & 1) {
+                            const v2d ab = rec_ab(va);
+                            const v4i hw = rec_hw(va);
+                            step(ab, hw, wi);
+                            va += 32;
+                            asm volatile("" : "+v"(va));
+                            wi += 1;
+                            n -= 1;
+                        }
+                        while (n) {                                        // both records of a pair are read before the first step
+                            const v2d ab0 = rec_ab(va), ab1 = rec_ab(va + 32);
+                            const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
+                            step(ab0, hw0, wi);
+                            step(ab1, hw1, wi + 1);
+                            va += 64;
+                            asm volatile("" : "+v"(va));
+                            wi += 2;
+                            n -= 2;
+                        }
                     }
                 }
                 if (MODE == 2 && WIDE) tau = (tau_t)td;
