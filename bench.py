@@ -348,6 +348,9 @@ def main():
             m = min(have, n - have)
             _ffi.check(lib.nfa_memcpy_d2d(C.c_void_p(buf['U'].value + have * step_bytes), buf['U'], m * step_bytes))
             have += m
+        # the copies run on the default stream, the runner's lanes do not wait for it: nothing may start (and transform
+        # rows in place) before every row holds its unit-cube values
+        _ffi.check(lib.nfa_device_synchronize())
 
     def step(handle, k):
         # consecutive steps may overlap on the device (stream lanes): no buffer is shared
@@ -483,6 +486,17 @@ def main():
                                   C.c_void_p(buf['lnL'].value + (n_steps - 1) * B * 8), B * 8))
     if not np.isfinite(lnL).all():
         raise SystemExit('non-finite log-likelihood in the benchmark batch')
+    # ... and the timed steps were fed what they are said to be fed: theta of the last step of the first and of the
+    # last repeat of the last block is the prior transform of the unit-cube rows (a step that found rows an earlier pass
+    # had already turned into theta would do different, cheaper work)
+    want = U_host.copy()
+    ut.transform_batch(want, ncomp)
+    theta = np.empty((B, ndim))
+    last_repeats = per_mode[modes[-1]]['repeats_per_block']
+    for k in sorted({n_steps - 1, args.warmup + args.steps * last_repeats - 1}):
+        _ffi.check(lib.nfa_memcpy_d2h(theta.ctypes.data_as(C.c_void_p), C.c_void_p(buf['U'].value + k * step_bytes), step_bytes))
+        if not np.allclose(theta, want, rtol=1e-9, atol=1e-9):
+            raise SystemExit(f'theta of timed step {k} is not the prior transform of its unit-cube rows: stale inputs')
     # end-of-run gather of fixed-size per-pixel records: here (i_lon, i_lat, rank, best lnL
     # of the last pixel walked, evaluations made per block by this rank)
     k_last = (n_steps - 1) % n_pix

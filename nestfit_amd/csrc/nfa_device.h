@@ -384,13 +384,12 @@ __device__ __forceinline__ const double *stage_exp_tables(double *smem, const do
 // offsets (c_rank), so that the lines whose windows touch a row of channels are ONE run of neighbours; the windows
 // themselves, [lo, hi), lie behind the table as an array of their own (the row loop's hit masks).
 //   nucen   line centre (hyperfine.pyx:73)
-//   k       exact modes and the wide form: idenom = 0.5 / width^2 (hyperfine.pyx:75);
-//           fast mode: sqrt(idenom) -- the argument is formed as ((x - nucen) k)^2, see line_step_fastz
+//   idenom  0.5 / width^2 (hyperfine.pyx:75)
 //   w       weight hf_tau (hyperfine.pyx:74): a double in the exact modes, a float in the low word in the fast mode
 //   mid, half   the window [lo, lo + len) as |j - mid| < half, mid = lo + (len - 1) / 2, half = len / 2: exact in
 //           fp32 for spectra below 2^22 channels (longer ones take the wide form, which tests integers)
 struct __attribute__((aligned(16))) LineRec {
-    double nucen, k;                             // first 16-byte read
+    double nucen, idenom;                        // first 16-byte read
     double w;                                    // second 16-byte read
     float mid, half;
 };
@@ -495,25 +494,22 @@ __device__ __forceinline__ double one_minus_fastexp_f32(float t, unsigned long l
 //  scalar loads).  lnl_sum_kernel adds the terms of an item in spectrum order
 //  (ammonia.pyx:429-432).
 // ---------------------------------------------------------------------------
-// The fast mode's line x row step as one instruction block: window test -> EXEC, float-narrowed Gaussian argument,
-// exp, tau += w e; EXEC is all ones on entry (every branch around it is wave-uniform) and on exit.
-//   * the Gaussian argument as ((x - nucen) k)^2 with k = sqrt(0.5) / width: two fp64 multiplications
-//     instead of three.  The reference forms (x - nucen)^2 * idenom (hyperfine.pyx:94) before it narrows the
-//     argument to float (math.pxd:17); the two forms differ by a few 2^-53 relative, so the narrowed float is
-//     the reference's except where the exact value lies that close to a rounding boundary of the float grid:
-//     about one (line, channel) pair in 2e8, and then by one ulp of the float (<= 7.5e-7 of that one term).
+// The fast mode's line x row step as one instruction block: window test -> EXEC, float-narrowed Gaussian argument
+// formed exactly as the reference forms it ((x - nucen)^2 * idenom in fp64, hyperfine.pyx:94, then narrowed,
+// math.pxd:17), exp, tau += w e; EXEC is all ones on entry (every branch around it is wave-uniform) and on exit.
 //   * the window as |j - mid| < half in fp32: an fp32 subtraction runs at twice the rate of an integer one.
 //   * exp as 2^yh (1 + r), r = -x - yh ln2 in ONE fused step (the exact product with the float nearest ln 2;
 //     what is dropped, yh (ln 2 - fl(ln 2)), is below 3.5e-8 relative inside a window, x <= 12.5).
-__device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj, double nucen, double sq,
+// (Tried and dropped: the argument as ((x - nucen) sqrt(idenom))^2 -- it is two multiplications either way.)
+__device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj, double nucen, double idenom,
                                                 float htau, float mid, float half) {
     double d;
     float t0, t1, t2;
     asm volatile("v_sub_f32 %[t0], %[jf], %[mid]\n\t"
                  "v_cmpx_lt_f32_e64 vcc, |%[t0]|, %[half]\n\t"
                  "v_add_f64 %[d], %[xj], -%[nucen]\n\t"
-                 "v_mul_f64 %[d], %[d], %[sq]\n\t"
                  "v_mul_f64 %[d], %[d], %[d]\n\t"
+                 "v_mul_f64 %[d], %[d], %[idenom]\n\t"
                  "v_cvt_f32_f64 %[t0], %[d]\n\t"                       // math.pxd:17 narrowing
                  "v_mul_f32 %[t1], 0xbfb8aa3b, %[t0]\n\t"               // yh = -x log2(e)
                  "v_exp_f32 %[t2], %[t1]\n\t"
@@ -523,73 +519,8 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
                  "s_mov_b64 exec, -1"
                  : [tau] "+v"(tau), [d] "=&v"(d), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
                  : [jf] "v"(jf), [mid] "v"(mid), [half] "v"(half), [xj] "v"(xj), [nucen] "v"(nucen),
-                   [sq] "v"(sq), [htau] "v"(htau), [kln2] "s"(-0.693147182464599609375f)
+                   [idenom] "v"(idenom), [htau] "v"(htau), [kln2] "s"(-0.693147182464599609375f)
                  : "vcc");
-}
-
-// The fast mode's walk over a run of `n` >= 1 neighbouring line records starting at LDS address `va`: line_step_fastz
-// for each of them, software-pipelined by hand -- the record of the NEXT line is read (two 16-byte broadcast reads
-// into the other of two fixed register sets) before the step of this one, so that the read's latency passes under
-// the step, and the address advances once per two lines.  The compiler will not schedule this (left to it the loop
-// came out with a wait for everything at its head and eight register copies per turn), and inline assembly cannot
-// name the halves of a 128-bit operand: hence fixed registers v48..v63 (record sets A = v48..55, B = v56..63:
-// nucen, k, w, -, mid, half, each its own temporary once read), declared clobbered.  The kernel stays at 64 registers.
-// EXEC is all ones on entry and on exit; nothing else of this wave is in flight on the LDS / scalar-memory counter
-// when the reads start (the wait at the top), so the counted waits below see only these reads.
-#define NF_STEP(S_NUCEN, S_K, S_W, S_T2, S_MID, S_HALF)      /* the record's own registers serve as temporaries once read */ \
-    "v_sub_f32 " S_MID ", %[jf], " S_MID "\n\t"                                                      \
-    "v_cmpx_lt_f32_e64 vcc, |" S_MID "|, " S_HALF "\n\t"                                             \
-    "v_add_f64 " S_NUCEN ", %[xj], -" S_NUCEN "\n\t"                                                 \
-    "v_mul_f64 " S_NUCEN ", " S_NUCEN ", " S_K "\n\t"                                                \
-    "v_mul_f64 " S_NUCEN ", " S_NUCEN ", " S_NUCEN "\n\t"                                            \
-    "v_cvt_f32_f64 " S_MID ", " S_NUCEN "\n\t"              /* math.pxd:17 narrowing */              \
-    "v_mul_f32 " S_HALF ", 0xbfb8aa3b, " S_MID "\n\t"       /* yh = -x log2(e) */                    \
-    "v_exp_f32 " S_T2 ", " S_HALF "\n\t"                                                             \
-    "v_fma_f32 " S_MID ", " S_HALF ", %[kln2], -" S_MID "\n\t"   /* r = -x - yh ln2 (and the wait state) */ \
-    "v_fmac_f32 " S_T2 ", " S_T2 ", " S_MID "\n\t"          /* e = 2^yh (1 + r) */                   \
-    "v_fmac_f32 %[tau], " S_W ", " S_T2 "\n\t"                                                       \
-    "s_mov_b64 exec, -1\n\t"
-#define NF_STEP_A NF_STEP("v[48:49]", "v[50:51]", "v52", "v53", "v54", "v55")
-#define NF_STEP_B NF_STEP("v[56:57]", "v[58:59]", "v60", "v61", "v62", "v63")
-__device__ __forceinline__ void line_run_fast(float &tau, unsigned va, int n, float jf, double xj) {
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    v4i ra, rb;
-    // the first record's reads go out before the wait for the channel's frequency (a global load the compiler waits
-    // for in front of the block that uses it): two blocks, tied through the register set A
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 "ds_read_b128 %[ra], %[va]\n\t"
-                 "ds_read_b128 %[rb], %[va] offset:16"
-                 : [ra] "={v[48:51]}"(ra), [rb] "={v[52:55]}"(rb)
-                 : [va] "v"(va)
-                 : "memory");
-    asm volatile("1:\n\t"
-                 "s_sub_u32 %[n], %[n], 1\n\t"
-                 "s_cmp_eq_u32 %[n], 0\n\t"
-                 "s_cbranch_scc1 3f\n\t"                                  // A is the last line
-                 "ds_read_b128 v[56:59], %[va] offset:32\n\t"
-                 "ds_read_b128 v[60:63], %[va] offset:48\n\t"
-                 "s_waitcnt lgkmcnt(2)\n\t"
-                 NF_STEP_A
-                 "s_sub_u32 %[n], %[n], 1\n\t"
-                 "s_cmp_eq_u32 %[n], 0\n\t"
-                 "s_cbranch_scc1 4f\n\t"                                  // B is the last line
-                 "v_add_u32 %[va], 64, %[va]\n\t"
-                 "ds_read_b128 v[48:51], %[va]\n\t"
-                 "ds_read_b128 v[52:55], %[va] offset:16\n\t"
-                 "s_waitcnt lgkmcnt(2)\n\t"
-                 NF_STEP_B
-                 "s_branch 1b\n\t"
-                 "3:\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 NF_STEP_A
-                 "s_branch 5f\n\t"
-                 "4:\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 NF_STEP_B
-                 "5:"
-                 : [tau] "+v"(tau), [va] "+v"(va), [n] "+s"(n), [ra] "+{v[48:51]}"(ra), [rb] "+{v[52:55]}"(rb)
-                 : [jf] "v"(jf), [xj] "v"(xj), [kln2] "s"(-0.693147182464599609375f)
-                 : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
 // The body of the likelihood kernel for workgroup `block_id` of a launch (lnl_kernel: the hardware's
@@ -697,7 +628,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
         }
         LineRec rec;
         rec.nucen = r_nucen;
-        rec.k = FASTN ? sqrt(r_idenom) : r_idenom;               // (sqrt: correctly rounded, no fast-math)
+        rec.idenom = r_idenom;
         // fast mode keeps the weight as a float in the low word (no union store: that goes through scratch)
         rec.w = MODE == 2 ? __longlong_as_double((long long)__float_as_uint((float)r_htau)) : r_htau;
         rec.mid = (float)r_lo + 0.5f * (float)(r_len - 1);
@@ -853,28 +784,24 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     unsigned va = lbase + ((unsigned)first << 5);
                     asm volatile("" : "+v"(va));
                     int wi = c * G.nhf_max + first;
-                    if constexpr (FASTN) {
-                        line_run_fast(tau, va, n, jf, xj);
-                    } else {
-                        if (n & 1) {
-                            const v2d ab = rec_ab(va);
-                            const v4i hw = rec_hw(va);
-                            step(ab, hw, wi);
-                            va += 32;
-                            asm volatile("" : "+v"(va));
-                            wi += 1;
-                            n -= 1;
-                        }
-                        while (n) {                                        // both records of a pair are read before the first step
-                            const v2d ab0 = rec_ab(va), ab1 = rec_ab(va + 32);
-                            const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
-                            step(ab0, hw0, wi);
-                            step(ab1, hw1, wi + 1);
-                            va += 64;
-                            asm volatile("" : "+v"(va));
-                            wi += 2;
-                            n -= 2;
-                        }
+                    if (n & 1) {
+                        const v2d ab = rec_ab(va);
+                        const v4i hw = rec_hw(va);
+                        step(ab, hw, wi);
+                        va += 32;
+                        asm volatile("" : "+v"(va));
+                        wi += 1;
+                        n -= 1;
+                    }
+                    while (n) {                                        // both records of a pair are read before the first step
+                        const v2d ab0 = rec_ab(va), ab1 = rec_ab(va + 32);
+                        const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
+                        step(ab0, hw0, wi);
+                        step(ab1, hw1, wi + 1);
+                        va += 64;
+                        asm volatile("" : "+v"(va));
+                        wi += 2;
+                        n -= 2;
                     }
                 }
                 if (MODE == 2 && WIDE) tau = (tau_t)td;
