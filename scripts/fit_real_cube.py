@@ -20,6 +20,7 @@ from nestfit_amd.store import HdfStore                     # noqa: E402
 def main():
     store_name = sys.argv[1] if len(sys.argv) > 1 else '/tmp/nestfit_amd_cutout'
     ncomp_max = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    quantum = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # 1: every pixel exactly the reference's number of live points
     rms = 0.35                                             # nestfit/test/__init__.py:12
     t0 = time.perf_counter()
     stack = CubeStack([
@@ -28,7 +29,8 @@ def main():
     t_read = time.perf_counter() - t0
     ut = na.get_irdc_priors(size=500, vsys=63.7)           # G23.481: v_lsr ~ 63.7 km/s
     fitter = CubeFitter(stack, ut, na.AmmoniaRunner, lnZ_thresh=11, ncomp_max=ncomp_max,
-                        mn_kwargs={'nlive': 100, 'tol': 1.0, 'efr': 0.3, 'seed': 1}, nlive_snr_fact=5)
+                        mn_kwargs={'nlive': 100, 'tol': 1.0, 'efr': 0.3, 'seed': 1}, nlive_snr_fact=5,
+                        nlive_quantum=quantum)
     t0 = time.perf_counter()
     fitter.fit_cube(store_name, nproc=1)
     t_fit = time.perf_counter() - t0
@@ -39,7 +41,7 @@ def main():
         v1 = np.array([g['1']['map_params'][0] for g in groups if g.attrs['nbest'] >= 1])
         n_runs = sum(len([k for k in g.keys()]) for g in groups)
         evals = sum(int(g[k].attrs['n_samples']) for g in groups for k in g.keys())
-    print(f'read 2 cubes in {t_read:.2f} s; fitted {len(groups)} pixels ({n_runs} runs) in {t_fit:.1f} s '
+    print(f'nlive_quantum {quantum}: read 2 cubes in {t_read:.2f} s; fitted {len(groups)} pixels ({n_runs} runs) in {t_fit:.1f} s '
           f'= {len(groups)/t_fit:.1f} pixels/s; posterior samples stored {evals}')
     print(f'nbest histogram: {np.bincount(nbest, minlength=ncomp_max + 1).tolist()}; '
           f'median lnZ gain of N=1 over the null model {np.median(gain):.1f}; '
