@@ -321,6 +321,11 @@ typedef struct nfa_sampler nfa_sampler;
 int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int64_t n_pix, int nlive,
                        int n_cand, int64_t batch_target, int64_t cap_iter, const int32_t *free_mask);
 int nfa_sampler_destroy(nfa_sampler *s);
+/* Optional, between create and begin: pixels with numbers of live points of their own (the cube driver gives every
+ * pixel nlive + int(5 SNR), nestfit/main.py:445-447) in ONE lock-step group: nlive[p] <= the nlive of
+ * nfa_sampler_create (which is then the stride of the live arrays nfa_sampler_live returns: pixel p's points are
+ * the first nlive[p] of its slice), cap[p] <= cap_iter dead-point slots, upd[p] replacements between refits. */
+int nfa_sampler_set_pixel_nlive(nfa_sampler *s, const int32_t *nlive, const int64_t *cap, const int32_t *upd);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
 /* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the

@@ -101,6 +101,7 @@ SIGNATURES = {
     'nfa_sampler_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, _ip, C.c_int64, C.c_int, C.c_int,
                                      C.c_int64, C.c_int64, _ip]),
     'nfa_sampler_destroy': (C.c_int, [C.c_void_p]),
+    'nfa_sampler_set_pixel_nlive': (C.c_int, [C.c_void_p, _ip, _lp, _ip]),
     'nfa_sampler_run': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int,
                                   C.c_double, C.c_int]),
     'nfa_sampler_begin': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int,

@@ -76,7 +76,16 @@ struct NsDev {
     int    *wnacc;                      // [P][NS_W] accepted steps of each walker in the cycle
     double *lnvol;                      // [P] ln volume of the bounding ellipsoid (last refit)
     int     stage_live;                 // the refit stages the centred live points in LDS
+    // Pixels of one lock-step group may run with different numbers of live points (the cube driver gives every pixel
+    // nlive + int(5 SNR), main.py:445-447): N is then the stride of the live arrays and the largest count, and these
+    // hold each pixel's own count, dead-point slots and refit interval (null: N, cap, upd for everybody)
+    const int  *nlive;                  // [P]
+    const long *capp;                   // [P]
+    const int  *updp;                   // [P]
 };
+__device__ __forceinline__ int  ns_n(const NsDev &S, int p)   { return S.nlive ? S.nlive[p] : S.N; }
+__device__ __forceinline__ long ns_cap(const NsDev &S, int p) { return S.capp ? S.capp[p] : S.cap; }
+__device__ __forceinline__ int  ns_upd(const NsDev &S, int p) { return S.updp ? S.updp[p] : S.upd; }
 
 // ---- live points -------------------------------------------------------------------------
 __global__ void ns_init_live_kernel(NsDev S, int *__restrict__ livepix) {
@@ -125,7 +134,8 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
         if (k >= W) { S.valid[gid] = 0; return; }
         double *wu = S.wU + ((long)p * NS_W + k) * D;
         if (step == 0) {
-            const int idx = min(S.N - 1, (int)(ns_uniform(S.seed, (uint64_t)p, a, NS_B_START) * S.N));
+            const int Np = ns_n(S, p);
+            const int idx = min(Np - 1, (int)(ns_uniform(S.seed, (uint64_t)p, a, NS_B_START) * Np));
             const double *lu = S.Ulive + ((long)p * S.N + idx) * D, *lt = S.Tlive + ((long)p * S.N + idx) * S.DT;
             double *wt = S.wT + ((long)p * NS_W + k) * S.DT;
             for (int j = 0; j < D; ++j) wu[j] = lu[j];
@@ -141,12 +151,12 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
         // live points, so its shape follows the constraint region whatever that looks like (measured
         // against ellipsoid-shaped steps and an alternation of both on 576 two-component pixels: half
         // the lnZ bias at equal length, scripts/sampler_bias_check.py)
-        const int N = S.N;
+        const int N = ns_n(S, p);
         int ia = min(N - 1, (int)(ns_uniform(S.seed, (uint64_t)p, a, 251ull) * N));
         int ib = min(N - 2, (int)(ns_uniform(S.seed, (uint64_t)p, a, 252ull) * (N - 1)));
         if (ib >= ia) ib += 1;
         const double gam = wscale * 2.38 / sqrt(2.0 * D);
-        const double *ua = S.Ulive + ((long)p * N + ia) * D, *ub = S.Ulive + ((long)p * N + ib) * D;
+        const double *ua = S.Ulive + ((long)p * S.N + ia) * D, *ub = S.Ulive + ((long)p * S.N + ib) * D;
         for (int j = 0; j < D; ++j) {
             const double v = origin[j] + gam * (ua[j] - ub[j]);
             ok = ok && (v >= 0.0) && (v < 1.0);
@@ -229,8 +239,8 @@ __device__ __forceinline__ double ns_logaddexp(double a, double b) {
 // growth bringing the volume up to X / efr where the bounding ellipsoid is smaller than that.
 // sA: D*D doubles of LDS, sc: D doubles.
 __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double *sc, double *sd, int lane) {
-    const int N = S.N, D = S.D;
-    const double *U = S.Ulive + (long)p * N * D;
+    const int N = ns_n(S, p), D = S.D;
+    const double *U = S.Ulive + (long)p * S.N * D;
     double tr = 0.0;
     if (sd) {
         // the live points fit in LDS (N * D doubles): staged once with coalesced loads, then lanes =
@@ -330,14 +340,16 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= n_act) return;
     const int p = force_refit ? q : S.actlist[q];
-    const int N = S.N, D = S.D, K = Kr;
+    const int N = ns_n(S, p), NS = S.N, D = S.D, K = Kr;      // live points of this pixel; stride of the live arrays
+    const long cap = ns_cap(S, p);
+    const double ln_shrink = S.nlive ? log1p(-exp(-1.0 / N)) : S.ln_shrink;
     double *sL = smem;                              // live log-likelihoods of the pixel
-    double *sA = sL + ((N + 1) & ~1);               // D*D
+    double *sA = sL + ((NS + 1) & ~1);              // D*D
     double *sc = sA + D * D;                        // D
     double *sd = S.stage_live ? sc + ((D + 1) & ~1) : nullptr;   // N*D centred live points (refit)
     if (force_refit) { ns_refit(S, p, 0, sA, sc, sd, lane); return; }
     if (!S.active[p]) return;
-    double *Ll = S.Llive + (long)p * N;
+    double *Ll = S.Llive + (long)p * NS;
     for (int i = lane; i < N; i += 64) sL[i] = Ll[i];
     wave_lds_sync();
     auto worst_point = [&](double &lmin, int &w) {
@@ -365,24 +377,24 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     // a candidate above the threshold replaces the worst live point, which dies with prior mass
     // X_it - X_(it+1); returns nothing, updates the wave-uniform state above
     auto replace = [&](const double *cU, const double *cT, double Lk) {
-        const double lnw = -(double)it / N + S.ln_shrink;
+        const double lnw = -(double)it / N + ln_shrink;
         lnZ = ns_logaddexp(lnZ, lnw + Lmin);
-        if (it < S.cap) {
+        if (it < cap) {
             double *dT = S.deadT + ((long)p * S.cap + it) * S.DT;
-            const double *Tw = S.Tlive + ((long)p * N + w) * S.DT;
+            const double *Tw = S.Tlive + ((long)p * NS + w) * S.DT;
             for (int j = lane; j < S.DT; j += 64) dT[j] = Tw[j];
             if (lane == 0) { S.deadL[(long)p * S.cap + it] = Lmin; S.deadlnw[(long)p * S.cap + it] = lnw; }
         }
         wave_lds_sync();
-        for (int j = lane; j < D; j += 64) S.Ulive[((long)p * N + w) * D + j] = cU[j];
-        for (int j = lane; j < S.DT; j += 64) S.Tlive[((long)p * N + w) * S.DT + j] = cT[j];
+        for (int j = lane; j < D; j += 64) S.Ulive[((long)p * NS + w) * D + j] = cU[j];
+        for (int j = lane; j < S.DT; j += 64) S.Tlive[((long)p * NS + w) * S.DT + j] = cT[j];
         if (lane == 0) { sL[w] = Lk; Ll[w] = Lk; }
         wave_lds_sync();
         it += 1; since += 1;
         Lmax = fmax(Lmax, Lk);                      // the point that left was the minimum
         worst_point(Lmin, w);
         const double remain = Lmax - (double)it / N;
-        done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= S.cap;
+        done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= cap;
     };
     const bool was_walking = S.walk[p] != 0;
     if (was_walking) {
@@ -491,7 +503,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     // A refit costs ~100 us and pixels are in lock-step: rejection-mode pixels refit only in every
     // fourth round, so that three launches out of four do not wait for anybody's refit (walking
     // pixels refit at their common cycle end).
-    if (!done && since >= S.upd && (was_walking || (round + 1) % 4 == 0)) {
+    if (!done && since >= ns_upd(S, p) && (was_walking || (round + 1) % 4 == 0)) {
         __threadfence();                            // the wave's own stores to Ulive, then its loads
         ns_refit(S, p, it, sA, sc, sd, lane);
         since = 0;
@@ -524,6 +536,9 @@ struct nfa_sampler {
     NsDev d = {};
     long b_target = 0;          // candidates per round the sampler aims for (all pixels together)
     int *d_pixmap = nullptr, *d_actlist = nullptr, *d_livepix = nullptr, *d_fmap = nullptr;
+    int *d_nlive = nullptr, *d_updp = nullptr;
+    long *d_capp = nullptr;
+    std::vector<int> h_nlive;   // per-pixel live points (empty: d.N for everybody)
     std::vector<int> h_active, h_act;
     long rounds = 0;
     int  n_act = 0, check_every = 8;
@@ -541,7 +556,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
                     d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol,
-                    s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap};
+                    s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap, s->d_nlive, s->d_updp, s->d_capp};
     for (void *p : ptrs) (void)hipFree(p);
     if (s->h_rows) { (void)hipHostFree(s->h_rows); for (int h = 0; h < NS_PARTS; ++h) (void)hipEventDestroy(s->ev[h]); }
     delete s;
@@ -602,6 +617,35 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     return NFA_OK;
 }
 
+// Pixels with numbers of live points of their own (call between create and begin): nlive[p] in ndim+2 .. the nlive given
+// to nfa_sampler_create (the stride of the live arrays), cap[p] in 1 .. cap_iter dead-point slots, upd[p] >= 1
+// replacements between refits.  The cube driver's pixels differ by a few live points each (main.py:445-447); one
+// lock-step group for all of them instead of a group per count.
+int nfa_sampler_set_pixel_nlive(nfa_sampler *s, const int32_t *nlive, const int64_t *cap, const int32_t *upd) {
+    if (!s || !nlive || !cap || !upd) return fail(NFA_ERR_ARG, "null argument");
+    if (s->ran) return fail(NFA_ERR_STATE, "call nfa_sampler_set_pixel_nlive before nfa_sampler_begin");
+    NsDev &d = s->d;
+    const size_t P = (size_t)d.P;
+    std::vector<int> hn(P), hu(P);
+    std::vector<long> hc(P);
+    for (size_t p = 0; p < P; ++p) {
+        if (nlive[p] < s->r->ndim + 2 || nlive[p] > d.N) return fail(NFA_ERR_ARG, "a pixel's nlive must be in ndim+2 .. the sampler's nlive");
+        if (cap[p] < 1 || cap[p] > d.cap || upd[p] < 1) return fail(NFA_ERR_ARG, "a pixel's cap / upd is out of range");
+        hn[p] = nlive[p]; hc[p] = (long)cap[p]; hu[p] = upd[p];
+    }
+    if (!s->d_nlive) {
+        HIP_TRY(hipMalloc((void **)&s->d_nlive, sizeof(int) * P));
+        HIP_TRY(hipMalloc((void **)&s->d_updp, sizeof(int) * P));
+        HIP_TRY(hipMalloc((void **)&s->d_capp, sizeof(long) * P));
+    }
+    HIP_TRY(hipMemcpy(s->d_nlive, hn.data(), sizeof(int) * P, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_updp, hu.data(), sizeof(int) * P, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_capp, hc.data(), sizeof(long) * P, hipMemcpyHostToDevice));
+    d.nlive = s->d_nlive; d.updp = s->d_updp; d.capp = s->d_capp;
+    s->h_nlive = hn;
+    return NFA_OK;
+}
+
 // tol, efr, seed, maxiter as run_multinest (core.pyx:727-744); upd = replacements between
 // ellipsoid refits; check_every = rounds between two looks at the set of active pixels.
 // nfa_sampler_begin draws and evaluates the live points and fits the first ellipsoids;
@@ -645,6 +689,7 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
         HIP_TRY(hipGetLastError());
     }
     std::vector<long> h_evals((size_t)P, (long)N);
+    for (size_t p = 0; p < s->h_nlive.size(); ++p) h_evals[p] = s->h_nlive[p];      // a pixel's own live points were its first evaluations
     std::vector<double> h_lnz((size_t)P, -INFINITY);
     s->h_active.assign((size_t)P, maxiter > 0 ? 1 : 0);
     HIP_TRY(hipMemcpyAsync(d.n_evals, h_evals.data(), sizeof(long) * P, hipMemcpyHostToDevice, st));

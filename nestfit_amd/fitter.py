@@ -61,6 +61,9 @@ class CubeFitter:
         self.mn_kwargs = {**MN_CUBE_DEFAULTS, **(mn_kwargs or {})}
         self.lnZ_thresh, self.ncomp_max, self.nlive_snr_fact = lnZ_thresh, ncomp_max, nlive_snr_fact
         self.nlive_quantum = max(1, int(nlive_quantum))
+        # all pixels of a stripe in one lock-step run, each with its own number of live points (False: one run per
+        # distinct count, side by side on `group_workers` threads -- round 2's scheme, kept for comparison)
+        self.one_group = True
         self.fit_backend = fit_backend
         self.group_workers = GROUP_WORKERS
         self._tree_lock = threading.Lock()           # the store tree and runner creation: one thread at a time
@@ -93,7 +96,12 @@ class CubeFitter:
         if lon.size:
             nlive = self._nlive(lon, lat)
             kw = {k: self.mn_kwargs[k] for k in ('tol', 'efr', 'seed', 'maxiter') if k in self.mn_kwargs}
-            groups = [(np.flatnonzero(nlive == nl), int(nl)) for nl in np.unique(nlive)]
+            if self.one_group:
+                # every pixel keeps its own number of live points inside ONE lock-step run (the device sampler's
+                # per-pixel counts, nfa_sampler_set_pixel_nlive): no group per count, no rounding of the counts
+                groups = [(np.arange(lon.size), nlive)]
+            else:
+                groups = [(np.flatnonzero(nlive == nl), int(nl)) for nl in np.unique(nlive)]
             workers = min(len(groups), self.group_workers) if self.fit_backend is None else 1
             if workers > 1:
                 # largest groups first; results do not depend on the company (the random streams are keyed by the
@@ -104,7 +112,7 @@ class CubeFitter:
                         f.result()
             else:
                 for sel, nl in groups:
-                    self._fit_group(hdf, lon[sel], lat[sel], nl, kw)
+                    self._fit_group(hdf, lon[sel], lat[sel], nl if np.ndim(nl) == 0 else np.asarray(nl)[sel], kw)
         hdf.close()                                  # saves the file (once)
         return hdf
 
@@ -116,28 +124,33 @@ class CubeFitter:
         # the sampler keeps every dead point of every pixel on the device: fit the group in passes that fit
         # the memory budget (a pass's pixels keep their slot numbers' random streams; the seed moves on)
         ndim = self.n_model * ncomp
-        cap = min(int(kw.get('maxiter', 10**6)), sampler.default_cap_iter(nlive))
-        per_pixel = 8 * (cap * (ndim + 2) + nlive * (2 * ndim + 2))
+        nl_max = int(np.max(nlive))
+        cap = min(int(kw.get('maxiter', 10**6)), sampler.default_cap_iter(nl_max))
+        per_pixel = 8 * (cap * (ndim + 2) + nl_max * (2 * ndim + 2))
         n_pass = max(1, SAMPLER_MEMORY_BUDGET // per_pixel)
         res = []
         for a in range(0, lon.size, n_pass):
             kw_pass = dict(kw)
             if a and kw.get('seed', -1) >= 0:
                 kw_pass['seed'] = int(kw['seed']) + a
-            res += sampler.fit_pixels(runner, np.arange(a, min(lon.size, a + n_pass)), nlive=nlive, **kw_pass)
+            b = min(lon.size, a + n_pass)
+            res += sampler.fit_pixels(runner, np.arange(a, b), nlive=nlive if np.ndim(nlive) == 0 else np.asarray(nlive)[a:b],
+                                      **kw_pass)
         return res, runner.null_lnZ.copy(), int(runner._ss.chan_tot)
 
     def _fit_group(self, hdf, lon, lat, nlive, kw):
+        """`nlive`: the group's number of live points, or one per pixel of the group."""
         old_lnZ = None
         nbest = np.zeros(lon.size, dtype=np.int64)
         alive = np.arange(lon.size)                      # pixels still adding components
         ncomp = 1
         while ncomp <= self.ncomp_max and alive.size:
-            print(f'-- {alive.size} pixels, nlive = {nlive} -> N = {ncomp}')
+            nl = nlive if np.ndim(nlive) == 0 else np.asarray(nlive)[alive]
+            print(f'-- {alive.size} pixels, nlive = {nl if np.ndim(nl) == 0 else f"{int(np.min(nl))}..{int(np.max(nl))}"} -> N = {ncomp}')
             if self.fit_backend is not None:
-                res, null_lnZ, n_chan_tot = self.fit_backend(self, lon[alive], lat[alive], ncomp, nlive, kw)
+                res, null_lnZ, n_chan_tot = self.fit_backend(self, lon[alive], lat[alive], ncomp, nl, kw)
             else:
-                res, null_lnZ, n_chan_tot = self._fit_on_device(lon[alive], lat[alive], ncomp, nlive, kw)
+                res, null_lnZ, n_chan_tot = self._fit_on_device(lon[alive], lat[alive], ncomp, nl, kw)
             if ncomp == 1:
                 old_lnZ = np.array(null_lnZ, dtype=np.float64)
                 assert np.isfinite(old_lnZ).all()

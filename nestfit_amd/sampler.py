@@ -153,8 +153,10 @@ def _fit_ellipsoids(U, efr, ln_x, enlarge=1.0):
 
 def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
     """NestedResult per pixel from dead points (theta, lnL, lnw per pixel) and final live points:
-    every live point carries the mass X_final / nlive.  With `tol` given a run whose live points could
-    still add more than `tol` to lnZ (the stop test it did not meet) is marked `truncated`."""
+    every live point carries the mass X_final / nlive.  `nlive`: one number, or one per pixel (a pixel's live
+    points are then the first nlive[p] of its slice of `Tlive` / `Llive`).  With `tol` given a run whose live
+    points could still add more than `tol` to lnZ (the stop test it did not meet) is marked `truncated`."""
+    nl_all = np.broadcast_to(np.asarray(nlive, dtype=np.int64), (len(n_iter),))
     def log_sum_exp(x):
         """ln sum exp(x) about the largest term (a sequential logaddexp.reduce costs five times as much: this
         loop runs once per pixel of a map)."""
@@ -164,19 +166,20 @@ def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
         return m if not np.isfinite(m) else m + math.log(np.exp(x - m).sum())
 
     results = []
-    ln_nlive = math.log(nlive)
     for p in range(len(n_iter)):
+        nlive = int(nl_all[p])
+        ln_nlive = math.log(nlive)
         dT, dL, dlnw = dead[p]
         n_dead = dL.shape[0]
         post = np.empty((n_dead + nlive, ndim + 2))
         post[:n_dead, :ndim] = dT
-        post[n_dead:, :ndim] = Tlive[p]
+        post[n_dead:, :ndim] = Tlive[p][:nlive]
         L = np.empty(n_dead + nlive)
         L[:n_dead] = dL
-        L[n_dead:] = Llive[p]
+        L[n_dead:] = Llive[p][:nlive]
         lw = np.empty(n_dead + nlive)                           # ln(prior mass x likelihood)
         np.add(dlnw, dL, out=lw[:n_dead])
-        np.add(Llive[p], -n_iter[p] / nlive - ln_nlive, out=lw[n_dead:])
+        np.add(Llive[p][:nlive], -n_iter[p] / nlive - ln_nlive, out=lw[n_dead:])
         lnZ_dead = log_sum_exp(lw[:n_dead])
         lnZ_tot = np.logaddexp(lnZ_dead, log_sum_exp(lw[n_dead:]))
         wt = np.exp(lw - lnZ_tot)
@@ -188,7 +191,7 @@ def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
         results.append(NestedResult(post, lnZ_tot, np.sqrt(max(Hp, 0.0) / nlive), L.max(), nlive,
                                     n_evals[p], n_iter[p], Hp))
         if tol is not None:
-            remain = Llive[p].max() - n_iter[p] / nlive
+            remain = Llive[p][:nlive].max() - n_iter[p] / nlive
             results[-1].truncated = bool(not (np.logaddexp(lnZ_dead, remain) - lnZ_dead < tol))
     return results
 
@@ -247,11 +250,18 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
     Returns a list of `NestedResult`, one per pixel.
     """
-    assert ndim > 0 and nlive > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
+    P = int(n_pix)
+    # live points per pixel: one number for everybody, or one per pixel (arrays are then laid out for the largest and a
+    # pixel uses the first nl[p] slots, like the device sampler after nfa_sampler_set_pixel_nlive)
+    nl = np.broadcast_to(np.asarray(nlive, dtype=np.int64), (P,)).copy()
+    nlive = int(nl.max())
+    assert ndim > 0 and nl.min() > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
     seed = _resolve_seed(seed)
     K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
-    P = int(n_pix)
-    cap = int(min(maxiter, default_cap_iter(nlive)) if cap_iter is None else min(cap_iter, maxiter) if maxiter > 0 else cap_iter)
+    if cap_iter is None:
+        capp = np.array([min(maxiter, default_cap_iter(int(n))) for n in nl], dtype=np.int64)
+    else:
+        capp = np.full(P, min(cap_iter, maxiter) if maxiter > 0 else cap_iter, dtype=np.int64)
     all_pix = np.arange(P, dtype=np.int32)
 
     def evaluate(pix, U):
@@ -276,14 +286,18 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     Tlive = expand(Ulive).reshape(-1, ndim)
     Llive = evaluate(np.repeat(all_pix, nlive), Tlive).reshape(P, nlive)
     Tlive = Tlive.reshape(P, nlive, ndim)
-    n_evals = np.full(P, nlive, dtype=np.int64)
+    n_evals = nl.copy()
     n_iter = np.zeros(P, dtype=np.int64)
     lnZ = np.full(P, -np.inf)
-    ln_shrink = np.log1p(-np.exp(-1.0 / nlive))                 # ln(X_i - X_{i+1}) - ln X_i
+    ln_shrink = np.log1p(-np.exp(-1.0 / nl))                    # ln(X_i - X_{i+1}) - ln X_i, per pixel
     active = np.full(P, maxiter > 0)
     since_fit = np.zeros(P, dtype=np.int64)
-    upd = max(1, int(upd_frac * nlive))
-    centre, axes, use_cube, lnvol = _fit_ellipsoids(Ulive, efr, np.zeros(P), enlarge)
+    updp = np.maximum(1, (upd_frac * nl).astype(np.int64))
+    centre, axes = np.empty((P, nd)), np.empty((P, nd, nd))
+    use_cube, lnvol = np.empty(P, dtype=bool), np.empty(P)
+    for n_same in np.unique(nl):                                # (one fit per group of equal counts)
+        sel = np.flatnonzero(nl == n_same)
+        centre[sel], axes[sel], use_cube[sel], lnvol[sel] = _fit_ellipsoids(Ulive[sel, :n_same], efr, np.zeros(sel.size), enlarge)
     dead_T, dead_L, dead_lnw, dead_pix = [], [], [], []
     rnd = 0
     b_target = max(P * K, int(batch_target))
@@ -306,9 +320,10 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
     def replace(p, cU, cT, Lk):
         """The worst live point of pixel p dies, the candidate takes its slot; True when p is done."""
-        w = int(np.argmin(Llive[p]))
+        nlive, cap = int(nl[p]), int(capp[p])
+        w = int(np.argmin(Llive[p, :nlive]))
         Lmin = Llive[p, w]
-        lnw = -n_iter[p] / nlive + ln_shrink
+        lnw = -n_iter[p] / nlive + ln_shrink[p]
         lnZ[p] = np.logaddexp(lnZ[p], lnw + Lmin)
         if n_iter[p] < cap:
             dead_T.append(Tlive[p, w][None].copy()); dead_L.append(np.array([Lmin]))
@@ -316,15 +331,17 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         Ulive[p, w], Tlive[p, w], Llive[p, w] = cU, cT, Lk
         n_iter[p] += 1
         since_fit[p] += 1
-        remain = Llive[p].max() - n_iter[p] / nlive
+        remain = Llive[p, :nlive].max() - n_iter[p] / nlive
         return bool((np.logaddexp(lnZ[p], remain) - lnZ[p] < tol) or n_iter[p] >= maxiter or n_iter[p] >= cap)
 
+    nlive_max = nlive
     while active.any():
         if rnd % check_every == 0:                              # the device compacts its pixel list here
             Kr = int(min(16384, max(K, b_target // int(active.sum()))))
         idx = np.flatnonzero(active)
         for p in idx:                                           # one wave per pixel on the device
             p = int(p)
+            nlive = int(nl[p])
             done = False
             was_walking = bool(walk[p])
             if walk[p]:
@@ -336,7 +353,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                     start = np.minimum(nlive - 1, (_uniform(seed, p, a, _B_START) * nlive).astype(np.int64))
                     wU[p, :W], wT[p, :W], wL[p, :W] = Ulive[p, start], Tlive[p, start], Llive[p, start]
                     wnacc[p, :W] = 0
-                    wLthr[p] = Llive[p].min()
+                    wLthr[p] = Llive[p, :nlive].min()
                     wW[p] = W
                 # differential-evolution move: a scaled difference of two random live points
                 ia = np.minimum(nlive - 1, (_uniform(seed, p, a, _U64(251)) * nlive).astype(np.int64))
@@ -360,7 +377,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                     for k in range(W):
                         if done:
                             break
-                        if wnacc[p, k] == 0 or not (wL[p, k] > Llive[p].min()):
+                        if wnacc[p, k] == 0 or not (wL[p, k] > Llive[p, :nlive].min()):
                             continue
                         done = replace(p, wU[p, k].copy(), wT[p, k].copy(), wL[p, k])
                     if wtot_sum[p] > 0:                         # acceptance near one half
@@ -382,7 +399,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                     for j in range(vi.size):                    # the wave's sequential scan
                         scanned += 1
                         n_evals[p] += 1
-                        if Lsub[j] > Llive[p].min():
+                        if Lsub[j] > Llive[p, :nlive].min():
                             accepted += 1
                             done = replace(p, cand[vi[j]].copy(), Tsub[j].copy(), Lsub[j])
                             if done:
@@ -394,10 +411,10 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             cand_base[p] += Kr
             if done:
                 active[p] = False
-            elif since_fit[p] >= upd and (was_walking or (rnd + 1) % 4 == 0):
+            elif since_fit[p] >= updp[p] and (was_walking or (rnd + 1) % 4 == 0):
                 # (rejection-mode pixels refit only in every fourth round: on the device a refit makes the
                 # whole launch wait, so they are taken together)
-                c1, a1, u1, v1 = _fit_ellipsoids(Ulive[p:p + 1], efr, -n_iter[p:p + 1] / nlive, enlarge)
+                c1, a1, u1, v1 = _fit_ellipsoids(Ulive[p:p + 1, :nlive], efr, -n_iter[p:p + 1] / nlive, enlarge)
                 centre[p], axes[p], use_cube[p], lnvol[p] = c1[0], a1[0], u1[0], v1[0]
                 since_fit[p] = 0
         rnd += 1
@@ -412,7 +429,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     bounds = np.searchsorted(dead_pix[order], np.arange(P + 1))
     dead = [(dead_T[order[bounds[p]:bounds[p + 1]]], dead_L[order[bounds[p]:bounds[p + 1]]],
              dead_lnw[order[bounds[p]:bounds[p + 1]]]) for p in range(P)]
-    res = _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol)
+    res = _assemble(ndim, nl, n_iter, n_evals, dead, Tlive, Llive, tol)
     for r in res:
         r.rounds = rnd
     return res
@@ -432,10 +449,15 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
     lib = _ffi.engine()
     pix = np.ascontiguousarray(pix, dtype=np.int32)
     P, ndim = int(pix.size), int(runner.ndim)
-    assert nlive > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
+    # live points: one number, or one per pixel (nfa_sampler_set_pixel_nlive: one lock-step group all the same)
+    nl = np.broadcast_to(np.asarray(nlive, dtype=np.int64), (P,)).copy()
+    per_pixel = bool((nl != nl[0]).any())
+    nlive = int(nl.max())
+    assert nl.min() > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
     seed = _resolve_seed(seed)
     K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
-    cap = int(cap_iter) if cap_iter else int(max(1, min(maxiter, default_cap_iter(nlive))))
+    capp = np.array([int(cap_iter) if cap_iter else int(max(1, min(maxiter, default_cap_iter(int(n))))) for n in nl], dtype=np.int64)
+    cap = int(capp.max())
     fm = None if free_mask is None else np.ascontiguousarray(free_mask, dtype=np.int32)
     assert fm is None or fm.shape == (ndim,)
     nd = ndim if fm is None else int(np.count_nonzero(fm))
@@ -444,6 +466,11 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
                                       int(nlive), K, int(batch_target), cap,
                                       None if fm is None else fm.ctypes.data_as(_ffi._ip)))
     try:
+        if per_pixel:
+            nl32 = nl.astype(np.int32)
+            upd32 = np.maximum(1, (upd_frac * nl).astype(np.int64)).astype(np.int32)
+            _ffi.check(lib.nfa_sampler_set_pixel_nlive(h, nl32.ctypes.data_as(_ffi._ip), capp.ctypes.data_as(_ffi._lp),
+                                                       upd32.ctypes.data_as(_ffi._ip)))
         _ffi.check(lib.nfa_sampler_begin(h, float(tol), float(efr), seed, int(maxiter),
                                          max(1, int(upd_frac * nlive)), float(log_zero), int(check_every),
                                          float(enlarge),
@@ -473,14 +500,14 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
         _ffi.check(lib.nfa_sampler_live(h, _ffi.dptr(Tlive), _ffi.dptr(Llive)))
         # the dead points of all pixels in one packed copy; a pixel's arrays are views into it
         off = np.zeros(P + 1, dtype=np.int64)
-        np.cumsum(np.minimum(n_iter, cap), out=off[1:])
+        np.cumsum(np.minimum(n_iter, capp), out=off[1:])
         tot = int(off[-1])
         allT, allL, allw = np.empty((tot, ndim)), np.empty(tot), np.empty(tot)
         _ffi.check(lib.nfa_sampler_dead_packed(h, off.ctypes.data_as(_ffi._lp), _ffi.dptr(allT), _ffi.dptr(allL), _ffi.dptr(allw)))
         dead = [(allT[off[p]:off[p + 1]], allL[off[p]:off[p + 1]], allw[off[p]:off[p + 1]]) for p in range(P)]
     finally:
         lib.nfa_sampler_destroy(h)
-    res = _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol)
+    res = _assemble(ndim, nl, n_iter, n_evals, dead, Tlive, Llive, tol)
     for r in res:
         r.rounds = int(rounds.value)
     return res

@@ -269,10 +269,15 @@ def test_real_cube_likelihood_and_fit(engine, nfo, stack, tmp_path):
             one = g['1']
             assert one.attrs['ncomp'] == 1 and one.attrs['n_params'] == 6 and one.attrs['n_chan_tot'] == 758
             assert one['posteriors'].shape == (one.attrs['n_samples'], 8)
-        first = {g.name: (g.attrs['nbest'], g['1'].attrs['global_lnZ'], g['1']['posteriors'].copy()) for g in groups}
-    # the groups of pixels (one per number of live points) are sampled side by side by default: one after the other
-    # the store comes out the same to the last bit
-    assert fitter.group_workers > 1
+            assert one.attrs['n_live'] == 40 + int(5 * sub.get_max_snr(g.attrs['i_lon'], g.attrs['i_lat']))   # main.py:445-447
+    # a stripe is one lock-step run whose pixels have live points of their own (fitter.one_group); the scheme before
+    # it -- a run per distinct number of live points, side by side on threads -- gives the same store to the last bit
+    # whether the runs go side by side or one after the other
+    assert fitter.one_group and fitter.group_workers > 1
+    fitter.one_group = False
+    fitter.fit_cube(str(tmp_path / 'cutout_groups'), nproc=2)
+    with HdfStore(str(tmp_path / 'cutout_groups')) as store:
+        first = {g.name: (g.attrs['nbest'], g['1'].attrs['global_lnZ'], g['1']['posteriors'].copy()) for g in store.iter_pix_groups()}
     fitter.group_workers = 1
     fitter.fit_cube(str(tmp_path / 'cutout_serial'), nproc=2)
     with HdfStore(str(tmp_path / 'cutout_serial')) as store:

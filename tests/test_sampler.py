@@ -115,6 +115,24 @@ def test_seed_reproducibility_and_independent_pixels():
     assert len({r.lnZ for r in a}) == 3
 
 
+def test_pixels_with_live_points_of_their_own():
+    """One lock-step run, a number of live points per pixel (the cube driver's nlive + int(5 SNR), main.py:445-447): every
+    pixel's run is the run it would have had alone with that number -- same random stream, same decisions."""
+    f = _gauss_problem(np.full(3, 0.4), 0.1)
+    nl = np.array([60, 75, 90, 75])
+    mixed = sampler.run_nested(f, 3, 4, nlive=nl, seed=7)
+    for p, r in enumerate(mixed):
+        assert r.n_live == nl[p] and r.n_samples == r.n_iter + nl[p]
+        assert r.posterior[:, -1].sum() == pytest.approx(1.0, abs=1e-12)
+    # pixels 1 and 3 (both 75) against a run in which everybody has 75: pixel p's stream is keyed by p alone
+    same = sampler.run_nested(f, 3, 4, nlive=75, seed=7)
+    for p in (1, 3):
+        assert mixed[p].lnZ == same[p].lnZ and np.array_equal(mixed[p].posterior, same[p].posterior)
+    assert mixed[0].lnZ != same[0].lnZ
+    truth = 3 * np.log(0.1 * np.sqrt(2 * np.pi))
+    assert all(abs(r.lnZ - truth) < 4 * r.lnZ_err + 0.1 for r in mixed)
+
+
 def test_maxiter_and_logzero():
     f = _gauss_problem(np.full(2, 0.5), 0.1)
     r = sampler.run_nested(f, 2, 2, nlive=50, maxiter=30, seed=1)
@@ -245,6 +263,17 @@ def test_sampler_on_gpu_matches_the_same_sampler_on_the_oracle(engine, nfo):
             assert g.n_iter == r.n_iter and g.n_evals == r.n_evals, (g.n_iter, r.n_iter, g.n_evals, r.n_evals)
             assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
             np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
+        # every pixel its own number of live points, one lock-step group (nfa_sampler_set_pixel_nlive): device = twin,
+        # rejection rounds and walks alike
+        for extra in (dict(), dict(method='walk', n_steps=7, maxiter=500)):
+            kwn = dict(kw, nlive=np.array([60, 71, 83]), **extra)
+            ref_n = sampler.run_nested(cpu_loglike, cube.ndim, n_pix, **kwn)
+            got_n = sampler.fit_pixels(cube, np.arange(n_pix), **kwn)
+            for g, r, n in zip(got_n, ref_n, (60, 71, 83)):
+                assert g.n_live == r.n_live == n
+                assert g.n_iter == r.n_iter and g.n_evals == r.n_evals, (n, g.n_iter, r.n_iter, g.n_evals, r.n_evals)
+                assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
+                np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
         engine.set_exp_mode('fast')
         fast = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
         for g, r in zip(fast, ref):

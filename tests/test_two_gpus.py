@@ -19,7 +19,7 @@ def _n_devices():
     return na.device_count()
 
 
-def _ranks(cmd, world, timeout=600):
+def _ranks(cmd, world, timeout=300):
     """`cmd` as `world` processes with a launcher's environment; returns their outputs (rank order)."""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -31,10 +31,16 @@ def _ranks(cmd, world, timeout=600):
         procs.append(subprocess.Popen([sys.executable] + cmd, env=env, cwd=str(ROOT), stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
-    for p in procs:
-        out, _ = p.communicate(timeout=timeout)
-        outs.append(out)
-        assert p.returncode == 0, out[-3000:]
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=timeout)
+            outs.append(out)
+            assert p.returncode == 0, out[-3000:]
+    finally:
+        for p in procs:                       # a rank that failed leaves the others at the barrier: end them
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     return outs
 
 
