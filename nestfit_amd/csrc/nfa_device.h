@@ -523,6 +523,93 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
                  : "vcc");
 }
 
+// Two line x row steps of the table mode as one instruction block: both lines' FastExp arguments and table addresses
+// are formed and all six gathers issued before the first product is taken, each line under its own window as the
+// EXEC mask.  (Compiled from C++ the two steps of a pair run one after the other, each waiting for its own gathers:
+// the wave then sits through two trips to LDS per pair with nothing of its own to issue, and the kernel was bound by
+// neither the vector ALUs (75 % busy) nor the LDS array.)  The arithmetic is nf_fastexp<0, true, true>'s, operation
+// for operation: (x - nucen)^2 idenom (hyperfine.pyx:94), the float narrowing (math.pxd:17), A B C in that order
+// (fastexp.c:276-279), the Taylor form below 2^-5 (fastexp.c:264-270) where a lane of the line needs it, tau += w e.
+// EXEC is all ones on entry and on exit; no instruction in here writes SCC (the compiler keeps the pair loop's
+// condition there across the block).
+__device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj,
+                                                double nucA, double idA, double wA, float midA, float halfA,
+                                                double nucB, double idB, double wB, float midB, float halfB,
+                                                uint32_t base_a, uint32_t base_c) {
+    float xA, xB;
+    uint32_t t0, t1;
+    double a0, a1, a2, b0, b1, b2;
+    unsigned long long mA, mB;
+#define NFA_TABLE_LOOKUP(X, G0, G1, G2, NUC, ID)                                                           \
+        "v_add_f64 %[" #G0 "], %[xj], -%[" #NUC "]\n\t"                                                    \
+        "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #G0 "]\n\t"                                                 \
+        "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #ID "]\n\t"                                                 \
+        "v_cvt_f32_f64 %[" #X "], %[" #G0 "]\n\t"                 /* math.pxd:17 narrowing */             \
+        "v_add_u32 %[t0], 0xc3000000, %[" #X "]\n\t"              /* bits - (122 << 23) */                 \
+        "v_bfe_u32 %[t1], %[t0], 16, 11\n\t"                      /* l * 128 + j0, fastexp.c:276 */        \
+        "v_lshl_add_u32 %[t1], %[t1], 3, %[ba]\n\t"                                                        \
+        "ds_read_b64 %[" #G0 "], %[t1]\n\t"                                                                \
+        "v_bfe_u32 %[t0], %[t0], 23, 4\n\t"                       /* row l of B and C */                   \
+        "v_lshl_add_u32 %[t0], %[t0], 11, %[bc]\n\t"                                                       \
+        "v_bfe_u32 %[t1], %[" #X "], 8, 8\n\t"                    /* j1, fastexp.c:277 */                  \
+        "v_lshl_add_u32 %[t1], %[t1], 3, %[t0]\n\t"                                                        \
+        "ds_read_b64 %[" #G1 "], %[t1] offset:20480\n\t"          /* B sits 2560 doubles behind C */       \
+        "v_and_b32 %[t1], 0xff, %[" #X "]\n\t"                    /* j2, fastexp.c:278 */                  \
+        "v_lshl_add_u32 %[t1], %[t1], 3, %[t0]\n\t"                                                        \
+        "ds_read_b64 %[" #G2 "], %[t1]\n\t"
+#define NFA_TABLE_TAYLOR(X, G0, G1, G2, LBL)                                                               \
+        "s_cbranch_vccz " LBL "%=\n\t"                                                                     \
+        "s_mov_b64 exec, vcc\n\t"                                 /* (a subset of the window; SCC untouched) */ \
+        "v_cvt_f64_f32 %[" #G1 "], %[" #X "]\n\t"                                                          \
+        "v_mul_f64 %[" #G2 "], %[" #G1 "], %[nthird]\n\t"          /* 1 - t / 3 */                         \
+        "v_add_f64 %[" #G2 "], %[" #G2 "], 1.0\n\t"                                                        \
+        "v_mul_f64 %[" #G2 "], %[" #G2 "], %[" #G1 "]\n\t"         /* 1 - (t ty) / 2 */                    \
+        "v_mul_f64 %[" #G2 "], %[" #G2 "], -0.5\n\t"                                                       \
+        "v_add_f64 %[" #G2 "], %[" #G2 "], 1.0\n\t"                                                        \
+        "v_mul_f64 %[" #G1 "], %[" #G2 "], %[" #G1 "]\n\t"         /* 1 - t ty */                          \
+        "v_add_f64 %[" #G0 "], -%[" #G1 "], 1.0\n\t"                                                       \
+        LBL "%=:\n\t"
+    asm volatile(
+        "v_sub_f32 %[t0], %[jf], %[midA]\n\t"
+        "v_cmp_lt_f32_e64 %[mA], |%[t0]|, %[halfA]\n\t"
+        "v_sub_f32 %[t0], %[jf], %[midB]\n\t"
+        "v_cmp_lt_f32_e64 %[mB], |%[t0]|, %[halfB]\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        NFA_TABLE_LOOKUP(xA, a0, a1, a2, nucA, idA)
+        "s_mov_b64 exec, %[mB]\n\t"
+        NFA_TABLE_LOOKUP(xB, b0, b1, b2, nucB, idB)
+        // line A: the product as its gathers land, the Taylor form where x < 2^-5, tau += w e
+        "s_mov_b64 exec, %[mA]\n\t"
+        "v_cmp_gt_f32 vcc, 0x3d000000, %[xA]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_mul_f64 %[a0], %[a0], %[a1]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_mul_f64 %[a0], %[a0], %[a2]\n\t"
+        NFA_TABLE_TAYLOR(xA, a0, a1, a2, ".Lnfa_tpa_")
+        "s_mov_b64 exec, %[mA]\n\t"
+        "v_fmac_f64 %[tau], %[wA], %[a0]\n\t"
+        // line B
+        "s_mov_b64 exec, %[mB]\n\t"
+        "v_cmp_gt_f32 vcc, 0x3d000000, %[xB]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_mul_f64 %[b0], %[b0], %[b1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_f64 %[b0], %[b0], %[b2]\n\t"
+        NFA_TABLE_TAYLOR(xB, b0, b1, b2, ".Lnfa_tpb_")
+        "s_mov_b64 exec, %[mB]\n\t"
+        "v_fmac_f64 %[tau], %[wB], %[b0]\n\t"
+        "s_mov_b64 exec, -1"
+        : [tau] "+v"(tau), [xA] "=&v"(xA), [xB] "=&v"(xB), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2),
+          [mA] "=&s"(mA), [mB] "=&s"(mB)
+        : [jf] "v"(jf), [xj] "v"(xj), [nucA] "v"(nucA), [idA] "v"(idA), [wA] "v"(wA), [midA] "v"(midA), [halfA] "v"(halfA),
+          [nucB] "v"(nucB), [idB] "v"(idB), [wB] "v"(wB), [midB] "v"(midB), [halfB] "v"(halfB),
+          [ba] "s"(base_a), [bc] "s"(base_c), [nthird] "s"(-(1.0 / 3.0))
+        : "vcc");
+#undef NFA_TABLE_LOOKUP
+#undef NFA_TABLE_TAYLOR
+}
+
 // The body of the likelihood kernel for workgroup `block_id` of a launch (lnl_kernel: the hardware's
 // workgroup; point_kernel: the one workgroup walks the few of a single point).  `sm` = the staged
 // exponential tables (n_shared doubles at the start of smem), the line tables follow them.
@@ -644,8 +731,13 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // 0..31 the first component's lines, lanes 32..63 the second's -- two compares per row instead of four
     // (a compare costs as much as an fp64 operation, profiles/r02/ubench_valu.txt)
     constexpr bool PACK2 = MODE == 2 && !WIDE && NCOMP == 2;
+    constexpr bool HOISTX = MODE != 2;                         // exact modes: a component's Tb constants are read once per unit
     int wlo2 = 0, whi2 = 0;
     double ck_kind[NC], ck_a0x[NC], ck_b0x[NC];
+    // exact modes: the constants of a component's Tb pass (excitation temperature, its reciprocal, the band's cell of
+    // the 1/(e^x - 1) table) are read once per unit -- read where they are used, each is a scalar load and a wait in
+    // the dependent chain of every (row, component)
+    double cx_tex[NC], cx_rtex[NC], cx_xkind[NC], cx_xs[NC], cx_xlo[NC], cx_ylo[NC];
     // the LDS address of each component's line table as a per-lane value, formed once: a line's record address
     // is then ONE vector shift-add of the scalar line index (left to itself the compiler forms it with two
     // scalar instructions and a move per step; the scalar unit is the shared resource, see the header)
@@ -666,6 +758,10 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             asm volatile("" : "+v"(lbase_c[c]));
             const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
             ck_kind[c] = Dk[dko + DK_KIND]; ck_a0x[c] = Dk[dko + DK_A0X]; ck_b0x[c] = Dk[dko + DK_B0X];
+            if (HOISTX) {
+                cx_tex[c] = Dk[c * 4]; cx_rtex[c] = Dk[c * 4 + 3];
+                cx_xkind[c] = Dk[dko + DK_XKIND]; cx_xs[c] = Dk[dko + DK_XS]; cx_xlo[c] = Dk[dko + DK_XLO]; cx_ylo[c] = Dk[dko + DK_YLO];
+            }
         }
     }
     if (PACK2) window_of(lane >> 5, lane & 31, wlo2, whi2);
@@ -795,9 +891,18 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     }
                     while (n) {                                        // both records of a pair are read before the first step
                         const v2d ab0 = rec_ab(va), ab1 = rec_ab(va + 32);
-                        const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
-                        step(ab0, hw0, wi);
-                        step(ab1, hw1, wi + 1);
+                        if constexpr (MODE == 0 && FWIN) {
+                            // (w | mid, half) read as two doubles: the weight is then a register pair as it stands
+                            const v2d wm0 = rec_ab(va + 16), wm1 = rec_ab(va + 48);
+                            line_pair_table(tau, jf, xj, ab0.x, ab0.y, wm0.x, __int_as_float(__double2loint(wm0.y)),
+                                            __int_as_float(__double2hiint(wm0.y)), ab1.x, ab1.y, wm1.x,
+                                            __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)),
+                                            (uint32_t)(uintptr_t)(sm + SM_FEA), (uint32_t)(uintptr_t)(sm + SM_FEC));
+                        } else {
+                            const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
+                            step(ab0, hw0, wi);
+                            step(ab1, hw1, wi + 1);
+                        }
                         va += 64;
                         asm volatile("" : "+v"(va));
                         wi += 2;
@@ -847,7 +952,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     // a tex whose mantissa is all ones, has probability 2^-52): the same bits as the division
                     // (400 M random pairs on the host: 0 differences).  A tex that is not an ordinary positive number
                     // takes the division.
-                    const double tex = Dk[c * 4], rtex = Dk[c * 4 + 3];
+                    const double tex = (HOISTX && NCOMP > 0) ? cx_tex[c] : Dk[c * 4], rtex = (HOISTX && NCOMP > 0) ? cx_rtex[c] : Dk[c * 4 + 3];
                     double x;
                     if (tex > 1e-100 && tex < 1e100) {
                         const double q = T0 * rtex;
@@ -857,10 +962,11 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     }
                     // the reference's order: pred[i] += T0 * (y - tbg) * (1 - FastExp(tau)), only where tau != 0
                     // (tau is a sum of non-negative terms, or NaN)
-                    if (Dk[dko + DK_XKIND] == 1.0) {
+                    if (((HOISTX && NCOMP > 0) ? cx_xkind[c] : Dk[dko + DK_XKIND]) == 1.0) {
                         // the band's table cell: y is finite, and where tau == 0 the last factor is exactly 1 - 1 = 0 --
                         // the product adds +0 there and needs no select
-                        const double y = Dk[dko + DK_XS] * (x - Dk[dko + DK_XLO]) + Dk[dko + DK_YLO];
+                        const double y = (HOISTX && NCOMP > 0) ? cx_xs[c] * (x - cx_xlo[c]) + cx_ylo[c]
+                                                   : Dk[dko + DK_XS] * (x - Dk[dko + DK_XLO]) + Dk[dko + DK_YLO];
                         pred += (T0 * (y - tbg)) * nf_one_minus_fastexp_row<MODE>((double)tau, sm);
                     } else {
                         const double y = nf_iemtex(x, g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
