@@ -328,13 +328,14 @@ __device__ __forceinline__ double nf_swift(double tkin) {    // ammonia.pyx:280-
     return tkin / (1.0 + (tkin / 41.18) * slow_log(1.0 + 0.6 * slow_exp(-15.7 / tkin)));
 }
 
+// E_J / (k trot) of the metastable level J (ammonia.pyx:289-295): grows with J (C j^2 + B j)
+__device__ __forceinline__ double nf_partition_arg(int j, double trot) {
+    const double dj = (double)j;
+    return NFA_H * (NFA_BROT * dj * (double)(j + 1) + (NFA_CROT - NFA_BROT) * dj * dj) / (NFA_KB * trot);
+}
 template <int MODE>
 __device__ __forceinline__ double nf_partition_level(int j, double trot, const double *sm) {
-    // ammonia.pyx:289-295
-    const double dj = (double)j;
-    const double arg = NFA_H * (NFA_BROT * dj * (double)(j + 1) + (NFA_CROT - NFA_BROT) * dj * dj)
-                       / (NFA_KB * trot);
-    return (double)(2 * j + 1) * nf_fastexp<MODE>(arg, sm);
+    return (double)(2 * j + 1) * nf_fastexp<MODE>(nf_partition_arg(j, trot), sm);
 }
 
 // Line centre, width and channel window of hyperfine line i of transition t

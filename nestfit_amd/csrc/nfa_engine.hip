@@ -739,7 +739,7 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     const bool tables = setup_uses_tables(r, mode);
     const size_t lds = setup_lds_bytes(r, mode, has_prior);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "too many parameters for the set-up kernel");
-    auto kern = tables ? setup_kernel<0> : setup_kernel<1>;
+    auto kern = tables ? setup_kernel<0, false> : mode == 2 ? setup_kernel<1, true> : setup_kernel<1, false>;
     { int rc2 = ensure_dynamic_lds((const void *)kern, lds); if (rc2) return rc2; }
     (void)d_U;                                               // the batches' arrays travel in r->cur_group
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, prog, S, r->cur_group, r->d_D[slot], (long)B,

@@ -249,38 +249,45 @@ __global__ void __launch_bounds__(64) prior_items_kernel(const PriorProg *__rest
 #undef TH
 
 // ---------------------------------------------------------------------------
-//  partition sums (ammonia.pyx:289-315): lane = (item, component, eighth of the 51 J levels)
+//  partition sums (ammonia.pyx:289-315): lane = (item, component, J mod 16)
 //  qrec[{0: qpara, 1: qorth, 2: trot', 3..11: (2J+1) FastExp(E_J/kT), J = 1..9}] per (item, component)
-//  Eight lanes of seven levels each: the chain of dependent exponentials a lone item waits for is 7
-//  long instead of 51, and the eight partial sums meet through three DPP steps.
+//  Sixteen lanes, one level each per pass of sixteen levels; the partial sums meet through four DPP steps.
+//  FastExp is exactly 0 from an argument of 32 on (fastexp.c:272-273) and the level energies grow with J, so a
+//  pass in which no lane of the wave has a level below that adds zeros, and so does every pass after it: it is
+//  not run.  Below ~100 K that leaves the first pass -- the sum of a lone item is then ONE exponential deep
+//  (it was seven with eight lanes of seven levels), and a batch runs a quarter of the exponentials.
 // ---------------------------------------------------------------------------
 #define QREC 12
-#define QSUM_LANES 8
-#define QSUM_LEVELS 7          // QSUM_LANES * QSUM_LEVELS >= NFA_NPART
+#define QSUM_LANES 16
 template <int MODE>
-__device__ __forceinline__ void qsum_lane(bool on, double trot_in, int cold, int chunk, double *qrec,
+__device__ __forceinline__ void qsum_lane(bool on, double trot_in, int cold, int j0, double *qrec,
                                           const double *sm) {
     double trot = trot_in;
     if (cold) trot = nf_swift(trot);                          // ammonia.pyx:344-345
     double qp = 0.0, qo = 0.0;
-    for (int k = 0; k < QSUM_LEVELS; ++k) {
-        const int j = chunk * QSUM_LEVELS + k;
+    for (int base = 0; base < NFA_NPART; base += QSUM_LANES) {
+        const int j = base + j0;
         const bool lev_on = on && j < NFA_NPART;
-        double lev = nf_partition_level<MODE>(lev_on ? j : 0, trot, sm);
+        const double arg = nf_partition_arg(lev_on ? j : 0, trot);
+        // (a NaN or a negative argument is "below 32": those sums run to the end like the reference's)
+        if (base > 0 && __builtin_amdgcn_ballot_w64(lev_on && !((float)arg >= 32.0f)) == 0ull) break;
+        double lev = (double)(2 * j + 1) * nf_fastexp<MODE>(arg, sm);
         if (!lev_on) lev = 0.0;
         if (j % 3 == 0) qo += 2 * lev; else qp += lev;
         if (lev_on && j >= 1 && j <= NFA_N_LEVELS) qrec[2 + j] = lev;
     }
-    // the eight lanes of one (item, component) are neighbours: pairs, quads, then the two quads (row_half_mirror)
-    qp += dpp_move<0xB1>(qp); qp += dpp_move<0x4E>(qp); qp += dpp_move<0x141>(qp);
-    qo += dpp_move<0xB1>(qo); qo += dpp_move<0x4E>(qo); qo += dpp_move<0x141>(qo);
-    if (on && chunk == 0) { qrec[0] = qp; qrec[1] = qo; qrec[2] = trot; }
+    // the sixteen lanes of one (item, component) are one DPP row: pairs, quads, half rows, the row
+    qp += dpp_move<0xB1>(qp); qp += dpp_move<0x4E>(qp); qp += dpp_move<0x141>(qp); qp += dpp_move<0x140>(qp);
+    qo += dpp_move<0xB1>(qo); qo += dpp_move<0x4E>(qo); qo += dpp_move<0x141>(qo); qo += dpp_move<0x140>(qo);
+    if (on && j0 == 0) { qrec[0] = qp; qrec[1] = qo; qrec[2] = trot; }
 }
 
 // y(T0) = 1/(e^(T0/tex) - 1) over the band of spectrum s, as the fast mode evaluates it:
 // kind 1 / 2 = the reference's table cell(s) (hyperfine.pyx:30-45) written as a line in T0,
 // kind 3 = band entirely outside the table (exact function there): quadratic about the band
 // centre, kind 0 = anything else (per-lane nf_iemtex).
+// FAST: the record is for the fast mode's kernel only (the exact modes' cell is left out).
+template <bool FAST>
 __device__ __forceinline__ void write_y_model(double *dk, const SpecDev &S, int s, double tex,
                                               const double *__restrict__ g_tabs) {
     const double T0a = S.t0[S.off[s]], T0b = S.t0[S.off[s] + S.size[s] - 1];
@@ -320,9 +327,9 @@ __device__ __forceinline__ void write_y_model(double *dk, const SpecDev &S, int 
     const double kappa = NFA_H / NFA_KB;                       // T0 = kappa x (hyperfine.pyx:106)
     dk[DK_A0X] = A0 * kappa; dk[DK_B0X] = B0 * (kappa * kappa);
     // the exact modes' cell (x by division, the cell found exactly as nf_iemtex finds it)
-    const double xad = T0a / tex, xbd = T0b / tex;
     double xkind = 0.0, xs = 0.0, xlo = 0.0, ylo = 0.0;
-    if (S.t0_xmin < xad && xad < S.t0_xmax && S.t0_xmin < xbd && xbd < S.t0_xmax) {
+    const double xad = FAST ? 0.0 : T0a / tex, xbd = FAST ? 0.0 : T0b / tex;
+    if (!FAST && S.t0_xmin < xad && xad < S.t0_xmax && S.t0_xmin < xbd && xbd < S.t0_xmax) {
         long ia = (long)((xad - S.t0_xmin) * S.t0_inv_dx), ib = (long)((xbd - S.t0_xmin) * S.t0_inv_dx);
         ia = ia > T0_SIZE - 2 ? T0_SIZE - 2 : ia;
         ib = ib > T0_SIZE - 2 ? T0_SIZE - 2 : ib;
@@ -339,6 +346,10 @@ __device__ __forceinline__ void write_y_model(double *dk, const SpecDev &S, int 
 //  lane's item (parameter-major, ammonia.pyx:338-343), qrec = its partition record.
 // ---------------------------------------------------------------------------
 #define TH(k) th[(k) * 64]
+// FAST (the fast mode, 1e-6 on Tb): 10^ntot by exp10, and tau_main as it stands -- the reference hands it on as
+// log10(tau_main) and c_hf_predict raises 10 to that (ammonia.pyx:361, hyperfine.pyx:63), a round trip of a few 1e-16
+// that the exact modes make as well.
+template <bool FAST>
 __device__ __forceinline__ void derive_lane(const SpecDev &S, const double *th, const double *qrec, double *Db,
                                             int c, int s, const double *__restrict__ g_tabs) {
     const int ncomp = S.ncomp, nspec = S.n_spec;
@@ -354,7 +365,7 @@ __device__ __forceinline__ void derive_lane(const SpecDev &S, const double *th, 
     const double zlev = qrec[2 + (t + 1)];
     const double qtot = para ? qrec[0] : qrec[1];
     const double species_frac = para ? 1.0 - orth : orth;
-    const double pop_rotstate = pow(10.0, ntot) * species_frac * zlev / qtot;
+    const double pop_rotstate = (FAST ? exp10(ntot) : pow(10.0, ntot)) * species_frac * zlev / qtot;
     const double ex = exp(-NFA_H * nu0 / (NFA_KB * tex));
     const double expterm = (1.0 - ex) / (1.0 + ex);
     const double fracterm = (NFA_CCMS * NFA_CCMS) * c_ea[t] / (8 * M_PI * (nu0 * nu0));
@@ -368,13 +379,14 @@ __device__ __forceinline__ void derive_lane(const SpecDev &S, const double *th, 
         d[3] = 1.0 / tex;
     }
     double *dk = Db + 4 * ncomp + (c * nspec + s) * DREC_CS;
-    dk[DK_TMAIN] = pow(10.0, log10(tau_main));                // ammonia.pyx:361, hyperfine.pyx:63
-    write_y_model(dk, S, s, tex, g_tabs);
+    dk[DK_TMAIN] = FAST ? tau_main : pow(10.0, log10(tau_main));      // ammonia.pyx:361, hyperfine.pyx:63
+    write_y_model<FAST>(dk, S, s, tex, g_tabs);
 }
 
 //  The sibling models hand c_hf_predict its arguments directly.
 //  N2H+ (diazenylium.pyx:138-154): voff, tex, ltau, sigm -> tau_main = 10**ltau (hyperfine.pyx:63)
 //  Gaussian (gaussian.pyx:17-35): voff, sigm, peak -> one line of weight `peak`, no Tb pass
+template <bool FAST>
 __device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const double *th, double *Db, int c, int s,
                                                    const double *__restrict__ g_tabs) {
     const int ncomp = S.ncomp, nspec = S.n_spec;
@@ -395,7 +407,7 @@ __device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const doubl
     if (gauss) {
         for (int q = 1; q < DREC_CS; ++q) dk[q] = 0.0;
     } else {
-        write_y_model(dk, S, s, tex, g_tabs);
+        write_y_model<FAST>(dk, S, s, tex, g_tabs);
     }
 }
 
@@ -404,7 +416,7 @@ __device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const doubl
 //  one launch per batch:
 //      all threads                          prior tables -> LDS (StageItem list of the program)
 //      wave 0, lanes = items                unit cube -> theta (written back to U in place)
-//      lanes = (item, component, quarter)   partition sums -> LDS
+//      lanes = (item, component, J mod 16)  partition sums -> LDS
 //      lanes = (item, component, spectrum)  derived record D of the item
 //  theta and the partition records stay in LDS between the phases (the three-kernel version of
 //  this stage paid three launch gaps and two round trips through global memory per batch, and
@@ -418,7 +430,7 @@ __device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const doubl
 #define SETUP_THREADS 256
 // the set-up stage of the 64 items of workgroup `block_id`, by the blockDim.x threads of the workgroup (`sm` =
 // the staged exponential tables, n_shared doubles at the start of smem)
-template <int MODE>
+template <int MODE, bool FAST = false>
 __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, const SpecDev &S,
                                            double *__restrict__ U, double *__restrict__ D, long B, int has_prior,
                                            const double *__restrict__ g_tabs, int ablate_in, double *smem,
@@ -477,9 +489,9 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
             U[b0 * ndim + q] = th_all[k * 64 + it];
         }
     const bool ammonia = S.model == NFA_MODEL_AMMONIA;
-    // ---- phase 2: lanes = (item, component, eighth)
+    // ---- phase 2: lanes = (item, component, J mod 16)
     if (ammonia && !(ablate & 32)) {
-        const int n_task = n_it * ncomp * QSUM_LANES;           // whole groups of eight are on or off
+        const int n_task = n_it * ncomp * QSUM_LANES;           // whole groups of sixteen are on or off
         for (int q0 = 0; q0 < n_task; q0 += nthr) {
             const int q = q0 + tid;
             const int pair = q / QSUM_LANES, chunk = q % QSUM_LANES;
@@ -496,12 +508,13 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
         const int it = q / per_item, k = q - it * per_item;
         const int c = k / nspec, s = k - c * nspec;
         double *Db = D + (b0 + it) * drec;
-        if (ammonia) derive_lane(S, th_all + it, q_all + (it * ncomp + c) * QREC, Db, c, s, g_tabs);
-        else derive_simple_lane(S, th_all + it, Db, c, s, g_tabs);
+        if (ammonia) derive_lane<FAST>(S, th_all + it, q_all + (it * ncomp + c) * QREC, Db, c, s, g_tabs);
+        else derive_simple_lane<FAST>(S, th_all + it, Db, c, s, g_tabs);
     }
 }
 
-template <int MODE>
+// MODE: the exponential of the partition sums (0 the reference's tables, 1 the polynomial); FAST: the record of the fast mode
+template <int MODE, bool FAST = false>
 __global__ void __launch_bounds__(512) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
                                                     BatchGroup grp, double *__restrict__ D,
                                                     long B, int has_prior,
@@ -514,7 +527,7 @@ __global__ void __launch_bounds__(512) setup_kernel(const PriorProg *__restrict_
     __builtin_amdgcn_s_setprio(3);
     int n_shared;
     const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
-    setup_body<MODE>(ppp, S, U, D, B, has_prior, g_tabs, ablate_in, smem, sm, n_shared, blockIdx.x, ti);
+    setup_body<MODE, FAST>(ppp, S, U, D, B, has_prior, g_tabs, ablate_in, smem, sm, n_shared, blockIdx.x, ti);
 }
 
 // ---------------------------------------------------------------------------
@@ -569,7 +582,7 @@ __global__ void __launch_bounds__(POINT_THREADS) point_kernel(const PriorProg *_
     }
     if (tid == 0 && in.pix >= 0) d_pix[b] = my_pix;
     __syncthreads();
-    setup_body<SMODE>(ppp, S, U, D, 1, 1, g_tabs, 0, smem, sm, n_shared, 0u);
+    setup_body<SMODE, MODE == 2>(ppp, S, U, D, 1, 1, g_tabs, 0, smem, sm, n_shared, 0u);
     __threadfence();                                            // theta in U, the derived record in D: at L2 ...
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();                            // ... where the scalar loads of the record find them

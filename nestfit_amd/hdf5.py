@@ -151,6 +151,10 @@ def _load():
     if _lib is not None or _lib_err is not None:
         return _lib
     tried = []
+    # a chunk file has one writer and is read only after it was closed (main.py:516-526): advisory file locks add
+    # nothing, and flock() on a network or overlay scratch directory is where such a job hangs; the user's own
+    # setting wins (the library reads the variable when it starts up)
+    os.environ.setdefault('HDF5_USE_FILE_LOCKING', 'FALSE')
     for cand in _candidates():
         try:
             _lib = _bind(C.CDLL(cand))
