@@ -193,6 +193,7 @@ def bench_c5(args):
         dt = time.perf_counter() - t0
         gain = np.array([x.lnZ for x in res]) - cube.null_lnZ
         out[ncomp] = {'seconds': dt, 'pixels_per_s': n_pix / dt, 'likelihood_evals': int(sum(x.n_evals for x in res)),
+                      'evals_per_pixel': float(np.mean([x.n_evals for x in res])), 'iterations_per_pixel': float(np.mean([x.n_iter for x in res])),
                       'evals_per_s': sum(x.n_evals for x in res) / dt, 'mean_lnZ_err': float(np.mean([x.lnZ_err for x in res])),
                       'detections': int((gain > 11).sum())}
     print(json.dumps({
