@@ -1087,7 +1087,8 @@ static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, doubl
         bool ok = hipHostMalloc((void **)&r->h_point, sizeof(double) * POINT_HOST_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess
                   && hipHostGetDevicePointer((void **)&r->d_point, r->h_point, 0) == hipSuccess
                   && hipMalloc((void **)&r->d_point_done, sizeof(unsigned)) == hipSuccess
-                  && hipMemset(r->d_point_done, 0, sizeof(unsigned)) == hipSuccess;
+                  && hipMemset(r->d_point_done, 0, sizeof(unsigned)) == hipSuccess
+                  && hipDeviceSynchronize() == hipSuccess;        // (a null-stream memset is not ordered before the lanes' work)
         if (!ok) {
             (void)hipGetLastError();
             if (r->h_point) (void)hipHostFree(r->h_point);

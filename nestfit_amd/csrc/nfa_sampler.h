@@ -66,6 +66,10 @@ struct NsDev {
     int    *candpix, *valid;            // [rows]: pixel of a compact row; validity of a proposal
     int    *slot;                       // [rows] compact row of a valid proposal
     int    *count;                      // number of compact rows filled in this round
+    // A one-thread launch behind the proposing one writes that number and the round's sequence number into host memory
+    // the device can address and zeroes the counter for the next round (ns_publish_kernel)
+    int    *host_rows;                  // mapped host memory: rows of the round
+    unsigned long long *host_seq;       // mapped host memory: sequence number of the round, written last
     const int *actlist;                 // [n_act] active pixels of this round
     // constrained random walks (pixels whose rejection sampling has become too inefficient)
     int     method, n_steps;            // 0 rejection only, 1 automatic switch, 2 walks from the start
@@ -111,9 +115,7 @@ __global__ void ns_sanitize_kernel(double *__restrict__ L, long n, double log_ze
 // ---- candidates --------------------------------------------------------------------------
 // Kr = candidates per pixel in this round (>= K: grows when few pixels are left, so the tail of
 // slow pixels does not cost one launch per handful of candidates)
-__global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)n_act * Kr) return;
+__device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_act, int Kr) {
     const int q = (int)(gid / Kr), k = (int)(gid - (long)q * Kr);
     const int p = S.actlist[q];
     const int D = S.D;
@@ -196,6 +198,22 @@ __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
     double *ct = S.candT + (long)row * S.DT;
     for (int j = 0; j < S.DT; ++j) ct[j] = 0.5;
     for (int j = 0; j < D; ++j) ct[S.fmap[j]] = cu[j];
+}
+
+__global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < (long)n_act * Kr) ns_propose_one(S, gid, n_act, Kr);
+}
+
+// One thread behind a proposing launch: the number of compact rows and the round's sequence number go into host
+// memory the device can address, the counter back to zero for the next round.  (In place of a memset before the
+// launch, a four-byte copy and an event behind it.  The same done by the proposing launch's last workgroup -- a
+// fence and a tick per workgroup -- made the rounds slower: an agent-scope fence writes the L2 back.)
+__global__ void ns_publish_kernel(NsDev S, unsigned long long seq) {
+    const int rows = *S.count;
+    *S.count = 0;
+    __hip_atomic_store(S.host_rows, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(S.host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- wave helpers (one 64-lane wave per pixel) -------------------------------------------------
@@ -544,8 +562,9 @@ struct nfa_sampler {
     int  n_act = 0, check_every = 8;
     size_t lds = 0;
     bool ran = false;
-    int *h_rows = nullptr;      // pinned: compact-row counts of the parts
-    hipEvent_t ev[NS_PARTS] = {};
+    // host memory the device writes (mapped): per part, [rows of the round][sequence number of the round], 16 bytes each
+    unsigned long long *h_pub = nullptr, *d_pub = nullptr;
+    unsigned long long seq = 0;  // sequence number of the last proposing launch
 };
 
 extern "C" {
@@ -558,7 +577,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol,
                     s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap, s->d_nlive, s->d_updp, s->d_capp};
     for (void *p : ptrs) (void)hipFree(p);
-    if (s->h_rows) { (void)hipHostFree(s->h_rows); for (int h = 0; h < NS_PARTS; ++h) (void)hipEventDestroy(s->ev[h]); }
+    if (s->h_pub) (void)hipHostFree(s->h_pub);
     delete s;
     return NFA_OK;
 }
@@ -723,9 +742,13 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
     // updating one group (latency-bound, few waves) overlaps the likelihood batch of another.  A pixel's random stream and decisions do not depend on its company, so the
     // split changes nothing in the results.
     const int n_half = std::max(1, std::min(std::min(r->n_lanes, NS_PARTS), g_eng.sampler_parts));
-    if (!s->h_rows) {
-        HIP_TRY(hipHostMalloc((void **)&s->h_rows, sizeof(int) * NS_PARTS));
-        for (int h = 0; h < NS_PARTS; ++h) HIP_TRY(hipEventCreateWithFlags(&s->ev[h], hipEventDisableTiming));
+    if (!s->h_pub) {
+        HIP_TRY(hipHostMalloc((void **)&s->h_pub, sizeof(unsigned long long) * 2 * NS_PARTS, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void **)&s->d_pub, s->h_pub, 0));
+        memset(s->h_pub, 0, sizeof(unsigned long long) * 2 * NS_PARTS);
+        // (a blocking copy: a memset on the null stream is not ordered before work on the runner's non-blocking lanes)
+        const int zeros[NS_PARTS] = {};
+        HIP_TRY(hipMemcpy(d.count, zeros, sizeof(int) * NS_PARTS, hipMemcpyHostToDevice));   // the publishing launches leave them at zero
     }
     for (int64_t chunk = 0; s->n_act > 0 && (max_chunks <= 0 || chunk < max_chunks); ++chunk) {
         // candidates per pixel: the round's batch stays near b_target however few pixels are left
@@ -742,6 +765,7 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                 dh[h].candU += off * D; dh[h].candT += off * d.DT; dh[h].candL += off;
                 dh[h].candpix += off; dh[h].valid += off; dh[h].slot += off;
                 dh[h].count += h; dh[h].actlist += first;
+                dh[h].host_rows = (int *)(s->d_pub + 2 * h); dh[h].host_seq = s->d_pub + 2 * h + 1;
                 first += n_pix_h[h];
             }
         }
@@ -750,18 +774,25 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                 if (n_pix_h[h] == 0) continue;
                 hipStream_t st = r->lanes[h];
                 const long B = (long)n_pix_h[h] * Kr;
-                HIP_TRY(hipMemsetAsync(dh[h].count, 0, sizeof(int), st));
                 hipLaunchKernelGGL(ns_propose_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr);
+                hipLaunchKernelGGL(ns_publish_kernel, dim3(1), dim3(1), 0, st, dh[h], s->seq + 1);
                 HIP_TRY(hipGetLastError());
-                // proposals inside the prior: the only ones worth a likelihood
-                HIP_TRY(hipMemcpyAsync(&s->h_rows[h], dh[h].count, sizeof(int), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipEventRecord(s->ev[h], st));
             }
+            s->seq += 1;
             for (int h = 0; h < NS_PARTS; ++h) {
                 if (n_pix_h[h] == 0) continue;
                 hipStream_t st = r->lanes[h];
-                HIP_TRY(hipEventSynchronize(s->ev[h]));
-                const int n_rows = s->h_rows[h];
+                // proposals inside the prior: the only ones worth a likelihood.  Their number is the launch's last store
+                // into the mapped buffer, behind it the round's sequence number
+                volatile unsigned long long *pub = s->h_pub + 2 * h;
+                const auto t_start = std::chrono::steady_clock::now();
+                for (uint64_t spins = 0; __atomic_load_n(pub + 1, __ATOMIC_ACQUIRE) != s->seq; ++spins) {
+                    if ((spins & 0x3fff) == 0x3fff && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) {
+                        // nothing came back: a fault surfaces here, a very slow launch finishes
+                        HIP_TRY(hipStreamSynchronize(st));
+                    }
+                }
+                const int n_rows = (int)(unsigned)(pub[0] & 0xffffffffull);
                 if (n_rows > 0) {
                     int rc = run_batch(r, dh[h].candpix, dh[h].candT, dh[h].candL, nullptr, n_rows, true, h, nullptr);
                     if (rc) return rc;
