@@ -164,7 +164,7 @@ def bench_c5(args):
     from nestfit_amd.synth import freq_axis
     na.set_exp_mode(args.exp_mode)
     for key, val in (('setup_ti', args.setup_ti), ('setup_threads', args.setup_threads), ('wpb', args.wpb), ('streams', args.streams),
-                     ('sampler_parts', args.sampler_parts)):
+                     ('sampler_parts', args.sampler_parts), ('sampler_refit_every', args.sampler_refit_every), ('sampler_walk_factor', args.sampler_walk_factor)):
         if val:
             _ffi.set_option(key, val)
     if args.prior_stage >= 0:
@@ -189,7 +189,12 @@ def bench_c5(args):
                           ncomp=ncomp)
         _ffi.check(_ffi.load().nfa_device_synchronize())
         t0 = time.perf_counter()
-        res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=nlive, tol=0.5, efr=0.3, seed=1)
+        knobs = {}
+        if args.sampler_batch_target:
+            knobs['batch_target'] = args.sampler_batch_target
+        if args.sampler_upd_frac:
+            knobs['upd_frac'] = args.sampler_upd_frac
+        res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=nlive, tol=0.5, efr=0.3, seed=1, **knobs)
         dt = time.perf_counter() - t0
         gain = np.array([x.lnZ for x in res]) - cube.null_lnZ
         out[ncomp] = {'seconds': dt, 'pixels_per_s': n_pix / dt, 'likelihood_evals': int(sum(x.n_evals for x in res)),
@@ -258,6 +263,10 @@ def main():
     ap.add_argument('--lnl-split', type=int, default=-1, help='engine A/B knob: waves per (item, spectrum) unit (0 = by launch size)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
     ap.add_argument('--coalesce', type=int, default=0, help='engine A/B knob: device-pointer batches launched together at most (1 = none; 0 = default 4)')
+    ap.add_argument('--sampler-walk-factor', type=int, default=0, help='engine A/B knob (C5): to walks below an acceptance of 1 / (factor n_steps)')
+    ap.add_argument('--sampler-refit-every', type=int, default=0, help='engine A/B knob (C5): rounds between the refits of rejection-mode pixels')
+    ap.add_argument('--sampler-batch-target', type=int, default=0, help='A/B knob (C5): candidates per round of all pixels together')
+    ap.add_argument('--sampler-upd-frac', type=float, default=0.0, help='A/B knob (C5): replacements (fraction of nlive) between refits')
     ap.add_argument('--sampler-parts', type=int, default=0, help='engine A/B knob (C5): groups of pixels pipelined over the lanes')
     ap.add_argument('--prior-stage', type=int, default=-1, help='engine A/B knob: prior tables staged in LDS (1) or left in global memory (0)')
     ap.add_argument('--setup-ti', type=int, default=0, help='engine A/B knob: items per set-up workgroup (0 = default)')

@@ -43,6 +43,9 @@ __host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t
     return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
 
+#define NS_WALK_LOWD 6             // up to this many sampled dimensions ...
+#define NS_WALK_FACTOR_LOWD 64     // ... the switch to walks waits for an acceptance below 1 / (64 n_steps)
+#define NS_WALK_FACTOR 2           // above: 1 / (2 n_steps)
 struct NsDev {
     int     P, N, D, K;                 // pixels, live points, SAMPLED dimensions, candidates per round (at least)
     int     DT;                         // length of a theta row (all unit-cube slots of the runner)
@@ -80,6 +83,8 @@ struct NsDev {
     int    *wnacc;                      // [P][NS_W] accepted steps of each walker in the cycle
     double *lnvol;                      // [P] ln volume of the bounding ellipsoid (last refit)
     int     stage_live;                 // the refit stages the centred live points in LDS
+    int     refit_every;                // rejection-mode pixels refit in rounds that are multiples of this
+    int     walk_factor;                // to walks below an acceptance of 1 / (walk_factor n_steps), back above 8 times that
     // Pixels of one lock-step group may run with different numbers of live points (the cube driver gives every pixel
     // nlive + int(5 SNR), main.py:445-447): N is then the stride of the live arrays and the largest count, and these
     // hold each pixel's own count, dead-point slots and refit interval (null: N, cap, upd for everybody)
@@ -457,7 +462,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
             acc_sum = 0; tot_sum = 0; next_step = 0;
             // back to rejection sampling once the bound promises clearly more than a walk delivers:
             // expected acceptance X / min(V_ellipsoid, 1) > 4 / n_steps
-            if (lane == 0 && S.method == 1 && (-(double)it / N - fmin(S.lnvol[p], 0.0)) > log(4.0 / S.n_steps)) S.walk[p] = 0;
+            if (lane == 0 && S.method == 1 && (-(double)it / N - fmin(S.lnvol[p], 0.0)) > log(8.0 / ((double)S.walk_factor * S.n_steps))) S.walk[p] = 0;
         }
         if (lane == 0) {
             if (step == 0) { S.wLthr[p] = Lthr; S.wW[p] = W; }
@@ -510,7 +515,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         // n_steps): the expensive cycle end then falls into the same launch for everybody instead of
         // making every launch wait for somebody's.
         if (lane == 0 && !done && (round + 1) % S.n_steps == 0 &&
-            (S.method == 2 || (S.method == 1 && scanned >= 64 && 2 * accepted * S.n_steps < scanned))) {
+            (S.method == 2 || (S.method == 1 && scanned >= 64 && S.walk_factor * accepted * S.n_steps < scanned))) {
             S.walk[p] = 1; S.wstep[p] = 0; S.wscale[p] = 1.0; S.wacc_sum[p] = 0; S.wtot_sum[p] = 0;
         }
     }
@@ -521,7 +526,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     // A refit costs ~100 us and pixels are in lock-step: rejection-mode pixels refit only in every
     // fourth round, so that three launches out of four do not wait for anybody's refit (walking
     // pixels refit at their common cycle end).
-    if (!done && since >= ns_upd(S, p) && (was_walking || (round + 1) % 4 == 0)) {
+    if (!done && since >= ns_upd(S, p) && (was_walking || (round + 1) % S.refit_every == 0)) {
         __threadfence();                            // the wave's own stores to Ulive, then its loads
         ns_refit(S, p, it, sA, sc, sd, lane);
         since = 0;
@@ -716,6 +721,13 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemcpyAsync(d.active, s->h_active.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
     s->lds = sizeof(double) * ((size_t)((N + 1) & ~1) + (size_t)D * D + (size_t)((D + 1) & ~1));
     d.stage_live = (size_t)N * D * sizeof(double) <= 96 * 1024 ? 1 : 0;
+    d.refit_every = g_eng.sampler_refit_every;
+    // When does a pixel give up rejection sampling for constrained walks?  Measured on config 5 (profiles/r03/
+    // sweep_walk_factor.txt): with ten sampled dimensions the walks win from an acceptance of ~1 in 2 n_steps down (the
+    // run takes 7.0-7.2 s for factors 1..4, 8.6 s at 32, 10.9 s at 64); with five they hardly ever do -- a rejection
+    // round is one large batch, a walk cycle n_steps small ones, and the run goes from 1.16 s (factor 2) to 0.84 s (64;
+    // rejection only: 0.79 s).  The walks stay as the way out of a bound that has become hopeless.
+    d.walk_factor = g_eng.sampler_walk_factor > 0 ? g_eng.sampler_walk_factor : (D <= NS_WALK_LOWD ? NS_WALK_FACTOR_LOWD : NS_WALK_FACTOR);
     if (d.stage_live) s->lds += sizeof(double) * (size_t)N * D;
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));

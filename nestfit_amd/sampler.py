@@ -83,6 +83,7 @@ def _uniform(seed, p, a, b):
 _B_START = _U64(250)
 _NS_W = 64
 _WALK_TARGET = 0.5              # acceptance the walk scale is tuned to (NS_WALK_TARGET on the device)
+_WALK_LOWD, _WALK_FACTOR_LOWD, _WALK_FACTOR = 6, 64, 2      # NS_WALK_LOWD, NS_WALK_FACTOR_LOWD, NS_WALK_FACTOR
 
 
 def _ball_points(seed, p, a, D):
@@ -211,7 +212,7 @@ def default_cap_iter(nlive):
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
-               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None,
+               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None,
                progress=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
@@ -305,6 +306,11 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     Kr = K
     method = {'reject': 0, 'auto': 1, 'walk': 2}[method] if isinstance(method, str) else int(method)
     n_steps = int(n_steps) if n_steps else 10 * nd
+    # a pixel turns to walks when a rejection round accepts fewer than 1 in walk_factor * n_steps candidates (and back
+    # above eight times that): 2 from seven sampled dimensions on, 64 below -- there a rejection round, one large batch,
+    # beats a walk cycle of n_steps small ones down to very low acceptances (csrc/nfa_sampler.h: NS_WALK_FACTOR*,
+    # profiles/r03/sweep_walk_factor.txt).  The device takes the same default (engine option `sampler_walk_factor`).
+    walk_factor = int(walk_factor) if walk_factor else (_WALK_FACTOR_LOWD if nd <= _WALK_LOWD else _WALK_FACTOR)
     # constrained random walks (ns_update_kernel's walk branch): state per pixel and per walker
     walk = np.zeros(P, dtype=bool)
     wstep = np.zeros(P, dtype=np.int64)
@@ -385,7 +391,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                                                                   / (0.5 * math.sqrt(nd))))
                     wacc_sum[p] = wtot_sum[p] = wstep[p] = 0
                     # back to rejection once the bound promises clearly more than a walk delivers
-                    if method == 1 and (-n_iter[p] / nlive - min(lnvol[p], 0.0)) > math.log(4.0 / n_steps):
+                    if method == 1 and (-n_iter[p] / nlive - min(lnvol[p], 0.0)) > math.log(8.0 / (walk_factor * n_steps)):
                         walk[p] = False
             else:
                 cand = _candidates(seed, [p], cand_base[p:p + 1], Kr, centre[p:p + 1], axes[p:p + 1],
@@ -406,7 +412,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                                 break
                 # walk cycles of all pixels stay in phase: they start at rounds that are multiples of n_steps
                 if not done and (rnd + 1) % n_steps == 0 and (
-                        method == 2 or (method == 1 and scanned >= 64 and 2 * accepted * n_steps < scanned)):
+                        method == 2 or (method == 1 and scanned >= 64 and walk_factor * accepted * n_steps < scanned)):
                     walk[p], wstep[p], wscale[p], wacc_sum[p], wtot_sum[p] = True, 0, 1.0, 0, 0
             cand_base[p] += Kr
             if done:

@@ -71,7 +71,9 @@ def test_walk_mode_evidence_and_switch():
     D, sig = 5, 0.01
     f2 = _gauss_problem(np.array([[0.25] * D, [0.75] * D]), sig)
     truth2 = np.log(2) + D * np.log(sig * np.sqrt(2 * np.pi))
-    auto = sampler.run_nested(f2, D, 1, nlive=100, tol=0.5, seed=4, method='auto', n_steps=20, batch_target=512)[0]
+    # (walk_factor = 2: the switch at 1 in 2 n_steps, the default from seven sampled dimensions on; with five the default
+    # waits for 1 in 64 n_steps -- on the GPU a rejection round is one large batch, a walk cycle n_steps small ones)
+    auto = sampler.run_nested(f2, D, 1, nlive=100, tol=0.5, seed=4, method='auto', n_steps=20, batch_target=512, walk_factor=2)[0]
     rej = sampler.run_nested(f2, D, 1, nlive=100, tol=0.5, seed=4, method='reject', batch_target=512)[0]
     assert auto.n_evals < 0.7 * rej.n_evals
     assert abs(auto.lnZ - truth2) < 4 * auto.lnZ_err and abs(rej.lnZ - truth2) < 4 * rej.lnZ_err
