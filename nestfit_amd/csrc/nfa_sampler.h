@@ -43,6 +43,14 @@ __host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t
     return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
 
+// Several bounding ellipsoids per pixel (MultiNest's `mmodal` bound in its simplest form): up to NS_ME of them where at
+// most NS_ME_MAXD dimensions are sampled.  A cluster of live points is cut in two across its principal axis at its
+// centre; the cut is kept when the two halves' ellipsoids together have less than NS_ME_GAIN of the parent's volume.
+#define NS_ME 4
+#define NS_ME_MAXD 6
+#define NS_ME_GAIN 0.7
+#define NS_B_ELL 253ull            // random-stream slots of a proposal: which ellipsoid, and the 1 / (number that hold it) test
+#define NS_B_KEEP 254ull
 #define NS_WALK_LOWD 6             // up to this many sampled dimensions ...
 #define NS_WALK_FACTOR_LOWD 64     // ... the switch to walks waits for an acceptance below 1 / (64 n_steps)
 #define NS_WALK_FACTOR 2           // above: 1 / (2 n_steps)
@@ -57,7 +65,10 @@ struct NsDev {
     uint64_t seed;
     const int *pixmap;                  // sampler pixel -> cube pixel
     double *Ulive, *Tlive, *Llive;      // [P][N][D], [P][N][DT], [P][N]
-    double *centre, *axes;              // [P][D], [P][D][D] (lower triangular, scaled)
+    double *centre, *axes;              // [P][NS_ME][D], [P][NS_ME][D][D] (lower triangular, scaled)
+    double *elnv;                       // [P][NS_ME] ln volume of each ellipsoid
+    int    *nell;                       // [P] ellipsoids in use
+    int     multi;                      // 1: the bound may be split (D <= NS_ME_MAXD and the live points fit in LDS)
     long   *n_iter, *n_evals;           // [P]
     long   *cand_base;                  // [P] candidates drawn so far (index into the pixel's random stream)
     double *lnZ;                        // [P] running evidence of the dead points
@@ -133,7 +144,7 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
     bool ok = true;
     const bool walking = S.walk[p] != 0;
     double wscale = 1.0;
-    const double *origin = S.centre + (long)p * D;
+    const double *origin = S.centre + (long)p * NS_ME * D;
     if (walking) {
         // Metropolis step of walker k inside {L > threshold}; a cycle starts from a random live point
         const int step = S.wstep[p];
@@ -185,12 +196,41 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
         }
         const double ur = ns_uniform(S.seed, (uint64_t)p, a, NS_B_RADIUS);
         const double f = exp(log(ur) / D) / sqrt(n2);               // uniform in the unit ball
-        const double *c = S.centre + (long)p * D, *A = S.axes + (long)p * D * D;
+        // several ellipsoids: one is drawn by volume, and a point that lies in q of them is kept with probability 1 / q
+        // (uniform over the union)
+        const int ne = S.multi ? S.nell[p] : 1;
+        int ke = 0;
+        if (ne > 1) {
+            const double usel = ns_uniform(S.seed, (uint64_t)p, a, NS_B_ELL), lv = S.lnvol[p];
+            double acc = 0.0;
+            ke = ne - 1;
+            for (int k = 0; k < ne - 1; ++k) {
+                acc += exp(S.elnv[(long)p * NS_ME + k] - lv);
+                if (usel < acc) { ke = k; break; }
+            }
+        }
+        const double *c = S.centre + ((long)p * NS_ME + ke) * D, *A = S.axes + ((long)p * NS_ME + ke) * D * D;
         for (int j = 0; j < D; ++j) {
             double v = c[j];
             for (int i = 0; i <= j; ++i) v += A[j * D + i] * (z[i] * f);
             ok = ok && (v >= 0.0) && (v < 1.0);               // outside the unit cube = outside the prior
             cu[j] = v;
+        }
+        if (ok && ne > 1) {
+            int q = 1;
+            for (int k = 0; k < ne; ++k) {
+                if (k == ke) continue;
+                const double *ck = S.centre + ((long)p * NS_ME + k) * D, *Ak = S.axes + ((long)p * NS_ME + k) * D * D;
+                double y[NS_MAXD], s2 = 0.0;
+                for (int j = 0; j < D; ++j) {
+                    double v = cu[j] - ck[j];
+                    for (int i = 0; i < j; ++i) v -= Ak[j * D + i] * y[i];
+                    y[j] = v / Ak[j * D + j];
+                    s2 += y[j] * y[j];
+                }
+                q += s2 <= 1.0 ? 1 : 0;
+            }
+            if (q > 1) ok = ns_uniform(S.seed, (uint64_t)p, a, NS_B_KEEP) * q < 1.0;
         }
     }
     S.valid[gid] = ok ? 1 : 0;
@@ -347,12 +387,158 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
     const double grow = fmax((ln_x - S.ln_efr) - lnv, 0.0);
     const double scale = sqrt(r2) * exp((grow + S.ln_enlarge) / D);
     if (lane == 0) { S.use_cube[p] = (lnv + grow) >= 0.0 ? 1 : 0; S.lnvol[p] = lnv + grow; }   // >= cube: use the cube
-    double *A = S.axes + (long)p * D * D, *c = S.centre + (long)p * D;
+    double *A = S.axes + (long)p * NS_ME * D * D, *c = S.centre + (long)p * NS_ME * D;     // ellipsoid 0 of the pixel
+    if (lane == 0) { S.nell[p] = 1; S.elnv[(long)p * NS_ME] = lnv + grow; }
     for (int e = lane; e < D * D; e += 64) {
         const int a = e / D, b = e - a * D;
         A[e] = b <= a ? sA[e] * scale : 0.0;
     }
     for (int j = lane; j < D; j += 64) c[j] = sc[j];
+    wave_lds_sync();
+}
+
+// ---- several ellipsoids ----------------------------------------------------------------------
+// One fit slot in LDS: [c: D][L: D*D, lower][cov: D*D, lower][r2, lnv, n, final]
+__host__ __device__ inline int ns_me_slot(int D) { return D + 2 * D * D + 4; }
+// Mean, covariance, Cholesky factor, largest Mahalanobis distance and ln volume (safety factor included) of the live
+// points whose label is k (and, with side >= 0, whose side bit is `side`); su = the pixel's live points in LDS.
+__device__ void ns_me_fit(const NsDev &S, const double *su, const int *lab, int N, int D, int k, int side, double *f, int lane) {
+    double *fc = f, *fL = f + D, *fC = f + D + D * D, *fs = f + D + 2 * D * D;
+    auto member = [&](int i) { const int l = lab[i]; return (l & 7) == k && (side < 0 || ((l >> 3) & 1) == side); };
+    double cnt = 0.0;
+    for (int i = lane; i < N; i += 64) cnt += member(i) ? 1.0 : 0.0;
+    cnt = ns_wave_sum(cnt);
+    for (int j = 0; j < D; ++j) {
+        double acc = 0.0;
+        for (int i = lane; i < N; i += 64) acc += member(i) ? su[i * D + j] : 0.0;
+        acc = ns_wave_sum(acc);
+        if (lane == 0) fc[j] = acc / cnt;
+    }
+    wave_lds_sync();
+    double tr = 0.0;
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b <= a; ++b) {
+            double acc = 0.0;
+            for (int i = lane; i < N; i += 64) acc += member(i) ? (su[i * D + a] - fc[a]) * (su[i * D + b] - fc[b]) : 0.0;
+            acc = ns_wave_sum(acc) / (cnt - 1.0);
+            if (lane == 0) { fC[a * D + b] = acc; fL[a * D + b] = acc; }
+            if (a == b) tr += acc;
+        }
+    wave_lds_sync();
+    if (lane == 0) {                    // Cholesky, lower triangle in place (as ns_refit)
+        const double eps = 1e-12 * fmax(tr, 1e-30);
+        for (int a = 0; a < D; ++a) fL[a * D + a] += eps;
+        for (int j = 0; j < D; ++j) {
+            double d = fL[j * D + j];
+            for (int q = 0; q < j; ++q) d -= fL[j * D + q] * fL[j * D + q];
+            d = sqrt(fmax(d, 1e-300));
+            fL[j * D + j] = d;
+            for (int i = j + 1; i < D; ++i) {
+                double v = fL[i * D + j];
+                for (int q = 0; q < j; ++q) v -= fL[i * D + q] * fL[j * D + q];
+                fL[i * D + j] = v / d;
+            }
+        }
+    }
+    wave_lds_sync();
+    double r2 = 0.0;
+    for (int i = lane; i < N; i += 64) {
+        if (!member(i)) continue;
+        double y[NS_ME_MAXD];
+        double s2 = 0.0;
+        for (int a = 0; a < D; ++a) {
+            double v = su[i * D + a] - fc[a];
+            for (int q = 0; q < a; ++q) v -= fL[a * D + q] * y[q];
+            y[a] = v / fL[a * D + a];
+            s2 += y[a] * y[a];
+        }
+        r2 = fmax(r2, s2);
+    }
+    r2 = ns_wave_max(r2);
+    double lnv = S.ln_vball + 0.5 * D * log(r2) + S.ln_enlarge;
+    for (int a = 0; a < D; ++a) lnv += log(fL[a * D + a]);
+    if (lane == 0) { fs[0] = r2; fs[1] = lnv; fs[2] = cnt; fs[3] = 0.0; }
+    wave_lds_sync();
+}
+
+// The bound of pixel p as up to NS_ME ellipsoids (same decisions as _fit_multi in nestfit_amd/sampler.py): the cluster
+// with the largest ellipsoid is cut across its principal axis at its centre; the cut stays when the halves' ellipsoids
+// together have less than NS_ME_GAIN of its volume, else the cluster is final; a cluster below 4 (D + 2) points is not
+// cut, a half below 2 (D + 2) not accepted.  Then MultiNest's rule on the sum of the volumes (X / efr at least).
+// su: N * D doubles, lab: N ints, wf: (NS_ME + 2) fit slots -- all LDS.
+__device__ void ns_refit_multi(const NsDev &S, int p, long n_iter, double *su, int *lab, double *wf, int lane) {
+    const int N = ns_n(S, p), D = S.D, FS = ns_me_slot(D), minp = 2 * (D + 2);
+    const double *U = S.Ulive + (long)p * S.N * D;
+    for (int e = lane; e < N * D; e += 64) su[e] = U[e];
+    for (int i = lane; i < N; i += 64) lab[i] = 0;
+    wave_lds_sync();
+    ns_me_fit(S, su, lab, N, D, 0, -1, wf, lane);
+    int ncl = 1;
+    while (ncl < NS_ME) {
+        int best = -1;
+        for (int k = 0; k < ncl; ++k) {
+            const double *fs = wf + k * FS + D + 2 * D * D;
+            if (fs[3] == 0.0 && fs[2] >= 2.0 * minp && (best < 0 || fs[1] > wf[best * FS + D + 2 * D * D + 1])) best = k;
+        }
+        if (best < 0) break;
+        double *fb = wf + best * FS;
+        // principal axis of the cluster's covariance: twenty steps of the power iteration from (1, ..., 1)
+        double v[NS_ME_MAXD];
+        for (int a = 0; a < D; ++a) v[a] = 1.0;
+        for (int it = 0; it < 20; ++it) {
+            double w[NS_ME_MAXD], n2 = 0.0;
+            for (int a = 0; a < D; ++a) {
+                double acc = 0.0;
+                for (int b = 0; b < D; ++b) acc += fb[D + D * D + (a >= b ? a * D + b : b * D + a)] * v[b];
+                w[a] = acc;
+                n2 += acc * acc;
+            }
+            const double inv = 1.0 / sqrt(n2);
+            for (int a = 0; a < D; ++a) v[a] = w[a] * inv;
+        }
+        for (int i = lane; i < N; i += 64) {
+            if ((lab[i] & 7) != best) continue;
+            double proj = 0.0;
+            for (int a = 0; a < D; ++a) proj += (su[i * D + a] - fb[a]) * v[a];
+            lab[i] = best | ((proj >= 0.0 ? 1 : 0) << 3);
+        }
+        wave_lds_sync();
+        double *fA = wf + NS_ME * FS, *fB = wf + (NS_ME + 1) * FS;
+        ns_me_fit(S, su, lab, N, D, best, 0, fA, lane);
+        ns_me_fit(S, su, lab, N, D, best, 1, fB, lane);
+        const double nA = fA[D + 2 * D * D + 2], nB = fB[D + 2 * D * D + 2];
+        const double lvA = fA[D + 2 * D * D + 1], lvB = fB[D + 2 * D * D + 1], lvP = fb[D + 2 * D * D + 1];
+        const bool keep = nA >= minp && nB >= minp && ns_logaddexp(lvA, lvB) < lvP + log(NS_ME_GAIN);
+        wave_lds_sync();
+        if (keep) {
+            for (int i = lane; i < N; i += 64) {
+                const int l = lab[i];
+                if ((l & 7) == best) lab[i] = ((l >> 3) & 1) ? ncl : best;
+            }
+            double *fn = wf + ncl * FS;
+            for (int e = lane; e < FS; e += 64) { fb[e] = fA[e]; fn[e] = fB[e]; }
+            ncl += 1;
+        } else if (lane == 0) {
+            fb[D + 2 * D * D + 3] = 1.0;
+        }
+        wave_lds_sync();
+    }
+    double tot = -INFINITY;
+    for (int k = 0; k < ncl; ++k) tot = ns_logaddexp(tot, wf[k * FS + D + 2 * D * D + 1]);
+    const double ln_x = -(double)n_iter / N;
+    const double grow = fmax((ln_x - S.ln_efr) - tot, 0.0);
+    for (int k = 0; k < ncl; ++k) {
+        const double *f = wf + k * FS;
+        const double scale = sqrt(f[D + 2 * D * D]) * exp((grow + S.ln_enlarge) / D);
+        double *A = S.axes + ((long)p * NS_ME + k) * D * D, *c = S.centre + ((long)p * NS_ME + k) * D;
+        for (int e = lane; e < D * D; e += 64) {
+            const int a = e / D, b = e - a * D;
+            A[e] = b <= a ? f[D + e] * scale : 0.0;
+        }
+        for (int j = lane; j < D; j += 64) c[j] = f[j];
+        if (lane == 0) S.elnv[(long)p * NS_ME + k] = f[D + 2 * D * D + 1] + grow;
+    }
+    if (lane == 0) { S.nell[p] = ncl; S.lnvol[p] = tot + grow; S.use_cube[p] = (tot + grow) >= 0.0 ? 1 : 0; }
     wave_lds_sync();
 }
 
@@ -370,7 +556,14 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     double *sA = sL + ((NS + 1) & ~1);              // D*D
     double *sc = sA + D * D;                        // D
     double *sd = S.stage_live ? sc + ((D + 1) & ~1) : nullptr;   // N*D centred live points (refit)
-    if (force_refit) { ns_refit(S, p, 0, sA, sc, sd, lane); return; }
+    // several ellipsoids: the fit slots and the points' labels follow the staged live points
+    double *wf = sd ? sd + (long)NS * D : nullptr;
+    int *lab = (int *)(wf + (NS_ME + 2) * ns_me_slot(D));
+    auto refit = [&](long n_iter_now) {
+        if (S.multi) ns_refit_multi(S, p, n_iter_now, sd, lab, wf, lane);
+        else ns_refit(S, p, n_iter_now, sA, sc, sd, lane);
+    };
+    if (force_refit) { refit(0); return; }
     if (!S.active[p]) return;
     double *Ll = S.Llive + (long)p * NS;
     for (int i = lane; i < N; i += 64) sL[i] = Ll[i];
@@ -528,7 +721,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     // pixels refit at their common cycle end).
     if (!done && since >= ns_upd(S, p) && (was_walking || (round + 1) % S.refit_every == 0)) {
         __threadfence();                            // the wave's own stores to Ulive, then its loads
-        ns_refit(S, p, it, sA, sc, sd, lane);
+        refit(it);
         since = 0;
     }
     if (lane == 0) S.since_fit[p] = since;
@@ -579,7 +772,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
     NsDev &d = s->d;
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
                     d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
-                    d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol,
+                    d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol, d.elnv, d.nell,
                     s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap, s->d_nlive, s->d_updp, s->d_capp};
     for (void *p : ptrs) (void)hipFree(p);
     if (s->h_pub) (void)hipHostFree(s->h_pub);
@@ -623,7 +816,8 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(s->d_pixmap, int, P); NS_ALLOC(s->d_actlist, int, P); NS_ALLOC(s->d_livepix, int, P * N);
     NS_ALLOC(s->d_fmap, int, D);
     NS_ALLOC(d.Ulive, double, P * N * D); NS_ALLOC(d.Tlive, double, P * N * DT); NS_ALLOC(d.Llive, double, P * N);
-    NS_ALLOC(d.centre, double, P * D); NS_ALLOC(d.axes, double, P * D * D);
+    NS_ALLOC(d.centre, double, P * NS_ME * D); NS_ALLOC(d.axes, double, P * NS_ME * D * D);
+    NS_ALLOC(d.elnv, double, P * NS_ME); NS_ALLOC(d.nell, int, P);
     NS_ALLOC(d.n_iter, long, P); NS_ALLOC(d.n_evals, long, P); NS_ALLOC(d.cand_base, long, P); NS_ALLOC(d.lnZ, double, P);
     NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P); NS_ALLOC(d.use_cube, int, P);
     NS_ALLOC(d.deadT, double, P * C * DT); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
@@ -729,6 +923,8 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     // rejection only: 0.79 s).  The walks stay as the way out of a bound that has become hopeless.
     d.walk_factor = g_eng.sampler_walk_factor > 0 ? g_eng.sampler_walk_factor : (D <= NS_WALK_LOWD ? NS_WALK_FACTOR_LOWD : NS_WALK_FACTOR);
     if (d.stage_live) s->lds += sizeof(double) * (size_t)N * D;
+    d.multi = (d.stage_live && D <= NS_ME_MAXD && g_eng.sampler_ellipsoids != 1) ? 1 : 0;
+    if (d.multi) s->lds += sizeof(double) * (size_t)((NS_ME + 2) * ns_me_slot(D)) + sizeof(int) * (size_t)((N + 3) & ~3);
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));
     hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), s->lds, st, d, P, 0, 1, 0L);   // first ellipsoids

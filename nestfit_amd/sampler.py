@@ -152,6 +152,90 @@ def _fit_ellipsoids(U, efr, ln_x, enlarge=1.0):
     return c, L * scale[:, None, None], lnv >= 0.0, lnv
 
 
+# ---- several ellipsoids per pixel (ns_refit_multi / the rejection branch of ns_propose_kernel) ----------
+_NS_ME, _NS_ME_MAXD, _NS_ME_GAIN = 4, 6, 0.7        # NS_ME, NS_ME_MAXD, NS_ME_GAIN
+_B_ELL, _B_KEEP = _U64(253), _U64(254)
+
+
+def _me_fit(Y, enlarge):
+    """Mean, Cholesky factor, covariance, largest Mahalanobis distance^2, ln volume (safety factor included) and size
+    of a cluster of live points Y[n, d] (ns_me_fit)."""
+    n, d = Y.shape
+    c = Y.sum(axis=0) / n
+    dl = Y - c
+    cov = dl.T @ dl / (n - 1)
+    Lc = np.linalg.cholesky(cov + 1e-12 * max(float(np.trace(cov)), 1e-30) * np.eye(d))
+    y = np.linalg.solve(Lc, dl.T)
+    r2 = float(np.max(np.sum(y * y, axis=0)))
+    ln_vball = 0.5 * d * math.log(math.pi) - math.lgamma(0.5 * d + 1.0)
+    lnv = ln_vball + 0.5 * d * math.log(r2) + float(np.log(np.diag(Lc)).sum()) + math.log(enlarge)
+    return c, Lc, cov, r2, lnv, n
+
+
+def _fit_multi(U, efr, ln_x, enlarge=1.0):
+    """The bound of one pixel's live points U[nlive, d] as up to four ellipsoids (ns_refit_multi): the cluster with the
+    largest ellipsoid is cut across its principal axis at its centre; the cut stays when the halves' ellipsoids together
+    have less than 0.7 of its volume, else the cluster is final.  Then MultiNest's rule on the summed volume.
+    Returns centres [4, d], axes [4, d, d], ln volumes [4], the number in use, ln of the summed volume, use_cube."""
+    n, d = U.shape
+    minp = 2 * (d + 2)
+    lab = np.zeros(n, dtype=np.int64)
+    fits, final = [_me_fit(U, enlarge)], [False]
+    while len(fits) < _NS_ME:
+        best = -1
+        for k, f in enumerate(fits):
+            if not final[k] and f[5] >= 2 * minp and (best < 0 or f[4] > fits[best][4]):
+                best = k
+        if best < 0:
+            break
+        c, _, cov, _, lnv, _ = fits[best]
+        v = np.ones(d)
+        for _ in range(20):                                      # power iteration from (1, ..., 1)
+            w = cov @ v
+            v = w * (1.0 / math.sqrt(float((w * w).sum())))
+        idx = np.flatnonzero(lab == best)
+        side = ((U[idx] - c) @ v) >= 0.0
+        ia, ib = idx[~side], idx[side]
+        if ia.size < minp or ib.size < minp:
+            final[best] = True
+            continue
+        fa, fb = _me_fit(U[ia], enlarge), _me_fit(U[ib], enlarge)
+        if np.logaddexp(fa[4], fb[4]) < lnv + math.log(_NS_ME_GAIN):
+            lab[ib] = len(fits)
+            fits[best] = fa
+            fits.append(fb)
+            final[best] = False
+            final.append(False)
+        else:
+            final[best] = True
+    tot = -np.inf
+    for f in fits:
+        tot = np.logaddexp(tot, f[4])
+    grow = max((ln_x - math.log(efr)) - tot, 0.0)
+    cs, As, lv = np.zeros((_NS_ME, d)), np.zeros((_NS_ME, d, d)), np.full(_NS_ME, -np.inf)
+    for k, (c, Lc, _, r2, lnv, _) in enumerate(fits):
+        cs[k], As[k], lv[k] = c, Lc * (math.sqrt(r2) * math.exp((grow + math.log(enlarge)) / d)), lnv + grow
+    return cs, As, lv, len(fits), tot + grow, (tot + grow) >= 0.0
+
+
+def _candidates_multi(seed, p, base, K, cs, As, lv, ne, lnvol):
+    """K candidates of pixel p, uniform over the union of its `ne` ellipsoids: one is drawn by volume, and a point that
+    lies in q of them is kept with probability 1 / q.  Returns the points and the keep flags."""
+    D = cs.shape[1]
+    a = np.asarray(base, dtype=_U64) + np.arange(K, dtype=_U64)
+    usel = _uniform(seed, _U64(p), a, _B_ELL)
+    cum = np.cumsum(np.exp(lv[:ne - 1] - lnvol))
+    ke = np.searchsorted(cum, usel, side='right')
+    z = _ball_points(seed, _U64(p), a, D)
+    cand = cs[ke] + np.einsum('kji,ki->kj', As[ke], z)
+    q = np.ones(K, dtype=np.int64)
+    for k in range(ne):
+        y = np.linalg.solve(As[k], (cand - cs[k]).T)
+        q += ((np.sum(y * y, axis=0) <= 1.0) & (ke != k)).astype(np.int64)
+    keep = (q == 1) | (_uniform(seed, _U64(p), a, _B_KEEP) * q < 1.0)
+    return cand, keep
+
+
 def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
     """NestedResult per pixel from dead points (theta, lnL, lnw per pixel) and final live points:
     every live point carries the mass X_final / nlive.  `nlive`: one number, or one per pixel (a pixel's live
@@ -212,7 +296,7 @@ def default_cap_iter(nlive):
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
-               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None,
+               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None,
                progress=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
@@ -294,11 +378,23 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     active = np.full(P, maxiter > 0)
     since_fit = np.zeros(P, dtype=np.int64)
     updp = np.maximum(1, (upd_frac * nl).astype(np.int64))
-    centre, axes = np.empty((P, nd)), np.empty((P, nd, nd))
+    # the bound: several ellipsoids per pixel where few dimensions are sampled (and the live points fit in the device's
+    # LDS), one otherwise; [pixel][ellipsoid]
+    multi = (nd <= _NS_ME_MAXD and nlive * nd * 8 <= 96 * 1024) if ellipsoids is None else bool(ellipsoids)
+    centre, axes = np.zeros((P, _NS_ME, nd)), np.zeros((P, _NS_ME, nd, nd))
+    elnv, nell = np.full((P, _NS_ME), -np.inf), np.ones(P, dtype=np.int64)
     use_cube, lnvol = np.empty(P, dtype=bool), np.empty(P)
-    for n_same in np.unique(nl):                                # (one fit per group of equal counts)
-        sel = np.flatnonzero(nl == n_same)
-        centre[sel], axes[sel], use_cube[sel], lnvol[sel] = _fit_ellipsoids(Ulive[sel, :n_same], efr, np.zeros(sel.size), enlarge)
+
+    def refit(p, ln_x):
+        n = int(nl[p])
+        if multi:
+            centre[p], axes[p], elnv[p], nell[p], lnvol[p], use_cube[p] = _fit_multi(Ulive[p, :n], efr, ln_x, enlarge)
+        else:
+            c1, a1, u1, v1 = _fit_ellipsoids(Ulive[p:p + 1, :n], efr, np.array([ln_x]), enlarge)
+            centre[p, 0], axes[p, 0], use_cube[p], lnvol[p], elnv[p, 0], nell[p] = c1[0], a1[0], u1[0], v1[0], v1[0], 1
+
+    for p in range(P):
+        refit(p, 0.0)
     dead_T, dead_L, dead_lnw, dead_pix = [], [], [], []
     rnd = 0
     b_target = max(P * K, int(batch_target))
@@ -394,9 +490,13 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                     if method == 1 and (-n_iter[p] / nlive - min(lnvol[p], 0.0)) > math.log(8.0 / (walk_factor * n_steps)):
                         walk[p] = False
             else:
-                cand = _candidates(seed, [p], cand_base[p:p + 1], Kr, centre[p:p + 1], axes[p:p + 1],
-                                   use_cube[p:p + 1])[0]
-                valid = np.all((cand >= 0.0) & (cand < 1.0), axis=1)   # outside the unit cube = outside the prior
+                if nell[p] > 1 and not use_cube[p]:
+                    cand, keep = _candidates_multi(seed, p, cand_base[p], Kr, centre[p], axes[p], elnv[p], int(nell[p]), lnvol[p])
+                else:
+                    cand = _candidates(seed, [p], cand_base[p:p + 1], Kr, centre[p:p + 1, 0], axes[p:p + 1, 0],
+                                       use_cube[p:p + 1])[0]
+                    keep = True
+                valid = np.all((cand >= 0.0) & (cand < 1.0), axis=1) & keep   # outside the unit cube = outside the prior
                 vi = np.flatnonzero(valid)
                 scanned = accepted = 0
                 if vi.size:
@@ -420,8 +520,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             elif since_fit[p] >= updp[p] and (was_walking or (rnd + 1) % 4 == 0):
                 # (rejection-mode pixels refit only in every fourth round: on the device a refit makes the
                 # whole launch wait, so they are taken together)
-                c1, a1, u1, v1 = _fit_ellipsoids(Ulive[p:p + 1, :nlive], efr, -n_iter[p:p + 1] / nlive, enlarge)
-                centre[p], axes[p], use_cube[p], lnvol[p] = c1[0], a1[0], u1[0], v1[0]
+                refit(p, -n_iter[p] / nlive)
                 since_fit[p] = 0
         rnd += 1
         if progress is not None:

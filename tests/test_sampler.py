@@ -67,18 +67,23 @@ def test_walk_mode_evidence_and_switch():
     per_iter = np.mean([r.n_evals / r.n_iter for r in res])
     assert 15 < per_iter < 30
     np.testing.assert_allclose(res[0].param_constr[1], sigma, rtol=0.25)
-    # two narrow modes in opposite corners: one ellipsoid around both accepts almost nothing, 'auto' walks
+    # two narrow modes in opposite corners: ONE ellipsoid around both accepts almost nothing and 'auto' turns to walks
+    # (walk_factor = 2: the switch at 1 in 2 n_steps, the default from seven sampled dimensions on; with five the default
+    # waits for 1 in 64 n_steps -- on the GPU a rejection round is one large batch, a walk cycle n_steps small ones) ...
     D, sig = 5, 0.01
     f2 = _gauss_problem(np.array([[0.25] * D, [0.75] * D]), sig)
     truth2 = np.log(2) + D * np.log(sig * np.sqrt(2 * np.pi))
-    # (walk_factor = 2: the switch at 1 in 2 n_steps, the default from seven sampled dimensions on; with five the default
-    # waits for 1 in 64 n_steps -- on the GPU a rejection round is one large batch, a walk cycle n_steps small ones)
-    auto = sampler.run_nested(f2, D, 1, nlive=100, tol=0.5, seed=4, method='auto', n_steps=20, batch_target=512, walk_factor=2)[0]
-    rej = sampler.run_nested(f2, D, 1, nlive=100, tol=0.5, seed=4, method='reject', batch_target=512)[0]
+    kw = dict(nlive=100, tol=0.5, seed=4, batch_target=512)
+    auto = sampler.run_nested(f2, D, 1, method='auto', n_steps=20, walk_factor=2, ellipsoids=False, **kw)[0]
+    rej = sampler.run_nested(f2, D, 1, method='reject', ellipsoids=False, **kw)[0]
     assert auto.n_evals < 0.7 * rej.n_evals
-    assert abs(auto.lnZ - truth2) < 4 * auto.lnZ_err and abs(rej.lnZ - truth2) < 4 * rej.lnZ_err
-    w, x = auto.posterior[:, -1], auto.posterior[:, 0]
-    assert 0.02 < w[x < 0.5].sum() < 0.98                                    # both modes kept (100 live points: noisy)
+    # ... and the default bound of a five-dimensional fit, up to four ellipsoids, puts one around each mode (mmodal)
+    multi = sampler.run_nested(f2, D, 1, method='auto', **kw)[0]
+    assert multi.n_evals < 0.4 * rej.n_evals and multi.n_evals < 0.7 * auto.n_evals
+    for r in (auto, rej, multi):
+        assert abs(r.lnZ - truth2) < 4 * r.lnZ_err
+        w, x = r.posterior[:, -1], r.posterior[:, 0]
+        assert 0.02 < w[x < 0.5].sum() < 0.98                                # both modes kept (100 live points: noisy)
 
 
 def test_dummy_dimensions_are_integrated_out():
