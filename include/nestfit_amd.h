@@ -326,6 +326,11 @@ int nfa_sampler_destroy(nfa_sampler *s);
  * nfa_sampler_create (which is then the stride of the live arrays nfa_sampler_live returns: pixel p's points are
  * the first nlive[p] of its slice), cap[p] <= cap_iter dead-point slots, upd[p] replacements between refits. */
 int nfa_sampler_set_pixel_nlive(nfa_sampler *s, const int32_t *nlive, const int64_t *cap, const int32_t *upd);
+/* Optional, between create and begin: bounding ellipsoids per pixel at most -- MultiNest's `mmodal` / `maxModes`
+ * (nestfit/core/core.pyx:727-760) as far as this sampler has them: 1 = one ellipsoid around all live points
+ * (mmodal = False), 2..4 = clusters of live points get ellipsoids of their own where at most six dimensions are
+ * sampled, 0 = the default (4 there, 1 above). */
+int nfa_sampler_set_ellipsoids(nfa_sampler *s, int max_ellipsoids);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
 /* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the

@@ -47,7 +47,9 @@ __host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t
 // most NS_ME_MAXD dimensions are sampled.  A cluster of live points is cut in two across its principal axis at its
 // centre; the cut is kept when the two halves' ellipsoids together have less than NS_ME_GAIN of the parent's volume.
 #define NS_ME 4
+#ifndef NS_ME_MAXD
 #define NS_ME_MAXD 6
+#endif
 #define NS_ME_GAIN 0.7
 #define NS_B_ELL 253ull            // random-stream slots of a proposal: which ellipsoid, and the 1 / (number that hold it) test
 #define NS_B_KEEP 254ull
@@ -69,6 +71,7 @@ struct NsDev {
     double *elnv;                       // [P][NS_ME] ln volume of each ellipsoid
     int    *nell;                       // [P] ellipsoids in use
     int     multi;                      // 1: the bound may be split (D <= NS_ME_MAXD and the live points fit in LDS)
+    int     max_ell;                    // ... into this many ellipsoids at most (2..NS_ME)
     long   *n_iter, *n_evals;           // [P]
     long   *cand_base;                  // [P] candidates drawn so far (index into the pixel's random stream)
     double *lnZ;                        // [P] running evidence of the dead points
@@ -474,7 +477,7 @@ __device__ void ns_refit_multi(const NsDev &S, int p, long n_iter, double *su, i
     wave_lds_sync();
     ns_me_fit(S, su, lab, N, D, 0, -1, wf, lane);
     int ncl = 1;
-    while (ncl < NS_ME) {
+    while (ncl < S.max_ell) {
         int best = -1;
         for (int k = 0; k < ncl; ++k) {
             const double *fs = wf + k * FS + D + 2 * D * D;
@@ -755,6 +758,7 @@ struct nfa_sampler {
     int *d_nlive = nullptr, *d_updp = nullptr;
     long *d_capp = nullptr;
     std::vector<int> h_nlive;   // per-pixel live points (empty: d.N for everybody)
+    int max_ell = 0;            // nfa_sampler_set_ellipsoids (0: the default)
     std::vector<int> h_active, h_act;
     long rounds = 0;
     int  n_act = 0, check_every = 8;
@@ -864,6 +868,13 @@ int nfa_sampler_set_pixel_nlive(nfa_sampler *s, const int32_t *nlive, const int6
     return NFA_OK;
 }
 
+int nfa_sampler_set_ellipsoids(nfa_sampler *s, int max_ellipsoids) {
+    if (!s || max_ellipsoids < 0 || max_ellipsoids > NS_ME) return fail(NFA_ERR_ARG, "ellipsoids per pixel: 0 (default) .. 4");
+    if (s->ran) return fail(NFA_ERR_STATE, "call nfa_sampler_set_ellipsoids before nfa_sampler_begin");
+    s->max_ell = max_ellipsoids;
+    return NFA_OK;
+}
+
 // tol, efr, seed, maxiter as run_multinest (core.pyx:727-744); upd = replacements between
 // ellipsoid refits; check_every = rounds between two looks at the set of active pixels.
 // nfa_sampler_begin draws and evaluates the live points and fits the first ellipsoids;
@@ -923,7 +934,8 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     // rejection only: 0.79 s).  The walks stay as the way out of a bound that has become hopeless.
     d.walk_factor = g_eng.sampler_walk_factor > 0 ? g_eng.sampler_walk_factor : (D <= NS_WALK_LOWD ? NS_WALK_FACTOR_LOWD : NS_WALK_FACTOR);
     if (d.stage_live) s->lds += sizeof(double) * (size_t)N * D;
-    d.multi = (d.stage_live && D <= NS_ME_MAXD && g_eng.sampler_ellipsoids != 1) ? 1 : 0;
+    d.max_ell = s->max_ell > 0 ? s->max_ell : (g_eng.sampler_ellipsoids == 1 ? 1 : NS_ME);
+    d.multi = (d.stage_live && D <= NS_ME_MAXD && d.max_ell > 1) ? 1 : 0;
     if (d.multi) s->lds += sizeof(double) * (size_t)((NS_ME + 2) * ns_me_slot(D)) + sizeof(int) * (size_t)((N + 3) & ~3);
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));

@@ -5,8 +5,9 @@ The reference drives one serial MultiNest instance per pixel
 (``run_multinest``, nestfit/core/core.pyx:727-823; pixel loop nestfit/main.py:452-469), one
 likelihood per callback.  Here every pixel of a cube is a nested-sampling run of its own, but all
 runs advance in lock-step: each round proposes candidates per active pixel -- uniform in the
-bounding ellipsoid of its live points (the idea of MultiNest's ellipsoidal rejection sampling,
-Feroz et al. 2009, without the mode clustering), or, where that has become hopeless, one
+bounding ellipsoid(s) of its live points (MultiNest's ellipsoidal rejection sampling, Feroz et al. 2009;
+up to four ellipsoids around clusters of live points where at most six dimensions are sampled),
+or, where that has become hopeless, one
 differential-evolution Metropolis step of each of 64 walkers inside the likelihood constraint --
 all candidates of all pixels go to the device in ONE likelihood batch, and every pixel scans its
 candidates in order: each one above the pixel's current threshold
@@ -18,8 +19,9 @@ Two implementations of one algorithm live side by side: `run_nested` (numpy, any
 callable) and `run_nested_device` (state and per-round logic on the GPU, csrc/nfa_sampler.h); they
 share a counter-based random stream, so the same seed gives the same run.
 
-This is not MultiNest: the random streams differ and there is no multi-ellipsoid decomposition,
-so evidences agree with a MultiNest run only within their sampling error.  What can be checked
+This is not MultiNest: the random streams differ and the decomposition into ellipsoids is a simpler one
+(principal-axis cuts kept by a volume test; none above six sampled dimensions, where constrained walks take
+over), so evidences agree with a MultiNest run only within their sampling error.  What can be checked
 bit-for-bit is the likelihood it is fed (tests drive the same sampler with the CPU oracle).
 """
 import math
@@ -172,7 +174,7 @@ def _me_fit(Y, enlarge):
     return c, Lc, cov, r2, lnv, n
 
 
-def _fit_multi(U, efr, ln_x, enlarge=1.0):
+def _fit_multi(U, efr, ln_x, enlarge=1.0, max_ell=4):
     """The bound of one pixel's live points U[nlive, d] as up to four ellipsoids (ns_refit_multi): the cluster with the
     largest ellipsoid is cut across its principal axis at its centre; the cut stays when the halves' ellipsoids together
     have less than 0.7 of its volume, else the cluster is final.  Then MultiNest's rule on the summed volume.
@@ -181,7 +183,7 @@ def _fit_multi(U, efr, ln_x, enlarge=1.0):
     minp = 2 * (d + 2)
     lab = np.zeros(n, dtype=np.int64)
     fits, final = [_me_fit(U, enlarge)], [False]
-    while len(fits) < _NS_ME:
+    while len(fits) < max_ell:
         best = -1
         for k, f in enumerate(fits):
             if not final[k] and f[5] >= 2 * minp and (best < 0 or f[4] > fits[best][4]):
@@ -380,7 +382,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     updp = np.maximum(1, (upd_frac * nl).astype(np.int64))
     # the bound: several ellipsoids per pixel where few dimensions are sampled (and the live points fit in the device's
     # LDS), one otherwise; [pixel][ellipsoid]
-    multi = (nd <= _NS_ME_MAXD and nlive * nd * 8 <= 96 * 1024) if ellipsoids is None else bool(ellipsoids)
+    max_ell = _NS_ME if not ellipsoids else int(ellipsoids)      # `ellipsoids`: None / 0 = the default, 1 = one, up to 4
+    multi = nd <= _NS_ME_MAXD and nlive * nd * 8 <= 96 * 1024 and max_ell > 1
     centre, axes = np.zeros((P, _NS_ME, nd)), np.zeros((P, _NS_ME, nd, nd))
     elnv, nell = np.full((P, _NS_ME), -np.inf), np.ones(P, dtype=np.int64)
     use_cube, lnvol = np.empty(P, dtype=bool), np.empty(P)
@@ -388,7 +391,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     def refit(p, ln_x):
         n = int(nl[p])
         if multi:
-            centre[p], axes[p], elnv[p], nell[p], lnvol[p], use_cube[p] = _fit_multi(Ulive[p, :n], efr, ln_x, enlarge)
+            centre[p], axes[p], elnv[p], nell[p], lnvol[p], use_cube[p] = _fit_multi(Ulive[p, :n], efr, ln_x, enlarge, max_ell)
         else:
             c1, a1, u1, v1 = _fit_ellipsoids(Ulive[p:p + 1, :n], efr, np.array([ln_x]), enlarge)
             centre[p, 0], axes[p, 0], use_cube[p], lnvol[p], elnv[p, 0], nell[p] = c1[0], a1[0], u1[0], v1[0], v1[0], 1
@@ -542,7 +545,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
                       upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=262144,
-                      enlarge=1.5, method='auto', n_steps=None, free_mask=None, progress=None, time_limit=None):
+                      enlarge=1.5, method='auto', n_steps=None, free_mask=None, progress=None, time_limit=None,
+                      ellipsoids=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
     work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive).  `progress`
@@ -571,6 +575,8 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
                                       int(nlive), K, int(batch_target), cap,
                                       None if fm is None else fm.ctypes.data_as(_ffi._ip)))
     try:
+        if ellipsoids:
+            _ffi.check(lib.nfa_sampler_set_ellipsoids(h, int(ellipsoids)))
         if per_pixel:
             nl32 = nl.astype(np.int32)
             upd32 = np.maximum(1, (upd_frac * nl).astype(np.int64)).astype(np.int32)
@@ -755,9 +761,11 @@ def run_multinest(runner, dumper, IS=False, mmodal=True, ceff=False, nlive=400, 
                   pWrap=None, fb=False, resume=False, initMPI=False, outfile=False, logZero=-1e100,
                   maxiter=int(1e6)):
     """Signature of the reference's ``run_multinest`` (core.pyx:727-823) on the built-in sampler,
-    for one runner (one pixel).  Options that only concern MultiNest's mode separation, importance
-    sampling or its output files are accepted and ignored; the argument checks are the
-    reference's."""
+    for one runner (one pixel).  `mmodal` / `maxModes`: clusters of live points get bounding ellipsoids of
+    their own (at most min(maxModes, 4), and only where at most six dimensions are sampled; mmodal = False: one
+    ellipsoid); the evidence is the global one either way (the reference's dumper stores no per-mode values).
+    Options that concern importance sampling, constant efficiency, the clustering parameters or MultiNest's output
+    files are accepted and ignored; the argument checks are the reference's."""
     assert runner.ndim > 0
     assert nlive > 0
     assert tol > 0
@@ -774,15 +782,16 @@ def run_multinest(runner, dumper, IS=False, mmodal=True, ceff=False, nlive=400, 
 
     utrans = getattr(runner, 'utrans', None)
     free_mask = utrans.free_mask(runner.ncomp) if hasattr(utrans, 'free_mask') else None
+    ellipsoids = min(int(maxModes), _NS_ME) if mmodal else 1
     if hasattr(runner, '_run'):          # engine runner: the whole run stays on the device
         res = run_nested_device(runner, np.zeros(1, dtype=np.int32), nlive=nlive, tol=tol, efr=efr, seed=seed,
-                                maxiter=maxiter, log_zero=logZero, free_mask=free_mask)[0]
+                                maxiter=maxiter, log_zero=logZero, free_mask=free_mask, ellipsoids=ellipsoids)[0]
     else:                                # any object with loglikelihood_batch(U): the numpy twin
         def loglike(pix, U):
             return runner.loglikelihood_batch(U)
 
         res = run_nested(loglike, runner.ndim, 1, nlive=nlive, tol=tol, efr=efr, seed=seed,
-                         maxiter=maxiter, log_zero=logZero, free_mask=free_mask)[0]
+                         maxiter=maxiter, log_zero=logZero, free_mask=free_mask, ellipsoids=ellipsoids)[0]
     dumper.dump(runner, res)
     return res
 

@@ -74,8 +74,8 @@ def test_walk_mode_evidence_and_switch():
     f2 = _gauss_problem(np.array([[0.25] * D, [0.75] * D]), sig)
     truth2 = np.log(2) + D * np.log(sig * np.sqrt(2 * np.pi))
     kw = dict(nlive=100, tol=0.5, seed=4, batch_target=512)
-    auto = sampler.run_nested(f2, D, 1, method='auto', n_steps=20, walk_factor=2, ellipsoids=False, **kw)[0]
-    rej = sampler.run_nested(f2, D, 1, method='reject', ellipsoids=False, **kw)[0]
+    auto = sampler.run_nested(f2, D, 1, method='auto', n_steps=20, walk_factor=2, ellipsoids=1, **kw)[0]
+    rej = sampler.run_nested(f2, D, 1, method='reject', ellipsoids=1, **kw)[0]
     assert auto.n_evals < 0.7 * rej.n_evals
     # ... and the default bound of a five-dimensional fit, up to four ellipsoids, puts one around each mode (mmodal)
     multi = sampler.run_nested(f2, D, 1, method='auto', **kw)[0]
@@ -202,7 +202,7 @@ def test_run_multinest_front_end_writes_the_reference_layout():
 
 
 # ---------------------------------------------------------------------------- GPU
-def _cube(engine, nfo, n_pix, seed):
+def _cube(engine, nfo, n_pix, seed, ntot=None):
     """Small synthetic cube: NH3 (1,1)+(2,2), 1 component, 256 channels, varying amplitude."""
     from nestfit_amd.cube import CubeRunner
     rng = np.random.default_rng(seed)
@@ -216,6 +216,8 @@ def _cube(engine, nfo, n_pix, seed):
     for p in range(n_pix):
         th = np.array([rng.uniform(-1, 1), rng.uniform(10, 18), rng.uniform(4, 8), rng.uniform(14.2, 14.8),
                        rng.uniform(0.3, 0.8), 0.0])
+        if ntot is not None:
+            th[3] = ntot
         truths.append(th)
         specs = []
         for k, t in enumerate((1, 2)):
@@ -330,6 +332,43 @@ def test_device_sampler_limits_and_errors(engine, nfo):
         sampler.run_nested_device(cube, pix, nlive=cube.ndim + 2 + 9000, seed=1)
     with pytest.raises(engine.EngineError, match='pixel index'):
         sampler.run_nested_device(cube, np.array([7]), nlive=40, seed=1)
+
+
+@pytest.mark.gpu
+def test_mmodal_on_the_device(engine, nfo):
+    """One bounding ellipsoid (mmodal = False) against up to four (the default with five sampled dimensions) on a faint
+    pixel, whose posterior is a curved ridge: the same evidence within the errors for fewer evaluations;
+    device = twin for both."""
+    cube, cpu_runners, truths, _, _ = _cube(engine, nfo, 2, seed=5, ntot=14.0)
+    mask = cube.utrans.free_mask(1)
+    kw = dict(nlive=200, tol=0.5, efr=0.3, seed=3, free_mask=mask, method='reject')
+    try:
+        engine.set_exp_mode('table')
+
+        def cpu_loglike(pix, U):
+            out = np.empty(U.shape[0])
+            for p in np.unique(pix):
+                m = pix == p
+                sub = U[m]
+                out[m] = cpu_runners[p].loglikelihood_batch(sub)
+                U[m] = sub
+            return out
+
+        res = {}
+        for ell in (1, 4):
+            dev = sampler.fit_pixels(cube, np.arange(2), ellipsoids=ell, **kw)
+            twin = sampler.run_nested(cpu_loglike, cube.ndim, 2, ellipsoids=ell, **kw)
+            for g, r in zip(dev, twin):
+                assert g.n_iter == r.n_iter and g.n_evals == r.n_evals, (ell, g.n_iter, r.n_iter, g.n_evals, r.n_evals)
+                assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
+            res[ell] = dev
+        for a, b in zip(res[1], res[4]):
+            assert abs(a.lnZ - b.lnZ) < 4 * np.hypot(a.lnZ_err, b.lnZ_err)
+        # (200 live points leave room for few cuts -- a cluster below 28 points is not cut: the 400 of config 5 gain
+        # a factor 2.2 on its faint pixels, profiles/r03/sweep_ellipsoids.txt)
+        assert sum(b.n_evals for b in res[4]) < 0.95 * sum(a.n_evals for a in res[1]), [(a.n_evals, b.n_evals) for a, b in zip(res[1], res[4])]
+    finally:
+        engine.set_exp_mode('fast')
 
 
 @pytest.mark.gpu
