@@ -178,6 +178,10 @@ def bench_c5(args):
     r = np.hypot(lon - side / 2, lat - side / 2) / (side / 2)
     out = {}
     for ncomp in (1, 2):
+        if args.c5_ncomp and ncomp != args.c5_ncomp:
+            rng.normal(0, noise, (n_pix, 2 * n))               # (the other run's noise draw: the cubes stay the same)
+            out[ncomp] = {'seconds': float('nan'), 'pixels_per_s': float('nan'), 'evals_per_pixel': float('nan'), 'mean_lnZ_err': float('nan')}
+            continue
         truths = np.zeros((n_pix, 6 * ncomp))
         for c in range(ncomp):
             truths[:, c] = (-1.0 + 2.0 * lon.ravel() / side) + 1.5 * c
@@ -263,6 +267,7 @@ def main():
     ap.add_argument('--lnl-split', type=int, default=-1, help='engine A/B knob: waves per (item, spectrum) unit (0 = by launch size)')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
     ap.add_argument('--coalesce', type=int, default=0, help='engine A/B knob: device-pointer batches launched together at most (1 = none; 0 = default 4)')
+    ap.add_argument('--c5-ncomp', type=int, default=0, help='C5: only this number of components (A/B runs)')
     ap.add_argument('--sampler-ellipsoids', type=int, default=0, help='engine A/B knob (C5): 1 = one bounding ellipsoid per pixel whatever the dimension')
     ap.add_argument('--sampler-walk-factor', type=int, default=0, help='engine A/B knob (C5): to walks below an acceptance of 1 / (factor n_steps)')
     ap.add_argument('--sampler-refit-every', type=int, default=0, help='engine A/B knob (C5): rounds between the refits of rejection-mode pixels')
