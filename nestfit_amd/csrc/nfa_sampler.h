@@ -748,7 +748,9 @@ __global__ void ns_pack_dead_kernel(NsDev S, const long *__restrict__ off, doubl
 }
 
 // ---- host side -----------------------------------------------------------------------------
+#ifndef NS_KMAX
 #define NS_KMAX 16384           // most proposals one pixel gets in a round
+#endif
 #define NS_PARTS 4              // at most this many groups of pixels, each on its own stream lane
 struct nfa_sampler {
     nfa_runner *r = nullptr;
