@@ -237,10 +237,17 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
         }
     }
     S.valid[gid] = ok ? 1 : 0;
+    // only candidates inside the prior go to the likelihood: compact rows (order is irrelevant, every proposal
+    // remembers its row).  One atomic per wave, not per proposal: tens of thousands of them on ONE counter took the
+    // proposing launch 40 us by themselves.
+    const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
     if (!ok) return;
-    // only candidates inside the prior go to the likelihood: compact rows (order is irrelevant,
-    // every proposal remembers its row)
-    const int row = atomicAdd(S.count, 1);
+    const int lane_id = (int)(threadIdx.x & 63);
+    const int leader = __builtin_ctzll(okm);
+    int base = 0;
+    if (lane_id == leader) base = atomicAdd(S.count, __builtin_popcountll(okm));
+    base = __builtin_amdgcn_readlane(base, leader);
+    const int row = base + __builtin_popcountll(okm & ((1ull << lane_id) - 1ull));
     S.slot[gid] = row;
     S.candpix[row] = S.pixmap[p];
     double *ct = S.candT + (long)row * S.DT;
