@@ -164,7 +164,7 @@ def bench_c5(args):
     from nestfit_amd.synth import freq_axis
     na.set_exp_mode(args.exp_mode)
     for key, val in (('setup_ti', args.setup_ti), ('setup_threads', args.setup_threads), ('wpb', args.wpb), ('streams', args.streams),
-                     ('sampler_parts', args.sampler_parts), ('sampler_refit_every', args.sampler_refit_every), ('sampler_walk_factor', args.sampler_walk_factor), ('sampler_ellipsoids', args.sampler_ellipsoids)):
+                     ('sampler_parts', args.sampler_parts), ('sampler_refit_every', args.sampler_refit_every), ('sampler_walk_factor', args.sampler_walk_factor), ('sampler_ellipsoids', args.sampler_ellipsoids), ('sampler_walkers', args.sampler_walkers)):
         if val:
             _ffi.set_option(key, val)
     if args.prior_stage >= 0:
@@ -268,6 +268,7 @@ def main():
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
     ap.add_argument('--coalesce', type=int, default=0, help='engine A/B knob: device-pointer batches launched together at most (1 = none; 0 = default 4)')
     ap.add_argument('--c5-ncomp', type=int, default=0, help='C5: only this number of components (A/B runs)')
+    ap.add_argument('--sampler-walkers', type=int, default=0, help='engine A/B knob (C5): walkers per pixel of a walk cycle (64, 128, 192, 256; 0 = by the live points)')
     ap.add_argument('--sampler-ellipsoids', type=int, default=0, help='engine A/B knob (C5): 1 = one bounding ellipsoid per pixel whatever the dimension')
     ap.add_argument('--sampler-walk-factor', type=int, default=0, help='engine A/B knob (C5): to walks below an acceptance of 1 / (factor n_steps)')
     ap.add_argument('--sampler-refit-every', type=int, default=0, help='engine A/B knob (C5): rounds between the refits of rejection-mode pixels')

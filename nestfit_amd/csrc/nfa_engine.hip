@@ -60,6 +60,7 @@ struct Engine {
     int    streams = 0;              // stream lanes of new runners; 0 = six, of which a batch uses four or six (run_batch)
     int    sampler_parts = 3;        // groups of pixels the device sampler pipelines over the lanes
     int    sampler_refit_every = 4;  // rejection-mode pixels refit their bound in every n-th round (A/B knob)
+    int    sampler_walkers = 0;      // walkers per pixel of a walk cycle (A/B knob: 64, 128, 192, 256); 0 = by the live points
     int    sampler_ellipsoids = 0;   // 1: one bounding ellipsoid per pixel whatever the dimension (A/B knob; 0: several where it pays)
     int    sampler_walk_factor = 0;  // a pixel turns to walks when rejection accepts fewer than 1 in factor * n_steps; 0 = by the
                                      // number of sampled dimensions (nfa_sampler_begin)
@@ -293,6 +294,7 @@ int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "setup_threads") && (value == 0 || value == 256 || value == 512)) { g_eng.setup_threads = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_refit_every") && value >= 1 && value <= 16) { g_eng.sampler_refit_every = value; return NFA_OK; }
+    if (key && !strcmp(key, "sampler_walkers") && value >= 0 && value <= 256 && value % 64 == 0) { g_eng.sampler_walkers = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_ellipsoids") && value >= 0 && value <= 1) { g_eng.sampler_ellipsoids = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_walk_factor") && value >= 0 && value <= 1024) { g_eng.sampler_walk_factor = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }

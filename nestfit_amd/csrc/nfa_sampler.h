@@ -28,7 +28,12 @@
 #define NS_B_RADIUS  255ull
 #define NS_B_START   250ull      // stream index of a walker's starting live point
 #define NS_WALK_TARGET 0.5     // acceptance the walk scale is tuned to
-#define NS_W         64          // walkers per pixel: one per lane of the update wave
+#define NS_W         64          // walkers per lane slice of the update wave
+#define NS_WMAX      256         // walkers per pixel at most
+// Walkers of a pixel with n live points: a cycle's walkers are harvested against a threshold that rises with every
+// replacement, so many more than a third of n mostly harvest each other's leftovers (of k walkers n ln(1 + k / n) pass);
+// 64 of them are a small batch once the pixels are few -- 128 from 384 live points, 256 from 768.
+__host__ __device__ inline int ns_walkers_for(int n) { return n >= 768 ? 256 : n >= 384 ? 128 : 64; }
 
 __host__ __device__ inline uint64_t ns_mix(uint64_t x) {             // splitmix64 finaliser
     x += 0x9E3779B97F4A7C15ull;
@@ -93,8 +98,10 @@ struct NsDev {
     int    *walk, *wstep, *wW;          // [P] mode flag, step inside the current cycle, walkers in it
     double *wscale, *wLthr;             // [P] proposal scale, threshold frozen at the cycle start
     long   *wacc_sum, *wtot_sum;        // [P] accepted / evaluated steps of the current cycle
-    double *wU, *wT, *wL;               // walker states [P][NS_W][D], [P][NS_W][DT], [P][NS_W]
-    int    *wnacc;                      // [P][NS_W] accepted steps of each walker in the cycle
+    double *wU, *wT, *wL;               // walker states [P][w_stride][D], [P][w_stride][DT], [P][w_stride]
+    int    *wnacc;                      // [P][w_stride] accepted steps of each walker in the cycle
+    int     w_stride;                   // walker slots per pixel (a multiple of 64)
+    int     w_fixed;                    // > 0: this many walkers whatever the live points (A/B knob), else ns_walkers_for
     double *lnvol;                      // [P] ln volume of the bounding ellipsoid (last refit)
     int     stage_live;                 // the refit stages the centred live points in LDS
     int     refit_every;                // rejection-mode pixels refit in rounds that are multiples of this
@@ -109,6 +116,7 @@ struct NsDev {
 __device__ __forceinline__ int  ns_n(const NsDev &S, int p)   { return S.nlive ? S.nlive[p] : S.N; }
 __device__ __forceinline__ long ns_cap(const NsDev &S, int p) { return S.capp ? S.capp[p] : S.cap; }
 __device__ __forceinline__ int  ns_upd(const NsDev &S, int p) { return S.updp ? S.updp[p] : S.upd; }
+__device__ __forceinline__ int  ns_wmax(const NsDev &S, int p) { return min(S.w_stride, S.w_fixed > 0 ? S.w_fixed : ns_walkers_for(ns_n(S, p))); }
 
 // ---- live points -------------------------------------------------------------------------
 __global__ void ns_init_live_kernel(NsDev S, int *__restrict__ livepix) {
@@ -151,18 +159,18 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
     if (walking) {
         // Metropolis step of walker k inside {L > threshold}; a cycle starts from a random live point
         const int step = S.wstep[p];
-        const int W = step == 0 ? min(NS_W, Kr) : S.wW[p];
+        const int W = step == 0 ? min(ns_wmax(S, p), Kr) : S.wW[p];
         if (k >= W) { S.valid[gid] = 0; return; }
-        double *wu = S.wU + ((long)p * NS_W + k) * D;
+        double *wu = S.wU + ((long)p * S.w_stride + k) * D;
         if (step == 0) {
             const int Np = ns_n(S, p);
             const int idx = min(Np - 1, (int)(ns_uniform(S.seed, (uint64_t)p, a, NS_B_START) * Np));
             const double *lu = S.Ulive + ((long)p * S.N + idx) * D, *lt = S.Tlive + ((long)p * S.N + idx) * S.DT;
-            double *wt = S.wT + ((long)p * NS_W + k) * S.DT;
+            double *wt = S.wT + ((long)p * S.w_stride + k) * S.DT;
             for (int j = 0; j < D; ++j) wu[j] = lu[j];
             for (int j = 0; j < S.DT; ++j) wt[j] = lt[j];
-            S.wL[(long)p * NS_W + k] = S.Llive[(long)p * S.N + idx];
-            S.wnacc[(long)p * NS_W + k] = 0;
+            S.wL[(long)p * S.w_stride + k] = S.Llive[(long)p * S.N + idx];
+            S.wnacc[(long)p * S.w_stride + k] = 0;
         }
         origin = wu;
         wscale = S.wscale[p];
@@ -626,23 +634,23 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     if (was_walking) {
         // ---- one Metropolis step of every walker (lane = walker), cycle end every n_steps rounds
         const int step = S.wstep[p];
-        const int W = step == 0 ? min(NS_W, K) : S.wW[p];
+        const int W = step == 0 ? min(ns_wmax(S, p), K) : S.wW[p];
         const double Lthr = step == 0 ? Lmin : S.wLthr[p];
         int tot = 0, acc = 0;
-        if (lane < W) {
-            const long g = (long)q * K + lane;
+        for (int kw = lane; kw < W; kw += 64) {         // walkers lane, lane + 64, ...
+            const long g = (long)q * K + kw;
             if (S.valid[g]) {
-                tot = 1;
+                tot += 1;
                 const long row = S.slot[g];
                 double Lk = S.candL[row];
                 if (!isfinite(Lk)) Lk = S.log_zero;
                 if (Lk > Lthr) {
-                    acc = 1;
-                    double *wu = S.wU + ((long)p * NS_W + lane) * D, *wt = S.wT + ((long)p * NS_W + lane) * S.DT;
+                    acc += 1;
+                    double *wu = S.wU + ((long)p * S.w_stride + kw) * D, *wt = S.wT + ((long)p * S.w_stride + kw) * S.DT;
                     for (int j = 0; j < D; ++j) wu[j] = S.candU[g * D + j];
                     for (int j = 0; j < S.DT; ++j) wt[j] = S.candT[row * S.DT + j];
-                    S.wL[(long)p * NS_W + lane] = Lk;
-                    S.wnacc[(long)p * NS_W + lane] += 1;
+                    S.wL[(long)p * S.w_stride + kw] = Lk;
+                    S.wnacc[(long)p * S.w_stride + kw] += 1;
                 }
             }
         }
@@ -654,11 +662,11 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         if (next_step >= S.n_steps) {
             __threadfence();                        // walker states written by other lanes of this wave
             for (int k = 0; k < W && !done; ++k) {
-                const int moved = __hip_atomic_load(&S.wnacc[(long)p * NS_W + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int moved = __hip_atomic_load(&S.wnacc[(long)p * S.w_stride + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!moved) continue;               // never left its starting live point: not a new sample
-                const double Lk = __hip_atomic_load(&S.wL[(long)p * NS_W + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double Lk = __hip_atomic_load(&S.wL[(long)p * S.w_stride + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!(Lk > Lmin)) continue;
-                replace(S.wU + ((long)p * NS_W + k) * D, S.wT + ((long)p * NS_W + k) * S.DT, Lk);
+                replace(S.wU + ((long)p * S.w_stride + k) * D, S.wT + ((long)p * S.w_stride + k) * S.DT, Lk);
             }
             // acceptance near one half (as dynesty's rwalk tunes it)
             if (tot_sum > 0) scale = fmin(1.0, scale * exp(((double)acc_sum / (double)tot_sum - NS_WALK_TARGET) / (0.5 * sqrt((double)D))));
@@ -838,8 +846,10 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K); NS_ALLOC(d.slot, int, P * K); NS_ALLOC(d.count, int, NS_PARTS);
     NS_ALLOC(d.walk, int, P); NS_ALLOC(d.wstep, int, P); NS_ALLOC(d.wW, int, P); NS_ALLOC(d.wscale, double, P);
     NS_ALLOC(d.wLthr, double, P); NS_ALLOC(d.wacc_sum, long, P); NS_ALLOC(d.wtot_sum, long, P);
-    NS_ALLOC(d.wU, double, P * NS_W * D); NS_ALLOC(d.wT, double, P * NS_W * DT); NS_ALLOC(d.wL, double, P * NS_W);
-    NS_ALLOC(d.wnacc, int, P * NS_W); NS_ALLOC(d.lnvol, double, P);
+    d.w_fixed = g_eng.sampler_walkers;
+    d.w_stride = d.w_fixed > 0 ? d.w_fixed : ns_walkers_for(N);      // (a pixel's own count can only be smaller than N)
+    NS_ALLOC(d.wU, double, P * d.w_stride * D); NS_ALLOC(d.wT, double, P * d.w_stride * DT); NS_ALLOC(d.wL, double, P * d.w_stride);
+    NS_ALLOC(d.wnacc, int, P * d.w_stride); NS_ALLOC(d.lnvol, double, P);
 #undef NS_ALLOC
     HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_fmap, fm.data(), sizeof(int) * D, hipMemcpyHostToDevice));

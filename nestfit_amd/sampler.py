@@ -84,6 +84,11 @@ def _uniform(seed, p, a, b):
 
 _B_START = _U64(250)
 _NS_W = 64
+
+
+def _walkers_for(n):
+    """Walkers of a pixel with n live points (ns_walkers_for): 64, 128 from 384 live points, 256 from 768."""
+    return 256 if n >= 768 else 128 if n >= 384 else 64
 _WALK_TARGET = 0.5              # acceptance the walk scale is tuned to (NS_WALK_TARGET on the device)
 _WALK_LOWD, _WALK_FACTOR_LOWD, _WALK_FACTOR = 6, 64, 2      # NS_WALK_LOWD, NS_WALK_FACTOR_LOWD, NS_WALK_FACTOR
 
@@ -298,7 +303,7 @@ def default_cap_iter(nlive):
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
-               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None,
+               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None, walkers=None,
                progress=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
@@ -418,10 +423,11 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     wLthr = np.zeros(P)
     wacc_sum = np.zeros(P, dtype=np.int64)
     wtot_sum = np.zeros(P, dtype=np.int64)
-    wU = np.zeros((P, _NS_W, nd))
-    wT = np.zeros((P, _NS_W, ndim))
-    wL = np.zeros((P, _NS_W))
-    wnacc = np.zeros((P, _NS_W), dtype=np.int64)
+    w_stride = int(walkers) if walkers else _walkers_for(nlive)     # walker slots per pixel (`walkers`: A/B knob, else by the live points)
+    wU = np.zeros((P, w_stride, nd))
+    wT = np.zeros((P, w_stride, ndim))
+    wL = np.zeros((P, w_stride))
+    wnacc = np.zeros((P, w_stride), dtype=np.int64)
 
     def replace(p, cU, cT, Lk):
         """The worst live point of pixel p dies, the candidate takes its slot; True when p is done."""
@@ -452,7 +458,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             if walk[p]:
                 # one Metropolis step of every walker inside {L > threshold frozen at the cycle start}
                 step = int(wstep[p])
-                W = min(_NS_W, Kr) if step == 0 else int(wW[p])
+                W = min(w_stride, int(walkers) if walkers else _walkers_for(nlive), Kr) if step == 0 else int(wW[p])
                 a = _U64(cand_base[p]) + np.arange(W, dtype=_U64)
                 if step == 0:
                     start = np.minimum(nlive - 1, (_uniform(seed, p, a, _B_START) * nlive).astype(np.int64))
