@@ -272,6 +272,13 @@ def test_sampler_on_gpu_matches_the_same_sampler_on_the_oracle(engine, nfo):
             assert g.n_iter == r.n_iter and g.n_evals == r.n_evals, (g.n_iter, r.n_iter, g.n_evals, r.n_evals)
             assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
             np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
+        # 400 live points: 128 walkers per pixel, two per lane of the update wave (ns_walkers_for)
+        kw2 = dict(kw, nlive=400, method='walk', n_steps=5, maxiter=500)
+        ref_2 = sampler.run_nested(cpu_loglike, cube.ndim, n_pix, **kw2)
+        got_2 = sampler.fit_pixels(cube, np.arange(n_pix), **kw2)
+        for g, r in zip(got_2, ref_2):
+            assert g.n_iter == r.n_iter == 500 and g.n_evals == r.n_evals, (g.n_iter, r.n_iter, g.n_evals, r.n_evals)
+            assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
         # every pixel its own number of live points, one lock-step group (nfa_sampler_set_pixel_nlive): device = twin,
         # rejection rounds and walks alike
         for extra in (dict(), dict(method='walk', n_steps=7, maxiter=500)):
