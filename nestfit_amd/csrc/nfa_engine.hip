@@ -213,6 +213,7 @@ struct nfa_runner {
     int     g1_mode = -1;
     double *h_pin = nullptr;         // pinned staging: ndim + 1 doubles
     uint64_t n_single = 0;
+    bool    part_only = false;       // a batch leaves the per-spectrum chi^2 parts; whoever set this sums them (the device sampler's update)
     double *h_point = nullptr;       // mapped host buffer of the point kernel: theta[ndim], lnL, sequence number
     double *d_point = nullptr;       // the same buffer as the device sees it
     unsigned *d_point_done = nullptr; // workgroups of a point launch that have finished
@@ -839,7 +840,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
                        (const double *)g_eng.d_tabs);
     HIP_TRY(hipGetLastError());
     if (r->ev_after_lnl) { HIP_TRY(hipEventRecord(r->ev_after_lnl, st)); r->ev_after_lnl = nullptr; }
-    if (d_lnL) {
+    if (d_lnL && !r->part_only) {
         hipLaunchKernelGGL(lnl_sum_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st,
                            (const double *)r->d_part[slot], S.noise, r->cur_group, (long)B, S.n_spec);
         HIP_TRY(hipGetLastError());

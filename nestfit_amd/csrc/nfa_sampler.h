@@ -86,6 +86,9 @@ struct NsDev {
     double *deadT, *deadL, *deadlnw;    // [P][cap][DT], [P][cap], [P][cap]
     double *candU, *candT, *candL;      // proposals [rows][D]; compact: theta [rows][DT], lnL [rows]
     int    *candpix, *valid;            // [rows]: pixel of a compact row; validity of a proposal
+    // the update wave sums a row's per-spectrum chi^2 parts itself (lnl_of_item's arithmetic): no summing launch per round
+    const double *part, *noise;         // [rows][nspec] of the round's batch (null: candL holds lnL); [pixels][nspec]
+    int     nspec;
     int    *slot;                       // [rows] compact row of a valid proposal
     int    *count;                      // number of compact rows filled in this round
     // A one-thread launch behind the proposing one writes that number and the round's sequence number into host memory
@@ -642,7 +645,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
             if (S.valid[g]) {
                 tot += 1;
                 const long row = S.slot[g];
-                double Lk = S.candL[row];
+                double Lk = S.part ? lnl_of_item(S.part, S.noise, (long)S.candpix[row], row, S.nspec) : S.candL[row];
                 if (!isfinite(Lk)) Lk = S.log_zero;
                 if (Lk > Lthr) {
                     acc += 1;
@@ -702,7 +705,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const bool mine = (masks[u] >> lane) & 1ull;
-                const double L = mine ? S.candL[rows[u]] : 0.0;
+                const double L = !mine ? 0.0 : S.part ? lnl_of_item(S.part, S.noise, (long)S.candpix[rows[u]], (long)rows[u], S.nspec) : S.candL[rows[u]];
                 Ls[u] = isfinite(L) ? L : S.log_zero;
             }
 #pragma unroll
@@ -1032,9 +1035,14 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                     }
                 }
                 const int n_rows = (int)(unsigned)(pub[0] & 0xffffffffull);
+                dh[h].part = nullptr;
                 if (n_rows > 0) {
+                    r->part_only = true;                                   // (the update wave sums the parts of a row)
                     int rc = run_batch(r, dh[h].candpix, dh[h].candT, dh[h].candL, nullptr, n_rows, true, h, nullptr);
+                    r->part_only = false;
                     if (rc) return rc;
+                    dh[h].part = r->d_part[h];                             // (after the batch: its buffers may have grown)
+                    dh[h].noise = r->ss->dev.noise; dh[h].nspec = r->ss->dev.n_spec;
                 }
                 hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_pix_h[h]), dim3(64), s->lds, st, dh[h], n_pix_h[h], Kr, 0,
                                    s->rounds);
