@@ -164,7 +164,7 @@ def bench_c5(args):
     from nestfit_amd.synth import freq_axis
     na.set_exp_mode(args.exp_mode)
     for key, val in (('setup_ti', args.setup_ti), ('setup_threads', args.setup_threads), ('wpb', args.wpb), ('streams', args.streams),
-                     ('sampler_parts', args.sampler_parts), ('sampler_refit_every', args.sampler_refit_every), ('sampler_walk_factor', args.sampler_walk_factor), ('sampler_ellipsoids', args.sampler_ellipsoids), ('sampler_walkers', args.sampler_walkers)):
+                     ('sampler_parts', args.sampler_parts), ('sampler_refit_every', args.sampler_refit_every), ('sampler_walk_factor', args.sampler_walk_factor), ('sampler_ellipsoids', args.sampler_ellipsoids), ('sampler_walkers', args.sampler_walkers), ('lnl_cap', max(args.lnl_cap, 0))):
         if val:
             _ffi.set_option(key, val)
     if args.prior_stage >= 0:
