@@ -74,6 +74,7 @@ struct SpecDev {
     double  rest[MAXSPEC];               // line rest frequency (tables, or Spectrum.rest_freq)
     int     size[MAXSPEC], trans[MAXSPEC], off[MAXSPEC];
     double  nu_min[MAXSPEC], nu_chan[MAXSPEC];
+    double  r_chan[MAXSPEC];             // correctly rounded 1 / nu_chan (0: take the division, nf_line)
     int64_t chan_tot;
     const double *xarr, *t0, *tbg, *data, *noise;
     const double *t0tbg;                 // T0 * tbg per channel (fast mode: g = B0x x^2 + A0x x - T0 tbg)
@@ -343,7 +344,7 @@ __device__ __forceinline__ double nf_partition_level(int j, double trot, const d
 // no contraction: the floor() arguments must round like the reference's.
 struct LineConst { double nucen, idenom; int lo, hi; };
 __device__ __forceinline__ LineConst nf_line(int t, int i, double v_over_c, double s_over_c, double nu0,
-                                             double nu_min, double nu_chan, int N) {
+                                             double nu_min, double nu_chan, int N, double r_chan = 0.0) {
     LineConst r;
     // hf_freq = (1 - voff_i / CKMS) nu0 (hyperfine.pyx:71) is a constant of the line: the host forms it
     // with the same two IEEE operations at start-up (c_hfreq); the Gaussian model's line has voff = 0
@@ -356,8 +357,21 @@ __device__ __forceinline__ LineConst nf_line(int t, int i, double v_over_c, doub
     const double nu_cutoff = sqrt(12.5 / hf_idenom);
     const double nu_lo = (hf_nucen - nu_min - nu_cutoff);
     const double nu_hi = (hf_nucen - nu_min + nu_cutoff);
-    long lo = (long)floor(nu_lo / nu_chan);
-    long hi = (long)floor(nu_hi / nu_chan);
+    // the two quotients by the channel width (hyperfine.pyx:78-79), correctly rounded without a division each: with
+    // r = RN(1 / nu_chan), q = a r, e = a - nu_chan q (exact, fused), x = q + e r is RN(a / nu_chan) -- Markstein's
+    // final step, as in the Tb pass (the same bits as the division; the host passes r = 0 for a width whose mantissa
+    // is all ones, the one case the theorem leaves out; a centre that is not finite ends as an empty window either way)
+    double q_lo, q_hi;
+    if (r_chan != 0.0) {
+        const double ql = nu_lo * r_chan, qh = nu_hi * r_chan;
+        q_lo = __builtin_fma(__builtin_fma(-nu_chan, ql, nu_lo), r_chan, ql);
+        q_hi = __builtin_fma(__builtin_fma(-nu_chan, qh, nu_hi), r_chan, qh);
+    } else {
+        q_lo = nu_lo / nu_chan;
+        q_hi = nu_hi / nu_chan;
+    }
+    long lo = (long)floor(q_lo);
+    long hi = (long)floor(q_hi);
     if (hi < 0 || lo > N - 1) { lo = 0; hi = 0; }             // `continue`: empty window
     else {
         lo = lo < 0 ? 0 : lo;
@@ -693,7 +707,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
         int r_lo = 0, r_len = 0, slot = p;
         if (i < nhf) {
             const LineConst lc = nf_line(t, i, D[b * drec + c * 4 + 2], D[b * drec + c * 4 + 1], nu0, S.nu_min[s],
-                                         S.nu_chan[s], N);
+                                         S.nu_chan[s], N, S.r_chan[s]);
             int lo = lc.lo;
             const int hi = lc.hi;
             // Only the first channel of a window can lie beyond the point where FastExp

@@ -377,6 +377,11 @@ static int specset_fill(nfa_specset *ss, int model, int n_spec, const int64_t *s
         d.row_off[s] = (int)rows;
         d.nu_min[s] = xarr[s][0];
         d.nu_chan[s] = nu_chan;
+        {   // the reciprocal nf_line divides with (0: a width that is not an ordinary number, or whose mantissa is all ones)
+            uint64_t bits; memcpy(&bits, &nu_chan, sizeof bits);
+            const bool ordinary = std::isnormal(nu_chan) && nu_chan > 1e-100 && nu_chan < 1e100;
+            d.r_chan[s] = ordinary && (bits & 0xfffffffffffffull) != 0xfffffffffffffull ? 1.0 / nu_chan : 0.0;
+        }
         tot += sizes[s];
         rows += (sizes[s] + 63) / 64;
     }
