@@ -370,14 +370,17 @@ __device__ __forceinline__ LineConst nf_line(int t, int i, double v_over_c, doub
         q_lo = nu_lo / nu_chan;
         q_hi = nu_hi / nu_chan;
     }
-    long lo = (long)floor(q_lo);
-    long hi = (long)floor(q_hi);
-    if (hi < 0 || lo > N - 1) { lo = 0; hi = 0; }             // `continue`: empty window
-    else {
-        lo = lo < 0 ? 0 : lo;
-        hi = hi > N - 1 ? N - 1 : hi;
+    // (long) floor(.) of both, `continue` on an empty window, clipping to the spectrum (hyperfine.pyx:78-86) -- in
+    // doubles, then ONE conversion each: the integers are below 2^31 once they are clipped, and a double converts to a
+    // 64-bit integer through six instructions here.  (A quotient that is not finite belongs to a centre or width that is
+    // not: the caller empties that window.)
+    const double flo = floor(q_lo), fhi = floor(q_hi), last = (double)(N - 1);
+    int lo = 0, hi = 0;
+    if (!(fhi < 0.0 || flo > last)) {
+        lo = (int)fmax(flo, 0.0);
+        hi = (int)fmin(fhi, last);
     }
-    r.nucen = hf_nucen; r.idenom = hf_idenom; r.lo = (int)lo; r.hi = (int)hi;
+    r.nucen = hf_nucen; r.idenom = hf_idenom; r.lo = lo; r.hi = hi;
     return r;
 }
 
