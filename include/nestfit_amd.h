@@ -85,6 +85,16 @@ int nfa_get_exp_mode(void);
  *                   point, the result written to a mapped host buffer) or through the batch kernels;
  *   "graph"         1 / 0: with "point" 0, replay single-point calls as one captured hipGraph or not (default:
  *                   on, off when the rocprofiler tool library is attached: capture crashed under it);
+ *   "sampler_parts"       1..4 (default 3): groups of pixels the device sampler pipelines over the stream lanes;
+ *   "sampler_ellipsoids"  1: one bounding ellipsoid per pixel whatever the dimension; 0 (default): up to four where at
+ *                   most six dimensions are sampled (per sampler: nfa_sampler_set_ellipsoids);
+ *   "sampler_walk_factor" a pixel turns from rejection rounds to constrained walks when a round accepts fewer than
+ *                   1 in factor * n_steps candidates (and back above 8 times that); 0 (default): 64 up to six sampled
+ *                   dimensions, 2 above (the numpy twin takes `walk_factor=`: the two must agree to run alike);
+ *   "sampler_walkers"     walkers per pixel of a walk cycle, 64 / 128 / 192 / 256; 0 (default): by the live points
+ *                   (128 from 384, 256 from 768);
+ *   "sampler_refit_every" rejection-mode pixels refit their bound in rounds that are multiples of this (default 4);
+ *                   the sampler_* keys are read when a sampler is created / begun, A/B knobs like the rest;
  *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid; the
  *                   shipped library rejects the key): bit mask, 1 skip the Tb pass, 2 skip the
  *                   hyperfine-line loop, 4 skip the rows, 8 skip the line set-up.
