@@ -56,6 +56,7 @@ __host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t
 #define NS_ME_MAXD 6
 #endif
 #define NS_ME_GAIN 0.7
+static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for up to six sampled dimensions");
 #define NS_B_ELL 253ull            // random-stream slots of a proposal: which ellipsoid, and the 1 / (number that hold it) test
 #define NS_B_KEEP 254ull
 #define NS_WALK_LOWD 6             // up to this many sampled dimensions ...
@@ -81,6 +82,7 @@ struct NsDev {
     long   *cand_base;                  // [P] candidates drawn so far (index into the pixel's random stream)
     double *lnZ;                        // [P] running evidence of the dead points
     int    *active, *since_fit;         // [P]
+    int    *refit_due;                  // [P] set by the update wave, cleared by the refit wave
     int    *use_cube;                   // [P] 1: the ellipsoid is larger than the unit cube, draw from the cube
     double  ln_vball;                   // ln volume of the unit D-ball
     double *deadT, *deadL, *deadlnw;    // [P][cap][DT], [P][cap], [P][cap]
@@ -423,27 +425,55 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
 __host__ __device__ inline int ns_me_slot(int D) { return D + 2 * D * D + 4; }
 // Mean, covariance, Cholesky factor, largest Mahalanobis distance and ln volume (safety factor included) of the live
 // points whose label is k (and, with side >= 0, whose side bit is `side`); su = the pixel's live points in LDS.
-__device__ void ns_me_fit(const NsDev &S, const double *su, const int *lab, int N, int D, int k, int side, double *f, int lane) {
+template <int DD>
+__device__ void ns_me_fit(const NsDev &S, const double *su, const int *lab, int N, int k, int side, double *f, int lane) {
+    constexpr int D = DD;                // (a compile-time dimension: every loop below unrolls)
     double *fc = f, *fL = f + D, *fC = f + D + D * D, *fs = f + D + 2 * D * D;
     auto member = [&](int i) { const int l = lab[i]; return (l & 7) == k && (side < 0 || ((l >> 3) & 1) == side); };
-    double cnt = 0.0;
-    for (int i = lane; i < N; i += 64) cnt += member(i) ? 1.0 : 0.0;
+    // One pass over the lane's points for the count and the sums of the coordinates, one for all entries of the
+    // covariance: a lane's partial sums are formed point by point in the order entry-by-entry loops would form them, but
+    // a pass is a handful of trips to LDS where those are one trip per (entry, point) -- the fit is a lone wave's chain
+    // of LDS latencies, not arithmetic.
+    constexpr int ME = DD * (DD + 1) / 2;
+    double cnt = 0.0, sm[DD];
+#pragma unroll
+    for (int j = 0; j < DD; ++j) sm[j] = 0.0;
+    for (int i = lane; i < N; i += 64) {
+        const bool in = member(i);
+        cnt += in ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < DD; ++j) sm[j] += in ? su[i * D + j] : 0.0;
+    }
     cnt = ns_wave_sum(cnt);
-    for (int j = 0; j < D; ++j) {
-        double acc = 0.0;
-        for (int i = lane; i < N; i += 64) acc += member(i) ? su[i * D + j] : 0.0;
-        acc = ns_wave_sum(acc);
+#pragma unroll
+    for (int j = 0; j < DD; ++j) {
+        const double acc = ns_wave_sum(sm[j]);
         if (lane == 0) fc[j] = acc / cnt;
     }
     wave_lds_sync();
+    double cv[ME], mean[DD];
+#pragma unroll
+    for (int e = 0; e < ME; ++e) cv[e] = 0.0;
+#pragma unroll
+    for (int j = 0; j < DD; ++j) mean[j] = fc[j];
+    for (int i = lane; i < N; i += 64) {
+        const bool in = member(i);
+        double dx[DD];
+#pragma unroll
+        for (int j = 0; j < DD; ++j) dx[j] = su[i * D + j] - mean[j];
+#pragma unroll
+        for (int a2 = 0; a2 < DD; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 <= a2; ++b2) cv[a2 * (a2 + 1) / 2 + b2] += in ? dx[a2] * dx[b2] : 0.0;
+    }
     double tr = 0.0;
-    for (int a = 0; a < D; ++a)
-        for (int b = 0; b <= a; ++b) {
-            double acc = 0.0;
-            for (int i = lane; i < N; i += 64) acc += member(i) ? (su[i * D + a] - fc[a]) * (su[i * D + b] - fc[b]) : 0.0;
-            acc = ns_wave_sum(acc) / (cnt - 1.0);
-            if (lane == 0) { fC[a * D + b] = acc; fL[a * D + b] = acc; }
-            if (a == b) tr += acc;
+#pragma unroll
+    for (int a2 = 0; a2 < DD; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 <= a2; ++b2) {
+            const double acc = ns_wave_sum(cv[a2 * (a2 + 1) / 2 + b2]) / (cnt - 1.0);
+            if (lane == 0) { fC[a2 * D + b2] = acc; fL[a2 * D + b2] = acc; }
+            if (a2 == b2) tr += acc;
         }
     wave_lds_sync();
     if (lane == 0) {                    // Cholesky, lower triangle in place (as ns_refit)
@@ -465,10 +495,12 @@ __device__ void ns_me_fit(const NsDev &S, const double *su, const int *lab, int 
     double r2 = 0.0;
     for (int i = lane; i < N; i += 64) {
         if (!member(i)) continue;
-        double y[NS_ME_MAXD];
+        double y[DD];
         double s2 = 0.0;
+#pragma unroll
         for (int a = 0; a < D; ++a) {
             double v = su[i * D + a] - fc[a];
+#pragma unroll
             for (int q = 0; q < a; ++q) v -= fL[a * D + q] * y[q];
             y[a] = v / fL[a * D + a];
             s2 += y[a] * y[a];
@@ -487,13 +519,15 @@ __device__ void ns_me_fit(const NsDev &S, const double *su, const int *lab, int 
 // together have less than NS_ME_GAIN of its volume, else the cluster is final; a cluster below 4 (D + 2) points is not
 // cut, a half below 2 (D + 2) not accepted.  Then MultiNest's rule on the sum of the volumes (X / efr at least).
 // su: N * D doubles, lab: N ints, wf: (NS_ME + 2) fit slots -- all LDS.
+template <int DD>
 __device__ void ns_refit_multi(const NsDev &S, int p, long n_iter, double *su, int *lab, double *wf, int lane) {
-    const int N = ns_n(S, p), D = S.D, FS = ns_me_slot(D), minp = 2 * (D + 2);
+    constexpr int D = DD;
+    const int N = ns_n(S, p), FS = ns_me_slot(D), minp = 2 * (D + 2);
     const double *U = S.Ulive + (long)p * S.N * D;
     for (int e = lane; e < N * D; e += 64) su[e] = U[e];
     for (int i = lane; i < N; i += 64) lab[i] = 0;
     wave_lds_sync();
-    ns_me_fit(S, su, lab, N, D, 0, -1, wf, lane);
+    ns_me_fit<DD>(S, su, lab, N, 0, -1, wf, lane);
     int ncl = 1;
     while (ncl < S.max_ell) {
         int best = -1;
@@ -504,18 +538,26 @@ __device__ void ns_refit_multi(const NsDev &S, int p, long n_iter, double *su, i
         if (best < 0) break;
         double *fb = wf + best * FS;
         // principal axis of the cluster's covariance: twenty steps of the power iteration from (1, ..., 1)
-        double v[NS_ME_MAXD];
-        for (int a = 0; a < D; ++a) v[a] = 1.0;
+        double v[DD], cm[DD][DD];       // (the covariance out of LDS once: 400 dependent reads otherwise)
+#pragma unroll
+        for (int a = 0; a < DD; ++a)
+#pragma unroll
+            for (int b = 0; b < DD; ++b) cm[a][b] = fb[D + D * D + (a >= b ? a * D + b : b * D + a)];
+#pragma unroll
+        for (int a = 0; a < DD; ++a) v[a] = 1.0;
         for (int it = 0; it < 20; ++it) {
-            double w[NS_ME_MAXD], n2 = 0.0;
-            for (int a = 0; a < D; ++a) {
+            double w[DD], n2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < DD; ++a) {
                 double acc = 0.0;
-                for (int b = 0; b < D; ++b) acc += fb[D + D * D + (a >= b ? a * D + b : b * D + a)] * v[b];
+#pragma unroll
+                for (int b = 0; b < DD; ++b) acc += cm[a][b] * v[b];
                 w[a] = acc;
                 n2 += acc * acc;
             }
             const double inv = 1.0 / sqrt(n2);
-            for (int a = 0; a < D; ++a) v[a] = w[a] * inv;
+#pragma unroll
+            for (int a = 0; a < DD; ++a) v[a] = w[a] * inv;
         }
         for (int i = lane; i < N; i += 64) {
             if ((lab[i] & 7) != best) continue;
@@ -525,8 +567,8 @@ __device__ void ns_refit_multi(const NsDev &S, int p, long n_iter, double *su, i
         }
         wave_lds_sync();
         double *fA = wf + NS_ME * FS, *fB = wf + (NS_ME + 1) * FS;
-        ns_me_fit(S, su, lab, N, D, best, 0, fA, lane);
-        ns_me_fit(S, su, lab, N, D, best, 1, fB, lane);
+        ns_me_fit<DD>(S, su, lab, N, best, 0, fA, lane);
+        ns_me_fit<DD>(S, su, lab, N, best, 1, fB, lane);
         const double nA = fA[D + 2 * D * D + 2], nB = fB[D + 2 * D * D + 2];
         const double lvA = fA[D + 2 * D * D + 1], lvB = fB[D + 2 * D * D + 1], lvP = fb[D + 2 * D * D + 1];
         const bool keep = nA >= minp && nB >= minp && ns_logaddexp(lvA, lvB) < lvP + log(NS_ME_GAIN);
@@ -564,27 +606,16 @@ __device__ void ns_refit_multi(const NsDev &S, int p, long n_iter, double *su, i
 }
 
 // ---- one wave per pixel: accept / replace / evidence / stop / refit ------------------------
-// q indexes actlist (force_refit: q indexes pixels directly, no candidates: initial ellipsoids)
-__global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int Kr, int force_refit, long round) {
+// q indexes actlist
+__global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int Kr, long round) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= n_act) return;
-    const int p = force_refit ? q : S.actlist[q];
+    const int p = S.actlist[q];
     const int N = ns_n(S, p), NS = S.N, D = S.D, K = Kr;      // live points of this pixel; stride of the live arrays
     const long cap = ns_cap(S, p);
     const double ln_shrink = S.nlive ? log1p(-exp(-1.0 / N)) : S.ln_shrink;
     double *sL = smem;                              // live log-likelihoods of the pixel
-    double *sA = sL + ((NS + 1) & ~1);              // D*D
-    double *sc = sA + D * D;                        // D
-    double *sd = S.stage_live ? sc + ((D + 1) & ~1) : nullptr;   // N*D centred live points (refit)
-    // several ellipsoids: the fit slots and the points' labels follow the staged live points
-    double *wf = sd ? sd + (long)NS * D : nullptr;
-    int *lab = (int *)(wf + (NS_ME + 2) * ns_me_slot(D));
-    auto refit = [&](long n_iter_now) {
-        if (S.multi) ns_refit_multi(S, p, n_iter_now, sd, lab, wf, lane);
-        else ns_refit(S, p, n_iter_now, sA, sc, sd, lane);
-    };
-    if (force_refit) { refit(0); return; }
     if (!S.active[p]) return;
     double *Ll = S.Llive + (long)p * NS;
     for (int i = lane; i < N; i += 64) sL[i] = Ll[i];
@@ -740,12 +771,40 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
     // A refit costs ~100 us and pixels are in lock-step: rejection-mode pixels refit only in every
     // fourth round, so that three launches out of four do not wait for anybody's refit (walking
     // pixels refit at their common cycle end).
-    if (!done && since >= ns_upd(S, p) && (was_walking || (round + 1) % S.refit_every == 0)) {
-        __threadfence();                            // the wave's own stores to Ulive, then its loads
-        refit(it);
-        since = 0;
+    // (the fit itself is ns_refit_kernel's, launched behind this one in the rounds where a pixel can be due: it needs
+    // four times the registers of everything above, and a round's update should not carry them)
+    const bool due = !done && since >= ns_upd(S, p) && (was_walking || (round + 1) % S.refit_every == 0);
+    if (lane == 0) { S.since_fit[p] = since; S.refit_due[p] = due ? 1 : 0; }
+}
+
+// The bounds of the pixels that are due (ns_update_kernel marks them; `direct`: all pixels, before the first round).
+// One wave per pixel.  LDS: [D*D][D][live points: N*D][fit slots][labels].
+__global__ void __launch_bounds__(64) ns_refit_kernel(NsDev S, int n_act, int direct) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= n_act) return;
+    const int p = direct ? q : S.actlist[q];
+    if (!direct && (!S.active[p] || !S.refit_due[p])) return;
+    const int NS = S.N, D = S.D;
+    double *sA = smem;                              // D*D
+    double *sc = sA + D * D;                        // D
+    double *sd = S.stage_live ? sc + ((D + 1) & ~1) : nullptr;   // N*D live points
+    double *wf = sd ? sd + (long)NS * D : nullptr;  // several ellipsoids: the fit slots, then the points' labels
+    int *lab = (int *)(wf + (NS_ME + 2) * ns_me_slot(D));
+    const long it = direct ? 0 : S.n_iter[p];
+    if (S.multi) {
+        switch (D) {                                // (D <= NS_ME_MAXD here)
+        case 1: ns_refit_multi<1>(S, p, it, sd, lab, wf, lane); break;
+        case 2: ns_refit_multi<2>(S, p, it, sd, lab, wf, lane); break;
+        case 3: ns_refit_multi<3>(S, p, it, sd, lab, wf, lane); break;
+        case 4: ns_refit_multi<4>(S, p, it, sd, lab, wf, lane); break;
+        case 5: ns_refit_multi<5>(S, p, it, sd, lab, wf, lane); break;
+        default: ns_refit_multi<6>(S, p, it, sd, lab, wf, lane); break;
+        }
+    } else {
+        ns_refit(S, p, it, sA, sc, sd, lane);
     }
-    if (lane == 0) S.since_fit[p] = since;
+    if (lane == 0) { S.since_fit[p] = 0; S.refit_due[p] = 0; }
 }
 
 // ---- results ---------------------------------------------------------------------------------
@@ -782,7 +841,7 @@ struct nfa_sampler {
     std::vector<int> h_active, h_act;
     long rounds = 0;
     int  n_act = 0, check_every = 8;
-    size_t lds = 0;
+    size_t lds = 0, lds_refit = 0;
     bool ran = false;
     // host memory the device writes (mapped): per part, [rows of the round][sequence number of the round], 16 bytes each
     unsigned long long *h_pub = nullptr, *d_pub = nullptr;
@@ -795,7 +854,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
     if (!s) return NFA_OK;
     NsDev &d = s->d;
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
-                    d.since_fit, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
+                    d.since_fit, d.refit_due, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol, d.elnv, d.nell,
                     s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap, s->d_nlive, s->d_updp, s->d_capp};
     for (void *p : ptrs) (void)hipFree(p);
@@ -843,7 +902,7 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.centre, double, P * NS_ME * D); NS_ALLOC(d.axes, double, P * NS_ME * D * D);
     NS_ALLOC(d.elnv, double, P * NS_ME); NS_ALLOC(d.nell, int, P);
     NS_ALLOC(d.n_iter, long, P); NS_ALLOC(d.n_evals, long, P); NS_ALLOC(d.cand_base, long, P); NS_ALLOC(d.lnZ, double, P);
-    NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P); NS_ALLOC(d.use_cube, int, P);
+    NS_ALLOC(d.active, int, P); NS_ALLOC(d.since_fit, int, P); NS_ALLOC(d.use_cube, int, P); NS_ALLOC(d.refit_due, int, P);
     NS_ALLOC(d.deadT, double, P * C * DT); NS_ALLOC(d.deadL, double, P * C); NS_ALLOC(d.deadlnw, double, P * C);
     NS_ALLOC(d.candU, double, P * K * D); NS_ALLOC(d.candT, double, P * K * DT); NS_ALLOC(d.candL, double, P * K);
     NS_ALLOC(d.candpix, int, P * K); NS_ALLOC(d.valid, int, P * K); NS_ALLOC(d.slot, int, P * K); NS_ALLOC(d.count, int, NS_PARTS);
@@ -925,6 +984,7 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemsetAsync(d.n_iter, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.cand_base, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.since_fit, 0, sizeof(int) * P, st));
+    HIP_TRY(hipMemsetAsync(d.refit_due, 0, sizeof(int) * P, st));
     HIP_TRY(hipMemsetAsync(d.walk, 0, sizeof(int) * P, st));
     HIP_TRY(hipMemsetAsync(d.wstep, 0, sizeof(int) * P, st));
     HIP_TRY(hipMemsetAsync(d.wacc_sum, 0, sizeof(long) * P, st));
@@ -946,7 +1006,8 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemcpyAsync(d.n_evals, h_evals.data(), sizeof(long) * P, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d.lnZ, h_lnz.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d.active, s->h_active.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
-    s->lds = sizeof(double) * ((size_t)((N + 1) & ~1) + (size_t)D * D + (size_t)((D + 1) & ~1));
+    s->lds = sizeof(double) * (size_t)((N + 1) & ~1);                       // the update wave: the live log-likelihoods
+    s->lds_refit = sizeof(double) * ((size_t)D * D + (size_t)((D + 1) & ~1));  // the refit wave: ...
     d.stage_live = (size_t)N * D * sizeof(double) <= 96 * 1024 ? 1 : 0;
     d.refit_every = g_eng.sampler_refit_every;
     // When does a pixel give up rejection sampling for constrained walks?  Measured on config 5 (profiles/r03/
@@ -955,13 +1016,15 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     // round is one large batch, a walk cycle n_steps small ones, and the run goes from 1.16 s (factor 2) to 0.84 s (64;
     // rejection only: 0.79 s).  The walks stay as the way out of a bound that has become hopeless.
     d.walk_factor = g_eng.sampler_walk_factor > 0 ? g_eng.sampler_walk_factor : (D <= NS_WALK_LOWD ? NS_WALK_FACTOR_LOWD : NS_WALK_FACTOR);
-    if (d.stage_live) s->lds += sizeof(double) * (size_t)N * D;
+    if (d.stage_live) s->lds_refit += sizeof(double) * (size_t)N * D;       // ... the live points ...
     d.max_ell = s->max_ell > 0 ? s->max_ell : (g_eng.sampler_ellipsoids == 1 ? 1 : NS_ME);
     d.multi = (d.stage_live && D <= NS_ME_MAXD && d.max_ell > 1) ? 1 : 0;
-    if (d.multi) s->lds += sizeof(double) * (size_t)((NS_ME + 2) * ns_me_slot(D)) + sizeof(int) * (size_t)((N + 3) & ~3);
+    if (d.multi) s->lds_refit += sizeof(double) * (size_t)((NS_ME + 2) * ns_me_slot(D)) + sizeof(int) * (size_t)((N + 3) & ~3);   // ... fit slots, labels
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));
-    hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)P), dim3(64), s->lds, st, d, P, 0, 1, 0L);   // first ellipsoids
+    if (s->lds_refit > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)ns_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_refit));
+    hipLaunchKernelGGL(ns_refit_kernel, dim3((unsigned)P), dim3(64), s->lds_refit, st, d, P, 1);   // first ellipsoids
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     s->rounds = 0;
@@ -1044,8 +1107,12 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                     dh[h].part = r->d_part[h];                             // (after the batch: its buffers may have grown)
                     dh[h].noise = r->ss->dev.noise; dh[h].nspec = r->ss->dev.n_spec;
                 }
-                hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_pix_h[h]), dim3(64), s->lds, st, dh[h], n_pix_h[h], Kr, 0,
-                                   s->rounds);
+                hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_pix_h[h]), dim3(64), s->lds, st, dh[h], n_pix_h[h], Kr, s->rounds);
+                // the refit wave of the pixels the update marked, in the rounds where a pixel can be due: rejection-mode
+                // pixels every refit_every-th round, walking ones at a cycle's end -- and in a cycle's first round, where a
+                // pixel that has just turned to walks brings along what it collected before
+                if ((s->rounds + 1) % d.refit_every == 0 || (d.method != 0 && ((s->rounds + 1) % d.n_steps == 0 || s->rounds % d.n_steps == 0)))
+                    hipLaunchKernelGGL(ns_refit_kernel, dim3((unsigned)n_pix_h[h]), dim3(64), s->lds_refit, st, dh[h], n_pix_h[h], 0);
                 HIP_TRY(hipGetLastError());
             }
             s->rounds += 1;
