@@ -41,14 +41,15 @@
 // table layout inside g_tabs (doubles); the LDS copy starts at SM_EXP2
 #define SM_T0X    0
 #define SM_T0Y    1000
-#define SM_EXP2   2000        // 2^(i/32), i = 0..31          (poly)
+#define NFA_EXP2_N 256        // entries of the polynomial mode's table
+#define SM_EXP2   2000        // 2^(i/256), i = 0..255        (poly)
 // (table; C first, A last: a lane outside the tables' range -- it is given its value by the branch for such
 // arguments -- still forms an address from its exponent bits, up to row 15 of a 10-row table: behind C lies B,
 // behind B lies A, behind A at least SM_TABLE_TAIL doubles of whatever the kernel keeps there)
-#define SM_FEC    2032              // exp(-j 2^(l-28)) [10][256]
+#define SM_FEC    (SM_EXP2 + NFA_EXP2_N)   // exp(-j 2^(l-28)) [10][256]
 #define SM_FEB    (SM_FEC + 2560)   // exp(-j 2^(l-20)) [10][256]
 #define SM_FEA    (SM_FEB + 2560)   // exp(-(128+j) 2^(l-12)) [10][128]
-#define SM_END_POLY   2032
+#define SM_END_POLY   (SM_EXP2 + NFA_EXP2_N)
 #define SM_END_TABLE  (SM_FEA + 1280)   // 8432 doubles
 #define SM_TABLE_TAIL 768               // doubles that must follow the staged tables in LDS (row 15 of A ends there)
 
@@ -202,20 +203,19 @@ __device__ __attribute__((noinline)) double slow_log(double x) { return log(x); 
 //  FastExp replacement (reference: nestfit/core/fastexp.c:234-283, entered with
 //  a double narrowed to float, nestfit/core/math.pxd:17)
 // ---------------------------------------------------------------------------
-// exp(-t) for t = (double)float in [2^-5, 32): n = rint(-t*32/ln2),
-// exp(-t) = 2^(n>>5) * 2^((n&31)/32) * exp(r), |r| <= ln2/64.
+// exp(-t) for t = (double)float in [2^-5, 32): n = rint(-t*256/ln2),
+// exp(-t) = 2^(n>>8) * 2^((n&255)/256) * exp(r), |r| <= ln2/512: a degree-4 polynomial is exact to 4e-17 there
+// (round 2 had 32 table entries and degree 6: two more fused multiply-adds in the dependent chain of every exponential).
 __device__ __forceinline__ double exp_neg_poly(double t, const double *sm) {
-    const double C32 = 46.16624130844682903551758979206054;   // 32/ln2
-    const double L_HI = 6.93147180369123816490e-01 / 32.0;    // fdlibm ln2 split
-    const double L_LO = 1.90821492927058770002e-10 / 32.0;
-    const double n = __builtin_rint(-t * C32);
+    const double C256 = 369.3299304675746322841407183364843;  // 256/ln2
+    const double L_HI = 6.93147180369123816490e-01 / 256.0;   // fdlibm ln2 split
+    const double L_LO = 1.90821492927058770002e-10 / 256.0;
+    const double n = __builtin_rint(-t * C256);
     double r = __builtin_fma(-n, L_HI, -t);
     r = __builtin_fma(-n, L_LO, r);
     const int ni = (int)n;
-    const int m = ni & 31, q = ni >> 5;
-    double p = 1.0 / 720.0;
-    p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);
+    const int m = ni & (NFA_EXP2_N - 1), q = ni >> 8;
+    double p = 1.0 / 24.0;
     p = __builtin_fma(p, r, 1.0 / 6.0);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
@@ -388,7 +388,7 @@ __device__ __forceinline__ LineConst nf_line(int t, int i, double v_over_c, doub
 // index with the absolute g_tabs offsets, hence the shifted base pointer.
 template <int MODE>
 __device__ __forceinline__ const double *stage_exp_tables(double *smem, const double *g_tabs, int *n_shared) {
-    const int n = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : 32;
+    const int n = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : NFA_EXP2_N;
     for (int i = threadIdx.x; i < n; i += blockDim.x) smem[i] = g_tabs[SM_EXP2 + i];
     __syncthreads();
     *n_shared = n;
@@ -630,8 +630,8 @@ __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj
 
 // The same for the polynomial mode: two line x row steps as one instruction block, the two chains of range reduction,
 // table read and six dependent fused multiply-adds interleaved by the hardware's own scoreboard instead of running one
-// after the other.  Operation for operation exp_neg_poly under nf_fastexp<1, true, true>: n = rint(-t 32/ln2),
-// r = -t - n ln2/32 in two fused steps, 2^((n & 31)/32) from the table, the degree-6 polynomial, the power of two by
+// after the other.  Operation for operation exp_neg_poly under nf_fastexp<1, true, true>: n = rint(-t 256/ln2),
+// r = -t - n ln2/256 in two fused steps, 2^((n & 255)/256) from the table, the degree-4 polynomial, the power of two by
 // ldexp (the result stays normal: the same bits as adding to the exponent field), the Taylor form below 2^-5.
 // EXEC is all ones on entry and on exit; nothing in here writes SCC.
 __device__ __forceinline__ void line_pair_poly(double &tau, float jf, double xj,
@@ -648,18 +648,16 @@ __device__ __forceinline__ void line_pair_poly(double &tau, float jf, double xj,
         "v_mul_f64 %[" #T "], %[" #T "], %[" #ID "]\n\t"                                                    \
         "v_cvt_f32_f64 %[" #X "], %[" #T "]\n\t"                   /* math.pxd:17 narrowing */              \
         "v_cvt_f64_f32 %[" #T "], %[" #X "]\n\t"                                                            \
-        "v_mul_f64 %[" #N "], %[" #T "], %[nc32]\n\t"               /* -t 32 / ln 2 */                       \
+        "v_mul_f64 %[" #N "], %[" #T "], %[nc32]\n\t"               /* -t 256 / ln 2 */                      \
         "v_rndne_f64 %[" #N "], %[" #N "]\n\t"                                                              \
         "v_fma_f64 %[" #R "], -%[" #N "], %[lhi], -%[" #T "]\n\t"   /* r = -t - n ln2/32 (hi, lo) */         \
         "v_fma_f64 %[" #R "], -%[" #N "], %[llo], %[" #R "]\n\t"                                            \
         "v_cvt_i32_f64 %[" #NI "], %[" #N "]\n\t"                                                           \
-        "v_and_b32 %[t0], 31, %[" #NI "]\n\t"                                                               \
+        "v_and_b32 %[t0], 0xff, %[" #NI "]\n\t"                                                             \
         "v_lshl_add_u32 %[t0], %[t0], 3, %[bt]\n\t"                                                         \
         "ds_read_b64 %[" #T "], %[t0]\n\t"                       /* (t is used up: its registers take the table value) */ \
-        "v_ashrrev_i32 %[" #NI "], 5, %[" #NI "]\n\t"                                                       \
-        "v_mov_b64 %[" #N "], %[c6]\n\t"                            /* the polynomial, Horner */            \
-        "v_fma_f64 %[" #N "], %[" #N "], %[" #R "], %[c5]\n\t"                                              \
-        "v_fma_f64 %[" #N "], %[" #N "], %[" #R "], %[c4]\n\t"                                              \
+        "v_ashrrev_i32 %[" #NI "], 8, %[" #NI "]\n\t"                                                       \
+        "v_mov_b64 %[" #N "], %[c4]\n\t"                            /* the polynomial, Horner */            \
         "v_fma_f64 %[" #N "], %[" #N "], %[" #R "], %[c3]\n\t"                                              \
         "v_fma_f64 %[" #N "], %[" #N "], %[" #R "], 0.5\n\t"                                                \
         "v_fma_f64 %[" #N "], %[" #N "], %[" #R "], 1.0\n\t"                                                \
@@ -709,9 +707,8 @@ __device__ __forceinline__ void line_pair_poly(double &tau, float jf, double xj,
         : [jf] "v"(jf), [xj] "v"(xj), [nucA] "v"(nucA), [idA] "v"(idA), [wA] "v"(wA), [midA] "v"(midA), [halfA] "v"(halfA),
           [nucB] "v"(nucB), [idB] "v"(idB), [wB] "v"(wB), [midB] "v"(midB), [halfB] "v"(halfB),
           [bt] "s"(base_t), [nthird] "s"(-(1.0 / 3.0)),
-          [nc32] "s"(-46.16624130844682903551758979206054), [lhi] "s"(6.93147180369123816490e-01 / 32.0),
-          [llo] "s"(1.90821492927058770002e-10 / 32.0), [c6] "s"(1.0 / 720.0), [c5] "s"(1.0 / 120.0), [c4] "s"(1.0 / 24.0),
-          [c3] "s"(1.0 / 6.0)
+          [nc32] "s"(-369.3299304675746322841407183364843), [lhi] "s"(6.93147180369123816490e-01 / 256.0),
+          [llo] "s"(1.90821492927058770002e-10 / 256.0), [c4] "s"(1.0 / 24.0), [c3] "s"(1.0 / 6.0)
         : "vcc");
 #undef NFA_POLY_HEAD
 #undef NFA_POLY_TAYLOR

@@ -151,8 +151,8 @@ static int engine_init_once() {
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_tauw), h_tauw, sizeof(h_tauw)));
     }
     std::vector<double> tabs(SM_END_TABLE, 0.0);
-    // 2^(i/32)
-    for (int i = 0; i < 32; ++i) tabs[SM_EXP2 + i] = (double)exp2l((long double)i / 32.0L);
+    // 2^(i/256)
+    for (int i = 0; i < NFA_EXP2_N; ++i) tabs[SM_EXP2 + i] = (double)exp2l((long double)i / (long double)NFA_EXP2_N);
     // FastExp product tables: host libm exp() of exactly representable
     // arguments, as the reference fills them (fastexp.c:203-226)
     for (int l = 0; l < 10; ++l) {
@@ -738,7 +738,7 @@ static bool setup_uses_tables(const nfa_runner *r, int mode) { return mode == 0 
 static size_t setup_lds_bytes(const nfa_runner *r, int mode, bool has_prior) {
     const size_t work = (size_t)64 * r->ndim + (size_t)SETUP_TI * r->ncomp * QREC + sizeof(PriorProg) / sizeof(double) + 1
                         + (has_prior ? (size_t)r->pr->prog.stage_doubles : 0);
-    return sizeof(double) * ((setup_uses_tables(r, mode) ? (SM_END_TABLE - SM_EXP2) : 32) + work);
+    return sizeof(double) * ((setup_uses_tables(r, mode) ? (SM_END_TABLE - SM_EXP2) : NFA_EXP2_N) + work);
 }
 
 static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot, int mode) {
@@ -807,7 +807,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     const int split = resolve_split(r, S, B);
     G.split = split;
     G.wave_doubles = lnl_wave_doubles(r);
-    const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? 32 : 0);
+    const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? NFA_EXP2_N : 0);
     // waves per workgroup.  Table mode stages 51 KB of product tables per workgroup, so the
     // workgroup is made as fat as keeps the most waves resident per CU (ties: more workgroups,
     // so that one stages while another computes).
@@ -1092,9 +1092,9 @@ static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, doubl
     if (G.split > POINT_WAVES) return 0;
     G.wave_doubles = lnl_wave_doubles(r);
     const int upw = POINT_WAVES / G.split;                       // units per pass of the workgroup
-    const int n_shared = mode == 0 ? (SM_END_TABLE - SM_EXP2) : (mode == 1 ? 32 : 0);
+    const int n_shared = mode == 0 ? (SM_END_TABLE - SM_EXP2) : (mode == 1 ? NFA_EXP2_N : 0);
     // the set-up stage and the likelihood waves use the same LDS one after the other, behind the staged tables
-    const size_t n_staged = mode == 0 ? (SM_END_TABLE - SM_EXP2) : 32;
+    const size_t n_staged = mode == 0 ? (SM_END_TABLE - SM_EXP2) : NFA_EXP2_N;
     const size_t lds = std::max(setup_lds_bytes(r, 1, true) + sizeof(double) * (n_staged - 32),
                                 sizeof(double) * ((size_t)n_shared + ((size_t)G.wave_doubles + (G.split > 1 ? LNL_PARTS * 64 : 0)) * upw));
     if (lds > 160 * 1024) return 0;

@@ -84,10 +84,10 @@ int nfa_test_fastexp(const double *x, double *out, int64_t n, int mode) {
         hipLaunchKernelGGL(test_fastexp_kernel<0>, dim3(blocks), dim3(256), lds, 0, dx, dout, (long)n,
                            (const double *)g_eng.d_tabs);
     } else if (mode == 1) {
-        hipLaunchKernelGGL(test_fastexp_kernel<1>, dim3(blocks), dim3(256), sizeof(double) * 32, 0,
+        hipLaunchKernelGGL(test_fastexp_kernel<1>, dim3(blocks), dim3(256), sizeof(double) * NFA_EXP2_N, 0,
                            dx, dout, (long)n, (const double *)g_eng.d_tabs);
     } else if (mode == 2) {
-        hipLaunchKernelGGL(test_fastexp_kernel<2>, dim3(blocks), dim3(256), sizeof(double) * 32, 0,
+        hipLaunchKernelGGL(test_fastexp_kernel<2>, dim3(blocks), dim3(256), sizeof(double) * NFA_EXP2_N, 0,
                            dx, dout, (long)n, (const double *)g_eng.d_tabs);
     } else {   // 3: 1 - FastExp(x) as the fast mode's Tb pass evaluates it
         hipLaunchKernelGGL(test_one_minus_fastexp_kernel, dim3(blocks), dim3(256), 0, 0, dx, dout, (long)n);
@@ -131,7 +131,7 @@ int nfa_test_partition(const double *trot, double *qpara, double *qorth, int64_t
         hipLaunchKernelGGL(test_partition_kernel<0>, dim3(blocks), dim3(256), lds, 0, dt, dp, dq, (long)n,
                            (const double *)g_eng.d_tabs);
     } else {
-        hipLaunchKernelGGL(test_partition_kernel<1>, dim3(blocks), dim3(256), sizeof(double) * 32, 0,
+        hipLaunchKernelGGL(test_partition_kernel<1>, dim3(blocks), dim3(256), sizeof(double) * NFA_EXP2_N, 0,
                            dt, dp, dq, (long)n, (const double *)g_eng.d_tabs);
     }
     HIP_TRY(hipGetLastError());
