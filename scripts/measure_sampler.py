@@ -2,7 +2,7 @@
 """BASELINE config 5 with the built-in sampler: nested sampling (400 live points) of every pixel of
 a 32x32 synthetic NH3 (1,1)+(2,2) cube, all pixels in lock-step on one GPU; a few pixels are
 repeated with the CPU oracle as likelihood (same sampler, same seed) for the evidence comparison
-and the CPU rate.  usage: measure_sampler.py [side=32] [ncomp=1] [nlive=400] [n_cpu_pix=4] [host]"""
+and the CPU rate.  usage: measure_sampler.py [side=32] [ncomp=1] [nlive=400] [n_cpu_pix=4] [host|gpu] [time_limit|0] [batch_target]"""
 import sys
 import time
 from pathlib import Path
@@ -55,7 +55,8 @@ def main():
         res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=nlive, tol=0.5, efr=0.3, seed=1,
                                  progress=lambda n_active, it: print(f'  ... {n_active} pixels active, '
                                                                      f'{time.perf_counter() - t0:.0f} s', flush=True),
-                                 time_limit=float(sys.argv[6]) if len(sys.argv) > 6 else None)
+                                 time_limit=float(sys.argv[6]) if len(sys.argv) > 6 and float(sys.argv[6]) > 0 else None,
+                                 **({'batch_target': int(sys.argv[7])} if len(sys.argv) > 7 else {}))
     dt = time.perf_counter() - t0
     evals = sum(r.n_evals for r in res)
     iters = np.array([r.n_iter for r in res])
