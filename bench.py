@@ -45,19 +45,22 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-MODES = ('table', 'poly', 'fast')
-DTYPES = {'table': 'f64 (reference FastExp: float-narrowed argument, f64 table product)',
-          'poly': 'f64 (exp(-(double)(float)x) by an f64 polynomial)',
+MODES = ('table', 'fast')
+# what each mode computes in.  `table` is the reference's own arithmetic (core/fastexp.c:234-283: the argument narrowed to
+# float, an f64 product of three f64 table entries; models/hyperfine.pyx:93-96: tau summed in f64): the like-for-like number
+DTYPES = {'table': 'f64 (reference FastExp: float-narrowed argument, f64 three-table product, f64 optical depth)',
           'fast': 'f64 indices and FastExp arguments, f32 exp and optical depth (mode fast, <= 1e-6 on Tb)'}
+REFERENCE_PRECISION_MODE = 'table'
 WORKLOADS = {
     # name: (trans ids, channels, vhalf, ncomp, truth key, B)
     'C2': ((1, 2), 1024, 30.0, 2, 'TRUTH_2COMP', 4096),
     'C4': ((1, 2, 3), 2048, 40.0, 3, 'TRUTH_3COMP', 4096),
     'C1': ((1,), 256, 30.0, 1, 'TRUTH_1COMP', 4096),
 }
-PROFILE_DIRS = [ROOT / 'profiles' / 'r03', ROOT / 'profiles' / 'r02']
+PROFILE_DIRS = [ROOT / 'profiles' / 'r04', ROOT / 'profiles' / 'r03', ROOT / 'profiles' / 'r02']
 MIN_BLOCK_S = 0.025            # length a timed block is sized for from a lone K-step probe (>= 20 ms in effect)
 MAX_BLOCK_STEPS = 4096
+LNL_KERNEL_NAME = {'fast': 'void lnl_kernel<2, false, false, 2>', 'table': 'void lnl_kernel<0, false, false, 2>'}
 
 
 def profile_file(name):
@@ -244,13 +247,273 @@ def relaunch_one_rank_per_gpu(args):
     raise SystemExit(rc)
 
 
+class Measure:
+    """One workload on this rank's stripe: its device-resident inputs and the timed blocks over them."""
+
+    def __init__(self, args, na, lib, comm, rank, world, workload, side, batch=0):
+        from nestfit_amd import _ffi
+        self._ffi, self.lib, self.comm, self.args, self.rank, self.world = _ffi, lib, comm, args, rank, world
+        self.workload = workload
+        self.trans, self.n_chan, self.vhalf, self.ncomp, _, self.B = WORKLOADS[workload]
+        if batch:
+            self.B = batch
+        self.ndim = 6 * self.ncomp
+        self.per_row = args.pixels_per_step == 'B'
+        if self.per_row and side * side // world < self.B:
+            raise SystemExit('--pixels-per-step B needs a stripe of at least B pixels')
+        na.set_exp_mode('fast')                        # the synthetic data are made in one mode, whatever is timed
+        self.cube, self.ut, self.lon, self.lat, self.spec0 = make_stripe(na, workload, side, rank, world, 0.2)
+        self.n_pix = self.cube.n_pix
+        self.rh = self.cube._run.handle
+        # inputs of all steps of a block resident in HBM before the clock starts: unit-cube rows of its own for every
+        # step (a pass overwrites them with theta in place), the pixel index of every row, one result vector per step
+        self.U_host = np.ascontiguousarray(np.random.default_rng(7 + rank).uniform(size=(self.B, self.ndim)))
+        self.step_bytes = self.U_host.nbytes
+        self.buf = {'cap': 0, 'U': C.c_void_p(), 'lnL': C.c_void_p(), 'pix': C.c_void_p()}
+        self.bytes_eval = algorithmic_bytes(self.trans, self.n_chan, self.ncomp)
+        # What the engine makes of the steps: device-pointer batches of one shape that arrive back to back are launched
+        # together (option coalesce: up to four, a group below four waves per wave slot), and a sequence of launches
+        # rotates over four stream lanes (six for launches of about one wave per wave slot).
+        units, slots = self.B * len(self.trans), 256 * 32
+        self.group = args.coalesce or 4
+        self.steps_per_launch = 1
+        if self.group > 1 and self.B % 64 == 0 and 2 * units <= 4 * slots:
+            self.steps_per_launch = int(max(1, min(self.group, (4 * slots) // units)))
+        launch_units = units * self.steps_per_launch
+        self.lanes_used = args.streams or (6 if 4 * launch_units >= 3 * slots and 2 * launch_units <= 3 * slots else 4)
+
+    def close(self):
+        for key in ('U', 'lnL', 'pix'):
+            if self.buf[key].value:
+                self.lib.nfa_free(self.buf[key])
+                self.buf[key] = C.c_void_p()
+        self.cube = None
+
+    def alloc_inputs(self, n_cap):
+        _ffi, lib, buf, B = self._ffi, self.lib, self.buf, self.B
+        for key in ('U', 'lnL', 'pix'):
+            if buf[key].value:
+                _ffi.check(lib.nfa_free(buf[key]))
+                buf[key] = C.c_void_p()
+        if self.per_row:
+            pix_all = (np.arange(n_cap)[:, None] * 977 + np.arange(B)[None, :]) % self.n_pix
+        else:
+            pix_all = np.repeat((np.arange(n_cap) % self.n_pix)[:, None], B, axis=1)
+        pix_all = np.ascontiguousarray(pix_all.astype(np.int32))
+        _ffi.check(lib.nfa_malloc(C.byref(buf['U']), n_cap * self.step_bytes))
+        _ffi.check(lib.nfa_malloc(C.byref(buf['lnL']), n_cap * B * 8))
+        _ffi.check(lib.nfa_malloc(C.byref(buf['pix']), pix_all.nbytes))
+        _ffi.check(lib.nfa_memcpy_h2d(buf['pix'], pix_all.ctypes.data_as(C.c_void_p), pix_all.nbytes))
+        buf['cap'] = n_cap
+
+    def reset_inputs(self, n):
+        """Fresh unit-cube rows for steps 0 .. n-1 (every step gets the same B rows): one upload, then copies on the
+        device that double the filled part."""
+        _ffi, lib, buf, step_bytes = self._ffi, self.lib, self.buf, self.step_bytes
+        assert n <= buf['cap']
+        _ffi.check(lib.nfa_memcpy_h2d(buf['U'], self.U_host.ctypes.data_as(C.c_void_p), step_bytes))
+        have = 1
+        while have < n:
+            m = min(have, n - have)
+            _ffi.check(lib.nfa_memcpy_d2d(C.c_void_p(buf['U'].value + have * step_bytes), buf['U'], m * step_bytes))
+            have += m
+        # the copies run on the default stream, the runner's lanes do not wait for it: nothing may start (and transform
+        # rows in place) before every row holds its unit-cube values
+        _ffi.check(lib.nfa_device_synchronize())
+
+    def step(self, handle, k):
+        # consecutive steps may overlap on the device (stream lanes): no buffer is shared
+        buf, B = self.buf, self.B
+        self._ffi.check(self.lib.nfa_runner_loglike_batch_dev(handle, C.c_void_p(buf['pix'].value + k * B * 4),
+                                                              C.c_void_p(buf['U'].value + k * self.step_bytes),
+                                                              C.c_void_p(buf['lnL'].value + k * B * 8), B))
+
+    def sync(self, handle):
+        self._ffi.check(self.lib.nfa_runner_synchronize(handle))
+        self._ffi.check(self.lib.nfa_device_synchronize())
+
+    def timed_blocks(self, handle, n_blocks, repeats, step=None):
+        """[seconds of each block]: `repeats` x --steps steps between barrier + synchronise, max (and min) over ranks."""
+        args, comm = self.args, self.comm
+        step = step or self.step
+        out = []
+        n_timed = args.steps * repeats
+        for _ in range(n_blocks):
+            self.reset_inputs(args.warmup + n_timed)
+            for k in range(args.warmup):
+                step(handle, k)
+            self.sync(handle)
+            comm.barrier()
+            t0 = time.perf_counter()
+            for k in range(args.warmup, args.warmup + n_timed):
+                step(handle, k)
+            t_enq = time.perf_counter() - t0         # host time to enqueue the steps (diagnostic, NFA_BENCH_HOST=1)
+            self.sync(handle)
+            out.append(time.perf_counter() - t0)     # this rank's steps; the block is the slowest rank's
+            if os.environ.get('NFA_BENCH_HOST') and self.rank == 0:
+                print(f'host enqueue {t_enq / n_timed * 1e6:.1f} us/step of {out[-1] / n_timed * 1e6:.1f}', file=sys.stderr)
+            comm.barrier()
+        mine = np.array(out)
+        return comm.allreduce(mine, 'max'), comm.allreduce(mine, 'min')
+
+    def repeats_for(self, handle, step=None):
+        """How often the K-step sequence is repeated inside a timed block so that the block lasts MIN_BLOCK_S: from
+        two probe blocks of K steps (the slowest rank's time, so that every rank repeats alike)."""
+        args = self.args
+        t, _ = self.timed_blocks(handle, 2, 1, step)
+        r = int(np.ceil(MIN_BLOCK_S / float(t.min())))       # (a lone K-step block pays fill and drain: the repeated block runs faster per step, hence the margin in MIN_BLOCK_S)
+        return max(1, min(r, MAX_BLOCK_STEPS // args.steps if args.steps <= MAX_BLOCK_STEPS else 1))
+
+    def one_lane_kernel_times(self, spl=1, launch=None):
+        """(lnl_kernel us, set-up kernel us, launches) on a one-lane runner: launches do not overlap, a
+        HIP-event interval is the execution time (what rocprofv3 shows for such a launch).  `spl` steps per
+        launch: the launch the engine makes of `spl` coalesced steps, here as one call over their (contiguous) rows."""
+        from nestfit_amd._model import _RunnerHandle
+        _ffi, lib, buf, B, args = self._ffi, self.lib, self.buf, self.B, self.args
+        _ffi.set_option('streams', 1)
+        solo = _RunnerHandle(self.cube._ss, self.ut, self.ncomp, False, False)
+        _ffi.set_option('streams', args.streams if args.streams else 0)
+        n_have = min(60, buf['cap'])
+        n = max(1, n_have // spl)
+
+        def plain(handle, k):
+            _ffi.check(lib.nfa_runner_loglike_batch_dev(handle, C.c_void_p(buf['pix'].value + k * spl * B * 4),
+                                                        C.c_void_p(buf['U'].value + k * spl * self.step_bytes),
+                                                        C.c_void_p(buf['lnL'].value + k * spl * B * 8), spl * B))
+        launch = launch or plain
+        self.reset_inputs(n_have)
+        for k in range(min(5, n)):
+            launch(solo.handle, k)
+        self.sync(solo.handle)
+        self.reset_inputs(n_have)
+        _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 1))
+        for k in range(n):
+            launch(solo.handle, k)
+        self.sync(solo.handle)
+        sp = (C.c_double * 4)(0, 0, 0, 0)
+        sc = C.c_int64(0)
+        _ffi.check(lib.nfa_runner_get_profile(solo.handle, sp, C.byref(sc)))
+        _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 0))
+        return sp[1] / sc.value * 1e3, sp[0] / sc.value * 1e3, int(sc.value)
+
+    def run_modes(self, na, modes, head_mode, n_blocks_head, n_blocks_other, extras=True):
+        """{mode: entry}: the timed blocks of every mode, the one-lane kernel times behind them."""
+        args, world, B = self.args, self.world, self.B
+        _ffi = self._ffi
+        per_mode = {}
+        # buffers for the longest block any mode will run: sized from a probe in the fastest mode of the run
+        self.alloc_inputs(args.warmup + args.steps)
+        na.set_exp_mode('fast' if 'fast' in modes else modes[0])
+        r_cap = self.repeats_for(self.rh) + 1
+        self.alloc_inputs(args.warmup + max(args.steps * r_cap, min(60, args.warmup + args.steps)))
+        for mode in modes:
+            na.set_exp_mode(mode)
+            n_blocks = n_blocks_head if mode == head_mode else n_blocks_other
+            repeats = min(r_cap, self.repeats_for(self.rh))
+            steps_block = args.steps * repeats
+            evals_per_block = steps_block * B * world
+            t, t_fastest = self.timed_blocks(self.rh, n_blocks, repeats)
+            med = float(np.median(t))
+            entry = {'value': evals_per_block / med, 'ms_per_step': med / steps_block * 1e3, 'blocks': int(n_blocks),
+                     'repeats_per_block': repeats, 'block_ms': med * 1e3,
+                     'min': evals_per_block / float(t.max()), 'max': evals_per_block / float(t.min()), 'dtype': DTYPES[mode]}
+            if world > 1:
+                # the slowest and the fastest rank of the median block: their ratio - 1 is the imbalance of the stripes
+                k_med = int(np.argsort(t)[len(t) // 2])
+                entry['rank_ms_per_step'] = {'slowest': float(t[k_med]) / steps_block * 1e3,
+                                             'fastest': float(t_fastest[k_med]) / steps_block * 1e3}
+            if extras and mode == head_mode and repeats > 1:
+                # blocks of exactly K steps, nothing repeated: what the fill and drain of the launch pipeline cost a short block
+                tk, _ = self.timed_blocks(self.rh, max(3, n_blocks // 3), 1)
+                entry['k_steps_alone'] = {'value': args.steps * B * world / float(np.median(tk)),
+                                          'ms_per_step': float(np.median(tk)) / args.steps * 1e3, 'block_ms': float(np.median(tk)) * 1e3}
+            if extras and mode == head_mode and self.steps_per_launch > 1 and not args.skip_single_step:
+                # the same blocks with every step launched on its own
+                _ffi.set_option('coalesce', 1)
+                ta, _ = self.timed_blocks(self.rh, max(3, n_blocks // 3), repeats)
+                _ffi.set_option('coalesce', self.group)
+                entry['one_step_per_launch'] = {'value': evals_per_block / float(np.median(ta)),
+                                                'ms_per_step': float(np.median(ta)) / steps_block * 1e3}
+            if self.rank == 0 and world == 1 and not self.per_row:
+                # the launch as the engine makes it (steps_per_launch steps together), alone on one lane ...
+                spl = self.steps_per_launch
+                lnl_us, setup_us, n_l = self.one_lane_kernel_times(spl)
+                entry.update({'lnl_kernel_us': lnl_us, 'setup_kernel_us': setup_us, 'one_lane_launches': n_l,
+                              'evals_per_launch': B * spl,
+                              'roofline_frac': self.bytes_eval * B * spl / (lnl_us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                if extras and spl > 1 and not args.skip_single_step and mode == head_mode:   # ... and the launch of a single step
+                    l1, s1, n1 = self.one_lane_kernel_times(1)
+                    entry['single_step_launch'] = {'lnl_kernel_us': l1, 'setup_kernel_us': s1, 'one_lane_launches': n1,
+                                                   'roofline_frac': self.bytes_eval * B / (l1 * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            per_mode[mode] = entry
+        return per_mode
+
+    def run_spectra_out(self, na, mode, n_blocks):
+        """The spectra-out mode (the one genuinely HBM-bound form of the path): B rows of physical parameters
+        -> B x chan_tot model spectra written to HBM through nfa_runner_predict_batch_dev -- what
+        deblend_hf_intensity / generate_predicted_profiles ask of `runner.predict` once per (pixel, component)
+        (nestfit/main.py:1106-1113, 1182-1188).  Algorithmic bytes per evaluation = the likelihood's + sum_s N_s * 8."""
+        args, B, lib, _ffi = self.args, self.B, self.lib, self._ffi
+        chan_tot = len(self.trans) * self.n_chan
+        n_out = 6                                              # output buffers in rotation: more than the stream lanes
+        out = C.c_void_p()
+        _ffi.check(lib.nfa_malloc(C.byref(out), n_out * B * chan_tot * 8))
+        theta = self.U_host.copy()
+        self.ut.transform_batch(theta, self.ncomp)             # physical parameters of the same draws
+        d_theta = C.c_void_p()
+        _ffi.check(lib.nfa_malloc(C.byref(d_theta), theta.nbytes))
+        _ffi.check(lib.nfa_memcpy_h2d(d_theta, theta.ctypes.data_as(C.c_void_p), theta.nbytes))
+        buf = self.buf
+
+        def step(handle, k):
+            _ffi.check(lib.nfa_runner_predict_batch_dev(handle, C.c_void_p(buf['pix'].value + k * B * 4), d_theta, B,
+                                                        C.c_void_p(out.value + (k % n_out) * B * chan_tot * 8),
+                                                        C.c_void_p(buf['lnL'].value + k * B * 8)))
+        na.set_exp_mode(mode)
+        repeats = self.repeats_for(self.rh, step)
+        repeats = max(1, min(repeats, (buf['cap'] - args.warmup) // args.steps))
+        steps_block = args.steps * repeats
+        t, _ = self.timed_blocks(self.rh, n_blocks, repeats, step)
+        med = float(np.median(t))
+        bytes_eval = self.bytes_eval + chan_tot * 8
+        entry = {'mode': mode, 'dtype': DTYPES[mode], 'value': steps_block * B * self.world / med, 'unit': 'evals/s',
+                 'ms_per_step': med / steps_block * 1e3, 'blocks': int(n_blocks), 'repeats_per_block': repeats,
+                 'algorithmic_bytes_per_eval': bytes_eval, 'bytes_written_per_step': B * chan_tot * 8,
+                 'entry_point': 'nfa_runner_predict_batch_dev (theta, spectra and lnL in HBM)'}
+        pipe = bytes_eval * B * self.world / (entry['ms_per_step'] * 1e-3) / 1e9
+        entry['pipeline_achieved_GBs'] = pipe
+        entry['pipeline_frac'] = pipe / (HBM_PEAK_GBS * self.world)
+        if self.rank == 0 and self.world == 1:
+            lnl_us, setup_us, n_l = self.one_lane_kernel_times(1, lambda h, k: step(h, k))
+            ach = bytes_eval * B / (lnl_us * 1e-6) / 1e9
+            entry.update({'lnl_kernel_us': lnl_us, 'setup_kernel_us': setup_us, 'one_lane_launches': n_l, 'evals_per_launch': B,
+                          'achieved_GBs': ach, 'frac': ach / HBM_PEAK_GBS,
+                          'kernel': f'lnl_kernel<{0 if mode == "table" else 2}, true, false, {self.ncomp}>'})
+        lib.nfa_free(out)
+        lib.nfa_free(d_theta)
+        return entry
+
+
+def rocprof_kernel_us(csv_name, kernel_prefix):
+    """(average us, path) of the kernel whose name starts with `kernel_prefix` in a committed rocprofv3 --stats summary."""
+    import csv
+    f = profile_file(csv_name)
+    if f is None:
+        return None, None
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if row['Name'].startswith(kernel_prefix):
+                return float(row['AverageNs']) * 1e-3, f
+    return None, f
+
+
 def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: what RCCL needs across processes on this driver
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--blocks', type=int, default=21, help='timed blocks of --steps steps (value = the median block)')
+    ap.add_argument('--blocks', type=int, default=61, help='timed blocks of --steps steps (value = the median block)')
     ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS) + ['C5'],
                     help='C2 (default) is the headline metric; C5 = nested sampling of a 32x32 cube (not a "step" bench)')
     ap.add_argument('--side', type=int, default=128, help='pixels per side of the synthetic cube (C3: 128)')
@@ -259,8 +522,13 @@ def main():
                     help="1: the B rows of a step share one pixel (C2, the metric); B: every row has its own pixel "
                          "(one evaluation per pixel: the shape whose data really stream from HBM)")
     ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'fast'), choices=list(MODES),
-                    help='the mode `value` is quoted in (all three are timed)')
-    ap.add_argument('--modes', default='all', choices=['all', 'one'], help='time all three numerical modes or only --exp-mode')
+                    help='the mode `value` is quoted in (both are timed)')
+    ap.add_argument('--modes', default='all', choices=['all', 'one'], help='time both numerical modes or only --exp-mode')
+    ap.add_argument('--spectra-out', default='auto', choices=['auto', 'on', 'off', 'only'],
+                    help='also time the spectra-out mode (nfa_runner_predict_batch_dev; auto: with the default C2 run on one GPU); '
+                         'only: nothing else (profiler runs)')
+    ap.add_argument('--configs', default='auto', choices=['auto', 'on', 'off'],
+                    help='also time a short C4 block in both modes (auto: with the default C2 run on one GPU)')
     ap.add_argument('--wpb', type=int, default=0, help='engine A/B knob: waves per workgroup (0 = default)')
     ap.add_argument('--wpb-table', type=int, default=0, help='engine A/B knob: waves per workgroup in table mode (0 = chosen per spectra set)')
     ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
@@ -320,183 +588,28 @@ def main():
     else:
         comm, comm_kind = nfcomm.comm_from_env()      # RCCL over xGMI through the C ABI (sockets if RCCL cannot start)
 
-    trans, n_chan, vhalf, ncomp, truth_key, B = WORKLOADS[args.workload]
-    if args.batch:
-        B = args.batch
-    ndim = 6 * ncomp
-    noise = 0.2
-    per_row = args.pixels_per_step == 'B'
-    if per_row and args.side * args.side // world < B:
-        raise SystemExit('--pixels-per-step B needs a stripe of at least B pixels')
-    na.set_exp_mode('fast')                            # the synthetic data are made in one mode, whatever is timed
-    cube, ut, lon, lat, spec0 = make_stripe(na, args.workload, args.side, rank, world, noise)
-    n_pix = cube.n_pix
-    rh = cube._run.handle
-
-    # inputs of all steps of a block resident in HBM before the clock starts: unit-cube rows of its own for every
-    # step (a pass overwrites them with theta in place), the pixel index of every row, one result vector per step
-    U_host = np.ascontiguousarray(np.random.default_rng(7 + rank).uniform(size=(B, ndim)))
-    step_bytes = U_host.nbytes
-    buf = {'cap': 0, 'U': C.c_void_p(), 'lnL': C.c_void_p(), 'pix': C.c_void_p()}
-
-    def alloc_inputs(n_cap):
-        for key in ('U', 'lnL', 'pix'):
-            if buf[key].value:
-                _ffi.check(lib.nfa_free(buf[key]))
-                buf[key] = C.c_void_p()
-        if per_row:
-            pix_all = (np.arange(n_cap)[:, None] * 977 + np.arange(B)[None, :]) % n_pix
-        else:
-            pix_all = np.repeat((np.arange(n_cap) % n_pix)[:, None], B, axis=1)
-        pix_all = np.ascontiguousarray(pix_all.astype(np.int32))
-        _ffi.check(lib.nfa_malloc(C.byref(buf['U']), n_cap * step_bytes))
-        _ffi.check(lib.nfa_malloc(C.byref(buf['lnL']), n_cap * B * 8))
-        _ffi.check(lib.nfa_malloc(C.byref(buf['pix']), pix_all.nbytes))
-        _ffi.check(lib.nfa_memcpy_h2d(buf['pix'], pix_all.ctypes.data_as(C.c_void_p), pix_all.nbytes))
-        buf['cap'] = n_cap
-
-    def reset_inputs(n):
-        """Fresh unit-cube rows for steps 0 .. n-1 (every step gets the same B rows): one upload, then copies on the
-        device that double the filled part."""
-        assert n <= buf['cap']
-        _ffi.check(lib.nfa_memcpy_h2d(buf['U'], U_host.ctypes.data_as(C.c_void_p), step_bytes))
-        have = 1
-        while have < n:
-            m = min(have, n - have)
-            _ffi.check(lib.nfa_memcpy_d2d(C.c_void_p(buf['U'].value + have * step_bytes), buf['U'], m * step_bytes))
-            have += m
-        # the copies run on the default stream, the runner's lanes do not wait for it: nothing may start (and transform
-        # rows in place) before every row holds its unit-cube values
-        _ffi.check(lib.nfa_device_synchronize())
-
-    def step(handle, k):
-        # consecutive steps may overlap on the device (stream lanes): no buffer is shared
-        _ffi.check(lib.nfa_runner_loglike_batch_dev(handle, C.c_void_p(buf['pix'].value + k * B * 4),
-                                                    C.c_void_p(buf['U'].value + k * step_bytes),
-                                                    C.c_void_p(buf['lnL'].value + k * B * 8), B))
-
-    def sync(handle):
-        _ffi.check(lib.nfa_runner_synchronize(handle))
-        _ffi.check(lib.nfa_device_synchronize())
-
-    def timed_blocks(handle, n_blocks, repeats):
-        """[seconds of each block]: `repeats` x --steps steps between barrier + synchronise, max (and min) over ranks."""
-        out = []
-        n_timed = args.steps * repeats
-        for _ in range(n_blocks):
-            reset_inputs(args.warmup + n_timed)
-            for k in range(args.warmup):
-                step(handle, k)
-            sync(handle)
-            comm.barrier()
-            t0 = time.perf_counter()
-            for k in range(args.warmup, args.warmup + n_timed):
-                step(handle, k)
-            t_enq = time.perf_counter() - t0         # host time to enqueue the steps (diagnostic, NFA_BENCH_HOST=1)
-            sync(handle)
-            out.append(time.perf_counter() - t0)     # this rank's steps; the block is the slowest rank's
-            if os.environ.get('NFA_BENCH_HOST') and rank == 0:
-                print(f'host enqueue {t_enq / n_timed * 1e6:.1f} us/step of {out[-1] / n_timed * 1e6:.1f}', file=sys.stderr)
-            comm.barrier()
-        mine = np.array(out)
-        return comm.allreduce(mine, 'max'), comm.allreduce(mine, 'min')
-
-    def repeats_for(handle):
-        """How often the K-step sequence is repeated inside a timed block so that the block lasts MIN_BLOCK_S: from
-        two probe blocks of K steps (the slowest rank's time, so that every rank repeats alike)."""
-        t, _ = timed_blocks(handle, 2, 1)
-        r = int(np.ceil(MIN_BLOCK_S / float(t.min())))       # (a lone K-step block pays fill and drain: the repeated block runs faster per step, hence the margin in MIN_BLOCK_S)
-        return max(1, min(r, MAX_BLOCK_STEPS // args.steps if args.steps <= MAX_BLOCK_STEPS else 1))
-
-    def one_lane_kernel_times(spl=1):
-        """(lnl_kernel us, set-up kernel us, launches) on a one-lane runner: launches do not overlap, a
-        HIP-event interval is the execution time (what rocprofv3 shows for such a launch).  `spl` steps per
-        launch: the launch the engine makes of `spl` coalesced steps, here as one call over their (contiguous) rows."""
-        from nestfit_amd._model import _RunnerHandle
-        _ffi.set_option('streams', 1)
-        solo = _RunnerHandle(cube._ss, ut, ncomp, False, False)
-        _ffi.set_option('streams', args.streams if args.streams else 0)
-        n_have = min(60, buf['cap'])
-        n = max(1, n_have // spl)
-
-        def launch(k):
-            _ffi.check(lib.nfa_runner_loglike_batch_dev(solo.handle, C.c_void_p(buf['pix'].value + k * spl * B * 4),
-                                                        C.c_void_p(buf['U'].value + k * spl * step_bytes),
-                                                        C.c_void_p(buf['lnL'].value + k * spl * B * 8), spl * B))
-        reset_inputs(n_have)
-        for k in range(min(5, n)):
-            launch(k)
-        sync(solo.handle)
-        reset_inputs(n_have)
-        _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 1))
-        for k in range(n):
-            launch(k)
-        sync(solo.handle)
-        sp = (C.c_double * 4)(0, 0, 0, 0)
-        sc = C.c_int64(0)
-        _ffi.check(lib.nfa_runner_get_profile(solo.handle, sp, C.byref(sc)))
-        _ffi.check(lib.nfa_runner_set_profiling(solo.handle, 0))
-        return sp[1] / sc.value * 1e3, sp[0] / sc.value * 1e3, int(sc.value)
-
-    # What the engine makes of the steps: device-pointer batches of one shape that arrive back to back are launched
-    # together (option coalesce: up to four, a group below four waves per wave slot), and a sequence of launches
-    # rotates over four stream lanes (six for launches of about one wave per wave slot).
-    units, slots = B * len(trans), 256 * 32
-    group = args.coalesce or 4
-    steps_per_launch = 1
-    if group > 1 and B % 64 == 0 and 2 * units <= 4 * slots:
-        steps_per_launch = int(max(1, min(group, (4 * slots) // units)))
-    launch_units = units * steps_per_launch
-    lanes_used = args.streams or (6 if 4 * launch_units >= 3 * slots and 2 * launch_units <= 3 * slots else 4)
+    # ---- everything that runs on the GPU first (the driver samples the device's activity while the command runs);
+    #      the CPU baseline, a quarter of a minute of host work, last
+    M = Measure(args, na, lib, comm, rank, world, args.workload, args.side, args.batch)
+    B, ncomp, ndim, trans, n_chan = M.B, M.ncomp, M.ndim, M.trans, M.n_chan
+    per_row, steps_per_launch, bytes_eval = M.per_row, M.steps_per_launch, M.bytes_eval
+    default_run = args.workload == 'C2' and world == 1 and not per_row and B == 4096 and not args.ablate
     modes = list(MODES) if args.modes == 'all' else [args.exp_mode]
-    per_mode = {}
-    bytes_eval = algorithmic_bytes(trans, n_chan, ncomp)
-    # buffers for the longest block any mode will run: sized from a probe in the fastest mode of the run
-    alloc_inputs(args.warmup + args.steps)
-    na.set_exp_mode('fast' if 'fast' in modes else modes[0])
-    r_cap = repeats_for(rh) + 1
-    alloc_inputs(args.warmup + max(args.steps * r_cap, min(60, args.warmup + args.steps)))
-    for mode in modes:
-        na.set_exp_mode(mode)
-        n_blocks = args.blocks if mode == args.exp_mode else max(3, args.blocks // 3)
-        repeats = min(r_cap, repeats_for(rh))
-        steps_block = args.steps * repeats
-        evals_per_block = steps_block * B * world
-        t, t_fastest = timed_blocks(rh, n_blocks, repeats)
-        med = float(np.median(t))
-        entry = {'value': evals_per_block / med, 'ms_per_step': med / steps_block * 1e3, 'blocks': int(n_blocks),
-                 'repeats_per_block': repeats, 'block_ms': med * 1e3,
-                 'min': evals_per_block / float(t.max()), 'max': evals_per_block / float(t.min()), 'dtype': DTYPES[mode]}
-        if world > 1:
-            # the slowest and the fastest rank of the median block: their ratio - 1 is the imbalance of the stripes
-            k_med = int(np.argsort(t)[len(t) // 2])
-            entry['rank_ms_per_step'] = {'slowest': float(t[k_med]) / steps_block * 1e3,
-                                         'fastest': float(t_fastest[k_med]) / steps_block * 1e3}
-        if mode == args.exp_mode and repeats > 1:
-            # blocks of exactly K steps, nothing repeated: what the fill and drain of the launch pipeline cost a short block
-            tk, _ = timed_blocks(rh, max(3, args.blocks // 3), 1)
-            entry['k_steps_alone'] = {'value': args.steps * B * world / float(np.median(tk)),
-                                      'ms_per_step': float(np.median(tk)) / args.steps * 1e3, 'block_ms': float(np.median(tk)) * 1e3}
-        if mode == args.exp_mode and steps_per_launch > 1 and not args.skip_single_step:
-            # the same blocks with every step launched on its own
-            _ffi.set_option('coalesce', 1)
-            ta, _ = timed_blocks(rh, max(3, args.blocks // 3), repeats)
-            _ffi.set_option('coalesce', group)
-            entry['one_step_per_launch'] = {'value': evals_per_block / float(np.median(ta)),
-                                            'ms_per_step': float(np.median(ta)) / steps_block * 1e3}
-        if rank == 0 and world == 1 and not per_row:
-            # the launch as the engine makes it (steps_per_launch steps together), alone on one lane ...
-            lnl_us, setup_us, n_l = one_lane_kernel_times(steps_per_launch)
-            entry.update({'lnl_kernel_us': lnl_us, 'setup_kernel_us': setup_us, 'one_lane_launches': n_l,
-                          'evals_per_launch': B * steps_per_launch,
-                          'roofline_frac': bytes_eval * B * steps_per_launch / (lnl_us * 1e-6) / 1e9 / HBM_PEAK_GBS})
-            if steps_per_launch > 1 and not args.skip_single_step:                      # ... and the launch of a single step
-                l1, s1, n1 = one_lane_kernel_times(1)
-                entry['single_step_launch'] = {'lnl_kernel_us': l1, 'setup_kernel_us': s1, 'one_lane_launches': n1,
-                                               'roofline_frac': bytes_eval * B / (l1 * 1e-6) / 1e9 / HBM_PEAK_GBS}
-        per_mode[mode] = entry
+    n_other = max(3, args.blocks // 2)
+    spectra = None
+    if args.spectra_out == 'only':
+        M.alloc_inputs(args.warmup + max(args.steps * 8, 60))
+        spectra = M.run_spectra_out(na, args.exp_mode, args.blocks)
+        if rank == 0:
+            print(json.dumps({'metric': 'spectra-out evals/sec (predict_batch), 1024-ch 2-comp NH3(1,1)+(2,2)', **spectra}), flush=True)
+        M.close()
+        comm.barrier()
+        comm.close()
+        return
+    per_mode = M.run_modes(na, modes, args.exp_mode, args.blocks, n_other)
 
     # results of the last step, for the end-of-run gather and a sanity check
+    buf, step_bytes, lon, lat, n_pix = M.buf, M.step_bytes, M.lon, M.lat, M.n_pix
     lnL = np.empty(B)
     n_steps = args.warmup + args.steps
     _ffi.check(lib.nfa_memcpy_d2h(lnL.ctypes.data_as(C.c_void_p),
@@ -506,8 +619,8 @@ def main():
     # ... and the timed steps were fed what they are said to be fed: theta of the last step of the first and of the
     # last repeat of the last block is the prior transform of the unit-cube rows (a step that found rows an earlier pass
     # had already turned into theta would do different, cheaper work)
-    want = U_host.copy()
-    ut.transform_batch(want, ncomp)
+    want = M.U_host.copy()
+    M.ut.transform_batch(want, ncomp)
     theta = np.empty((B, ndim))
     last_repeats = per_mode[modes[-1]]['repeats_per_block']
     for k in sorted({n_steps - 1, args.warmup + args.steps * last_repeats - 1}):
@@ -520,6 +633,24 @@ def main():
     rec = np.array([[lon[k_last], lat[k_last], rank, float(lnL.max()), float(args.steps * B)]])
     allrec = nfcomm.gather_pixel_records(rec, comm)
     assert allrec.shape == (world, 5) and (allrec[:, 0] % world == allrec[:, 2]).all()
+
+    # the spectra-out mode (the HBM-bound form of the path) on the same stripe, in the headline's mode
+    if args.spectra_out == 'on' or (args.spectra_out == 'auto' and default_run):
+        spectra = M.run_spectra_out(na, args.exp_mode, max(5, args.blocks // 4))
+    spec0, ut, U_host = M.spec0, M.ut, M.U_host
+    M.close()
+    # BASELINE config 4 (three transitions x 2048 channels x 3 components: the LDS hyperfine-table stress), a short block
+    # in both modes on a small cube of its own
+    configs = {}
+    if args.configs == 'on' or (args.configs == 'auto' and default_run):
+        M4 = Measure(args, na, lib, comm, rank, world, 'C4', 32)
+        pm4 = M4.run_modes(na, list(MODES), None, 0, max(5, args.blocks // 6), extras=False)
+        configs['C4'] = {
+            'workload': f'C4: B={M4.B} draws per step against one pixel, NH3 (1,1)+(2,2)+(3,3), {M4.n_chan} ch, {M4.ncomp} comp; 32x32 cube',
+            'algorithmic_bytes_per_eval': M4.bytes_eval, 'steps_per_launch': M4.steps_per_launch,
+            **{m: {k: e.get(k) for k in ('value', 'ms_per_step', 'blocks', 'repeats_per_block', 'lnl_kernel_us', 'evals_per_launch',
+                                          'roofline_frac', 'min', 'max', 'dtype')} for m, e in pm4.items()}}
+        M4.close()
 
     # which device every rank computes on (two ranks on one GPU, or a silent fallback, show on the line)
     ubuf = C.create_string_buffer(40)
@@ -549,16 +680,19 @@ def main():
                             'note': 'the same bytes / the time per step of the timed blocks (the engine launches '
                                     f'{steps_per_launch} step(s) together and overlaps launches on its stream lanes): '
                                     'the rate the job sustains, a hard bound on the kernel'}
+        roof['pipeline_frac'] = roof['pipeline']['frac']
         # figures that need their own profiler passes come from the committed summaries of the latest round that has them
         def rel(path):
             return str(path.relative_to(ROOT))
         try:
-            f = profile_file('pmc_lnl_fast.json')
+            f = profile_file(f'pmc_lnl_{args.exp_mode}.json')
             pmc = json.loads(f.read_text())
             roof['valu'] = {'busy_frac_one_lane': pmc.get('valu_busy_frac'),
                             'valu_instructions_per_eval': pmc['instructions_per_eval'].get('valu'),
                             'salu_instructions_per_eval': pmc['instructions_per_eval'].get('salu'),
                             'source': f'{rel(f)} (rocprofv3 --pmc passes of the one-lane command, profiles/collect_round.sh pmc)'}
+            roof['valu_busy_frac'] = pmc.get('valu_busy_frac')
+            roof['valu_instructions_per_eval'] = pmc['instructions_per_eval'].get('valu')
         except Exception:
             pass
         try:
@@ -570,25 +704,69 @@ def main():
             roof['traffic_source'] = f'{rel(f)} (FETCH_SIZE x calibration + WRITE_SIZE, separate passes, per 4096-row batch) x steps_per_launch'
         except Exception:
             pass
-        try:
-            import csv
-            f = profile_file('onelane_kernel_stats.csv')
-            with open(f) as fh:
-                for row in csv.DictReader(fh):
-                    if row['Name'].startswith('void lnl_kernel<2, false, false, 2>') and args.workload == 'C2' and B == 4096:
-                        us = float(row['AverageNs']) * 1e-3
-                        roof['rocprof_avg_launch_us'] = us
-                        roof['rocprof_frac'] = bytes_eval * B * steps_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
-                        roof['rocprof'] = (f'{rel(f)} (rocprofv3 --kernel-trace --stats -- python bench.py --streams 1 '
-                                           '--modes one --no-cpu-baseline --skip-single-step)')
-        except Exception:
-            pass
+        if args.workload == 'C2' and B == 4096:
+            csv_name = 'onelane_kernel_stats.csv' if args.exp_mode == 'fast' else f'onelane_kernel_stats_{args.exp_mode}.csv'
+            us, f = rocprof_kernel_us(csv_name, LNL_KERNEL_NAME[args.exp_mode])
+            if us:
+                roof['rocprof_avg_launch_us'] = us
+                roof['rocprof_frac'] = bytes_eval * B * steps_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                roof['rocprof'] = (f'{rel(f)} (rocprofv3 --kernel-trace --stats -- python bench.py --streams 1 --modes one '
+                                   f'--exp-mode {args.exp_mode} --no-cpu-baseline --skip-single-step --spectra-out off --configs off)')
+        # the like-for-like number: the same workload in the reference's own arithmetic (f64 table product, f64 tau).
+        # Flat keys beside the block: what reads this line keeps scalars of `roofline` and drops nested objects.
+        rp = per_mode.get(REFERENCE_PRECISION_MODE)
+        if rp:
+            block = {'mode': REFERENCE_PRECISION_MODE, 'dtype': DTYPES[REFERENCE_PRECISION_MODE], 'value': rp['value'],
+                     'ms_per_step': rp['ms_per_step'], 'kernel': LNL_KERNEL_NAME[REFERENCE_PRECISION_MODE] if ncomp == 2 else 'lnl_kernel<0, ...>',
+                     'blocks': rp['blocks'], 'min': rp['min'], 'max': rp['max'],
+                     'avg_launch_us': rp.get('lnl_kernel_us'), 'frac': rp.get('roofline_frac'),
+                     'pipeline_frac': bytes_eval * B * world / (rp['ms_per_step'] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)}
+            if args.workload == 'C2' and B == 4096:
+                us, f = rocprof_kernel_us('onelane_kernel_stats_table.csv', LNL_KERNEL_NAME['table'])
+                if us:
+                    block['rocprof_avg_launch_us'] = us
+                    block['rocprof_frac'] = bytes_eval * B * steps_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                    block['rocprof'] = rel(f)
+            try:
+                f = profile_file('pmc_lnl_table.json')
+                pmc = json.loads(f.read_text())
+                block['valu_busy_frac'] = pmc.get('valu_busy_frac')
+                block['valu_instructions_per_eval'] = pmc['instructions_per_eval'].get('valu')
+                block['lds_bank_conflict_frac'] = pmc.get('lds_bank_conflict_frac')
+                block['pmc'] = rel(f)
+            except Exception:
+                pass
+            roof['reference_precision'] = block
+            for k, v in block.items():
+                if not isinstance(v, (dict, list)):
+                    roof[f'reference_precision_{k}'] = v
+        if spectra:
+            roof['spectra_out'] = spectra
+            for k in ('value', 'ms_per_step', 'frac', 'achieved_GBs', 'lnl_kernel_us', 'algorithmic_bytes_per_eval', 'pipeline_frac'):
+                if k in spectra:
+                    roof[f'spectra_out_{k}'] = spectra[k]
+            try:
+                f = profile_file('pmc_traffic_spectra_out.json')
+                tr = json.loads(f.read_text())
+                spectra['traffic'] = tr['bytes_per_launch']
+                spectra['traffic_frac_of_peak'] = tr['bytes_per_launch'] / (spectra['lnl_kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                spectra['traffic_source'] = rel(f)
+                roof['spectra_out_traffic'] = spectra['traffic']
+                roof['spectra_out_traffic_frac_of_peak'] = spectra['traffic_frac_of_peak']
+            except Exception:
+                pass
+        for cname, cfg in configs.items():
+            for m in MODES:
+                if m in cfg:
+                    roof[f'{cname}_{m}_value'] = cfg[m]['value']
+                    roof[f'{cname}_{m}_frac'] = cfg[m].get('roofline_frac')
         roof['note'] = ('achieved / frac: algorithmic bytes (SURVEY 8d) per launch / lnl_kernel time per launch -- the launch the '
                         'engine makes of `steps_per_launch` steps that arrive back to back -- HIP events on a one-lane runner after '
                         'the timed blocks; `single_step_launch` = the same for the launch of one step; `rocprof` names the '
                         'committed summary of the one-lane command whose average agrees. The kernel is VALU bound: `valu` = busy fraction of the vector ALUs from '
                         'SQ_ACTIVE_INST_VALU and instructions per evaluation (separate --pmc passes); with --pixels-per-step 1 '
-                        'the pixel stays in L2 (traffic << algorithmic bytes), see DESIGN.md')
+                        'the pixel stays in L2 (traffic << algorithmic bytes), see DESIGN.md.  `reference_precision` (and the flat '
+                        'reference_precision_* keys): the same workload and timing in the table mode, the reference\'s own f64 arithmetic')
         cpu = None
         if args.gpus == 1 and not args.no_cpu_baseline and not per_row:
             cpu = cpu_baseline(spec0, ut.lower(), ncomp, U_host)
@@ -618,8 +796,11 @@ def main():
                             f'get_irdc_priors(size=500); pixels = rank stripe (i_lon % {world}) of the C3 cube '
                             f'{args.side}x{args.side}, one pixel per '
                             + ('ROW (one evaluation per pixel)' if per_row else 'step'),
-                'exp_mode': args.exp_mode, 'stream_lanes': lanes_used, 'steps_per_launch': steps_per_launch, 'pixels_per_gpu': int(n_pix),
+                'exp_mode': args.exp_mode, 'stream_lanes': M.lanes_used, 'steps_per_launch': steps_per_launch, 'pixels_per_gpu': int(n_pix),
                 'repeats_per_block': head['repeats_per_block'], 'block_ms': head['block_ms'],
+                **({'reference_precision_mode': REFERENCE_PRECISION_MODE, 'reference_precision_value': per_mode[REFERENCE_PRECISION_MODE]['value'],
+                    'reference_precision_ms_per_step': per_mode[REFERENCE_PRECISION_MODE]['ms_per_step']}
+                   if REFERENCE_PRECISION_MODE in per_mode else {}),
                 'comm': comm_kind, 'devices': uuids,
                 **({'rccl_fallback': 'RCCL did not come up on every rank: barrier / max-time / record gather went over TCP sockets'}
                    if comm_kind == 'tcp' and not same_gpu else {}),
@@ -634,14 +815,18 @@ def main():
                        **({'rank_ms_per_step': head['rank_ms_per_step']} if 'rank_ms_per_step' in head else {})},
             'modes': per_mode, 'roofline': roof, 'cpu_baseline': cpu,
         }
+        if configs:
+            line['configs'] = configs
+        if spectra:
+            line['spectra_out'] = spectra
         if cpu:
             line['speedup_vs_cpu_all_cores'] = value / cpu['value']
             if 'reference_equivalent' in cpu:       # against what the reference itself would deliver on these cores
                 line['speedup_vs_reference_all_cores'] = value / cpu['reference_equivalent']
+                if REFERENCE_PRECISION_MODE in per_mode:
+                    line['reference_precision_speedup_vs_reference_all_cores'] = per_mode[REFERENCE_PRECISION_MODE]['value'] / cpu['reference_equivalent']
         print(json.dumps(line), flush=True)
 
-    for key in ('U', 'lnL', 'pix'):
-        lib.nfa_free(buf[key])
     comm.barrier()
     stuck = getattr(comm, 'stuck_thread', None)
     comm.close()

@@ -45,9 +45,8 @@ int nfa_device_uuid(char *buf, int buflen);
  * its own with nfa_runner_set_exp_mode):
  *   0 = "table": the reference's three-table product held in LDS
  *       (nestfit/core/fastexp.c:234-283), bit-identical table indices;
- *   1 = "poly" : exp(-(double)(float)x) by fp64 range reduction + polynomial,
- *       same branch structure (negative / zero / Taylor / >=32), <=4e-16 rel
- *       from the table product;
+ *   (1, an fp64 polynomial form of the same exponential, was a likelihood mode until round 3:
+ *       slower than the table mode and less faithful, it is refused now);
  *   2 = "fast" : window / table indices and the float-narrowed FastExp argument
  *       in fp64 exactly as above, exponentials in fp32 with split exponents;
  *       <= 1e-6 relative on brightness temperature (the metric's tolerance). */
@@ -229,6 +228,13 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
  * nfa_device_synchronize), which launches what is still held and waits for all of it. */
 int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_U,
                                  double *d_lnL, int64_t B);
+/* Spectra-out with device pointers (what AmmoniaRunner.predict is to deblend_hf_intensity /
+ * generate_predicted_profiles, nestfit/main.py:1106-1113, 1182-1188, for a caller whose MAP cube and
+ * profile cube stay in HBM): d_theta [B x ndim] physical parameters (read only), d_spectra
+ * [B x chan_tot] or NULL, d_lnL [B] or NULL (not both NULL).  Asynchronous and rotating over the
+ * runner's streams like nfa_runner_loglike_batch_dev; same results as nfa_runner_predict_batch. */
+int nfa_runner_predict_batch_dev(nfa_runner *r, const int32_t *d_pix, const double *d_theta, int64_t B,
+                                 double *d_spectra, double *d_lnL);
 int nfa_runner_synchronize(nfa_runner *r);
 /* Per-kernel timing of nfa_runner_loglike_batch_dev with HIP events recorded on
  * the stream each kernel is launched on, over the calls made since profiling was

@@ -68,6 +68,7 @@ SIGNATURES = {
     'nfa_runner_get_exp_mode': (C.c_int, [C.c_void_p]),
     'nfa_runner_loglike_batch': (C.c_int, [C.c_void_p, _ip, _dp, _dp, C.c_int64]),
     'nfa_runner_predict_batch': (C.c_int, [C.c_void_p, _ip, _dp, C.c_int64, _dp, _dp]),
+    'nfa_runner_predict_batch_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'nfa_runner_loglike_batch_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int64]),
     'nfa_runner_synchronize': (C.c_int, [C.c_void_p]),
@@ -254,9 +255,9 @@ def device_count():
 
 
 def set_exp_mode(mode):
-    """0/'table': LDS product tables (reference FastExp); 1/'poly': fp64 polynomial;
+    """0/'table': LDS product tables (reference FastExp, f64 throughout);
     2/'fast': fp32 exponentials on the fp64 float-narrowed arguments."""
-    mode = {'table': 0, 'poly': 1, 'fast': 2}.get(mode, mode)
+    mode = {'table': 0, 'fast': 2}.get(mode, mode)
     check(load().nfa_set_exp_mode(int(mode)))
 
 

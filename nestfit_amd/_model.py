@@ -71,9 +71,9 @@ class _RunnerHandle:
         self.handle = h
 
     def set_exp_mode(self, mode):
-        """Pin the numerical mode of this runner ('table' / 'poly' / 'fast' or 0 / 1 / 2); None or -1
+        """Pin the numerical mode of this runner ('table' / 'fast' or 0 / 2); None or -1
         = follow the process default (`nestfit_amd.set_exp_mode`) again."""
-        mode = -1 if mode is None else {'table': 0, 'poly': 1, 'fast': 2}.get(mode, mode)
+        mode = -1 if mode is None else {'table': 0, 'fast': 2}.get(mode, mode)
         _ffi.check(_ffi.load().nfa_runner_set_exp_mode(self.handle, int(mode)))
 
     def get_exp_mode(self):

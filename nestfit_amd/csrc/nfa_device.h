@@ -23,11 +23,14 @@
 //     added in spectrum order by lnl_sum_kernel (bitwise reproducible).
 // No MFMA: the path is elementwise fp64/fp32 plus reductions.
 //
-// Numerical modes (template MODE): 0 "table" and 1 "poly" evaluate FastExp like
-// the reference (float-narrowed argument, Taylor below 2^-5, zero from 32, same
-// table indices) in fp64; 2 "fast" keeps every index computation in fp64 but
-// evaluates the exponentials in fp32 with split exponents (<= 3e-7 relative on
-// Tb, tolerance of the metric: 1e-6).
+// Numerical modes (template MODE): 0 "table" evaluates FastExp like the reference
+// (float-narrowed argument, Taylor below 2^-5, zero from 32, the three-table product
+// with the same table indices) in fp64; 2 "fast" keeps every index computation in fp64
+// but evaluates the exponentials in fp32 with split exponents (<= 3e-7 relative on
+// Tb, tolerance of the metric: 1e-6).  (MODE 1, the fp64 polynomial form of the same
+// exponential, survives in the set-up stage of the fast mode -- nf_fastexp<1> for the
+// partition sums -- and in the test hooks; as a likelihood mode it was slower than the
+// table mode and less faithful, and is gone.)
 //
 // Compile with -ffp-contract=off: FMA only where written, so window and table
 // indices round like the reference's plain double arithmetic.
@@ -628,92 +631,6 @@ __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj
 #undef NFA_TABLE_TAYLOR
 }
 
-// The same for the polynomial mode: two line x row steps as one instruction block, the two chains of range reduction,
-// table read and six dependent fused multiply-adds interleaved by the hardware's own scoreboard instead of running one
-// after the other.  Operation for operation exp_neg_poly under nf_fastexp<1, true, true>: n = rint(-t 256/ln2),
-// r = -t - n ln2/256 in two fused steps, 2^((n & 255)/256) from the table, the degree-4 polynomial, the power of two by
-// ldexp (the result stays normal: the same bits as adding to the exponent field), the Taylor form below 2^-5.
-// EXEC is all ones on entry and on exit; nothing in here writes SCC.
-__device__ __forceinline__ void line_pair_poly(double &tau, float jf, double xj,
-                                               double nucA, double idA, double wA, float midA, float halfA,
-                                               double nucB, double idB, double wB, float midB, float halfB,
-                                               uint32_t base_t) {
-    float xA, xB;
-    uint32_t t0, iA, iB;
-    double a0, a1, a2, b0, b1, b2;
-    unsigned long long mA, mB;
-#define NFA_POLY_HEAD(X, NI, T, N, R, NUC, ID)                                                              \
-        "v_add_f64 %[" #T "], %[xj], -%[" #NUC "]\n\t"                                                      \
-        "v_mul_f64 %[" #T "], %[" #T "], %[" #T "]\n\t"                                                     \
-        "v_mul_f64 %[" #T "], %[" #T "], %[" #ID "]\n\t"                                                    \
-        "v_cvt_f32_f64 %[" #X "], %[" #T "]\n\t"                   /* math.pxd:17 narrowing */              \
-        "v_cvt_f64_f32 %[" #T "], %[" #X "]\n\t"                                                            \
-        "v_mul_f64 %[" #N "], %[" #T "], %[nc32]\n\t"               /* -t 256 / ln 2 */                      \
-        "v_rndne_f64 %[" #N "], %[" #N "]\n\t"                                                              \
-        "v_fma_f64 %[" #R "], -%[" #N "], %[lhi], -%[" #T "]\n\t"   /* r = -t - n ln2/32 (hi, lo) */         \
-        "v_fma_f64 %[" #R "], -%[" #N "], %[llo], %[" #R "]\n\t"                                            \
-        "v_cvt_i32_f64 %[" #NI "], %[" #N "]\n\t"                                                           \
-        "v_and_b32 %[t0], 0xff, %[" #NI "]\n\t"                                                             \
-        "v_lshl_add_u32 %[t0], %[t0], 3, %[bt]\n\t"                                                         \
-        "ds_read_b64 %[" #T "], %[t0]\n\t"                       /* (t is used up: its registers take the table value) */ \
-        "v_ashrrev_i32 %[" #NI "], 8, %[" #NI "]\n\t"                                                       \
-        "v_mov_b64 %[" #N "], %[c4]\n\t"                            /* the polynomial, Horner */            \
-        "v_fma_f64 %[" #N "], %[" #N "], %[" #R "], %[c3]\n\t"                                              \
-        "v_fma_f64 %[" #N "], %[" #N "], %[" #R "], 0.5\n\t"                                                \
-        "v_fma_f64 %[" #N "], %[" #N "], %[" #R "], 1.0\n\t"                                                \
-        "v_fma_f64 %[" #N "], %[" #N "], %[" #R "], 1.0\n\t"
-#define NFA_POLY_TAYLOR(X, G0, G1, G2, LBL)                                                                \
-        "s_cbranch_vccz " LBL "%=\n\t"                                                                     \
-        "s_mov_b64 exec, vcc\n\t"                                                                          \
-        "v_cvt_f64_f32 %[" #G1 "], %[" #X "]\n\t"                                                          \
-        "v_mul_f64 %[" #G2 "], %[" #G1 "], %[nthird]\n\t"                                                  \
-        "v_add_f64 %[" #G2 "], %[" #G2 "], 1.0\n\t"                                                        \
-        "v_mul_f64 %[" #G2 "], %[" #G2 "], %[" #G1 "]\n\t"                                                 \
-        "v_mul_f64 %[" #G2 "], %[" #G2 "], -0.5\n\t"                                                       \
-        "v_add_f64 %[" #G2 "], %[" #G2 "], 1.0\n\t"                                                        \
-        "v_mul_f64 %[" #G1 "], %[" #G2 "], %[" #G1 "]\n\t"                                                 \
-        "v_add_f64 %[" #G0 "], -%[" #G1 "], 1.0\n\t"                                                       \
-        LBL "%=:\n\t"
-    asm volatile(
-        "v_sub_f32 %[t0], %[jf], %[midA]\n\t"
-        "v_cmp_lt_f32_e64 %[mA], |%[t0]|, %[halfA]\n\t"
-        "v_sub_f32 %[t0], %[jf], %[midB]\n\t"
-        "v_cmp_lt_f32_e64 %[mB], |%[t0]|, %[halfB]\n\t"
-        "s_mov_b64 exec, %[mA]\n\t"
-        NFA_POLY_HEAD(xA, iA, a0, a1, a2, nucA, idA)
-        "s_mov_b64 exec, %[mB]\n\t"
-        NFA_POLY_HEAD(xB, iB, b0, b1, b2, nucB, idB)
-        // line A: table value x polynomial, the power of two, the Taylor form where x < 2^-5, tau += w e
-        "s_mov_b64 exec, %[mA]\n\t"
-        "v_cmp_gt_f32 vcc, 0x3d000000, %[xA]\n\t"
-        "s_waitcnt lgkmcnt(1)\n\t"
-        "v_mul_f64 %[a0], %[a0], %[a1]\n\t"
-        "v_ldexp_f64 %[a0], %[a0], %[iA]\n\t"
-        NFA_POLY_TAYLOR(xA, a0, a1, a2, ".Lnfa_ppa_")
-        "s_mov_b64 exec, %[mA]\n\t"
-        "v_fmac_f64 %[tau], %[wA], %[a0]\n\t"
-        "s_mov_b64 exec, %[mB]\n\t"
-        "v_cmp_gt_f32 vcc, 0x3d000000, %[xB]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mul_f64 %[b0], %[b0], %[b1]\n\t"
-        "v_ldexp_f64 %[b0], %[b0], %[iB]\n\t"
-        NFA_POLY_TAYLOR(xB, b0, b1, b2, ".Lnfa_ppb_")
-        "s_mov_b64 exec, %[mB]\n\t"
-        "v_fmac_f64 %[tau], %[wB], %[b0]\n\t"
-        "s_mov_b64 exec, -1"
-        : [tau] "+v"(tau), [xA] "=&v"(xA), [xB] "=&v"(xB), [t0] "=&v"(t0), [iA] "=&v"(iA), [iB] "=&v"(iB),
-          [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2),
-          [mA] "=&s"(mA), [mB] "=&s"(mB)
-        : [jf] "v"(jf), [xj] "v"(xj), [nucA] "v"(nucA), [idA] "v"(idA), [wA] "v"(wA), [midA] "v"(midA), [halfA] "v"(halfA),
-          [nucB] "v"(nucB), [idB] "v"(idB), [wB] "v"(wB), [midB] "v"(midB), [halfB] "v"(halfB),
-          [bt] "s"(base_t), [nthird] "s"(-(1.0 / 3.0)),
-          [nc32] "s"(-369.3299304675746322841407183364843), [lhi] "s"(6.93147180369123816490e-01 / 256.0),
-          [llo] "s"(1.90821492927058770002e-10 / 256.0), [c4] "s"(1.0 / 24.0), [c3] "s"(1.0 / 6.0)
-        : "vcc");
-#undef NFA_POLY_HEAD
-#undef NFA_POLY_TAYLOR
-}
-
 // The body of the likelihood kernel for workgroup `block_id` of a launch (lnl_kernel: the hardware's
 // workgroup; point_kernel: the one workgroup walks the few of a single point).  `sm` = the staged
 // exponential tables (n_shared doubles at the start of smem), the line tables follow them.
@@ -1002,12 +919,6 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                                             __int_as_float(__double2hiint(wm0.y)), ab1.x, ab1.y, wm1.x,
                                             __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)),
                                             (uint32_t)(uintptr_t)(sm + SM_FEA), (uint32_t)(uintptr_t)(sm + SM_FEC));
-                        } else if constexpr (MODE == 1 && FWIN) {
-                            const v2d wm0 = rec_ab(va + 16), wm1 = rec_ab(va + 48);
-                            line_pair_poly(tau, jf, xj, ab0.x, ab0.y, wm0.x, __int_as_float(__double2loint(wm0.y)),
-                                           __int_as_float(__double2hiint(wm0.y)), ab1.x, ab1.y, wm1.x,
-                                           __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)),
-                                           (uint32_t)(uintptr_t)(sm + SM_EXP2));
                         } else {
                             const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
                             step(ab0, hw0, wi);
@@ -1125,18 +1036,6 @@ lnl_kernel(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__re
     const double *sm = smem;
     if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);   // fast: no tables
     lnl_body<MODE, WRITE_SPEC, WIDE, NCOMP>(S, nullptr, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x, &grp);
-}
-
-// The polynomial mode's kernel: the same body under a cap of 96 scalar registers -- its occupancy is set by its vector
-// registers (4-5 waves per SIMD), and its constants belong in scalar ones.
-template <bool WRITE_SPEC, int NCOMP>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(5, 8)))
-lnl_kernel_poly(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__restrict__ part,
-                double *__restrict__ spec_out, long B, LnlGeom G, const double *__restrict__ g_tabs) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    int n_shared = 0;
-    const double *sm = stage_exp_tables<1>(smem, g_tabs, &n_shared);
-    lnl_body<1, WRITE_SPEC, false, NCOMP>(S, nullptr, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x, &grp);
 }
 
 // chi^2 parts of one item -> its log-likelihood: the sum over the spectra, in order (ammonia.pyx:425-432), of

@@ -277,7 +277,7 @@ int nfa_device_uuid(char *buf, int buflen) {
 }
 
 int nfa_set_exp_mode(int mode) {
-    if (mode < 0 || mode > 2) return fail(NFA_ERR_ARG, "exp mode must be 0 (table), 1 (poly) or 2 (fast)");
+    if (mode != 0 && mode != 2) return fail(NFA_ERR_ARG, "exp mode must be 0 (table) or 2 (fast)");
     { int rc = flush_all_runners(); if (rc) return rc; }       // what is held was enqueued under the old mode
     g_eng.exp_mode = mode;
     return NFA_OK;
@@ -661,7 +661,7 @@ int nfa_runner_ndim(const nfa_runner *r) { return r ? r->ndim : 0; }
 int nfa_runner_set_exp_mode(nfa_runner *r, int mode) {
     if (!r) return fail(NFA_ERR_ARG, "null runner");
     RUNNER_LOCK(r);
-    if (mode < -1 || mode > 2) return fail(NFA_ERR_ARG, "exp mode must be -1 (process default), 0 (table), 1 (poly) or 2 (fast)");
+    if (mode != -1 && mode != 0 && mode != 2) return fail(NFA_ERR_ARG, "exp mode must be -1 (process default), 0 (table) or 2 (fast)");
     { int rc = flush_pending(r); if (rc) return rc; }
     r->exp_mode = mode;
     return NFA_OK;
@@ -807,7 +807,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     const int split = resolve_split(r, S, B);
     G.split = split;
     G.wave_doubles = lnl_wave_doubles(r);
-    const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : (MODE == 1 ? NFA_EXP2_N : 0);
+    const int n_shared = (MODE == 0) ? (SM_END_TABLE - SM_EXP2) : 0;
     // waves per workgroup.  Table mode stages 51 KB of product tables per workgroup, so the
     // workgroup is made as fat as keeps the most waves resident per CU (ties: more workgroups,
     // so that one stages while another computes).
@@ -833,7 +833,6 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     if (MODE != 0 && r->lnl_cap > 0 && waves * r->lnl_cap < 32)      // residency cap: see Engine::lnl_cap
         lds = std::max(lds, (size_t)((160 * 1024) / r->lnl_cap) & ~(size_t)15);
     void (*kern)(SpecDev, BatchGroup, const double *, double *, double *, long, LnlGeom, const double *) = lnl_kernel<MODE, WS, WIDE, NCOMP>;
-    if constexpr (MODE == 1 && !WIDE) kern = lnl_kernel_poly<WS, NCOMP>;
     { int rc2 = ensure_dynamic_lds((const void *)kern, lds); if (rc2) return rc2; }
     const int64_t units = B * S.n_spec;
     const int64_t upw = waves / split;
@@ -871,9 +870,6 @@ static int launch_lnl(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, 
     case 0:
         return d_spec ? launch_lnl_n<0, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
                       : launch_lnl_n<0, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
-    case 1:
-        return d_spec ? launch_lnl_n<1, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
-                      : launch_lnl_n<1, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
     default:
         if (lnl_wide(r))                // more lines than any NH3 transition (or 2^22 channels): fp64 running sum of tau
             return d_spec ? launch_lnl_n<2, true, true>(r, d_pix, slot, d_lnL, d_spec, B)
@@ -1092,10 +1088,10 @@ static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, doubl
     if (G.split > POINT_WAVES) return 0;
     G.wave_doubles = lnl_wave_doubles(r);
     const int upw = POINT_WAVES / G.split;                       // units per pass of the workgroup
-    const int n_shared = mode == 0 ? (SM_END_TABLE - SM_EXP2) : (mode == 1 ? NFA_EXP2_N : 0);
+    const int n_shared = mode == 0 ? (SM_END_TABLE - SM_EXP2) : 0;
     // the set-up stage and the likelihood waves use the same LDS one after the other, behind the staged tables
     const size_t n_staged = mode == 0 ? (SM_END_TABLE - SM_EXP2) : NFA_EXP2_N;
-    const size_t lds = std::max(setup_lds_bytes(r, 1, true) + sizeof(double) * (n_staged - 32),
+    const size_t lds = std::max(setup_lds_bytes(r, 1, true) + sizeof(double) * (n_staged - NFA_EXP2_N),
                                 sizeof(double) * ((size_t)n_shared + ((size_t)G.wave_doubles + (G.split > 1 ? LNL_PARTS * 64 : 0)) * upw));
     if (lds > 160 * 1024) return 0;
     if (reserve_lane(r, 0, B) != NFA_OK) return -1;
@@ -1134,7 +1130,6 @@ static int few_points_kernel(nfa_runner *r, const int32_t *pix, double *U, doubl
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     switch (mode) {
     case 0: launch_point_n<0>(r, S, in, G, lds); break;
-    case 1: launch_point_n<1>(r, S, in, G, lds); break;
     default: launch_point_n<2>(r, S, in, G, lds); break;
     }
     if (hipGetLastError() != hipSuccess) { fail(NFA_ERR_DEVICE, "point kernel launch failed"); return -1; }
@@ -1300,6 +1295,19 @@ int nfa_runner_predict_batch(nfa_runner *r, const int32_t *pix, const double *th
     HIP_TRY(hipStreamSynchronize(st));
     r->lane_busy &= ~1u;
     return NFA_OK;
+}
+
+// The spectra-out call for a caller whose buffers live in HBM: theta in, model spectra (and, where asked for, lnL)
+// out, nothing copied, nothing waited for -- what deblend_hf_intensity / generate_predicted_profiles
+// (nestfit/main.py:1106-1113, 1182-1188) become when the MAP cube and the profile cube stay on the device.
+// Consecutive calls rotate over the runner's stream lanes like nfa_runner_loglike_batch_dev's.
+int nfa_runner_predict_batch_dev(nfa_runner *r, const int32_t *d_pix, const double *d_theta, int64_t B,
+                                 double *d_spectra, double *d_lnL) {
+    if (!r || !d_theta || (!d_spectra && !d_lnL)) return fail(NFA_ERR_ARG, "null argument");
+    if (B <= 0) return NFA_OK;
+    RUNNER_LOCK(r);
+    int rc = flush_pending(r); if (rc) return rc;
+    return run_batch(r, d_pix, const_cast<double *>(d_theta), d_lnL, d_spectra, B, false, -1, nullptr);
 }
 
 void nfa_loglike_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx) {

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <fcntl.h>
@@ -32,7 +33,7 @@
 #include <unistd.h>
 
 #define NFA_RING_MAGIC   0x4e46524eu       // "NFRN"
-#define NFA_RING_VERSION 3u
+#define NFA_RING_VERSION 4u
 #define NFA_RING_MAXBATCH 1024             // points one serving round hands the engine at most
 #define NFA_RING_MAXPOINTS 64              // points a client may post in one call (nfa_ring_loglike_many)
 #define NFA_RING_GRACE_MS 5000             // a client gives up after this long without any serving loop on the ring
@@ -50,7 +51,9 @@ struct RingHeader {
     std::atomic<uint32_t> n_servers;       // serving loops at work (each with a runner of its own): they share the clients
     std::atomic<uint32_t> servers_asleep;  // serving loops inside a futex wait on `posts`: only then does a post pay for a wake call
     std::atomic<uint64_t> n_batches, n_evals, max_batch_seen;
-    uint8_t  pad[64];
+    std::atomic<int64_t>  last_serve_us;   // heartbeat (CLOCK_MONOTONIC): refreshed by every nfa_ring_poll / nfa_ring_complete --
+                                           // a server built on poll / complete alone (no nfa_ring_serve) is seen through it
+    uint8_t  pad[56];
 };
 
 struct RingSlot {
@@ -89,7 +92,22 @@ static inline RingSlot *ring_slot(const nfa_ring *r, int k) {
 }
 static inline double *slot_lnl(RingSlot *s) { return s->data; }
 static inline double *slot_cube(const RingHeader *h, RingSlot *s) { return s->data + h->max_points; }
-static inline bool ring_pid_gone(int32_t pid) { return pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH; }
+// a process that no longer runs: no such pid, or a zombie (it has exited, its parent has not collected it yet --
+// kill(pid, 0) still succeeds for those; /proc/<pid>/stat says "Z" behind the command name)
+static inline bool ring_pid_gone(int32_t pid) {
+    if (pid <= 0) return false;
+    if (kill((pid_t)pid, 0) != 0 && errno == ESRCH) return true;
+    char path[64], buf[512];
+    snprintf(path, sizeof path, "/proc/%d/stat", (int)pid);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    const ssize_t n = read(fd, buf, sizeof buf - 1);
+    close(fd);
+    if (n <= 0) return false;
+    buf[n] = 0;
+    const char *q = strrchr(buf, ')');                        // the command name may hold anything, also ')'
+    return q && q[1] == ' ' && (q[2] == 'Z' || q[2] == 'X');
+}
 
 static inline long ring_futex(std::atomic<uint32_t> *word, int op, uint32_t val, const timespec *ts) {
     return syscall(SYS_futex, (uint32_t *)word, op, val, ts, nullptr, 0);      // shared (not _PRIVATE): across processes
@@ -99,6 +117,16 @@ static inline int64_t ring_now_us() {
     timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
     return (int64_t)t.tv_sec * 1000000 + t.tv_nsec / 1000;
+}
+
+// how long a client waits without any sign of a serving loop (NFA_RING_GRACE_MS in the environment overrides the default)
+static inline int64_t ring_grace_us() {
+    static const int64_t us = [] {
+        const char *e = getenv("NFA_RING_GRACE_MS");
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v > 0 ? v : NFA_RING_GRACE_MS) * 1000;
+    }();
+    return us;
 }
 
 static inline void ring_pause() {
@@ -245,7 +273,9 @@ int nfa_ring_stop(nfa_ring *r) {
 // call (k = 1: nfa_ring_loglike); a sampler that draws its next proposals independently of each other -- points
 // uniform in the current bounding ellipsoid are -- may post several and use them in order.
 // Returns NFA_ERR_STATE when the ring was stopped, when the process that created the ring is gone, or when no
-// serving loop has been on the ring for NFA_RING_GRACE_MS: a client never waits for a dead server.
+// serving loop has shown on the ring for NFA_RING_GRACE_MS -- neither a thread inside nfa_ring_serve nor the heartbeat
+// that nfa_ring_poll / nfa_ring_complete leave --: a client never waits for a dead server.  A request a server has
+// claimed is never timed out while the ring's creator lives (an evaluator may take as long as it likes over a batch).
 int nfa_ring_loglike_many(nfa_ring *r, int32_t pix, double *cubes, double *lnew, int k) {
     if (!r || !cubes || !lnew || r->slot < 0) return fail(NFA_ERR_ARG, "not an attached ring client");
     RingHeader *h = r->hdr;
@@ -276,10 +306,18 @@ int nfa_ring_loglike_many(nfa_ring *r, int32_t pix, double *cubes, double *lnew,
         // is anybody going to answer?  the creator's death ends the ring; no serving loop for a while does too
         const char *dead = nullptr;
         if (ring_pid_gone(h->server_pid)) dead = "the ring's server process is gone";
-        else if (h->n_servers.load(std::memory_order_acquire) == 0) {
+        else if (h->n_servers.load(std::memory_order_acquire) == 0 && s->state.load(std::memory_order_acquire) != RING_CLAIMED) {
+            // nobody inside nfa_ring_serve: a server built on nfa_ring_poll / nfa_ring_complete shows through the
+            // heartbeat those calls leave (it may take as long as it likes over a batch it has CLAIMED: a claimed
+            // request is never taken back while the ring's creator lives)
+            // (a ring nobody has served yet belongs to a server that is still starting -- its process lives, that was
+            // checked above --: twelve grace periods for that)
             const int64_t now = ring_now_us();
-            if (unserved_since < 0) unserved_since = now;
-            else if (now - unserved_since > (int64_t)NFA_RING_GRACE_MS * 1000) dead = "no serving loop on the ring";
+            const int64_t beat = h->last_serve_us.load(std::memory_order_acquire);
+            const int64_t grace = ring_grace_us() * (beat == 0 ? 12 : 1);
+            if (beat != 0 && now - beat <= grace) unserved_since = -1;
+            else if (unserved_since < 0) unserved_since = now;
+            else if (now - unserved_since > grace) dead = "no serving loop on the ring";
         } else unserved_since = -1;
         if (dead && s->state.load(std::memory_order_acquire) != RING_DONE) {
             uint32_t posted = RING_POSTED;                     // take the request back unless a server holds it
@@ -332,6 +370,7 @@ int nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, 
     int rows = 0, claimed = 0;                                 // points and requests this call has claimed so far
     for (int spin = 0;; ++spin) {
         if (h->stop.load(std::memory_order_acquire)) { if (stopped) *stopped = 1; return NFA_OK; }
+        if ((spin & 1023) == 0) h->last_serve_us.store(ring_now_us(), std::memory_order_release);     // heartbeat
         const uint32_t posts = h->posts.load(std::memory_order_acquire);
         for (int k = 0; k < h->n_slots && rows < max_batch; ++k) {
             uint32_t posted = RING_POSTED;
@@ -381,6 +420,7 @@ int nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms, 
 int nfa_ring_complete(nfa_ring *r, int n, const int32_t *slots, const double *U, const double *lnL, int rc) {
     if (!r || n < 0 || (n > 0 && (!slots || !U || !lnL))) return fail(NFA_ERR_ARG, "null argument");
     RingHeader *h = r->hdr;
+    h->last_serve_us.store(ring_now_us(), std::memory_order_release);          // heartbeat
     for (int k = 0; k < n;) {
         const int sl = slots[k];
         int np = 1;

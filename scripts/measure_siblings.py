@@ -54,7 +54,7 @@ def timed(runner, ndim, B=4096, steps=200, warmup=20):
 def main():
     rng = np.random.default_rng(1)
     n = 1024
-    for mode in ('fast', 'poly', 'table'):
+    for mode in ('fast', 'table'):
         na.set_exp_mode(mode)
         # N2H+ 1-0 + 2-1
         args = []

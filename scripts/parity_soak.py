@@ -20,7 +20,7 @@ import nestfit_amd as na                                   # noqa: E402
 from nestfit_amd.synth import freq_axis                    # noqa: E402
 from oracle import nfo                                     # noqa: E402
 
-BARS = {'table': (1e-11, 1e-11, 1e-8), 'poly': (1e-11, 1e-11, 1e-8), 'fast': (1e-6, 1e-6, 1e-6)}     # Tb, lnL at theta, lnL end to end
+BARS = {'table': (1e-11, 1e-11, 1e-8), 'fast': (1e-6, 1e-6, 1e-6)}     # Tb, lnL at theta, lnL end to end
 
 
 def main():

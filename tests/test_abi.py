@@ -41,6 +41,8 @@ def test_test_hooks_live_in_the_test_library_only():
     for n in _declared():
         assert hasattr(test_lib, n)                       # the test library is the whole engine plus the hooks
     assert product.nfa_set_option(b'ablate', 1) != 0      # the shipped library rejects the timing experiment key
+    assert product.nfa_set_exp_mode(1) != 0               # the polynomial likelihood mode is gone (0 table, 2 fast)
+    assert b'table' in product.nfa_last_error()
 
 
 def test_product_fails_loudly_without_gpu():

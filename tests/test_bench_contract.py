@@ -1,4 +1,4 @@
-"""bench.py as the driver runs it (short): ONE JSON line with the contract's keys, the three modes, the
+"""bench.py as the driver runs it (short): ONE JSON line with the contract's keys, the two modes, the
 roofline and -- with two ranks sharing the one GPU (`NFA_BENCH_SAME_GPU`, the rehearsal of `--gpus N`) --
 the whole-job value of two stripes."""
 import json
@@ -31,7 +31,7 @@ def test_default_line_has_the_contract_keys():
     assert d['n_gpus'] == 1 and d['steps'] == 6 and d['warmup'] == 2 and d['unit'] == 'evals/s'
     assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
     assert 'workload' in d['config'] and 'model' not in d['config']
-    assert set(d['modes']) == {'table', 'poly', 'fast'} and d['modes']['fast']['value'] == d['value']
+    assert set(d['modes']) == {'table', 'fast'} and d['modes']['fast']['value'] == d['value']
     r = d['roofline']
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert key in r, key
@@ -39,6 +39,18 @@ def test_default_line_has_the_contract_keys():
     # value = evaluations of the timed block / its time
     assert d['value'] == pytest.approx(4096 / (d['ms_per_step'] * 1e-3), rel=1e-6)
     assert d['modes']['table']['value'] < d['value']
+    # the like-for-like number (the reference's own f64 arithmetic) travels inside `roofline`, as a block and as flat keys
+    rp = r['reference_precision']
+    assert rp['mode'] == 'table' and rp['dtype'].startswith('f64') and rp['value'] == d['modes']['table']['value']
+    assert r['reference_precision_value'] == rp['value'] and 0 < r['reference_precision_frac'] < r['frac']
+    assert d['config']['reference_precision_value'] == rp['value']
+    # the spectra-out mode and the short C4 block of the default command
+    so = d['spectra_out']
+    assert so['algorithmic_bytes_per_eval'] == 16584 + 16384 and so['value'] > 0 and 0 < so['frac'] < 1
+    assert r['spectra_out_value'] == so['value']
+    c4 = d['configs']['C4']
+    assert c4['algorithmic_bytes_per_eval'] == 49448 and c4['table']['value'] < c4['fast']['value']
+    assert r['C4_fast_value'] == c4['fast']['value'] and r['C4_table_frac'] == c4['table']['roofline_frac']
 
 
 def test_two_ranks_on_one_gpu_report_the_whole_job():

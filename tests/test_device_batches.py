@@ -180,3 +180,44 @@ def test_predict_batch_writes_pinned_spectra_in_place(engine):
     peak, tot = run.peak_and_integrated(pix, theta)          # goes through a pinned scratch buffer of its own
     assert np.array_equal(peak[:, 0], np.nanmax(want_spec[:, :384], axis=1))
     np.testing.assert_allclose(tot[:, 1], np.nansum(want_spec[:, 384:], axis=1), rtol=1e-13)
+
+
+@pytest.mark.parametrize('mode', ['fast', 'table'])
+def test_predict_batch_dev_equals_the_host_call(engine, mode):
+    """nfa_runner_predict_batch_dev (theta, spectra, lnL in HBM; asynchronous, rotating over the lanes): the host
+    call's spectra and lnL bit for bit, theta untouched, with spectra only and with lnL only as well."""
+    from nestfit_amd import _ffi
+    from nestfit_amd.cube import CubeRunner
+    engine.set_exp_mode(mode)
+    rng = np.random.default_rng(21)
+    xarrs = [freq_axis(t, 320) for t in (1, 2)]
+    data = rng.normal(0, 0.2, (4, 640))
+    run = CubeRunner(xarrs, [1, 2], data, np.full((4, 2), 0.2), None, ncomp=2)
+    lib = _ffi.load()
+    dev = _DeviceArrays(lib, _ffi.check)
+    try:
+        calls = []
+        for rows in (256, 70, 1024):
+            theta = np.column_stack([rng.uniform(-2, 2, rows), rng.uniform(-2, 2, rows), rng.uniform(8, 20, rows), rng.uniform(8, 20, rows),
+                                     rng.uniform(3, 8, rows), rng.uniform(3, 8, rows), rng.uniform(13.5, 15, rows), rng.uniform(13.5, 15, rows),
+                                     rng.uniform(0.2, 1, rows), rng.uniform(0.2, 1, rows), rng.uniform(0, 0.5, rows), rng.uniform(0, 0.5, rows)])
+            pix = rng.integers(0, 4, rows).astype(np.int32)
+            want_spec, want_lnl = run.predict_batch(pix, theta)
+            d_t, d_p = dev.upload(theta), dev.upload(pix)
+            d_s, d_l, d_s2, d_l2 = dev.empty(rows * 640 * 8), dev.empty(rows * 8), dev.empty(rows * 640 * 8), dev.empty(rows * 8)
+            calls.append((rows, theta, want_spec, want_lnl, d_t, d_p, d_s, d_l, d_s2, d_l2))
+        for rows, theta, want_spec, want_lnl, d_t, d_p, d_s, d_l, d_s2, d_l2 in calls:     # all in flight together
+            _ffi.check(lib.nfa_runner_predict_batch_dev(run._run.handle, d_p, d_t, rows, d_s, d_l))
+            _ffi.check(lib.nfa_runner_predict_batch_dev(run._run.handle, d_p, d_t, rows, d_s2, None))
+            _ffi.check(lib.nfa_runner_predict_batch_dev(run._run.handle, d_p, d_t, rows, None, d_l2))
+        _ffi.check(lib.nfa_runner_synchronize(run._run.handle))
+        for rows, theta, want_spec, want_lnl, d_t, d_p, d_s, d_l, d_s2, d_l2 in calls:
+            assert np.array_equal(dev.download(d_s, want_spec), want_spec)
+            assert np.array_equal(dev.download(d_s2, want_spec), want_spec)
+            assert np.array_equal(dev.download(d_l, want_lnl), want_lnl)
+            assert np.array_equal(dev.download(d_l2, want_lnl), want_lnl)
+            assert np.array_equal(dev.download(d_t, theta), theta)
+        assert lib.nfa_runner_predict_batch_dev(run._run.handle, None, calls[0][4], 8, None, None) != 0     # nothing asked for
+    finally:
+        dev.free()
+        engine.set_exp_mode('fast')

@@ -24,17 +24,17 @@ def _exact_mode_unless_stated(engine):
     engine.set_exp_mode('fast')
 
 TB_RTOL = 1e-6          # north_star tolerance on floating-point Tb
-MODES = ['table', 'poly', 'fast']
+MODES = ['table', 'fast']
 # what each mode is expected to reach on Tb (pinned so that regressions show)
-TIGHT = {'table': 1e-11, 'poly': 1e-11, 'fast': 5e-7}
+TIGHT = {'table': 1e-11, 'fast': 5e-7}
 # relative tolerance on lnL / theta-dependent scalars per mode
-LNL_RTOL = {'table': 1e-9, 'poly': 1e-9, 'fast': 1e-6}
+LNL_RTOL = {'table': 1e-9, 'fast': 1e-6}
 # The reference evaluates 1 - FastExp(tau) as 1 - (1 - tau + ...): for tau below ~1e-9 its own
 # result is quantised at the 1e-7 .. 1e-4 relative level (1.1e-16 / tau).  The exact modes
 # reproduce tau to ~1e-16 and therefore that rounding; the fast mode (tau to ~1e-7) cannot, so
 # its per-channel check carries an absolute floor of a few quantisation steps of the reference,
 # T0 (y - tbg) 2^-53 ~ 1e-15 K (fifteen orders below the noise), next to the 1e-6 relative bar.
-TB_ATOL_K = {'table': 0.0, 'poly': 0.0, 'fast': 4e-15}
+TB_ATOL_K = {'table': 0.0, 'fast': 4e-15}
 
 
 def _test_fastexp(engine, x, mode):
@@ -72,7 +72,8 @@ def test_fastexp_table_mode_is_bit_identical(engine, nfo):
 
 def test_fastexp_golden_set_g1_on_device(engine):
     """The device against the reference's own outputs (tests/golden/g1_fastexp.npz, recorded from fastexp.c):
-    table mode bit for bit, polynomial mode to 1e-15, fast mode to 2e-7; exact zeros (x >= 32) in all three."""
+    table mode bit for bit, the set-up stage's polynomial form (test hook 'poly': nf_fastexp<1>, the fast mode's partition
+    sums) to 1e-15, the fast mode's fp32 form to 2e-7; exact zeros (x >= 32) in all three."""
     from pathlib import Path
     g = np.load(Path(__file__).parent / 'golden' / 'g1_fastexp.npz')
     x, want = g['x'].astype(np.float64), g['y']
@@ -88,7 +89,8 @@ def test_fastexp_golden_set_g1_on_device(engine):
         assert np.max(np.abs(got[ok] - w[ok]) / w[ok]) < tol
 
 
-def test_fastexp_poly_mode(engine, nfo):
+def test_fastexp_poly_form_of_the_setup_stage(engine, nfo):
+    """nf_fastexp<1>: what the fast mode's set-up stage evaluates its partition sums with (no likelihood mode of its own)."""
     x = _fastexp_inputs()
     got = _test_fastexp(engine, x, 'poly')
     want = nfo.fast_expn(x)
@@ -140,8 +142,8 @@ def test_iemtex_and_partition(engine, nfo):
     inside = (x > lo) & (x < hi)
     assert np.array_equal(out[inside].view(np.uint64), want[inside].view(np.uint64))  # same index, same lerp
     np.testing.assert_allclose(out[~inside], want[~inside], rtol=1e-15)               # expm1 branch
-    for mode in ('table', 'poly'):
-        _ffi.test_check(lib.nfa_set_exp_mode({'table': 0, 'poly': 1}[mode]))
+    for mode in ('table', 'fast'):               # fast: the set-up stage's polynomial form of the exponential
+        _ffi.test_check(lib.nfa_set_exp_mode({'table': 0, 'fast': 2}[mode]))
         trot = np.concatenate([np.linspace(3, 300, 500), [2.0, 7.0, 1000.0]])
         qp, qo = np.empty_like(trot), np.empty_like(trot)
         _ffi.test_check(lib.nfa_test_partition(_ffi.dptr(trot), _ffi.dptr(qp), _ffi.dptr(qo), trot.size))
@@ -638,7 +640,7 @@ def test_single_point_calls_replay_a_graph_and_match_batches(engine, nfo, mode):
             u = U[k].copy()
             assert run.loglikelihood(u) == want[k]
             assert np.array_equal(u, Ub[k])
-    other = 'poly' if mode != 'poly' else 'fast'
+    other = 'table' if mode != 'table' else 'fast'
     engine.set_exp_mode(other)
     u = U[3].copy()
     l_other = runs[1].loglikelihood(u)

@@ -444,3 +444,68 @@ def _gpu_client(name, rank, n_points, out, start):
         rows.append((u, theta, client.loglikelihood(theta)))
     client.close()
     out.put((rank, rows))
+
+
+def _patient_client(name, out):
+    client = RingClient(name, wait_ms=20000)
+    rows = []
+    for i in range(2):
+        u = np.full(NDIM, 0.125 * (i + 1))
+        theta = u.copy()
+        try:
+            rows.append((u, theta, client.loglikelihood(theta)))
+        except _ffi.EngineError as e:
+            rows.append(('error', str(e), i))
+    client.close()
+    out.put(rows)
+
+
+def test_a_slow_poll_complete_server_is_not_taken_for_dead(monkeypatch):
+    """A server built on nfa_ring_poll / nfa_ring_complete alone (never inside nfa_ring_serve, which is what the
+    serving-loop counter counts) that starts polling later than the clients' grace period, and then sits on a claimed
+    batch for longer than that period: the clients wait -- the heartbeat of poll / complete and the CLAIMED state tell
+    them a server is there (advisor finding of round 3).  The grace period is shortened to 0.4 s for the test."""
+    import time
+    monkeypatch.setenv('NFA_RING_GRACE_MS', '400')             # read by the client process at its first wait
+    name = f'nfa_test_ring_slow_{os.getpid()}'
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    with RingServer(name, n_slots=2, ndim=NDIM) as server:
+        p = ctx.Process(target=_patient_client, args=(name, out))
+        p.start()
+        time.sleep(1.5)                                        # the server's start-up: several grace periods, no poll yet
+        for held in (1.2, 0.0):                                # first batch: held (claimed) for three grace periods
+            slots, pix, U, stopped = server.poll(max_wait_us=2000, idle_ms=20000)
+            assert not stopped and slots.size == 1
+            time.sleep(held)
+            theta, lnl = _evaluate(pix.copy(), U.copy())
+            server.complete(slots, theta, lnl)
+        rows = out.get(timeout=60)
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for u, theta, lnl in rows:
+        assert not isinstance(u, str), (theta, lnl)
+        t, l = _evaluate(np.array([-1]), u[None, :])
+        assert np.array_equal(theta, t[0]) and lnl == l[0]
+
+
+def test_a_client_gives_up_on_a_server_that_went_quiet(monkeypatch):
+    """... and a server that HAS served and then stops polling (no claimed request in its hands) is given up on after
+    the grace period: the post comes back as an error instead of blocking for ever."""
+    import time
+    monkeypatch.setenv('NFA_RING_GRACE_MS', '300')
+    name = f'nfa_test_ring_quiet_{os.getpid()}'
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    with RingServer(name, n_slots=2, ndim=NDIM) as server:
+        p = ctx.Process(target=_patient_client, args=(name, out))
+        p.start()
+        slots, pix, U, stopped = server.poll(max_wait_us=2000, idle_ms=20000)
+        theta, lnl = _evaluate(pix.copy(), U.copy())
+        server.complete(slots, theta, lnl)                     # the first point is served, the second never polled
+        t0 = time.time()
+        rows = out.get(timeout=60)
+        assert time.time() - t0 < 20
+        p.join(timeout=60)
+    assert not isinstance(rows[0][0], str)
+    assert rows[1][0] == 'error' and 'no serving loop' in rows[1][1]

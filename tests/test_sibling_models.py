@@ -116,11 +116,11 @@ def test_host_mirror_metadata():
 
 
 # ---------------------------------------------------------------------------- GPU
-MODES = ['table', 'poly', 'fast']
+MODES = ['table', 'fast']
 TB_RTOL = 1e-6
-TB_ATOL_K = {'table': 0.0, 'poly': 0.0, 'fast': 4e-15}
-TIGHT = {'table': 1e-11, 'poly': 1e-11, 'fast': 5e-7}
-LNL_RTOL = {'table': 1e-9, 'poly': 1e-9, 'fast': 1e-6}
+TB_ATOL_K = {'table': 0.0, 'fast': 4e-15}
+TIGHT = {'table': 1e-11, 'fast': 5e-7}
+LNL_RTOL = {'table': 1e-9, 'fast': 1e-6}
 
 
 @pytest.fixture
