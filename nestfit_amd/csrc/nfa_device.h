@@ -544,6 +544,52 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
                  : "vcc");
 }
 
+// The staged product tables start at LDS address 0 (the kernels hold no static LDS; stage_exp_tables copies
+// g_tabs[SM_EXP2 ...] to smem[0 ...]): their byte offsets are instruction immediates.
+#define NFA_LDS_OFF_C ((SM_FEC - SM_EXP2) * 8)     //  2048
+#define NFA_LDS_OFF_B ((SM_FEB - SM_EXP2) * 8)     // 22528
+#define NFA_LDS_OFF_A ((SM_FEA - SM_EXP2) * 8)     // 43008
+#define NFA_STR2(x) #x
+#define NFA_STR(x) NFA_STR2(x)
+
+// FastExp's table product for the float X (its bits in a register), all lanes of EXEC: the three gathers issued, nothing
+// waited for.  u = bits - (122 << 23) holds l = exponent - 122 (fastexp.c:262) in bits 23..26 and (l, j0) = the A index
+// as its upper half-word; j1 and j2 are bytes 1 and 0 of the bits (fastexp.c:276-278).  Sub-dword operand selects do
+// the extractions inside the shifts: seven address instructions (round 3: nine -- a bit-field extract and a shift-add
+// per index).  A lane below 2^-5 (u negative; its value comes from the Taylor form) forms an A address far beyond the
+// workgroup's LDS: such a read returns nothing and faults nothing; its B and C addresses stay inside row 15's reach.
+#define NFA_TABLE_GATHER(X, G0, G1, G2)                                                                    \
+        "v_add_u32 %[t0], 0xc3000000, %[" #X "]\n\t"              /* bits - (122 << 23) */                 \
+        "v_lshlrev_b32_sdwa %[t1], 3, %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* (l, j0) * 8 */ \
+        "ds_read_b64 %[" #G0 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_A) "\n\t"                              \
+        "v_bfe_u32 %[t0], %[t0], 23, 4\n\t"                       /* row l of B and C */                   \
+        "v_lshlrev_b32_sdwa %[t1], 3, %[" #X "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" /* j1 * 8 */ \
+        "v_lshl_add_u32 %[t1], %[t0], 11, %[t1]\n\t"                                                       \
+        "ds_read_b64 %[" #G1 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_B) "\n\t"                              \
+        "v_lshlrev_b32_sdwa %[t1], 3, %[" #X "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" /* j2 * 8 */ \
+        "v_lshl_add_u32 %[t1], %[t0], 11, %[t1]\n\t"                                                       \
+        "ds_read_b64 %[" #G2 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_C) "\n\t"
+#define NFA_TABLE_LOOKUP(X, G0, G1, G2, NUC, ID)                                                           \
+        "v_add_f64 %[" #G0 "], %[xj], -%[" #NUC "]\n\t"                                                    \
+        "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #G0 "]\n\t"                                                 \
+        "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #ID "]\n\t"                                                 \
+        "v_cvt_f32_f64 %[" #X "], %[" #G0 "]\n\t"                 /* math.pxd:17 narrowing */             \
+        NFA_TABLE_GATHER(X, G0, G1, G2)
+// FastExp's Taylor form (fastexp.c:264-270: 1 - t (1 - t/2 (1 - t/3)), one IEEE operation per operation of the
+// reference) for the lanes in VCC.  The middle step 1 - (t ty) 0.5 is ONE fused multiply-add: a product with 0.5 is
+// exact, so fma(t ty, -0.5, 1) rounds once, where the reference's multiplication and subtraction round once too.
+#define NFA_TABLE_TAYLOR(X, G0, G1, G2, LBL)                                                               \
+        "s_cbranch_vccz " LBL "%=\n\t"                                                                     \
+        "s_mov_b64 exec, vcc\n\t"                                 /* (a subset of the window; SCC untouched) */ \
+        "v_cvt_f64_f32 %[" #G1 "], %[" #X "]\n\t"                                                          \
+        "v_mul_f64 %[" #G2 "], %[" #G1 "], %[nthird]\n\t"          /* 1 - t / 3 */                         \
+        "v_add_f64 %[" #G2 "], %[" #G2 "], 1.0\n\t"                                                        \
+        "v_mul_f64 %[" #G2 "], %[" #G2 "], %[" #G1 "]\n\t"         /* 1 - (t ty) / 2 */                    \
+        "v_fma_f64 %[" #G2 "], %[" #G2 "], -0.5, 1.0\n\t"                                                  \
+        "v_mul_f64 %[" #G1 "], %[" #G2 "], %[" #G1 "]\n\t"         /* 1 - t ty */                          \
+        "v_add_f64 %[" #G0 "], -%[" #G1 "], 1.0\n\t"                                                       \
+        LBL "%=:\n\t"
+
 // Two line x row steps of the table mode as one instruction block: both lines' FastExp arguments and table addresses
 // are formed and all six gathers issued before the first product is taken, each line under its own window as the
 // EXEC mask.  (Compiled from C++ the two steps of a pair run one after the other, each waiting for its own gathers:
@@ -555,41 +601,11 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
 // condition there across the block).
 __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj,
                                                 double nucA, double idA, double wA, float midA, float halfA,
-                                                double nucB, double idB, double wB, float midB, float halfB,
-                                                uint32_t base_a, uint32_t base_c) {
+                                                double nucB, double idB, double wB, float midB, float halfB) {
     float xA, xB;
     uint32_t t0, t1;
     double a0, a1, a2, b0, b1, b2;
     unsigned long long mA, mB;
-#define NFA_TABLE_LOOKUP(X, G0, G1, G2, NUC, ID)                                                           \
-        "v_add_f64 %[" #G0 "], %[xj], -%[" #NUC "]\n\t"                                                    \
-        "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #G0 "]\n\t"                                                 \
-        "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #ID "]\n\t"                                                 \
-        "v_cvt_f32_f64 %[" #X "], %[" #G0 "]\n\t"                 /* math.pxd:17 narrowing */             \
-        "v_add_u32 %[t0], 0xc3000000, %[" #X "]\n\t"              /* bits - (122 << 23) */                 \
-        "v_bfe_u32 %[t1], %[t0], 16, 11\n\t"                      /* l * 128 + j0, fastexp.c:276 */        \
-        "v_lshl_add_u32 %[t1], %[t1], 3, %[ba]\n\t"                                                        \
-        "ds_read_b64 %[" #G0 "], %[t1]\n\t"                                                                \
-        "v_bfe_u32 %[t0], %[t0], 23, 4\n\t"                       /* row l of B and C */                   \
-        "v_lshl_add_u32 %[t0], %[t0], 11, %[bc]\n\t"                                                       \
-        "v_bfe_u32 %[t1], %[" #X "], 8, 8\n\t"                    /* j1, fastexp.c:277 */                  \
-        "v_lshl_add_u32 %[t1], %[t1], 3, %[t0]\n\t"                                                        \
-        "ds_read_b64 %[" #G1 "], %[t1] offset:20480\n\t"          /* B sits 2560 doubles behind C */       \
-        "v_and_b32 %[t1], 0xff, %[" #X "]\n\t"                    /* j2, fastexp.c:278 */                  \
-        "v_lshl_add_u32 %[t1], %[t1], 3, %[t0]\n\t"                                                        \
-        "ds_read_b64 %[" #G2 "], %[t1]\n\t"
-#define NFA_TABLE_TAYLOR(X, G0, G1, G2, LBL)                                                               \
-        "s_cbranch_vccz " LBL "%=\n\t"                                                                     \
-        "s_mov_b64 exec, vcc\n\t"                                 /* (a subset of the window; SCC untouched) */ \
-        "v_cvt_f64_f32 %[" #G1 "], %[" #X "]\n\t"                                                          \
-        "v_mul_f64 %[" #G2 "], %[" #G1 "], %[nthird]\n\t"          /* 1 - t / 3 */                         \
-        "v_add_f64 %[" #G2 "], %[" #G2 "], 1.0\n\t"                                                        \
-        "v_mul_f64 %[" #G2 "], %[" #G2 "], %[" #G1 "]\n\t"         /* 1 - (t ty) / 2 */                    \
-        "v_mul_f64 %[" #G2 "], %[" #G2 "], -0.5\n\t"                                                       \
-        "v_add_f64 %[" #G2 "], %[" #G2 "], 1.0\n\t"                                                        \
-        "v_mul_f64 %[" #G1 "], %[" #G2 "], %[" #G1 "]\n\t"         /* 1 - t ty */                          \
-        "v_add_f64 %[" #G0 "], -%[" #G1 "], 1.0\n\t"                                                       \
-        LBL "%=:\n\t"
     asm volatile(
         "v_sub_f32 %[t0], %[jf], %[midA]\n\t"
         "v_cmp_lt_f32_e64 %[mA], |%[t0]|, %[halfA]\n\t"
@@ -625,10 +641,70 @@ __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj
           [mA] "=&s"(mA), [mB] "=&s"(mB)
         : [jf] "v"(jf), [xj] "v"(xj), [nucA] "v"(nucA), [idA] "v"(idA), [wA] "v"(wA), [midA] "v"(midA), [halfA] "v"(halfA),
           [nucB] "v"(nucB), [idB] "v"(idB), [wB] "v"(wB), [midB] "v"(midB), [halfB] "v"(halfB),
-          [ba] "s"(base_a), [bc] "s"(base_c), [nthird] "s"(-(1.0 / 3.0))
+          [nthird] "s"(-(1.0 / 3.0))
         : "vcc");
-#undef NFA_TABLE_LOOKUP
-#undef NFA_TABLE_TAYLOR
+}
+
+// One line x row step of the table mode (the odd line of a run), the same arithmetic.
+__device__ __forceinline__ void line_single_table(double &tau, float jf, double xj,
+                                                  double nucA, double idA, double wA, float midA, float halfA) {
+    float xA;
+    uint32_t t0, t1;
+    double a0, a1, a2;
+    unsigned long long mA;
+    asm volatile(
+        "v_sub_f32 %[t0], %[jf], %[midA]\n\t"
+        "v_cmp_lt_f32_e64 %[mA], |%[t0]|, %[halfA]\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        NFA_TABLE_LOOKUP(xA, a0, a1, a2, nucA, idA)
+        "v_cmp_gt_f32 vcc, 0x3d000000, %[xA]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_mul_f64 %[a0], %[a0], %[a1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_f64 %[a0], %[a0], %[a2]\n\t"
+        NFA_TABLE_TAYLOR(xA, a0, a1, a2, ".Lnfa_tps_")
+        "s_mov_b64 exec, %[mA]\n\t"
+        "v_fmac_f64 %[tau], %[wA], %[a0]\n\t"
+        "s_mov_b64 exec, -1"
+        : [tau] "+v"(tau), [xA] "=&v"(xA), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [mA] "=&s"(mA)
+        : [jf] "v"(jf), [xj] "v"(xj), [nucA] "v"(nucA), [idA] "v"(idA), [wA] "v"(wA), [midA] "v"(midA), [halfA] "v"(halfA),
+          [nthird] "s"(-(1.0 / 3.0))
+        : "vcc");
+}
+
+// 1 - FastExp(tau) for the Tb pass of the table mode (hyperfine.pyx:109-113), tau >= +0 or NaN, every lane of a full
+// EXEC: bit for bit 1.0 - nf_fastexp<0, true>(tau).  The Taylor form (fastexp.c:264-270) for every lane first -- in the
+// line wings, most rows, every lane is below 2^-5 and that is all there is --; the table product only when a lane of
+// the row needs it, ONE select between the two, and the exact zero from 32 on (and for NaN: fastexp.c:272-273) under a
+// branch of its own that optically thin rows never take.  (Round 3 went through the general nf_fastexp there: a second
+// Taylor evaluation and three more selects per pass.)
+__device__ __forceinline__ double one_minus_fastexp_table_row(double tau) {
+    const float x = (float)tau;                               // math.pxd:17 narrowing
+    const double t = (double)x;
+    double r = 1.0 - t * (1.0 / 3.0);                         // x == 0 gives exactly 1
+    r = __builtin_fma(t * r, -0.5, 1.0);                      // = 1 - (t r) 0.5: the product with 0.5 is exact
+    r = 1.0 - (t * r);
+    const int32_t u = (int32_t)(__float_as_uint(x) - (122u << 23));
+    const unsigned long long big = __builtin_amdgcn_sicmp(u, 0, 39 /* sge */);     // l >= 0: the table's range and beyond
+    if (big != 0ull) {
+        asm volatile("" ::: "memory");                        // keep it a branch
+        uint32_t t0, t1;
+        double a0, a1, a2;
+        asm volatile(NFA_TABLE_GATHER(x, a0, a1, a2)
+                     "s_waitcnt lgkmcnt(1)\n\t"
+                     "v_mul_f64 %[a0], %[a0], %[a1]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_mul_f64 %[a0], %[a0], %[a2]"
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2)
+                     : [x] "v"(x));
+        r = u >= 0 ? a0 : r;
+        if (__builtin_amdgcn_sicmp(u, (int32_t)(10u << 23), 39 /* sge */) != 0ull) {      // l >= 10: x >= 32, inf, NaN
+            asm volatile("" ::: "memory");
+            r = u >= (int32_t)(10u << 23) ? 0.0 : r;
+        }
+    }
+    return 1.0 - r;
 }
 
 // The body of the likelihood kernel for workgroup `block_id` of a launch (lnl_kernel: the hardware's
@@ -903,8 +979,14 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     int wi = c * G.nhf_max + first;
                     if (n & 1) {
                         const v2d ab = rec_ab(va);
-                        const v4i hw = rec_hw(va);
-                        step(ab, hw, wi);
+                        if constexpr (MODE == 0 && FWIN) {
+                            const v2d wm = rec_ab(va + 16);
+                            line_single_table(tau, jf, xj, ab.x, ab.y, wm.x, __int_as_float(__double2loint(wm.y)),
+                                              __int_as_float(__double2hiint(wm.y)));
+                        } else {
+                            const v4i hw = rec_hw(va);
+                            step(ab, hw, wi);
+                        }
                         va += 32;
                         asm volatile("" : "+v"(va));
                         wi += 1;
@@ -917,8 +999,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                             const v2d wm0 = rec_ab(va + 16), wm1 = rec_ab(va + 48);
                             line_pair_table(tau, jf, xj, ab0.x, ab0.y, wm0.x, __int_as_float(__double2loint(wm0.y)),
                                             __int_as_float(__double2hiint(wm0.y)), ab1.x, ab1.y, wm1.x,
-                                            __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)),
-                                            (uint32_t)(uintptr_t)(sm + SM_FEA), (uint32_t)(uintptr_t)(sm + SM_FEC));
+                                            __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)));
                         } else {
                             const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
                             step(ab0, hw0, wi);
@@ -988,10 +1069,10 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         // the product adds +0 there and needs no select
                         const double y = (HOISTX && NCOMP > 0) ? cx_xs[c] * (x - cx_xlo[c]) + cx_ylo[c]
                                                    : Dk[dko + DK_XS] * (x - Dk[dko + DK_XLO]) + Dk[dko + DK_YLO];
-                        pred += (T0 * (y - tbg)) * nf_one_minus_fastexp_row<MODE>((double)tau, sm);
+                        pred += (T0 * (y - tbg)) * (MODE == 0 ? one_minus_fastexp_table_row((double)tau) : nf_one_minus_fastexp_row<MODE>((double)tau, sm));
                     } else {
                         const double y = nf_iemtex(x, g_t0x, g_t0y, S.t0_xmin, S.t0_xmax, S.t0_inv_dx);
-                        const double tb = (T0 * (y - tbg)) * nf_one_minus_fastexp_row<MODE>((double)tau, sm);
+                        const double tb = (T0 * (y - tbg)) * (MODE == 0 ? one_minus_fastexp_table_row((double)tau) : nf_one_minus_fastexp_row<MODE>((double)tau, sm));
                         pred += !(tau == 0) ? tb : 0.0;
                     }
                 }

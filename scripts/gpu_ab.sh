@@ -6,11 +6,11 @@ rounds=$1; shift
 args=()
 while [ "$1" != "--" ]; do args+=("$1"); shift; done
 shift
-out=gpurun_out/r03/ab; mkdir -p $out
+out=gpurun_out/r04/ab; mkdir -p $out
 for r in $(seq $rounds); do
   for lib in "$@"; do
     tag=$(basename $lib .so)
-    NFA_ENGINE_LIB=$lib python bench.py --no-cpu-baseline --skip-single-step --modes one "${args[@]}" > $out/${tag}_$r.json 2>> $out/err.log || { tail -3 $out/err.log; exit 1; }
+    NFA_ENGINE_LIB=$lib python bench.py --no-cpu-baseline --skip-single-step --modes one --spectra-out off --configs off "${args[@]}" > $out/${tag}_$r.json 2>> $out/err.log || { tail -3 $out/err.log; exit 1; }
   done
 done
 python - "$@" <<'P'
@@ -18,7 +18,7 @@ import json, sys, glob, statistics as st
 for lib in sys.argv[1:]:
     tag = lib.split('/')[-1][:-3]
     v, k, s = [], [], []
-    for f in sorted(glob.glob(f'gpurun_out/r03/ab/{tag}_[0-9].json')):
+    for f in sorted(glob.glob(f'gpurun_out/r04/ab/{tag}_[0-9].json')):
         d = json.loads(open(f).read().strip().splitlines()[-1])
         m = d['modes'][d['config']['exp_mode']]
         v.append(d['value'] / 1e6); k.append(m.get('lnl_kernel_us', 0)); s.append(m.get('setup_kernel_us', 0))
