@@ -92,6 +92,8 @@ int nfa_get_exp_mode(void);
  *                   dimensions, 2 above (the numpy twin takes `walk_factor=`: the two must agree to run alike);
  *   "sampler_walkers"     walkers per pixel of a walk cycle, 64 / 128 / 192 / 256; 0 (default): by the live points
  *                   (128 from 384, 256 from 768);
+ *   "sampler_frames"      rotated box frames of a one-ellipsoid bound (nfa_sampler_set_boxes): -2 (default) and -1
+ *                   none, 0..64; "sampler_margin_pct": the boxes' margin factor in hundredths (0 = 175);
  *   "sampler_refit_every" rejection-mode pixels refit their bound in rounds that are multiples of this (default 4);
  *                   the sampler_* keys are read when a sampler is created / begun, A/B knobs like the rest;
  *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid; the
@@ -347,6 +349,14 @@ int nfa_sampler_set_pixel_nlive(nfa_sampler *s, const int32_t *nlive, const int6
  * (mmodal = False), 2..4 = clusters of live points get ellipsoids of their own where at most six dimensions are
  * sampled, 0 = the default (4 there, 1 above). */
 int nfa_sampler_set_ellipsoids(nfa_sampler *s, int max_ellipsoids);
+/* Free rejections of a one-ellipsoid bound (between create and begin).  Above six sampled dimensions no ellipsoid bounds
+ * the live region of a fit well; but every superset of the region may veto a proposal before its likelihood is evaluated:
+ * the bounding boxes of the live points in the unit cube's axes, in the ellipsoid's own frame and in n_frames fixed
+ * rotations of it (-2: the default = none; -1: none; 0..64, 32 being the measured choice).  margin: a face lies
+ * beyond the extreme live point by margin * max(0.1 s, extreme - mean - 1.5 s), s the spread along its direction
+ * (0: the default, 1.75).  MultiNest has no counterpart; `efr` keeps its meaning for the ellipsoid the proposals are drawn
+ * from (nestfit/core/core.pyx:727-732). */
+int nfa_sampler_set_boxes(nfa_sampler *s, int n_frames, double margin);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
 /* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the

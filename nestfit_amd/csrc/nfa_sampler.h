@@ -59,6 +59,20 @@ __host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t
 static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for up to six sampled dimensions");
 #define NS_B_ELL 253ull            // random-stream slots of a proposal: which ellipsoid, and the 1 / (number that hold it) test
 #define NS_B_KEEP 254ull
+// Free rejections of a one-ellipsoid bound: a proposal outside the bounding box of the live points -- in the unit cube's
+// axes, in the ellipsoid's own (Cholesky) frame, or in one of NS_FRAMES fixed rotations of that frame -- is dropped before
+// its likelihood is evaluated.  Every box holds the live region, so what passes is uniform over the intersection.  A face
+// lies beyond the extreme live point by c max(0.1 s, extreme - mean - 1.5 s), s = the spread along the face's direction:
+// small where the marginal ends abruptly (a flat direction), large where it thins out (the projection of a round body).
+// scripts/proto_intersection.py measured what each family of bounds cuts off the true region and what it saves; the
+// numpy twin's _fit_boxes / _box_veto hold the same arithmetic.
+#define NS_FRAMES 32               // rotated frames a caller gets who asks for boxes without naming a number
+#define NS_FRAMES_MAX 64
+#define NS_MARGIN_C 1.75
+#define NS_MARGIN_A 1.5
+#define NS_MARGIN_FLOOR 0.1
+#define NS_RATIO_MAX 8             // proposals drawn per round: at most this multiple of the evaluations aimed for
+#define NS_FRAME_SEED 0x5EEDF00Dull
 #define NS_WALK_LOWD 6             // up to this many sampled dimensions ...
 #define NS_WALK_FACTOR_LOWD 64     // ... the switch to walks waits for an acceptance below 1 / (64 n_steps)
 #define NS_WALK_FACTOR 2           // above: 1 / (2 n_steps)
@@ -117,7 +131,40 @@ struct NsDev {
     const int  *nlive;                  // [P]
     const long *capp;                   // [P]
     const int  *updp;                   // [P]
+    // free rejections by boxes (one-ellipsoid bounds whose live points are staged in LDS)
+    int     boxes, n_frames;            // on / off; rotated frames beside the unit cube's axes and the ellipsoid's own
+    double  margin_c;
+    const double *frames;               // [n_frames][D][D]: column b of frame k = direction of its coordinate b
+    double *ubox;                       // [P][D][2] box in the unit cube's axes
+    double *fbox;                       // [P][n_frames + 1][D][2] boxes around zz = A^-1 (u - c): frame 0 = the Cholesky frame itself
+    // what a pixel's rejection rounds did since the last decision point (every n_steps rounds): candidates scanned and
+    // accepted, proposals drawn and evaluated; ln of the last window's evaluated / drawn when the pixel turned to walks
+    long   *rj_scan, *rj_acc, *rj_raw, *rj_val;   // [P]
+    double *ln_pass;                    // [P]
 };
+
+// The fixed frames (host; the twin's _frames): entries 2 u - 1 from the counter-based stream, columns orthonormalised one
+// after the other (modified Gram-Schmidt).
+static void ns_make_frames(int D, int K, std::vector<double> &Q) {
+    Q.assign((size_t)K * D * D, 0.0);
+    std::vector<double> v((size_t)D);
+    for (int k = 0; k < K; ++k) {
+        double *q = Q.data() + (size_t)k * D * D;
+        for (int b = 0; b < D; ++b) {
+            for (int a = 0; a < D; ++a) v[a] = 2.0 * ns_uniform(NS_FRAME_SEED, (uint64_t)(k + 1), (uint64_t)a, (uint64_t)b) - 1.0;
+            for (int c = 0; c < b; ++c) {
+                double dot = 0.0;
+                for (int a = 0; a < D; ++a) dot += q[a * D + c] * v[a];
+                for (int a = 0; a < D; ++a) v[a] -= dot * q[a * D + c];
+            }
+            double n2 = 0.0;
+            for (int a = 0; a < D; ++a) n2 += v[a] * v[a];
+            const double inv = 1.0 / sqrt(n2);
+            for (int a = 0; a < D; ++a) q[a * D + b] = v[a] / sqrt(n2);
+            (void)inv;
+        }
+    }
+}
 __device__ __forceinline__ int  ns_n(const NsDev &S, int p)   { return S.nlive ? S.nlive[p] : S.N; }
 __device__ __forceinline__ long ns_cap(const NsDev &S, int p) { return S.capp ? S.capp[p] : S.cap; }
 __device__ __forceinline__ int  ns_upd(const NsDev &S, int p) { return S.updp ? S.updp[p] : S.upd; }
@@ -144,13 +191,40 @@ __global__ void ns_sanitize_kernel(double *__restrict__ L, long n, double log_ze
     if (gid < n) { const double v = L[gid]; L[gid] = isfinite(v) ? v : log_zero; }
 }
 
+// Is the proposal x (zz = its coordinates in the ellipsoid's frame, A^-1 (x - c)) inside every box of pixel p?  The tests
+// in order of their price: the unit cube's axes, the ellipsoid's frame, then the rotated frames, each a D x D product
+// that the first failure cuts short.
+template <int DD>
+__device__ __forceinline__ bool ns_in_boxes(const NsDev &S, int p, const double *x, const double *zz) {
+    const int D = DD > 0 ? DD : S.D;
+    const double *ub = S.ubox + (long)p * D * 2;
+    bool ok = true;
+    for (int j = 0; j < D; ++j) ok = ok && (x[j] >= ub[2 * j]) && (x[j] <= ub[2 * j + 1]);
+    if (!ok) return false;
+    const double *fb = S.fbox + (long)p * (S.n_frames + 1) * D * 2;
+    for (int j = 0; j < D; ++j) ok = ok && (zz[j] >= fb[2 * j]) && (zz[j] <= fb[2 * j + 1]);
+    for (int k = 1; k <= S.n_frames && ok; ++k) {
+        const double *Q = S.frames + (long)(k - 1) * D * D;
+        fb += D * 2;
+        for (int j = 0; j < D; ++j) {
+            double w = 0.0;
+            for (int a = 0; a < D; ++a) w += zz[a] * Q[a * D + j];
+            ok = ok && (w >= fb[2 * j]) && (w <= fb[2 * j + 1]);
+        }
+    }
+    return ok;
+}
+
 // ---- candidates --------------------------------------------------------------------------
 // Kr = candidates per pixel in this round (>= K: grows when few pixels are left, so the tail of
 // slow pixels does not cost one launch per handful of candidates)
+// DD > 0: the number of sampled dimensions at compile time (loops unroll, the proposal's coordinates live in registers)
+template <int DD>
 __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_act, int Kr) {
+    constexpr int DM = DD > 0 ? DD : NS_MAXD;
     const int q = (int)(gid / Kr), k = (int)(gid - (long)q * Kr);
     const int p = S.actlist[q];
-    const int D = S.D;
+    const int D = DD > 0 ? DD : S.D;
     double *cu = S.candU + gid * D;
     if (!S.active[p]) {                 // finished since the last compaction of the pixel list
         S.valid[gid] = 0;
@@ -197,9 +271,20 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
             cu[j] = v;
         }
     } else if (!walking && S.use_cube[p]) {    // early on the bounding ellipsoid is no better than the prior itself
-        for (int j = 0; j < D; ++j) cu[j] = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)j);
+        double x[DM];
+        for (int j = 0; j < D; ++j) { x[j] = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)j); cu[j] = x[j]; }
+        if (S.boxes) {                         // the boxes hold the live region whatever the proposal was drawn from
+            const double *c = S.centre + (long)p * NS_ME * D, *A = S.axes + (long)p * NS_ME * D * D;
+            double zz[DM];
+            for (int j = 0; j < D; ++j) {       // zz = A^-1 (x - c)
+                double v = x[j] - c[j];
+                for (int i = 0; i < j; ++i) v -= A[j * D + i] * zz[i];
+                zz[j] = v / A[j * D + j];
+            }
+            ok = ns_in_boxes<DD>(S, p, x, zz);
+        }
     } else {
-        double z[NS_MAXD];
+        double z[DM];
         double n2 = 0.0;
         for (int m = 0; m < D; m += 2) {    // Box-Muller pairs
             const double u1 = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)m);
@@ -226,20 +311,24 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
             }
         }
         const double *c = S.centre + ((long)p * NS_ME + ke) * D, *A = S.axes + ((long)p * NS_ME + ke) * D * D;
+        double x[DM];
+        for (int i = 0; i < D; ++i) z[i] *= f;                // the point of the unit ball
         for (int j = 0; j < D; ++j) {
             double v = c[j];
-            for (int i = 0; i <= j; ++i) v += A[j * D + i] * (z[i] * f);
+            for (int i = 0; i <= j; ++i) v += A[j * D + i] * z[i];
             ok = ok && (v >= 0.0) && (v < 1.0);               // outside the unit cube = outside the prior
+            x[j] = v;
             cu[j] = v;
         }
+        if (ok && S.boxes) ok = ns_in_boxes<DD>(S, p, x, z);   // (one ellipsoid: the ball point IS A^-1 (x - c))
         if (ok && ne > 1) {
             int q = 1;
             for (int k = 0; k < ne; ++k) {
                 if (k == ke) continue;
                 const double *ck = S.centre + ((long)p * NS_ME + k) * D, *Ak = S.axes + ((long)p * NS_ME + k) * D * D;
-                double y[NS_MAXD], s2 = 0.0;
+                double y[DM], s2 = 0.0;
                 for (int j = 0; j < D; ++j) {
-                    double v = cu[j] - ck[j];
+                    double v = x[j] - ck[j];
                     for (int i = 0; i < j; ++i) v -= Ak[j * D + i] * y[i];
                     y[j] = v / Ak[j * D + j];
                     s2 += y[j] * y[j];
@@ -268,9 +357,10 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
     for (int j = 0; j < D; ++j) ct[S.fmap[j]] = cu[j];
 }
 
+template <int DD>
 __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < (long)n_act * Kr) ns_propose_one(S, gid, n_act, Kr);
+    if (gid < (long)n_act * Kr) ns_propose_one<DD>(S, gid, n_act, Kr);
 }
 
 // One thread behind a proposing launch: the number of compact rows and the round's sequence number go into host
@@ -389,17 +479,44 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         }
     }
     wave_lds_sync();
-    double r2 = 0.0;
+    const bool boxes = S.boxes && sd;
+    if (boxes) {
+        // the box in the unit cube's own axes (the centred points are still in LDS): lanes = dimensions
+        for (int j = lane; j < D; j += 64) {
+            double lo = INFINITY, hi = -INFINITY, acc = 0.0;
+            for (int i = 0; i < N; ++i) {
+                const double d = sd[i * D + j];
+                lo = fmin(lo, d); hi = fmax(hi, d); acc += d * d;
+            }
+            const double sg = sqrt(acc / (N - 1));
+            double *ub = S.ubox + ((long)p * D + j) * 2;
+            ub[0] = sc[j] + lo - S.margin_c * fmax(NS_MARGIN_FLOOR * sg, -lo - NS_MARGIN_A * sg);
+            ub[1] = sc[j] + hi + S.margin_c * fmax(NS_MARGIN_FLOOR * sg, hi - NS_MARGIN_A * sg);
+        }
+        wave_lds_sync();
+    }
+    double r2 = 0.0, ssq = 0.0;
     for (int i = lane; i < N; i += 64) {           // y = L^-1 (u_i - c), forward substitution
-        double y[NS_MAXD];
         double s2 = 0.0;
-        for (int a = 0; a < D; ++a) {
-            double v = sd ? sd[i * D + a] : U[(long)i * D + a] - sc[a];
-            for (int k = 0; k < a; ++k) v -= sA[a * D + k] * y[k];
-            y[a] = v / sA[a * D + a];
-            s2 += y[a] * y[a];
+        if (boxes) {                               // in place: the boxes below want every point's y
+            for (int a = 0; a < D; ++a) {
+                double v = sd[i * D + a];
+                for (int k = 0; k < a; ++k) v -= sA[a * D + k] * sd[i * D + k];
+                v /= sA[a * D + a];
+                sd[i * D + a] = v;
+                s2 += v * v;
+            }
+        } else {
+            double y[NS_MAXD];
+            for (int a = 0; a < D; ++a) {
+                double v = sd ? sd[i * D + a] : U[(long)i * D + a] - sc[a];
+                for (int k = 0; k < a; ++k) v -= sA[a * D + k] * y[k];
+                y[a] = v / sA[a * D + a];
+                s2 += y[a] * y[a];
+            }
         }
         r2 = fmax(r2, s2);
+        ssq += s2;
     }
     r2 = ns_wave_max(r2);
     // the covariance ellipsoid scaled to enclose every live point, then MultiNest's rule: enlarged
@@ -417,6 +534,37 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         A[e] = b <= a ? sA[e] * scale : 0.0;
     }
     for (int j = lane; j < D; j += 64) c[j] = sc[j];
+    if (boxes) {
+        // zz = A^-1 (u - c) = y / scale: the live points in the frame a proposal is drawn in (its unit-ball point);
+        // their boxes in that frame and in the fixed rotations of it.  lanes = points, one (frame, coordinate) at a time
+        const double inv = 1.0 / scale;
+        ssq = ns_wave_sum(ssq);
+        const double sz = sqrt(ssq * inv * inv / ((double)(N - 1) * D));     // the spread of zz, the same in every direction
+        const double mfloor = NS_MARGIN_FLOOR * sz, moff = NS_MARGIN_A * sz;
+        for (int k = 0; k <= S.n_frames; ++k) {
+            const double *Q = S.frames + (long)(k - 1) * D * D;
+            for (int j = 0; j < D; ++j) {
+                double lo = INFINITY, hi = -INFINITY;
+                for (int i = lane; i < N; i += 64) {
+                    double w;
+                    if (k == 0) {
+                        w = sd[i * D + j] * inv;
+                    } else {
+                        w = 0.0;
+                        for (int a = 0; a < D; ++a) w += (sd[i * D + a] * inv) * Q[a * D + j];
+                    }
+                    lo = fmin(lo, w); hi = fmax(hi, w);
+                }
+                hi = ns_wave_max(hi);
+                lo = -ns_wave_max(-lo);
+                if (lane == 0) {
+                    double *fb = S.fbox + (((long)p * (S.n_frames + 1) + k) * D + j) * 2;
+                    fb[0] = lo - S.margin_c * fmax(mfloor, -lo - moff);
+                    fb[1] = hi + S.margin_c * fmax(mfloor, hi - moff);
+                }
+            }
+        }
+    }
     wave_lds_sync();
 }
 
@@ -707,7 +855,8 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
             acc_sum = 0; tot_sum = 0; next_step = 0;
             // back to rejection sampling once the bound promises clearly more than a walk delivers:
             // expected acceptance X / min(V_ellipsoid, 1) > 4 / n_steps
-            if (lane == 0 && S.method == 1 && (-(double)it / N - fmin(S.lnvol[p], 0.0)) > log(8.0 / ((double)S.walk_factor * S.n_steps))) S.walk[p] = 0;
+            // (with boxes the bound is the ellipsoid's share that passes them: ln_pass, measured before the pixel left)
+            if (lane == 0 && S.method == 1 && (-(double)it / N - fmin(S.lnvol[p] + S.ln_pass[p], 0.0)) > log(8.0 / ((double)S.walk_factor * S.n_steps))) S.walk[p] = 0;
         }
         if (lane == 0) {
             if (step == 0) { S.wLthr[p] = Lthr; S.wW[p] = W; }
@@ -717,7 +866,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         // ---- rejection sampling: every candidate of the round is used: within a round the bound only
         // goes stale by the factor exp(-replacements / N) in volume, far cheaper than throwing evaluated
         // points away.  The proposals are walked 64 at a time; only the valid ones cost anything.
-        long scanned = 0, accepted = 0;
+        long scanned = 0, accepted = 0, n_valid = 0;
         for (int kb = 0; kb < K && !done; kb += 512) {
             // validity flags of 512 proposals at a time: eight independent loads per lane, so that a
             // round of 16 k proposals costs 32 memory latencies, not 256
@@ -732,6 +881,7 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
                 const bool v = kk < K && S.valid[(long)q * K + kk] != 0;
                 masks[u] = __ballot(v);
                 rows[u] = v ? S.slot[(long)q * K + kk] : 0;
+                n_valid += __builtin_popcountll(masks[u]);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -759,9 +909,18 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         // Walk cycles of all pixels are kept in phase (they start at rounds that are multiples of
         // n_steps): the expensive cycle end then falls into the same launch for everybody instead of
         // making every launch wait for somebody's.
-        if (lane == 0 && !done && (round + 1) % S.n_steps == 0 &&
-            (S.method == 2 || (S.method == 1 && scanned >= 64 && S.walk_factor * accepted * S.n_steps < scanned))) {
-            S.walk[p] = 1; S.wstep[p] = 0; S.wscale[p] = 1.0; S.wacc_sum[p] = 0; S.wtot_sum[p] = 0;
+        // The decision looks at all rejection rounds since the last decision point: one round of a few hundred
+        // candidates is noise (a pixel that a single unlucky round sent to the walks stayed there for thousands of rounds).
+        if (lane == 0) {
+            long ws = S.rj_scan[p] + scanned, wa = S.rj_acc[p] + accepted, wr = S.rj_raw[p] + K, wv = S.rj_val[p] + n_valid;
+            if ((round + 1) % S.n_steps == 0) {
+                if (!done && (S.method == 2 || (S.method == 1 && ws >= 64 && S.walk_factor * wa * S.n_steps < ws))) {
+                    S.walk[p] = 1; S.wstep[p] = 0; S.wscale[p] = 1.0; S.wacc_sum[p] = 0; S.wtot_sum[p] = 0;
+                    S.ln_pass[p] = S.boxes ? log((double)(wv > 1 ? wv : 1) / (double)(wr > 1 ? wr : 1)) : 0.0;
+                }
+                ws = 0; wa = 0; wr = 0; wv = 0;
+            }
+            S.rj_scan[p] = ws; S.rj_acc[p] = wa; S.rj_raw[p] = wr; S.rj_val[p] = wv;
         }
     }
     if (lane == 0) {
@@ -836,6 +995,11 @@ struct nfa_sampler {
     int *d_pixmap = nullptr, *d_actlist = nullptr, *d_livepix = nullptr, *d_fmap = nullptr;
     int *d_nlive = nullptr, *d_updp = nullptr;
     long *d_capp = nullptr;
+    double *d_frames = nullptr;
+    int set_frames = -2;        // nfa_sampler_set_boxes: -2 = the default (NS_FRAMES above NS_ME_MAXD sampled dimensions), -1 = no boxes
+    double set_margin = 0.0;    // ... 0 = the default
+    size_t k_alloc = 0;         // proposal rows allocated per pixel
+    long raw_sum = 0, val_sum = 0;   // proposals drawn / evaluated since the last look at the active pixels
     std::vector<int> h_nlive;   // per-pixel live points (empty: d.N for everybody)
     int max_ell = 0;            // nfa_sampler_set_ellipsoids (0: the default)
     std::vector<int> h_active, h_act;
@@ -856,7 +1020,8 @@ int nfa_sampler_destroy(nfa_sampler *s) {
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
                     d.since_fit, d.refit_due, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol, d.elnv, d.nell,
-                    s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap, s->d_nlive, s->d_updp, s->d_capp};
+                    s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap, s->d_nlive, s->d_updp, s->d_capp,
+                    s->d_frames, d.ubox, d.fbox, d.rj_scan, d.rj_acc, d.rj_raw, d.rj_val, d.ln_pass};
     for (void *p : ptrs) (void)hipFree(p);
     if (s->h_pub) (void)hipHostFree(s->h_pub);
     delete s;
@@ -889,8 +1054,10 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     d.P = (int)n_pix; d.N = nlive; d.D = (int)fm.size(); d.DT = r->ndim; d.K = n_cand; d.cap = (long)cap_iter;
     const size_t P = (size_t)n_pix, N = (size_t)nlive, D = fm.size(), DT = (size_t)r->ndim, C = (size_t)cap_iter;
     s->b_target = std::max<long>((long)n_pix * n_cand, (long)batch_target);
-    // rows of the candidate buffers: n_act * Kr <= max(b_target, n_act * K) <= b_target
-    const size_t K = ((size_t)s->b_target + P - 1) / P;       // so that P * K >= b_target
+    // rows of the candidate buffers: n_act * Kr <= max(b_target, n_act * K) <= b_target -- times NS_RATIO_MAX where boxes
+    // may veto proposals for free (one-ellipsoid bounds: more than NS_ME_MAXD sampled dimensions, or on request)
+    const size_t K = ((size_t)s->b_target * NS_RATIO_MAX + P - 1) / P;       // so that P * K >= NS_RATIO_MAX * b_target
+    s->k_alloc = K;
     std::vector<int> pm(P);
     for (size_t p = 0; p < P; ++p) pm[p] = pix ? pix[p] : 0;
 #define NS_ALLOC(ptr, type, count) \
@@ -912,6 +1079,10 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     d.w_stride = d.w_fixed > 0 ? d.w_fixed : ns_walkers_for(N);      // (a pixel's own count can only be smaller than N)
     NS_ALLOC(d.wU, double, P * d.w_stride * D); NS_ALLOC(d.wT, double, P * d.w_stride * DT); NS_ALLOC(d.wL, double, P * d.w_stride);
     NS_ALLOC(d.wnacc, int, P * d.w_stride); NS_ALLOC(d.lnvol, double, P);
+    NS_ALLOC(d.ubox, double, P * D * 2); NS_ALLOC(d.fbox, double, P * (NS_FRAMES_MAX + 1) * D * 2);
+    NS_ALLOC(d.rj_scan, long, P); NS_ALLOC(d.rj_acc, long, P); NS_ALLOC(d.rj_raw, long, P); NS_ALLOC(d.rj_val, long, P);
+    NS_ALLOC(d.ln_pass, double, P);
+    NS_ALLOC(s->d_frames, double, (size_t)NS_FRAMES_MAX * D * D);
 #undef NS_ALLOC
     HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_fmap, fm.data(), sizeof(int) * D, hipMemcpyHostToDevice));
@@ -946,6 +1117,17 @@ int nfa_sampler_set_pixel_nlive(nfa_sampler *s, const int32_t *nlive, const int6
     HIP_TRY(hipMemcpy(s->d_capp, hc.data(), sizeof(long) * P, hipMemcpyHostToDevice));
     d.nlive = s->d_nlive; d.updp = s->d_updp; d.capp = s->d_capp;
     s->h_nlive = hn;
+    return NFA_OK;
+}
+
+// Free rejections by boxes (one-ellipsoid bounds): n_frames rotated frames beside the unit cube's axes and the ellipsoid's
+// own (-2: the default -- none; -1: no boxes; 0..64; NS_FRAMES = 32 is the measured choice), margin = the
+// factor c of a face's distance beyond the extreme live point (0: the default, NS_MARGIN_C).  Before nfa_sampler_begin.
+int nfa_sampler_set_boxes(nfa_sampler *s, int n_frames, double margin) {
+    if (!s || n_frames < -2 || n_frames > NS_FRAMES_MAX || !(margin >= 0.0) || margin > 100.0) return fail(NFA_ERR_ARG, "boxes: frames -2 (default), -1 (none) .. 64; margin >= 0");
+    if (s->ran) return fail(NFA_ERR_STATE, "call nfa_sampler_set_boxes before nfa_sampler_begin");
+    s->set_frames = n_frames;
+    s->set_margin = margin;
     return NFA_OK;
 }
 
@@ -989,6 +1171,11 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemsetAsync(d.wstep, 0, sizeof(int) * P, st));
     HIP_TRY(hipMemsetAsync(d.wacc_sum, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.wtot_sum, 0, sizeof(long) * P, st));
+    HIP_TRY(hipMemsetAsync(d.rj_scan, 0, sizeof(long) * P, st));
+    HIP_TRY(hipMemsetAsync(d.rj_acc, 0, sizeof(long) * P, st));
+    HIP_TRY(hipMemsetAsync(d.rj_raw, 0, sizeof(long) * P, st));
+    HIP_TRY(hipMemsetAsync(d.rj_val, 0, sizeof(long) * P, st));
+    HIP_TRY(hipMemsetAsync(d.ln_pass, 0, sizeof(double) * P, st));
     {   // live points
         const long tot = (long)P * N;
         hipLaunchKernelGGL(ns_init_live_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, s->d_livepix);
@@ -1020,6 +1207,22 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     d.max_ell = s->max_ell > 0 ? s->max_ell : (g_eng.sampler_ellipsoids == 1 ? 1 : NS_ME);
     d.multi = (d.stage_live && D <= NS_ME_MAXD && d.max_ell > 1) ? 1 : 0;
     if (d.multi) s->lds_refit += sizeof(double) * (size_t)((NS_ME + 2) * ns_me_slot(D)) + sizeof(int) * (size_t)((N + 3) & ~3);   // ... fit slots, labels
+    {   // free rejections by boxes: one-ellipsoid bounds whose live points are staged in LDS
+        // (off unless asked for: on BASELINE config 5 the boxes save a quarter of the evaluations of the two-component runs
+        // and cost more than that in longer rounds -- DESIGN section 10; a bright pixel alone needs a third of the walks' evaluations)
+        int nf = s->set_frames != -2 ? s->set_frames : g_eng.sampler_frames != -2 ? g_eng.sampler_frames : -1;
+        d.boxes = (!d.multi && d.stage_live && nf >= 0) ? 1 : 0;
+        d.n_frames = d.boxes ? nf : 0;
+        d.margin_c = s->set_margin > 0.0 ? s->set_margin : g_eng.sampler_margin_pct > 0 ? 0.01 * g_eng.sampler_margin_pct : NS_MARGIN_C;
+        if (d.boxes && d.n_frames > 0) {
+            std::vector<double> Q;
+            ns_make_frames(D, d.n_frames, Q);
+            HIP_TRY(hipMemcpyAsync(s->d_frames, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));                   // (Q goes out of scope)
+        }
+        d.frames = s->d_frames;
+        s->raw_sum = s->val_sum = 0;
+    }
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));
     if (s->lds_refit > 64 * 1024)
@@ -1058,7 +1261,11 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
     for (int64_t chunk = 0; s->n_act > 0 && (max_chunks <= 0 || chunk < max_chunks); ++chunk) {
         // candidates per pixel: the round's batch stays near b_target however few pixels are left
         const int n_act = s->n_act;
-        const int Kr = (int)std::min<long>(NS_KMAX, std::max<long>(K, s->b_target / n_act));
+        // with boxes most proposals are vetoed for free: so many more are drawn that a round still evaluates ~b_target
+        long ratio = 1;
+        if (d.boxes && s->raw_sum > 0) ratio = std::min<long>(NS_RATIO_MAX, std::max<long>(1, (s->raw_sum + s->val_sum / 2) / std::max<long>(s->val_sum, 1)));
+        s->raw_sum = s->val_sum = 0;
+        const int Kr = (int)std::min<long>(NS_KMAX, std::max<long>(K, (s->b_target * ratio) / n_act));    // (n_act * Kr rows <= NS_RATIO_MAX * b_target: what nfa_sampler_create allocated)
         int n_pix_h[NS_PARTS];
         NsDev dh[NS_PARTS];
         {   // every part works on its own slices of the proposal / compact-row buffers
@@ -1079,11 +1286,17 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                 if (n_pix_h[h] == 0) continue;
                 hipStream_t st = r->lanes[h];
                 const long B = (long)n_pix_h[h] * Kr;
-                hipLaunchKernelGGL(ns_propose_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr);
+                switch (D) {                                        // compile-time dimensions where they are common
+                case 5: hipLaunchKernelGGL(ns_propose_kernel<5>, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
+                case 10: hipLaunchKernelGGL(ns_propose_kernel<10>, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
+                case 15: hipLaunchKernelGGL(ns_propose_kernel<15>, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
+                default: hipLaunchKernelGGL(ns_propose_kernel<0>, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
+                }
                 hipLaunchKernelGGL(ns_publish_kernel, dim3(1), dim3(1), 0, st, dh[h], s->seq + 1);
                 HIP_TRY(hipGetLastError());
             }
             s->seq += 1;
+            s->raw_sum += (long)n_act * Kr;
             for (int h = 0; h < NS_PARTS; ++h) {
                 if (n_pix_h[h] == 0) continue;
                 hipStream_t st = r->lanes[h];
@@ -1098,6 +1311,7 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                     }
                 }
                 const int n_rows = (int)(unsigned)(pub[0] & 0xffffffffull);
+                s->val_sum += n_rows;
                 dh[h].part = nullptr;
                 if (n_rows > 0) {
                     r->part_only = true;                                   // (the update wave sums the parts of a row)

@@ -110,7 +110,7 @@ def _ball_points(seed, p, a, D):
     return z * (np.exp(np.log(ur) / D) / np.sqrt((z * z).sum(axis=1)))[:, None]
 
 
-def _candidates(seed, pix, base, K, centre, axes, use_cube):
+def _candidates(seed, pix, base, K, centre, axes, use_cube, with_ball=False):
     """K candidates per pixel of `pix`, uniform in the bounding ellipsoids, or in the unit cube
     where `use_cube` says the ellipsoid is the larger of the two (ns_propose_kernel);
     base[n] = how many candidates each pixel has drawn before."""
@@ -128,10 +128,13 @@ def _candidates(seed, pix, base, K, centre, axes, use_cube):
             z[:, :, m + 1] = r * np.sin(ang)
     ur = _uniform(seed, p, a, _B_RADIUS)[..., 0]
     f = np.exp(np.log(ur) / D) / np.sqrt((z * z).sum(axis=2))
-    cand = centre[:, None, :] + np.einsum('pji,pki->pkj', axes, z * f[:, :, None])
+    zf = z * f[:, :, None]
+    cand = centre[:, None, :] + np.einsum('pji,pki->pkj', axes, zf)
     if use_cube.any():
         cube = _uniform(seed, p, a, np.arange(D, dtype=_U64)[None, None, :])
         cand[use_cube] = cube[use_cube]
+    if with_ball:
+        return cand, zf
     return cand
 
 
@@ -243,6 +246,73 @@ def _candidates_multi(seed, p, base, K, cs, As, lv, ne, lnvol):
     return cand, keep
 
 
+# ---- free rejections: boxes around the live points in several frames (ns_refit / ns_propose_kernel) ---------------
+# Above six sampled dimensions no ellipsoid bounds the live region well (a two-component fit: its ten-dimensional live set
+# is box-like in some directions, curved in others), and a proposal uniform in the bounding ellipsoid is rarely inside
+# the region.  But every superset of the region may veto a proposal BEFORE its likelihood is evaluated, and what is left
+# is still uniform over the intersection: the axis-aligned bounding box of the live points in the unit cube, their
+# bounding box in the ellipsoid's own (Cholesky) frame, and their bounding boxes in `n_frames` fixed rotations of that
+# frame.  A face sits beyond the extreme live point by c max(0.1 s, extreme - mean - 1.5 s), s the standard deviation
+# along that direction: a marginal that ends abruptly (a flat, box-like direction: extreme near 1.7 s) gets a margin of
+# a quarter of s, one that thins out (the projection of a round body: extreme near 2.9 s) one and a half s -- what the
+# spacing of the extreme order statistics would give (scripts/proto_intersection.py: the fraction of the true region a
+# bound cuts off, and the evaluations per iteration it saves).
+_FRAME_SEED = _U64(0x5EEDF00D)
+_NS_FRAMES, _NS_MARGIN_C, _NS_MARGIN_A, _NS_MARGIN_FLOOR = 32, 1.75, 1.5, 0.1     # NS_FRAMES, NS_MARGIN_C, NS_MARGIN_A, NS_MARGIN_FLOOR
+_NS_RATIO_MAX = 8                                                              # NS_RATIO_MAX
+
+
+def _frames(D, K):
+    """K fixed orthogonal D x D matrices (ns_make_frames): entries 2 u - 1 from the counter-based stream, columns
+    orthonormalised one after the other (modified Gram-Schmidt).  Column b of frame k is the direction of coordinate b."""
+    Q = np.zeros((K, D, D))
+    for k in range(K):
+        M = 2.0 * _uniform(_FRAME_SEED, _U64(k + 1), np.arange(D, dtype=_U64)[:, None], np.arange(D, dtype=_U64)[None, :]) - 1.0
+        for b in range(D):
+            v = M[:, b].copy()
+            for q in range(b):
+                dot = 0.0
+                for a in range(D):
+                    dot += Q[k, a, q] * v[a]
+                v -= dot * Q[k, :, q]
+            n2 = 0.0
+            for a in range(D):
+                n2 += v[a] * v[a]
+            Q[k, :, b] = v / math.sqrt(n2)
+    return Q
+
+
+def _fit_boxes(U, c, A, frames, margin_c):
+    """The boxes of one pixel (ns_refit's last part): `ubox` [D, 2] around U[n, D] in the unit cube's own axes, `fbox`
+    [K + 1, D, 2] around zz = A^-1 (u - c) in the Cholesky frame (k = 0) and in frame k's rotation of it."""
+    n, D = U.shape
+    d = U - c
+    cov_diag = np.einsum('ni,ni->i', d, d) / (n - 1)
+    sg = np.sqrt(cov_diag)
+    lo, hi = d.min(axis=0), d.max(axis=0)
+    ubox = np.stack([c + lo - margin_c * np.maximum(_NS_MARGIN_FLOOR * sg, -lo - _NS_MARGIN_A * sg),
+                     c + hi + margin_c * np.maximum(_NS_MARGIN_FLOOR * sg, hi - _NS_MARGIN_A * sg)], axis=1)
+    zz = np.linalg.solve(A, d.T).T                                     # [n, D]; every direction of it has the same spread:
+    sz = math.sqrt(float((zz * zz).sum()) / ((n - 1) * D))              # sqrt(trace of its covariance / D)
+    K = frames.shape[0]
+    fbox = np.empty((K + 1, D, 2))
+    for k in range(K + 1):
+        W = zz if k == 0 else zz @ frames[k - 1]
+        wlo, whi = W.min(axis=0), W.max(axis=0)
+        fbox[k, :, 0] = wlo - margin_c * np.maximum(_NS_MARGIN_FLOOR * sz, -wlo - _NS_MARGIN_A * sz)
+        fbox[k, :, 1] = whi + margin_c * np.maximum(_NS_MARGIN_FLOOR * sz, whi - _NS_MARGIN_A * sz)
+    return ubox, fbox
+
+
+def _box_veto(cand, zz, ubox, fbox, frames):
+    """Flags of the proposals cand[K, D] (zz[K, D] = their coordinates in the Cholesky frame) that lie inside every box."""
+    ok = np.all((cand >= ubox[:, 0]) & (cand <= ubox[:, 1]), axis=1)
+    for k in range(fbox.shape[0]):
+        W = zz if k == 0 else zz @ frames[k - 1]
+        ok &= np.all((W >= fbox[k, :, 0]) & (W <= fbox[k, :, 1]), axis=1)
+    return ok
+
+
 def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
     """NestedResult per pixel from dead points (theta, lnL, lnw per pixel) and final live points:
     every live point carries the mass X_final / nlive.  `nlive`: one number, or one per pixel (a pixel's live
@@ -304,7 +374,7 @@ def default_cap_iter(nlive):
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
                check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None, walkers=None,
-               progress=None):
+               progress=None, frames=None, margin=None, refit_every=4):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -337,6 +407,11 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     free_mask : ndim flags, 0 for unit-cube slots the likelihood does not depend on (constant or
         duplicated parameters: `PriorTransformer.free_mask`).  They are not sampled -- a uniform dummy
         dimension integrates to one -- and stay at u = 0.5: fewer dimensions for the same evidence.
+    frames, margin : the free rejections of a one-ellipsoid bound (`_fit_boxes`): `frames` rotated frames beside the unit
+        cube's axes and the ellipsoid's own (None or -1: no boxes, the default; 32 is the measured choice), `margin` the factor c of a face's distance beyond the extreme live point (1.75).
+        With boxes the proposals per round are scaled by the last rounds' ratio of drawn to evaluated proposals (at most 8).
+    refit_every : rejection-mode pixels refit their bound in rounds that are multiples of this (the device's engine option
+        `sampler_refit_every`).
     enlarge : safety factor on the volume of the ellipsoid that just encloses the live points
         (scripts/sampler_bias_check.py: 1.0 biases lnZ by +0.020, 1.25 by +0.011, 2.0 by nothing measurable; the error is 0.18).
 
@@ -392,6 +467,13 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     centre, axes = np.zeros((P, _NS_ME, nd)), np.zeros((P, _NS_ME, nd, nd))
     elnv, nell = np.full((P, _NS_ME), -np.inf), np.ones(P, dtype=np.int64)
     use_cube, lnvol = np.empty(P, dtype=bool), np.empty(P)
+    # free rejections (one-ellipsoid bounds only): boxes in the unit cube's axes, the ellipsoid's frame and n_frames rotations
+    n_frames = -1 if frames is None else int(frames)            # (off unless asked for: DESIGN section 10)
+    boxes = (not multi) and n_frames >= 0 and nlive * nd * 8 <= 96 * 1024
+    margin_c = _NS_MARGIN_C if margin is None else float(margin)
+    Qf = _frames(nd, max(n_frames, 0)) if boxes else None
+    ubox = np.zeros((P, nd, 2))
+    fbox = np.zeros((P, max(n_frames, 0) + 1, nd, 2))
 
     def refit(p, ln_x):
         n = int(nl[p])
@@ -400,6 +482,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         else:
             c1, a1, u1, v1 = _fit_ellipsoids(Ulive[p:p + 1, :n], efr, np.array([ln_x]), enlarge)
             centre[p, 0], axes[p, 0], use_cube[p], lnvol[p], elnv[p, 0], nell[p] = c1[0], a1[0], u1[0], v1[0], v1[0], 1
+            if boxes:
+                ubox[p], fbox[p] = _fit_boxes(Ulive[p, :n], c1[0], a1[0], Qf, margin_c)
 
     for p in range(P):
         refit(p, 0.0)
@@ -428,6 +512,12 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     wT = np.zeros((P, w_stride, ndim))
     wL = np.zeros((P, w_stride))
     wnacc = np.zeros((P, w_stride), dtype=np.int64)
+    # what a pixel's rejection rounds did since the last decision point (every n_steps rounds): candidates scanned and
+    # accepted, proposals drawn and evaluated; ln of the last window's evaluated / drawn (the boxes' share of the
+    # ellipsoid: what the way back from the walks counts the bound's volume with)
+    rj_scan, rj_acc = np.zeros(P, dtype=np.int64), np.zeros(P, dtype=np.int64)
+    rj_raw, rj_val = np.zeros(P, dtype=np.int64), np.zeros(P, dtype=np.int64)
+    ln_pass = np.zeros(P)
 
     def replace(p, cU, cT, Lk):
         """The worst live point of pixel p dies, the candidate takes its slot; True when p is done."""
@@ -446,9 +536,15 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         return bool((np.logaddexp(lnZ[p], remain) - lnZ[p] < tol) or n_iter[p] >= maxiter or n_iter[p] >= cap)
 
     nlive_max = nlive
+    raw_sum = val_sum = 0                                       # proposals drawn / evaluated since the last look
     while active.any():
         if rnd % check_every == 0:                              # the device compacts its pixel list here
-            Kr = int(min(16384, max(K, b_target // int(active.sum()))))
+            # with boxes most proposals are vetoed for free: draw so many more that a round still evaluates ~b_target
+            ratio = min(_NS_RATIO_MAX, max(1, (raw_sum + val_sum // 2) // max(val_sum, 1))) if boxes and raw_sum else 1
+            n_chunk = int(active.sum())                          # the pixels the device's list holds until the next look
+            Kr = int(min(16384, max(K, (b_target * ratio) // n_chunk)))
+            raw_sum = val_sum = 0
+        raw_sum += Kr * n_chunk
         idx = np.flatnonzero(active)
         for p in idx:                                           # one wave per pixel on the device
             p = int(p)
@@ -474,6 +570,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                 cand = wU[p, :W] + gam * (Ulive[p, ia] - Ulive[p, ib])
                 valid = np.all((cand >= 0.0) & (cand < 1.0), axis=1)
                 vi = np.flatnonzero(valid)
+                val_sum += int(vi.size)
                 if vi.size:
                     Tsub = expand(cand[vi])
                     Lsub = evaluate(np.full(vi.size, p, dtype=np.int32), Tsub)
@@ -496,18 +593,24 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                                                                   / (0.5 * math.sqrt(nd))))
                     wacc_sum[p] = wtot_sum[p] = wstep[p] = 0
                     # back to rejection once the bound promises clearly more than a walk delivers
-                    if method == 1 and (-n_iter[p] / nlive - min(lnvol[p], 0.0)) > math.log(8.0 / (walk_factor * n_steps)):
+                    if method == 1 and (-n_iter[p] / nlive - min(lnvol[p] + ln_pass[p], 0.0)) > math.log(8.0 / (walk_factor * n_steps)):
                         walk[p] = False
             else:
                 if nell[p] > 1 and not use_cube[p]:
                     cand, keep = _candidates_multi(seed, p, cand_base[p], Kr, centre[p], axes[p], elnv[p], int(nell[p]), lnvol[p])
                 else:
-                    cand = _candidates(seed, [p], cand_base[p:p + 1], Kr, centre[p:p + 1, 0], axes[p:p + 1, 0],
-                                       use_cube[p:p + 1])[0]
-                    keep = True
+                    cand, zf = _candidates(seed, [p], cand_base[p:p + 1], Kr, centre[p:p + 1, 0], axes[p:p + 1, 0],
+                                           use_cube[p:p + 1], with_ball=True)
+                    cand, keep = cand[0], True
+                    if boxes:
+                        # the proposal's coordinates in the ellipsoid's frame: the unit-ball point it was made from, or
+                        # (drawn from the unit cube) A^-1 (u - c)
+                        zz = np.linalg.solve(axes[p, 0], (cand - centre[p, 0]).T).T if use_cube[p] else zf[0]
+                        keep = _box_veto(cand, zz, ubox[p], fbox[p], Qf)
                 valid = np.all((cand >= 0.0) & (cand < 1.0), axis=1) & keep   # outside the unit cube = outside the prior
                 vi = np.flatnonzero(valid)
                 scanned = accepted = 0
+                val_sum += int(vi.size)
                 if vi.size:
                     Tsub = expand(cand[vi])
                     Lsub = evaluate(np.full(vi.size, p, dtype=np.int32), Tsub)
@@ -519,14 +622,18 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                             done = replace(p, cand[vi[j]].copy(), Tsub[j].copy(), Lsub[j])
                             if done:
                                 break
-                # walk cycles of all pixels stay in phase: they start at rounds that are multiples of n_steps
-                if not done and (rnd + 1) % n_steps == 0 and (
-                        method == 2 or (method == 1 and scanned >= 64 and walk_factor * accepted * n_steps < scanned)):
-                    walk[p], wstep[p], wscale[p], wacc_sum[p], wtot_sum[p] = True, 0, 1.0, 0, 0
+                # walk cycles of all pixels stay in phase: they start at rounds that are multiples of n_steps.  The decision
+                # looks at all rejection rounds since the last one (a single round of a few hundred candidates is noise)
+                rj_scan[p] += scanned; rj_acc[p] += accepted; rj_raw[p] += Kr; rj_val[p] += int(vi.size)
+                if (rnd + 1) % n_steps == 0:
+                    if not done and (method == 2 or (method == 1 and rj_scan[p] >= 64 and walk_factor * rj_acc[p] * n_steps < rj_scan[p])):
+                        walk[p], wstep[p], wscale[p], wacc_sum[p], wtot_sum[p] = True, 0, 1.0, 0, 0
+                        ln_pass[p] = math.log(max(int(rj_val[p]), 1) / max(int(rj_raw[p]), 1)) if boxes else 0.0
+                    rj_scan[p] = rj_acc[p] = rj_raw[p] = rj_val[p] = 0
             cand_base[p] += Kr
             if done:
                 active[p] = False
-            elif since_fit[p] >= updp[p] and (was_walking or (rnd + 1) % 4 == 0):
+            elif since_fit[p] >= updp[p] and (was_walking or (rnd + 1) % refit_every == 0):
                 # (rejection-mode pixels refit only in every fourth round: on the device a refit makes the
                 # whole launch wait, so they are taken together)
                 refit(p, -n_iter[p] / nlive)
@@ -552,7 +659,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
                       upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=262144,
                       enlarge=1.5, method='auto', n_steps=None, free_mask=None, progress=None, time_limit=None,
-                      ellipsoids=None):
+                      ellipsoids=None, frames=None, margin=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
     work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive).  `progress`
@@ -583,6 +690,8 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
     try:
         if ellipsoids:
             _ffi.check(lib.nfa_sampler_set_ellipsoids(h, int(ellipsoids)))
+        if frames is not None or margin is not None:
+            _ffi.check(lib.nfa_sampler_set_boxes(h, -2 if frames is None else int(frames), 0.0 if margin is None else float(margin)))
         if per_pixel:
             nl32 = nl.astype(np.int32)
             upd32 = np.maximum(1, (upd_frac * nl).astype(np.int64)).astype(np.int32)

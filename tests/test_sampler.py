@@ -461,3 +461,65 @@ def test_marginals_are_numpy_quantiles_bit_for_bit():
     post = rng.normal(size=(50, 8))
     post[3, 2] = np.nan
     assert np.array_equal(d.calc_marginals(post), np.quantile(post[:, :6], d.quantiles, axis=0), equal_nan=True)
+
+
+def test_box_vetoes_of_a_one_ellipsoid_bound():
+    """frames=K: proposals outside the bounding boxes of the live points (unit-cube axes, the ellipsoid's frame, K
+    fixed rotations of it) are dropped before they are evaluated.  The frames are orthogonal; on a region no ellipsoid
+    bounds well -- a flat likelihood inside a small cube, eight dimensions -- the evidence stays inside its error and a
+    third of the evaluations go; on a Gaussian, which the ellipsoid bounds as well as anything, nothing changes."""
+    Q = sampler._frames(8, 5)
+    for k in range(5):
+        np.testing.assert_allclose(Q[k].T @ Q[k], np.eye(8), atol=1e-12)
+    assert not np.allclose(Q[0], Q[1])
+    D, half = 8, 0.11
+
+    def cube_like(pix, U):      # a gentle slope inside |u - 0.5| < half in every coordinate (no plateau), a steep wall outside
+        d = np.maximum(np.abs(U - 0.5).max(axis=1) - half, 0.0)
+        return -0.5 * (d / 0.004) ** 2 - 0.5 * (((U - 0.5) / 0.2) ** 2).sum(axis=1)
+    kw = dict(nlive=200, tol=0.1, efr=0.3, seed=11, method='reject', batch_target=1024)
+    plain = sampler.run_nested(cube_like, D, 2, **kw)
+    boxed = sampler.run_nested(cube_like, D, 2, frames=16, **kw)
+    # the wall is steep, the slope gentle: Z is close to the integral of the Gaussian slope over the cube
+    from math import erf, log, pi, sqrt
+    truth = D * log(0.2 * sqrt(2 * pi) * erf(half / (0.2 * sqrt(2))))
+    for r in plain + boxed:
+        assert abs(r.lnZ - truth) < 4 * r.lnZ_err + 0.25, (r.lnZ, truth, r.lnZ_err)       # (the soft wall adds ~ D * 0.03)
+    assert sum(r.n_evals for r in boxed) < 0.67 * sum(r.n_evals for r in plain)
+    f = _gauss_problem(np.full(D, 0.5), 0.05)
+    g0 = sampler.run_nested(f, D, 1, **kw)[0]
+    g1 = sampler.run_nested(f, D, 1, frames=16, **kw)[0]
+    assert abs(g1.n_iter - g0.n_iter) < 0.01 * g0.n_iter and abs(g1.n_evals - g0.n_evals) < 0.05 * g0.n_evals and abs(g1.lnZ - g0.lnZ) < 0.1
+
+
+@pytest.mark.gpu
+def test_box_vetoes_on_the_device_follow_the_twin(engine, nfo):
+    """Two velocity components (ten sampled dimensions), boxes on: the device sampler and the numpy twin fed by the
+    GPU's table-mode likelihood take the same decisions -- iteration and evaluation counts equal, lnZ to 1e-10 -- in
+    rejection rounds with vetoes, through the switch to walks and back."""
+    from nestfit_amd.cube import CubeRunner
+    n_pix, n, noise = 3, 128, 0.1
+    rng = np.random.default_rng(3)
+    axes = [freq_axis(1, n), freq_axis(2, n)]
+    ut = engine.get_irdc_priors(size=500, vsys=0.0)
+    truths = np.tile(np.array([-0.5, 1.0, 12.0, 15.0, 5.0, 6.0, 14.4, 14.6, 0.4, 0.4, 0.0, 0.0]), (n_pix, 1))
+    truths[:, 6] += np.array([0.0, -0.4, 0.2])
+    try:
+        engine.set_exp_mode('table')
+        probe = CubeRunner(axes, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=2)
+        model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
+        cube = CubeRunner(axes, (1, 2), model + rng.normal(0, noise, model.shape), np.full((n_pix, 2), noise), ut, ncomp=2)
+        for extra in (dict(frames=8), dict(frames=32, margin=1.5, n_steps=20), dict(frames=0, method='reject')):
+            kw = dict(nlive=150, tol=0.5, efr=0.3, seed=7, maxiter=900, batch_target=2048, **extra)
+            dev = sampler.fit_pixels(cube, np.arange(n_pix), device=True, **kw)
+            twin = sampler.fit_pixels(cube, np.arange(n_pix), device=False, **kw)
+            for d, t in zip(dev, twin):
+                assert (d.n_iter, d.n_evals) == (t.n_iter, t.n_evals), (extra, d.n_iter, t.n_iter, d.n_evals, t.n_evals)
+                assert d.lnZ == pytest.approx(t.lnZ, rel=1e-10)
+        # and the vetoes do veto: fewer evaluations than the same run without them
+        kw = dict(nlive=150, tol=0.5, efr=0.3, seed=7, maxiter=900, batch_target=2048, method='reject')
+        with_boxes = sampler.fit_pixels(cube, np.arange(n_pix), frames=32, **kw)
+        without = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
+        assert sum(r.n_evals for r in with_boxes) < 0.8 * sum(r.n_evals for r in without)
+    finally:
+        engine.set_exp_mode('fast')
