@@ -47,6 +47,12 @@ __host__ __device__ inline double ns_uniform(uint64_t seed, uint64_t p, uint64_t
     const uint64_t h = ns_mix(ns_mix(ns_mix(ns_mix(seed) + p) + a) + b);
     return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
+// the same in two steps: what (seed, pixel, a) contribute is formed once per proposal (three of the four mixing rounds)
+__host__ __device__ inline uint64_t ns_stream(uint64_t seed, uint64_t p, uint64_t a) { return ns_mix(ns_mix(ns_mix(seed) + p) + a); }
+__host__ __device__ inline double ns_uniform_of(uint64_t stream, uint64_t b) {
+    const uint64_t h = ns_mix(stream + b);
+    return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
 
 // Several bounding ellipsoids per pixel (MultiNest's `mmodal` bound in its simplest form): up to NS_ME of them where at
 // most NS_ME_MAXD dimensions are sampled.  A cluster of live points is cut in two across its principal axis at its
@@ -197,14 +203,17 @@ __global__ void ns_sanitize_kernel(double *__restrict__ L, long n, double log_ze
 template <int DD>
 __device__ __forceinline__ bool ns_in_boxes(const NsDev &S, int p, const double *x, const double *zz) {
     const int D = DD > 0 ? DD : S.D;
-    const double *ub = S.ubox + (long)p * D * 2;
+    // (the bound is read through the constant address space: written by the refit launch, not by this one, and the same
+    // for the whole workgroup -- scalar loads; as ordinary global loads the compiler sent every one of the 110 reads per
+    // frame through the vector memory pipe, and a wave of proposals took 90 us)
+    const k_dbl_p ub = (k_dbl_p)(S.ubox + (long)p * D * 2);
     bool ok = true;
     for (int j = 0; j < D; ++j) ok = ok && (x[j] >= ub[2 * j]) && (x[j] <= ub[2 * j + 1]);
     if (!ok) return false;
-    const double *fb = S.fbox + (long)p * (S.n_frames + 1) * D * 2;
+    k_dbl_p fb = (k_dbl_p)(S.fbox + (long)p * (S.n_frames + 1) * D * 2);
     for (int j = 0; j < D; ++j) ok = ok && (zz[j] >= fb[2 * j]) && (zz[j] <= fb[2 * j + 1]);
     for (int k = 1; k <= S.n_frames && ok; ++k) {
-        const double *Q = S.frames + (long)(k - 1) * D * D;
+        const k_dbl_p Q = (k_dbl_p)(S.frames + (long)(k - 1) * D * D);
         fb += D * 2;
         for (int j = 0; j < D; ++j) {
             double w = 0.0;
@@ -220,10 +229,10 @@ __device__ __forceinline__ bool ns_in_boxes(const NsDev &S, int p, const double 
 // slow pixels does not cost one launch per handful of candidates)
 // DD > 0: the number of sampled dimensions at compile time (loops unroll, the proposal's coordinates live in registers)
 template <int DD>
-__device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_act, int Kr) {
+__device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int n_act, int Kr) {
     constexpr int DM = DD > 0 ? DD : NS_MAXD;
-    const int q = (int)(gid / Kr), k = (int)(gid - (long)q * Kr);
-    const int p = S.actlist[q];
+    const long gid = (long)q * Kr + k;
+    const int p = __builtin_amdgcn_readfirstlane(S.actlist[q]);      // a workgroup serves ONE pixel: its bound comes through scalar loads
     const int D = DD > 0 ? DD : S.D;
     double *cu = S.candU + gid * D;
     if (!S.active[p]) {                 // finished since the last compaction of the pixel list
@@ -231,10 +240,15 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
         return;
     }
     const uint64_t a = (uint64_t)S.cand_base[p] + (uint64_t)k;
+    const uint64_t strm = ns_stream(S.seed, (uint64_t)p, a);
+    // the proposal is kept in registers and written once it is known to be worth a likelihood: a proposal the bound
+    // vetoes is never looked at again, and with no store ahead of them the loads of the bound (uniform over the
+    // workgroup) go through the scalar cache -- as per-lane loads, 3200 of them per proposal, they were the kernel
+    double x[DM];
     bool ok = true;
     const bool walking = S.walk[p] != 0;
-    double wscale = 1.0;
-    const double *origin = S.centre + (long)p * NS_ME * D;
+    // (ONE branch per mode: stores of the walkers' branch ahead of the rejection branch on a common path -- a join
+    // between two ifs -- would make the compiler read the bound with per-lane loads instead of scalar ones)
     if (walking) {
         // Metropolis step of walker k inside {L > threshold}; a cycle starts from a random live point
         const int step = S.wstep[p];
@@ -243,7 +257,7 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
         double *wu = S.wU + ((long)p * S.w_stride + k) * D;
         if (step == 0) {
             const int Np = ns_n(S, p);
-            const int idx = min(Np - 1, (int)(ns_uniform(S.seed, (uint64_t)p, a, NS_B_START) * Np));
+            const int idx = min(Np - 1, (int)(ns_uniform_of(strm, NS_B_START) * Np));
             const double *lu = S.Ulive + ((long)p * S.N + idx) * D, *lt = S.Tlive + ((long)p * S.N + idx) * S.DT;
             double *wt = S.wT + ((long)p * S.w_stride + k) * S.DT;
             for (int j = 0; j < D; ++j) wu[j] = lu[j];
@@ -251,30 +265,27 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
             S.wL[(long)p * S.w_stride + k] = S.Llive[(long)p * S.N + idx];
             S.wnacc[(long)p * S.w_stride + k] = 0;
         }
-        origin = wu;
-        wscale = S.wscale[p];
-    }
-    if (walking) {
+        const double *origin = wu;
+        const double wscale = S.wscale[p];
         // differential-evolution move (ter Braak 2006): the step is a scaled difference of two random
         // live points, so its shape follows the constraint region whatever that looks like (measured
         // against ellipsoid-shaped steps and an alternation of both on 576 two-component pixels: half
         // the lnZ bias at equal length, scripts/sampler_bias_check.py)
         const int N = ns_n(S, p);
-        int ia = min(N - 1, (int)(ns_uniform(S.seed, (uint64_t)p, a, 251ull) * N));
-        int ib = min(N - 2, (int)(ns_uniform(S.seed, (uint64_t)p, a, 252ull) * (N - 1)));
+        int ia = min(N - 1, (int)(ns_uniform_of(strm, 251ull) * N));
+        int ib = min(N - 2, (int)(ns_uniform_of(strm, 252ull) * (N - 1)));
         if (ib >= ia) ib += 1;
         const double gam = wscale * 2.38 / sqrt(2.0 * D);
         const double *ua = S.Ulive + ((long)p * S.N + ia) * D, *ub = S.Ulive + ((long)p * S.N + ib) * D;
         for (int j = 0; j < D; ++j) {
             const double v = origin[j] + gam * (ua[j] - ub[j]);
             ok = ok && (v >= 0.0) && (v < 1.0);
-            cu[j] = v;
+            x[j] = v;
         }
-    } else if (!walking && S.use_cube[p]) {    // early on the bounding ellipsoid is no better than the prior itself
-        double x[DM];
-        for (int j = 0; j < D; ++j) { x[j] = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)j); cu[j] = x[j]; }
+    } else if (S.use_cube[p]) {    // early on the bounding ellipsoid is no better than the prior itself
+        for (int j = 0; j < D; ++j) x[j] = ns_uniform_of(strm, (uint64_t)j);
         if (S.boxes) {                         // the boxes hold the live region whatever the proposal was drawn from
-            const double *c = S.centre + (long)p * NS_ME * D, *A = S.axes + (long)p * NS_ME * D * D;
+            const k_dbl_p c = (k_dbl_p)(S.centre + (long)p * NS_ME * D), A = (k_dbl_p)(S.axes + (long)p * NS_ME * D * D);
             double zz[DM];
             for (int j = 0; j < D; ++j) {       // zz = A^-1 (x - c)
                 double v = x[j] - c[j];
@@ -287,22 +298,22 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
         double z[DM];
         double n2 = 0.0;
         for (int m = 0; m < D; m += 2) {    // Box-Muller pairs
-            const double u1 = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)m);
-            const double u2 = ns_uniform(S.seed, (uint64_t)p, a, (uint64_t)(m + 1));
+            const double u1 = ns_uniform_of(strm, (uint64_t)m);
+            const double u2 = ns_uniform_of(strm, (uint64_t)(m + 1));
             const double r = sqrt(-2.0 * log(u1));
             const double ang = 6.283185307179586 * u2;
             z[m] = r * cos(ang);
             n2 += z[m] * z[m];
             if (m + 1 < D) { z[m + 1] = r * sin(ang); n2 += z[m + 1] * z[m + 1]; }
         }
-        const double ur = ns_uniform(S.seed, (uint64_t)p, a, NS_B_RADIUS);
+        const double ur = ns_uniform_of(strm, NS_B_RADIUS);
         const double f = exp(log(ur) / D) / sqrt(n2);               // uniform in the unit ball
         // several ellipsoids: one is drawn by volume, and a point that lies in q of them is kept with probability 1 / q
         // (uniform over the union)
         const int ne = S.multi ? S.nell[p] : 1;
         int ke = 0;
         if (ne > 1) {
-            const double usel = ns_uniform(S.seed, (uint64_t)p, a, NS_B_ELL), lv = S.lnvol[p];
+            const double usel = ns_uniform_of(strm, NS_B_ELL), lv = S.lnvol[p];
             double acc = 0.0;
             ke = ne - 1;
             for (int k = 0; k < ne - 1; ++k) {
@@ -310,15 +321,13 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
                 if (usel < acc) { ke = k; break; }
             }
         }
-        const double *c = S.centre + ((long)p * NS_ME + ke) * D, *A = S.axes + ((long)p * NS_ME + ke) * D * D;
-        double x[DM];
+        const k_dbl_p c = (k_dbl_p)(S.centre + ((long)p * NS_ME + ke) * D), A = (k_dbl_p)(S.axes + ((long)p * NS_ME + ke) * D * D);
         for (int i = 0; i < D; ++i) z[i] *= f;                // the point of the unit ball
         for (int j = 0; j < D; ++j) {
             double v = c[j];
             for (int i = 0; i <= j; ++i) v += A[j * D + i] * z[i];
             ok = ok && (v >= 0.0) && (v < 1.0);               // outside the unit cube = outside the prior
             x[j] = v;
-            cu[j] = v;
         }
         if (ok && S.boxes) ok = ns_in_boxes<DD>(S, p, x, z);   // (one ellipsoid: the ball point IS A^-1 (x - c))
         if (ok && ne > 1) {
@@ -335,10 +344,11 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
                 }
                 q += s2 <= 1.0 ? 1 : 0;
             }
-            if (q > 1) ok = ns_uniform(S.seed, (uint64_t)p, a, NS_B_KEEP) * q < 1.0;
+            if (q > 1) ok = ns_uniform_of(strm, NS_B_KEEP) * q < 1.0;
         }
     }
     S.valid[gid] = ok ? 1 : 0;
+    if (ok) for (int j = 0; j < D; ++j) cu[j] = x[j];
     // only candidates inside the prior go to the likelihood: compact rows (order is irrelevant, every proposal
     // remembers its row).  One atomic per wave, not per proposal: tens of thousands of them on ONE counter took the
     // proposing launch 40 us by themselves.
@@ -354,13 +364,15 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, long gid, int n_a
     S.candpix[row] = S.pixmap[p];
     double *ct = S.candT + (long)row * S.DT;
     for (int j = 0; j < S.DT; ++j) ct[j] = 0.5;
-    for (int j = 0; j < D; ++j) ct[S.fmap[j]] = cu[j];
+    for (int j = 0; j < D; ++j) ct[S.fmap[j]] = x[j];
 }
 
+// grid: x = chunks of a pixel's Kr proposals, y = the active pixels of this part (z: beyond 65535 of them)
 template <int DD>
 __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < (long)n_act * Kr) ns_propose_one<DD>(S, gid, n_act, Kr);
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int q = (int)(blockIdx.y + blockIdx.z * 65535u);
+    if (q < n_act && k < Kr) ns_propose_one<DD>(S, q, k, n_act, Kr);
 }
 
 // One thread behind a proposing launch: the number of compact rows and the round's sequence number go into host
@@ -541,27 +553,45 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         ssq = ns_wave_sum(ssq);
         const double sz = sqrt(ssq * inv * inv / ((double)(N - 1) * D));     // the spread of zz, the same in every direction
         const double mfloor = NS_MARGIN_FLOOR * sz, moff = NS_MARGIN_A * sz;
-        for (int k = 0; k <= S.n_frames; ++k) {
-            const double *Q = S.frames + (long)(k - 1) * D * D;
-            for (int j = 0; j < D; ++j) {
-                double lo = INFINITY, hi = -INFINITY;
-                for (int i = lane; i < N; i += 64) {
-                    double w;
-                    if (k == 0) {
-                        w = sd[i * D + j] * inv;
-                    } else {
-                        w = 0.0;
-                        for (int a = 0; a < D; ++a) w += (sd[i * D + a] * inv) * Q[a * D + j];
-                    }
+        // (zz in place first: one multiplication per coordinate instead of one per use)
+        for (int e = lane; e < N * D; e += 64) sd[e] *= inv;
+        wave_lds_sync();
+        // lanes = (frame, coordinate) pairs, each walking all points: a lane keeps its column of the frame in registers
+        // (up to NS_QCOL entries at a time) and its own minimum and maximum -- no wave reductions, and every point's
+        // coordinates are one broadcast read for all lanes.  (The first version had lanes = points: 660 wave reductions
+        // and a scalar load of the frame's entry inside the innermost loop made a refit 2 ms.)
+        constexpr int NS_QCOL = 16;
+        const int n_pair = (S.n_frames + 1) * D;
+        for (int e0 = 0; e0 < n_pair; e0 += 64) {
+            const int e = e0 + lane;
+            const bool on = e < n_pair;
+            const int k = on ? e / D : 0, j = on ? e - k * D : 0;
+            double lo = INFINITY, hi = -INFINITY;
+            if (k == 0) {
+                for (int i = 0; i < N; ++i) { const double w = sd[i * D + j]; lo = fmin(lo, w); hi = fmax(hi, w); }
+            } else if (D <= NS_QCOL) {
+                double qc[NS_QCOL];
+                const double *Q = S.frames + (long)(k - 1) * D * D;
+#pragma unroll
+                for (int a = 0; a < NS_QCOL; ++a) qc[a] = a < D ? Q[a * D + j] : 0.0;
+                for (int i = 0; i < N; ++i) {
+                    double w = 0.0;
+#pragma unroll
+                    for (int a = 0; a < NS_QCOL; ++a) if (a < D) w += sd[i * D + a] * qc[a];
                     lo = fmin(lo, w); hi = fmax(hi, w);
                 }
-                hi = ns_wave_max(hi);
-                lo = -ns_wave_max(-lo);
-                if (lane == 0) {
-                    double *fb = S.fbox + (((long)p * (S.n_frames + 1) + k) * D + j) * 2;
-                    fb[0] = lo - S.margin_c * fmax(mfloor, -lo - moff);
-                    fb[1] = hi + S.margin_c * fmax(mfloor, hi - moff);
+            } else {
+                const double *Q = S.frames + (long)(k - 1) * D * D;
+                for (int i = 0; i < N; ++i) {
+                    double w = 0.0;
+                    for (int a = 0; a < D; ++a) w += sd[i * D + a] * Q[a * D + j];
+                    lo = fmin(lo, w); hi = fmax(hi, w);
                 }
+            }
+            if (on) {
+                double *fb = S.fbox + ((long)p * n_pair + e) * 2;
+                fb[0] = lo - S.margin_c * fmax(mfloor, -lo - moff);
+                fb[1] = hi + S.margin_c * fmax(mfloor, hi - moff);
             }
         }
     }
@@ -1286,11 +1316,13 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                 if (n_pix_h[h] == 0) continue;
                 hipStream_t st = r->lanes[h];
                 const long B = (long)n_pix_h[h] * Kr;
+                (void)B;
+                const dim3 pg((unsigned)((Kr + 127) / 128), (unsigned)std::min(n_pix_h[h], 65535), (unsigned)((n_pix_h[h] + 65534) / 65535));
                 switch (D) {                                        // compile-time dimensions where they are common
-                case 5: hipLaunchKernelGGL(ns_propose_kernel<5>, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
-                case 10: hipLaunchKernelGGL(ns_propose_kernel<10>, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
-                case 15: hipLaunchKernelGGL(ns_propose_kernel<15>, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
-                default: hipLaunchKernelGGL(ns_propose_kernel<0>, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
+                case 5: hipLaunchKernelGGL(ns_propose_kernel<5>, pg, dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
+                case 10: hipLaunchKernelGGL(ns_propose_kernel<10>, pg, dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
+                case 15: hipLaunchKernelGGL(ns_propose_kernel<15>, pg, dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
+                default: hipLaunchKernelGGL(ns_propose_kernel<0>, pg, dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
                 }
                 hipLaunchKernelGGL(ns_publish_kernel, dim3(1), dim3(1), 0, st, dh[h], s->seq + 1);
                 HIP_TRY(hipGetLastError());
