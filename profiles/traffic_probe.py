@@ -36,4 +36,9 @@ for _ in range(5):
 pix = np.arange(4096, dtype=np.int32)
 for _ in range(5):
     cube.loglikelihood_batch(pix, U.copy())
+# 4. the spectra-out mode (predict_batch): 4096 rows of physical parameters against one pixel, 4096 x 2048 doubles written
+theta = U.copy()
+ut.transform_batch(theta, 2)
+for _ in range(5):
+    cube.predict_batch(np.zeros(4096, dtype=np.int32), theta)
 print('done')
