@@ -316,6 +316,13 @@ int  nfa_ring_poll(nfa_ring *r, int max_batch, int64_t max_wait_us, int idle_ms,
                    int32_t *pix, double *U, int *n, int *stopped);
 int  nfa_ring_complete(nfa_ring *r, int n, const int32_t *slots, const double *U, const double *lnL, int rc);
 int  nfa_ring_serve(nfa_ring *r, nfa_runner *run, int64_t max_wait_us, int64_t max_batches, int idle_ms);
+/* The same service from a RESIDENT kernel (engine library only; one point per slot: rings made with nfa_ring_create).
+ * The ring's mapping is registered with the runtime; the kernel's workgroups poll the slots themselves, claim a posted
+ * point, run the point kernel's path and write theta, lnL and the DONE state into the slot the client spins on: a
+ * LogLike call (mn_loglikelihood, nestfit/core/core.pyx:622-624) costs the path itself, no launch and no host thread.
+ * Every kernel instance ends after lifetime_ms (0 = 20) or when the ring is stopped, and is launched again while there is
+ * work; the call returns when the ring was stopped or nothing was served for idle_ms.  Bitwise nfa_runner_loglike_batch. */
+int  nfa_ring_serve_device(nfa_ring *r, nfa_runner *run, int lifetime_ms, int idle_ms);
 /* out[0] batches served, out[1] evaluations served, out[2] largest batch, out[3] clients attached */
 int  nfa_ring_stats(nfa_ring *r, int64_t *out);
 /* ---- device-resident batched nested sampler --------------------

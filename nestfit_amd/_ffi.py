@@ -98,6 +98,7 @@ SIGNATURES = {
                                 C.POINTER(C.c_int)]),
     'nfa_ring_complete': (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, _dp, C.c_int]),
     'nfa_ring_serve': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
+    'nfa_ring_serve_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     'nfa_ring_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'nfa_sampler_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, _ip, C.c_int64, C.c_int, C.c_int,
                                      C.c_int64, C.c_int64, _ip]),

@@ -1363,6 +1363,7 @@ int nfa_event_elapsed_ms(void *start, void *stop, float *ms) {
 
 #include "nfa_broker.h"
 #include "nfa_ring.h"
+#include "nfa_ring_serve.h"
 #include "nfa_sampler.h"
 #include "nfa_comm.h"
 #ifdef NFA_TEST_HOOKS

@@ -74,6 +74,7 @@ struct nfa_ring {
     bool        creator = false;
     int         slot = -1;                 // client: the slot it holds
     uint32_t   *claim_gen = nullptr;       // server: generation of every slot at the time this handle claimed it
+    void       *dev_base = nullptr;        // engine library: the mapping as the device addresses it (nfa_ring_serve_device)
 };
 
 #ifndef NFA_RING_STANDALONE
@@ -250,6 +251,9 @@ int nfa_ring_close(nfa_ring *r) {
         r->hdr->n_attached.fetch_sub(1, std::memory_order_acq_rel);
         ring_futex(&r->hdr->posts, FUTEX_WAKE, 1, nullptr);
     }
+#ifndef NFA_RING_STANDALONE
+    if (r->dev_base) (void)hipHostUnregister(r->base);
+#endif
     munmap(r->base, r->bytes);
     if (r->creator) shm_unlink(r->name.c_str());
     delete[] r->claim_gen;

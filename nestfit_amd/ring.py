@@ -121,6 +121,15 @@ class RingServer:
         self._pix = np.zeros(cap, dtype=np.int32)
         self._U = np.zeros((cap, self.ndim))
 
+    def serve_device(self, lifetime_ms=20, idle_ms=1000, runner=None):
+        """Serve from a resident kernel (`nfa_ring_serve_device`): its workgroups poll the slots themselves and answer
+        a posted point without a launch or a host thread in the round trip.  One point per slot; returns when the ring
+        was stopped or nothing was served for `idle_ms`.  Run it in a thread like `serve`."""
+        runner = runner if runner is not None else self.runner
+        if runner is None:
+            raise ValueError('serve_device needs a runner')
+        _ffi.check(self._lib.nfa_ring_serve_device(self.handle, runner._run.handle, int(lifetime_ms), int(idle_ms)))
+
     def serve(self, max_wait_us=50, max_batches=0, idle_ms=1000, runner=None):
         """Serve until `stop`, `max_batches` (> 0) batches, or `idle_ms` without a request.  ctypes releases the
         GIL for the call: run it in a thread to keep the interpreter free.  Several threads may serve one ring,

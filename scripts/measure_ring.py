@@ -104,14 +104,19 @@ def main():
     ctx = mp.get_context('spawn')
     argv = [a for a in sys.argv[1:] if a != 'native']
     native = 'native' in sys.argv[1:]
-    cases = [tuple(int(v) for v in (a + ':1:1').split(':')[:3]) for a in argv] or [(1, 1, 1), (2, 1, 1), (4, 1, 1), (8, 1, 1), (14, 1, 1)]
+    # 'N:dev' = N processes served by the resident kernel (nfa_ring_serve_device); 'N:S:K' = S serving threads, K points per call
+    cases = [tuple((0 if v == 'dev' else int(v)) for v in (a + ':1:1').split(':')[:3]) for a in argv] or [(1, 1, 1), (2, 1, 1), (4, 1, 1), (8, 1, 1), (14, 1, 1)]
     for n_proc, n_serv, k_pts in cases:
-        while len(runners) < n_serv:                   # one runner (its own streams) per serving thread
+        while len(runners) < max(1, n_serv):                   # one runner (its own streams) per serving thread
             runners.append(na.AmmoniaRunner.from_data(args, priors, ncomp=2))
         n_calls = (20000 if n_proc <= 16 else 8000) // max(1, k_pts // 4)
         name = f'nfa_measure_ring_{n_proc}_{n_serv}_{k_pts}'
         with RingServer(name, n_slots=n_proc, runner=runners[0], max_points=k_pts) as server:
-            threads = server.serve_in_threads(runners[:n_serv], max_wait_us=30, idle_ms=120000)
+            if n_serv == 0:
+                threads = [threading.Thread(target=server.serve_device, kwargs=dict(lifetime_ms=20, idle_ms=120000))]
+                threads[0].start()
+            else:
+                threads = server.serve_in_threads(runners[:n_serv], max_wait_us=30, idle_ms=120000)
             if native:
                 res = [(k, a, b) for k, (a, b) in enumerate(native_clients(name, n_proc, n_calls, k_pts))]
             else:
@@ -128,7 +133,7 @@ def main():
             st = server.stats
         wall = max(r[2] for r in res) - min(r[1] for r in res)
         per_call = np.mean([r[2] - r[1] for r in res]) / n_calls
-        print(f'{n_proc:2d} {"compiled" if native else "Python"} processes x {k_pts} point(s) per call, {n_serv} serving thread(s): '
+        print(f'{n_proc:2d} {"compiled" if native else "Python"} processes x {k_pts} point(s) per call, {"the resident kernel" if n_serv == 0 else str(n_serv) + " serving thread(s)"}: '
               f'{n_proc * n_calls * k_pts / wall / 1e3:7.1f} k evals/s in all, '
               f'{per_call * 1e6:6.1f} us per call in each, {st["evals"] / st["batches"]:5.2f} points per launch '
               f'(largest {st["largest_batch"]})', flush=True)

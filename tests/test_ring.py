@@ -509,3 +509,106 @@ def test_a_client_gives_up_on_a_server_that_went_quiet(monkeypatch):
         p.join(timeout=60)
     assert not isinstance(rows[0][0], str)
     assert rows[1][0] == 'error' and 'no serving loop' in rows[1][1]
+
+
+def _gpu_client_pix(name, rank, n_points, n_pix, out, start):
+    client = RingClient(name, wait_ms=30000)
+    start.wait(60)
+    rng = np.random.default_rng(300 + rank)
+    rows = []
+    for i in range(n_points):
+        u = rng.random(client.ndim)
+        theta = u.copy()
+        pix = int(rng.integers(0, n_pix))
+        rows.append((u, theta, client.loglikelihood(theta, pix=pix), pix))
+    # a pixel the cube does not have: this request fails alone
+    try:
+        client.loglikelihood(rng.random(client.ndim), pix=n_pix + 5)
+        rows.append('no error')
+    except _ffi.EngineError:
+        rows.append('refused')
+    u = rng.random(client.ndim)
+    theta = u.copy()
+    rows.append((u, theta, client.loglikelihood(theta, pix=0), 0))      # ... and the service goes on
+    client.close()
+    out.put((rank, rows))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['fast', 'table'])
+def test_ring_served_by_the_resident_kernel(engine, nfo, mode):
+    """nfa_ring_serve_device: the resident kernel polls the slots itself.  Sampler processes without a GPU context post
+    point by point (MultiNest's pattern); every answer is bitwise what the runner gives directly -- a single-pixel
+    runner and a cube runner with pixel indices --, a request with a pixel beyond the cube fails alone, kernel
+    instances of 3 ms follow each other without a request being lost, and the loop ends by itself when the ring
+    goes idle or is stopped."""
+    import time
+    from nestfit_amd.cube import CubeRunner
+    from nestfit_amd.synth import TRUTH_2COMP, freq_axis
+    engine.set_exp_mode(mode)
+    try:
+        rng = np.random.default_rng(5)
+        n = 256
+        axes = [freq_axis(t, n) for t in (1, 2)]
+        clean = []
+        for t, x in zip((1, 2), axes):
+            s = nfo.AmmoniaSpectrum(x, np.zeros(n), 0.2, t)
+            nfo.amm_predict(s, TRUTH_2COMP)
+            clean.append(s.get_spec())
+        ut = engine.get_irdc_priors(size=500)
+        n_pix = 5
+        data = np.concatenate(clean)[None, :] + rng.normal(0, 0.2, (n_pix, 2 * n))
+        single = engine.AmmoniaRunner.from_data([[x, data[0, k * n:(k + 1) * n], 0.2, t] for k, (x, t) in enumerate(zip(axes, (1, 2)))], ut, ncomp=2)
+        cube = CubeRunner(axes, (1, 2), data, np.full((n_pix, 2), 0.2), ut, ncomp=2)
+        ctx = mp.get_context('spawn')
+        # (a) single-pixel runner, three processes, short-lived kernel instances
+        name = f'nfa_test_ring_dev_{os.getpid()}_{mode}'
+        n_clients, n_points = 3, 120
+        out, start = ctx.Queue(), ctx.Barrier(n_clients)
+        with RingServer(name, n_slots=n_clients, runner=single) as server:
+            procs = [ctx.Process(target=_gpu_client, args=(name, r, n_points, out, start)) for r in range(n_clients)]
+            for p in procs:
+                p.start()
+            th = threading.Thread(target=server.serve_device, kwargs=dict(lifetime_ms=3, idle_ms=30000))
+            th.start()
+            got = dict(out.get(timeout=120) for _ in procs)
+            for p in procs:
+                p.join(timeout=60)
+                assert p.exitcode == 0
+            server.stop()
+            th.join(timeout=30)
+            assert not th.is_alive()
+            assert server.stats['evals'] == n_clients * n_points
+        for rank, rows in got.items():
+            U = np.array([r[0] for r in rows])
+            want_theta = U.copy()
+            want = single.loglikelihood_batch(want_theta)
+            assert np.array_equal(np.array([r[1] for r in rows]), want_theta)
+            assert np.array_equal(np.array([r[2] for r in rows]), want)
+        # (b) cube runner: pixel indices, a bad one, and the loop ending by itself after 5 s without requests
+        name = f'nfa_test_ring_devc_{os.getpid()}_{mode}'
+        out, start = ctx.Queue(), ctx.Barrier(2)
+        with RingServer(name, n_slots=2, runner=cube) as server:
+            procs = [ctx.Process(target=_gpu_client_pix, args=(name, r, 40, n_pix, out, start)) for r in range(2)]
+            for p in procs:
+                p.start()
+            th = threading.Thread(target=server.serve_device, kwargs=dict(lifetime_ms=5, idle_ms=5000))      # (the clients are fresh interpreters: seconds to start)
+            th.start()
+            got = dict(out.get(timeout=120) for _ in procs)
+            for p in procs:
+                p.join(timeout=60)
+                assert p.exitcode == 0
+            t0 = time.time()
+            th.join(timeout=30)                                 # nobody posts any more: idle_ms ends the loop
+            assert not th.is_alive() and time.time() - t0 < 20
+        for rank, rows in got.items():
+            assert rows[-2] == 'refused'
+            good = [r for r in rows if not isinstance(r, str)]
+            U = np.array([r[0] for r in good])
+            pix = np.array([r[3] for r in good], dtype=np.int32)
+            want_theta = U.copy()
+            want = cube.loglikelihood_batch(pix, want_theta)
+            assert np.array_equal(np.array([r[1] for r in good]), want_theta)
+            assert np.array_equal(np.array([r[2] for r in good]), want)
+    finally:
+        engine.set_exp_mode('fast')
