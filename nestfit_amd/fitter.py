@@ -36,6 +36,19 @@ GROUP_WORKERS = 3
 # device memory the sampler state of one lock-step group may take (dead points dominate: cap x (ndim + 2) doubles
 # per pixel); larger groups are fitted in several passes
 SAMPLER_MEMORY_BUDGET = 24 << 30
+SAMPLER_MAX_NLIVE = 8192               # nfa_sampler_create's limit
+
+
+def _runs_within_a_factor(nlive, factor):
+    """Index sets of the pixels, cut so that inside a set the largest count is at most `factor` times the smallest
+    (pixels sorted by count, sets grown greedily from the smallest; every set in ascending pixel order)."""
+    order = np.argsort(nlive, kind='stable')
+    runs, start = [], 0
+    for k in range(1, order.size + 1):
+        if k == order.size or nlive[order[k]] > factor * nlive[order[start]]:
+            runs.append(np.sort(order[start:k]))
+            start = k
+    return runs
 
 
 class CubeFitter:
@@ -99,7 +112,17 @@ class CubeFitter:
             if self.one_group:
                 # every pixel keeps its own number of live points inside ONE lock-step run (the device sampler's
                 # per-pixel counts, nfa_sampler_set_pixel_nlive): no group per count, no rounding of the counts
-                groups = [(np.arange(lon.size), nlive)]
+                # -- but not across more than a factor of two: the live arrays of a run are laid out for its largest
+                # count (memory passes, the LDS staging of the refits and the several-ellipsoid bound are decided on
+                # that stride), so ONE very bright pixel (nlive + 5 SNR) would size the run of a whole stripe.  Pixels
+                # sorted by their counts are cut into runs whose largest count is at most twice the smallest (the real
+                # test cube's 100 .. 180 stay one run); a count beyond the sampler's limit is clamped for that pixel alone.
+                nlive = np.asarray(nlive)
+                if np.ndim(nlive) and nlive.max() > SAMPLER_MAX_NLIVE:
+                    over = np.flatnonzero(nlive > SAMPLER_MAX_NLIVE)
+                    print(f'-- {over.size} pixel(s) ask for more than {SAMPLER_MAX_NLIVE} live points (up to {int(nlive.max())}): clamped')
+                    nlive = np.minimum(nlive, SAMPLER_MAX_NLIVE)
+                groups = [(sel, nlive) for sel in _runs_within_a_factor(nlive, 2.0)] if np.ndim(nlive) else [(np.arange(lon.size), nlive)]
             else:
                 groups = [(np.flatnonzero(nlive == nl), int(nl)) for nl in np.unique(nlive)]
             workers = min(len(groups), self.group_workers) if self.fit_backend is None else 1

@@ -171,3 +171,16 @@ def test_truncated_flag_and_default_cap():
     assert q[9] == 1.58655254e-1 and q[10] == 0.84134475 and q[13] == 1.34989803e-3 and q[14] == 0.99865010
     bic, aic, aicc = sampler.information_criteria(2048, 12, -1000.0)
     assert bic == pytest.approx(np.log(2048) * 12 + 2000) and aic == 2024.0 and aicc == pytest.approx(2024 + 312 / 2035)
+
+
+def test_lock_step_runs_are_cut_by_the_spread_of_live_points():
+    """One very bright pixel (nlive + 5 SNR) must not size the lock-step run of a whole stripe: pixels are cut into runs
+    whose largest count is at most twice the smallest; the reference test cube's spread (100 .. 180) stays one run."""
+    from nestfit_amd.fitter import _runs_within_a_factor
+    nl = np.array([100, 180, 120, 400, 90, 1000, 95, 181])
+    runs = _runs_within_a_factor(nl, 2.0)
+    assert [r.tolist() for r in runs] == [[0, 1, 2, 4, 6], [7], [3], [5]]
+    assert sorted(np.concatenate(runs).tolist()) == list(range(8))
+    for r in runs:
+        assert nl[r].max() <= 2 * nl[r].min()
+    assert len(_runs_within_a_factor(np.arange(100, 181), 2.0)) == 1
