@@ -94,6 +94,8 @@ int nfa_get_exp_mode(void);
  *                   (128 from 384, 256 from 768);
  *   "sampler_frames"      rotated box frames of a one-ellipsoid bound (nfa_sampler_set_boxes): -2 (default) and -1
  *                   none, 0..64; "sampler_margin_pct": the boxes' margin factor in hundredths (0 = 175);
+ *   "sampler_shear_pct"   the shear in front of one-ellipsoid bounds (nfa_sampler_set_shear): its safety factor in
+ *                   hundredths, 0 = off, 100..100000 (400 is the measured choice);
  *   "sampler_refit_every" rejection-mode pixels refit their bound in rounds that are multiples of this (default 4);
  *                   the sampler_* keys are read when a sampler is created / begun, A/B knobs like the rest;
  *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid; the
@@ -364,6 +366,16 @@ int nfa_sampler_set_ellipsoids(nfa_sampler *s, int max_ellipsoids);
  * (0: the default, 1.75).  MultiNest has no counterpart; `efr` keeps its meaning for the ellipsoid the proposals are drawn
  * from (nestfit/core/core.pyx:727-732). */
 int nfa_sampler_set_boxes(nfa_sampler *s, int n_frames, double margin);
+/* A volume-preserving shear in front of a one-ellipsoid bound (between create and begin).  The live region of a faint
+ * pixel is a curved ridge (tex against ntot) that an ellipsoid holds badly.  The bound is therefore fitted AFTER the map
+ * w_j = z_j - q_j(z_0 .. z_j-1), z = (u - mean) / spread, q_j the least-squares quadratic of the live points (squares and,
+ * inside one velocity component, products of the earlier coordinates): an additive triangular map has a unit Jacobian, so
+ * a point drawn uniformly in the w-ellipsoid and mapped back is uniform over its curved image in the unit cube.  Boxes, if
+ * on, are fitted and tested in the w frame.  enlarge: the safety factor on the sheared ellipsoid's enclosing volume (>= 1;
+ * 4 is the measured choice), 0 = off, < 0 = the default (engine option "sampler_shear_pct", hundredths; 0 = off).  Applies
+ * where all five free parameters of two or three components are sampled (10 or 15 dimensions); accepted and without effect
+ * elsewhere.  MultiNest has no counterpart (its answer to curved regions is more ellipsoids: nestfit/core/core.pyx:727-760). */
+int nfa_sampler_set_shear(nfa_sampler *s, double enlarge);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
 /* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the

@@ -79,6 +79,13 @@ static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for 
 #define NS_MARGIN_FLOOR 0.1
 #define NS_RATIO_MAX 8             // proposals drawn per round: at most this multiple of the evaluations aimed for
 #define NS_FRAME_SEED 0x5EEDF00Dull
+// A volume-preserving shear in front of the one-ellipsoid bound (the twin's _fit_shear): every sampled coordinate minus a
+// quadratic function of the earlier ones -- the curved tex / ntot ridges of faint pixels come out straight, and an
+// ellipsoid around straight things is small
+#define NS_SHEAR_RIDGE 1e-6        // on the Gram matrix's diagonal, times the live points
+#define NS_SHEAR_ENLARGE 4.0       // safety factor on the enclosing volume of the sheared ellipsoid
+#define NS_SHEAR_MMAX 64           // monomials at most
+#define NS_REFIT_THREADS 512       // of the workgroup that fits a one-ellipsoid bound
 #define NS_WALK_LOWD 6             // up to this many sampled dimensions ...
 #define NS_WALK_FACTOR_LOWD 64     // ... the switch to walks waits for an acceptance below 1 / (64 n_steps)
 #define NS_WALK_FACTOR 2           // above: 1 / (2 n_steps)
@@ -147,7 +154,29 @@ struct NsDev {
     // accepted, proposals drawn and evaluated; ln of the last window's evaluated / drawn when the pixel turned to walks
     long   *rj_scan, *rj_acc, *rj_raw, *rj_val;   // [P]
     double *ln_pass;                    // [P]
+    // the shear (one-ellipsoid bounds of 10 or 15 sampled dimensions, component of dimension j = j % (D / 5))
+    int     shear, sh_M;                // on / off; monomials
+    double  ln_enlarge_shear;
+    const int *sh_mono;                 // [sh_M][2] factors of monomial m (-1: the factor 1)
+    const int *sh_start;                // [D] monomials before coordinate j's own = the features z_j is regressed on
+    double *sh_mu, *sh_sg;              // [P][D] z = (u - mu) / sg
+    double *sh_beta;                    // [P][D][sh_M] w_j = z_j - phi(z_<j) . beta_j
 };
+
+// The monomials of the shear (host; the twin's _shear_monomials): [1], then per coordinate j its own z_j, z_j^2 and
+// z_k z_j for the earlier coordinates k of the same velocity component (k % nc == j % nc).
+static void ns_shear_monomials(int D, int nc, std::vector<int> &mono, std::vector<int> &start) {
+    mono.assign({-1, -1});
+    start.clear();
+    for (int j = 0; j < D; ++j) {
+        start.push_back((int)mono.size() / 2);
+        mono.push_back(j); mono.push_back(-1);
+        mono.push_back(j); mono.push_back(j);
+        for (int k = 0; k < j; ++k)
+            if (k % nc == j % nc) { mono.push_back(k); mono.push_back(j); }
+    }
+    mono.resize((size_t)(start.back() + 1) * 2);      // the last coordinate is nobody's feature
+}
 
 // The fixed frames (host; the twin's _frames): entries 2 u - 1 from the counter-based stream, columns orthonormalised one
 // after the other (modified Gram-Schmidt).
@@ -200,8 +229,10 @@ __global__ void ns_sanitize_kernel(double *__restrict__ L, long n, double log_ze
 // Is the proposal x (zz = its coordinates in the ellipsoid's frame, A^-1 (x - c)) inside every box of pixel p?  The tests
 // in order of their price: the unit cube's axes, the ellipsoid's frame, then the rotated frames, each a D x D product
 // that the first failure cuts short.
+// (in two parts: the axis boxes cost 4 D comparisons, the rotated frames D x D products each -- where a workgroup can, it
+// packs the survivors of the first part, and of the unit cube's test, before it pays for the second)
 template <int DD>
-__device__ __forceinline__ bool ns_in_boxes(const NsDev &S, int p, const double *x, const double *zz) {
+__device__ __forceinline__ bool ns_in_axis_boxes(const NsDev &S, int p, const double *x, const double *zz) {
     const int D = DD > 0 ? DD : S.D;
     // (the bound is read through the constant address space: written by the refit launch, not by this one, and the same
     // for the whole workgroup -- scalar loads; as ordinary global loads the compiler sent every one of the 110 reads per
@@ -210,8 +241,15 @@ __device__ __forceinline__ bool ns_in_boxes(const NsDev &S, int p, const double 
     bool ok = true;
     for (int j = 0; j < D; ++j) ok = ok && (x[j] >= ub[2 * j]) && (x[j] <= ub[2 * j + 1]);
     if (!ok) return false;
-    k_dbl_p fb = (k_dbl_p)(S.fbox + (long)p * (S.n_frames + 1) * D * 2);
+    const k_dbl_p fb = (k_dbl_p)(S.fbox + (long)p * (S.n_frames + 1) * D * 2);
     for (int j = 0; j < D; ++j) ok = ok && (zz[j] >= fb[2 * j]) && (zz[j] <= fb[2 * j + 1]);
+    return ok;
+}
+template <int DD>
+__device__ __forceinline__ bool ns_in_frames(const NsDev &S, int p, const double *zz) {
+    const int D = DD > 0 ? DD : S.D;
+    bool ok = true;
+    k_dbl_p fb = (k_dbl_p)(S.fbox + (long)p * (S.n_frames + 1) * D * 2);
     for (int k = 1; k <= S.n_frames && ok; ++k) {
         const k_dbl_p Q = (k_dbl_p)(S.frames + (long)(k - 1) * D * D);
         fb += D * 2;
@@ -223,20 +261,54 @@ __device__ __forceinline__ bool ns_in_boxes(const NsDev &S, int p, const double 
     }
     return ok;
 }
+template <int DD>
+__device__ __forceinline__ bool ns_in_boxes(const NsDev &S, int p, const double *x, const double *zz) {
+    return ns_in_axis_boxes<DD>(S, p, x, zz) && ns_in_frames<DD>(S, p, zz);
+}
+
+// The shear of pixel p on a point in registers.  DD sampled dimensions, NC = DD / 5 components: the monomial list is known at
+// compile time (same order as ns_shear_monomials), the loops unroll, the coefficients come through the scalar cache.
+// inverse: z holds w on entry, the standardised unit-cube point on return (coordinate by coordinate, each from the ones before)
+template <int DD, bool INVERSE>
+__device__ __forceinline__ void ns_shear_apply(const k_dbl_p beta, int M, double *z) {
+    constexpr int NC = DD / 5;
+    double acc[DD];
+#pragma unroll
+    for (int j = 1; j < DD; ++j) {
+        const k_dbl_p b = beta + j * M;
+        double a = b[0];
+        int m = 1;
+#pragma unroll
+        for (int t = 0; t < j; ++t) {
+            a += b[m++] * z[t];
+            a += b[m++] * (z[t] * z[t]);
+#pragma unroll
+            for (int k = 0; k < t; ++k)
+                if (k % NC == t % NC) a += b[m++] * (z[k] * z[t]);
+        }
+        if (INVERSE) z[j] += a;
+        else acc[j] = a;
+    }
+    if (!INVERSE) {
+#pragma unroll
+        for (int j = 1; j < DD; ++j) z[j] -= acc[j];
+    }
+}
 
 // ---- candidates --------------------------------------------------------------------------
 // Kr = candidates per pixel in this round (>= K: grows when few pixels are left, so the tail of
 // slow pixels does not cost one launch per handful of candidates)
 // DD > 0: the number of sampled dimensions at compile time (loops unroll, the proposal's coordinates live in registers)
+#define NS_PROPOSE_THREADS 128
+// in_range: the thread has a proposal of its own (k < Kr); the others of a pixel's last workgroup go along to the barriers
 template <int DD>
-__device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int n_act, int Kr) {
+__device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int n_act, int Kr, bool in_range) {
     constexpr int DM = DD > 0 ? DD : NS_MAXD;
-    const long gid = (long)q * Kr + k;
+    long gid = (long)q * Kr + k;
     const int p = __builtin_amdgcn_readfirstlane(S.actlist[q]);      // a workgroup serves ONE pixel: its bound comes through scalar loads
     const int D = DD > 0 ? DD : S.D;
-    double *cu = S.candU + gid * D;
     if (!S.active[p]) {                 // finished since the last compaction of the pixel list
-        S.valid[gid] = 0;
+        if (in_range) S.valid[gid] = 0;
         return;
     }
     const uint64_t a = (uint64_t)S.cand_base[p] + (uint64_t)k;
@@ -244,13 +316,16 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
     // the proposal is kept in registers and written once it is known to be worth a likelihood: a proposal the bound
     // vetoes is never looked at again, and with no store ahead of them the loads of the bound (uniform over the
     // workgroup) go through the scalar cache -- as per-lane loads, 3200 of them per proposal, they were the kernel
-    double x[DM];
-    bool ok = true;
+    double x[DM], zq[DM];
+    bool ok = in_range;
     const bool walking = S.walk[p] != 0;
+    // the rotated frames' tests on packed survivors (compile-time dimensions: the queue's LDS is sized by them)
+    const bool queued = DD > 0 && !walking && S.boxes && S.n_frames > 0;
     // (ONE branch per mode: stores of the walkers' branch ahead of the rejection branch on a common path -- a join
     // between two ifs -- would make the compiler read the bound with per-lane loads instead of scalar ones)
     if (walking) {
         // Metropolis step of walker k inside {L > threshold}; a cycle starts from a random live point
+        if (!in_range) return;
         const int step = S.wstep[p];
         const int W = step == 0 ? min(ns_wmax(S, p), Kr) : S.wW[p];
         if (k >= W) { S.valid[gid] = 0; return; }
@@ -286,13 +361,22 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
         for (int j = 0; j < D; ++j) x[j] = ns_uniform_of(strm, (uint64_t)j);
         if (S.boxes) {                         // the boxes hold the live region whatever the proposal was drawn from
             const k_dbl_p c = (k_dbl_p)(S.centre + (long)p * NS_ME * D), A = (k_dbl_p)(S.axes + (long)p * NS_ME * D * D);
-            double zz[DM];
-            for (int j = 0; j < D; ++j) {       // zz = A^-1 (x - c)
-                double v = x[j] - c[j];
+            double *zz = zq, w[DM];
+            for (int j = 0; j < D; ++j) w[j] = x[j];
+            if constexpr (DD == 10 || DD == 15) {
+                if (S.shear) {                 // the boxes live in the sheared frame
+                    const k_dbl_p mu = (k_dbl_p)(S.sh_mu + (long)p * D), sg = (k_dbl_p)(S.sh_sg + (long)p * D);
+                    for (int j = 0; j < D; ++j) w[j] = (x[j] - mu[j]) / sg[j];
+                    ns_shear_apply<DD, false>((k_dbl_p)(S.sh_beta + (long)p * D * S.sh_M), S.sh_M, w);
+                }
+            }
+            for (int j = 0; j < D; ++j) {       // zz = A^-1 (w - c)
+                double v = w[j] - c[j];
                 for (int i = 0; i < j; ++i) v -= A[j * D + i] * zz[i];
                 zz[j] = v / A[j * D + j];
             }
-            ok = ns_in_boxes<DD>(S, p, x, zz);
+            ok = ok && ns_in_axis_boxes<DD>(S, p, w, zz);
+            if (!queued) ok = ok && ns_in_frames<DD>(S, p, zz);
         }
     } else {
         double z[DM];
@@ -323,13 +407,28 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
         }
         const k_dbl_p c = (k_dbl_p)(S.centre + ((long)p * NS_ME + ke) * D), A = (k_dbl_p)(S.axes + ((long)p * NS_ME + ke) * D * D);
         for (int i = 0; i < D; ++i) z[i] *= f;                // the point of the unit ball
+        bool sheared = false;
+        if constexpr (DD == 10 || DD == 15) sheared = S.shear != 0;
         for (int j = 0; j < D; ++j) {
             double v = c[j];
             for (int i = 0; i <= j; ++i) v += A[j * D + i] * z[i];
-            ok = ok && (v >= 0.0) && (v < 1.0);               // outside the unit cube = outside the prior
+            ok = ok && (sheared || ((v >= 0.0) && (v < 1.0)));   // outside the unit cube = outside the prior
             x[j] = v;
         }
-        if (ok && S.boxes) ok = ns_in_boxes<DD>(S, p, x, z);   // (one ellipsoid: the ball point IS A^-1 (x - c))
+        if (ok && S.boxes) ok = ns_in_axis_boxes<DD>(S, p, x, z);   // (one ellipsoid: the ball point IS A^-1 (x - c))
+        if (queued) { for (int j = 0; j < D; ++j) zq[j] = z[j]; }
+        else if (ok && S.boxes) ok = ns_in_frames<DD>(S, p, z);
+        if constexpr (DD == 10 || DD == 15) {
+            if (sheared && ok) {                // the ellipsoid's point is w: back through the shear to the unit cube
+                const k_dbl_p mu = (k_dbl_p)(S.sh_mu + (long)p * D), sg = (k_dbl_p)(S.sh_sg + (long)p * D);
+                ns_shear_apply<DD, true>((k_dbl_p)(S.sh_beta + (long)p * D * S.sh_M), S.sh_M, x);
+                for (int j = 0; j < D; ++j) {
+                    const double v = mu[j] + sg[j] * x[j];
+                    ok = ok && (v >= 0.0) && (v < 1.0);
+                    x[j] = v;
+                }
+            }
+        }
         if (ok && ne > 1) {
             int q = 1;
             for (int k = 0; k < ne; ++k) {
@@ -347,7 +446,39 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
             if (q > 1) ok = ns_uniform_of(strm, NS_B_KEEP) * q < 1.0;
         }
     }
-    S.valid[gid] = ok ? 1 : 0;
+    if constexpr (DD > 0) {
+        if (queued) {
+            // Survivors of the cheap tests (the axis boxes, the unit cube) queue up in LDS; the first `n` threads of the
+            // workgroup take one each through the rotated frames -- D x D products per frame that the whole wave pays while
+            // any of its lanes is alive: packed, a quarter of the waves do
+            __shared__ double qbuf[2 * DM * NS_PROPOSE_THREADS];
+            __shared__ int qk[NS_PROPOSE_THREADS];
+            __shared__ int qn;
+            const int tid = (int)threadIdx.x;
+            if (tid == 0) qn = 0;
+            __syncthreads();
+            if (ok) {
+                const int e = atomicAdd(&qn, 1);
+                for (int j = 0; j < DM; ++j) { qbuf[j * NS_PROPOSE_THREADS + e] = zq[j]; qbuf[(DM + j) * NS_PROPOSE_THREADS + e] = x[j]; }
+                qk[e] = k;
+            } else if (in_range) {
+                S.valid[gid] = 0;
+            }
+            __syncthreads();
+            ok = tid < qn;
+            if (ok) {
+                for (int j = 0; j < DM; ++j) { zq[j] = qbuf[j * NS_PROPOSE_THREADS + tid]; x[j] = qbuf[(DM + j) * NS_PROPOSE_THREADS + tid]; }
+                gid = (long)q * Kr + qk[tid];
+                ok = ns_in_frames<DD>(S, p, zq);
+                S.valid[gid] = ok ? 1 : 0;
+            }
+        } else if (in_range) {
+            S.valid[gid] = ok ? 1 : 0;
+        }
+    } else if (in_range) {
+        S.valid[gid] = ok ? 1 : 0;
+    }
+    double *cu = S.candU + gid * D;
     if (ok) for (int j = 0; j < D; ++j) cu[j] = x[j];
     // only candidates inside the prior go to the likelihood: compact rows (order is irrelevant, every proposal
     // remembers its row).  One atomic per wave, not per proposal: tens of thousands of them on ONE counter took the
@@ -372,7 +503,7 @@ template <int DD>
 __global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
     const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int q = (int)(blockIdx.y + blockIdx.z * 65535u);
-    if (q < n_act && k < Kr) ns_propose_one<DD>(S, q, k, n_act, Kr);
+    if (q < n_act) ns_propose_one<DD>(S, q, k, n_act, Kr, k < Kr);
 }
 
 // One thread behind a proposing launch: the number of compact rows and the round's sequence number go into host
@@ -426,27 +557,139 @@ __device__ __forceinline__ double ns_logaddexp(double a, double b) {
 // nestfit_amd/sampler.py): centre = mean, A = chol(cov) * sqrt(max Mahalanobis^2) * growth, the
 // growth bringing the volume up to X / efr where the bounding ellipsoid is smaller than that.
 // sA: D*D doubles of LDS, sc: D doubles.
-__device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double *sc, double *sd, int lane) {
+// sum / maximum over the workgroup's NT threads (a multiple of 64), every thread gets the result; sred: 8 doubles of LDS
+__device__ __forceinline__ double ns_block_sum(double v, double *sred, int tid, int NT) {
+    v = ns_wave_sum(v);
+    if (NT == 64) return v;
+    __syncthreads();
+    if ((tid & 63) == 0) sred[tid >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < NT / 64; ++k) t += sred[k];
+    return t;
+}
+__device__ __forceinline__ double ns_block_max(double v, double *sred, int tid, int NT) {
+    v = ns_wave_max(v);
+    if (NT == 64) return v;
+    __syncthreads();
+    if ((tid & 63) == 0) sred[tid >> 6] = v;
+    __syncthreads();
+    double t = sred[0];
+    for (int k = 1; k < NT / 64; ++k) t = fmax(t, sred[k]);
+    return t;
+}
+
+// The shear of pixel p from its live points, staged in sd[N][D] (LDS); on return sd holds the sheared points w, the
+// coefficients are in global memory and the result is ln |du / dw| = sum ln sg.  sh = LDS scratch: [M*M][D*M][2 D].
+// One Gram matrix of all monomials and ONE Cholesky factorisation serve every coordinate: the factor of a leading block is
+// the leading block of the factor, and row start[j] of the factor is the forward substitution of coordinate j's normal
+// equations (its right-hand side is the Gram column of the monomial z_j itself).
+__device__ double ns_shear_fit(const NsDev &S, int p, int N, double *sd, double *sh, int tid, int NT, double *sred) {
+    const int D = S.D, M = S.sh_M;
+    double *sG = sh, *sB = sG + M * M, *smu = sB + D * M, *ssg = smu + D;
+    const int *mono = S.sh_mono, *start = S.sh_start;
+    for (int j = tid; j < D; j += NT) {
+        double acc = 0.0;
+        for (int i = 0; i < N; ++i) acc += sd[i * D + j];
+        const double mu = acc / N;
+        double q = 0.0;
+        for (int i = 0; i < N; ++i) { const double d = sd[i * D + j] - mu; q += d * d; }
+        smu[j] = mu;
+        ssg[j] = fmax(sqrt(q / (N - 1)), 1e-300);
+    }
+    __syncthreads();
+    for (int e = tid; e < N * D; e += NT) { const int j = e % D; sd[e] = (sd[e] - smu[j]) / ssg[j]; }
+    __syncthreads();
+    // Gram matrix, lower triangle: lanes = entries, each walking all points
+    const int n_ent = M * (M + 1) / 2;
+    for (int e = tid; e < n_ent; e += NT) {
+        int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while (r * (r + 1) / 2 > e) --r;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        const int c = e - r * (r + 1) / 2;
+        const int a0 = mono[2 * r], a1 = mono[2 * r + 1], b0 = mono[2 * c], b1 = mono[2 * c + 1];
+        double acc = 0.0;
+        for (int i = 0; i < N; ++i) {
+            const double *z = sd + i * D;
+            const double fr = a0 < 0 ? 1.0 : (a1 < 0 ? z[a0] : z[a0] * z[a1]);
+            const double fc = b0 < 0 ? 1.0 : (b1 < 0 ? z[b0] : z[b0] * z[b1]);
+            acc += fr * fc;
+        }
+        sG[r * M + c] = acc + (r == c ? NS_SHEAR_RIDGE * N : 0.0);
+    }
+    __syncthreads();
+    // Cholesky in place, column by column: lane 0 the diagonal, lanes = rows below it
+    for (int j = 0; j < M; ++j) {
+        if (tid == 0) {
+            double d = sG[j * M + j];
+            for (int k = 0; k < j; ++k) d -= sG[j * M + k] * sG[j * M + k];
+            sG[j * M + j] = sqrt(fmax(d, 1e-300));
+        }
+        __syncthreads();
+        const double dj = sG[j * M + j];
+        for (int i = j + 1 + tid; i < M; i += NT) {
+            double v = sG[i * M + j];
+            for (int k = 0; k < j; ++k) v -= sG[i * M + k] * sG[j * M + k];
+            sG[i * M + j] = v / dj;
+        }
+        __syncthreads();
+    }
+    // coefficients: lanes = coordinates, back substitution with the transposed leading block
+    for (int j = tid; j < D; j += NT) {
+        const int pj = j == 0 ? 0 : start[j];
+        double *b = sB + j * M;
+        for (int r = 0; r < M; ++r) b[r] = 0.0;
+        for (int r = pj - 1; r >= 0; --r) {
+            double v = sG[pj * M + r];
+            for (int k = r + 1; k < pj; ++k) v -= sG[k * M + r] * b[k];
+            b[r] = v / sG[r * M + r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < D * M; e += NT) S.sh_beta[(long)p * D * M + e] = sB[e];
+    for (int j = tid; j < D; j += NT) { S.sh_mu[(long)p * D + j] = smu[j]; S.sh_sg[(long)p * D + j] = ssg[j]; }
+    // w in place: lanes = points, from the last coordinate down (a coordinate's features are the earlier z)
+    for (int i = tid; i < N; i += NT) {
+        double *z = sd + i * D;
+        for (int j = D - 1; j >= 1; --j) {
+            const int pj = start[j];
+            const double *b = sB + j * M;
+            double acc = b[0];
+            for (int m = 1; m < pj; ++m) {
+                const int a0 = mono[2 * m], a1 = mono[2 * m + 1];
+                acc += b[m] * (a1 < 0 ? z[a0] : z[a0] * z[a1]);
+            }
+            z[j] -= acc;
+        }
+    }
+    double lj = 0.0;
+    for (int j = 0; j < D; ++j) lj += log(ssg[j]);
+    __syncthreads();
+    return lj;
+}
+
+__device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double *sc, double *sd, double *sh, int tid, int NT, double *sred) {
     const int N = ns_n(S, p), D = S.D;
     const double *U = S.Ulive + (long)p * S.N * D;
-    double tr = 0.0;
+    double tr = 0.0, ln_jac = 0.0, ln_enl = S.ln_enlarge;
     if (sd) {
         // the live points fit in LDS (N * D doubles): staged once with coalesced loads, then lanes =
         // dimensions for the mean and lanes = entries of the covariance matrix, each walking all
         // points in LDS -- the D(D+1)/2 wave reductions over global memory of the fallback below cost
         // ~200 us per refit for D = 12
-        for (int e = lane; e < N * D; e += 64) sd[e] = U[e];
-        wave_lds_sync();
-        for (int j = lane; j < D; j += 64) {
+        for (int e = tid; e < N * D; e += NT) sd[e] = U[e];
+        __syncthreads();
+        if (S.shear) { ln_jac = ns_shear_fit(S, p, N, sd, sh, tid, NT, sred); ln_enl = S.ln_enlarge_shear; }   // sd: w from here on
+        for (int j = tid; j < D; j += NT) {
             double acc = 0.0;
             for (int i = 0; i < N; ++i) acc += sd[i * D + j];
             sc[j] = acc / N;
         }
-        wave_lds_sync();
-        for (int e = lane; e < N * D; e += 64) sd[e] -= sc[e % D];
-        wave_lds_sync();
+        __syncthreads();
+        for (int e = tid; e < N * D; e += NT) sd[e] -= sc[e % D];
+        __syncthreads();
         const int n_ent = D * (D + 1) / 2;
-        for (int e = lane; e < n_ent; e += 64) {
+        for (int e = tid; e < n_ent; e += NT) {
             int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);          // row of the lower triangle
             while (a * (a + 1) / 2 > e) --a;
             while ((a + 1) * (a + 2) / 2 <= e) ++a;
@@ -455,27 +698,27 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
             for (int i = 0; i < N; ++i) acc += sd[i * D + a] * sd[i * D + b];
             sA[a * D + b] = acc / (N - 1);
         }
-        wave_lds_sync();
+        __syncthreads();
         for (int a = 0; a < D; ++a) tr += sA[a * D + a];
     } else {
         for (int j = 0; j < D; ++j) {
             double acc = 0.0;
-            for (int i = lane; i < N; i += 64) acc += U[(long)i * D + j];
-            acc = ns_wave_sum(acc);
-            if (lane == 0) sc[j] = acc / N;
+            for (int i = tid; i < N; i += NT) acc += U[(long)i * D + j];
+            acc = ns_block_sum(acc, sred, tid, NT);
+            if (tid == 0) sc[j] = acc / N;
         }
-        wave_lds_sync();
+        __syncthreads();
         for (int a = 0; a < D; ++a)
             for (int b = 0; b <= a; ++b) {
                 double acc = 0.0;
-                for (int i = lane; i < N; i += 64) acc += (U[(long)i * D + a] - sc[a]) * (U[(long)i * D + b] - sc[b]);
-                acc = ns_wave_sum(acc) / (N - 1);
-                if (lane == 0) sA[a * D + b] = acc;
+                for (int i = tid; i < N; i += NT) acc += (U[(long)i * D + a] - sc[a]) * (U[(long)i * D + b] - sc[b]);
+                acc = ns_block_sum(acc, sred, tid, NT) / (N - 1);
+                if (tid == 0) sA[a * D + b] = acc;
                 if (a == b) tr += acc;
             }
-        wave_lds_sync();
+        __syncthreads();
     }
-    if (lane == 0) {                    // Cholesky, lower triangle in place
+    if (tid == 0) {                    // Cholesky, lower triangle in place
         const double eps = 1e-12 * fmax(tr, 1e-30);
         for (int a = 0; a < D; ++a) sA[a * D + a] += eps;
         for (int j = 0; j < D; ++j) {
@@ -490,11 +733,11 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
             }
         }
     }
-    wave_lds_sync();
+    __syncthreads();
     const bool boxes = S.boxes && sd;
     if (boxes) {
         // the box in the unit cube's own axes (the centred points are still in LDS): lanes = dimensions
-        for (int j = lane; j < D; j += 64) {
+        for (int j = tid; j < D; j += NT) {
             double lo = INFINITY, hi = -INFINITY, acc = 0.0;
             for (int i = 0; i < N; ++i) {
                 const double d = sd[i * D + j];
@@ -505,10 +748,10 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
             ub[0] = sc[j] + lo - S.margin_c * fmax(NS_MARGIN_FLOOR * sg, -lo - NS_MARGIN_A * sg);
             ub[1] = sc[j] + hi + S.margin_c * fmax(NS_MARGIN_FLOOR * sg, hi - NS_MARGIN_A * sg);
         }
-        wave_lds_sync();
+        __syncthreads();
     }
     double r2 = 0.0, ssq = 0.0;
-    for (int i = lane; i < N; i += 64) {           // y = L^-1 (u_i - c), forward substitution
+    for (int i = tid; i < N; i += NT) {           // y = L^-1 (u_i - c), forward substitution
         double s2 = 0.0;
         if (boxes) {                               // in place: the boxes below want every point's y
             for (int a = 0; a < D; ++a) {
@@ -530,40 +773,42 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         r2 = fmax(r2, s2);
         ssq += s2;
     }
-    r2 = ns_wave_max(r2);
+    r2 = ns_block_max(r2, sred, tid, NT);
     // the covariance ellipsoid scaled to enclose every live point, then MultiNest's rule: enlarged
     // until its volume is at least the expected prior volume over the target efficiency, X / efr
-    double lnv = S.ln_vball + 0.5 * D * log(r2) + S.ln_enlarge;   // safety factor on the enclosing volume
+    double lnv = S.ln_vball + 0.5 * D * log(r2) + ln_enl;   // safety factor on the enclosing volume
     for (int a = 0; a < D; ++a) lnv += log(sA[a * D + a]);
-    const double ln_x = -(double)n_iter / N;
+    // (with the shear the ellipsoid is in w units: the prior volume to hold is X / |du / dw| there)
+    const double ln_x = -(double)n_iter / N - ln_jac;
     const double grow = fmax((ln_x - S.ln_efr) - lnv, 0.0);
-    const double scale = sqrt(r2) * exp((grow + S.ln_enlarge) / D);
-    if (lane == 0) { S.use_cube[p] = (lnv + grow) >= 0.0 ? 1 : 0; S.lnvol[p] = lnv + grow; }   // >= cube: use the cube
+    const double scale = sqrt(r2) * exp((grow + ln_enl) / D);
+    const double lnvol_u = (lnv + grow) + ln_jac;
+    if (tid == 0) { S.use_cube[p] = lnvol_u >= 0.0 ? 1 : 0; S.lnvol[p] = lnvol_u; }   // >= cube: use the cube
     double *A = S.axes + (long)p * NS_ME * D * D, *c = S.centre + (long)p * NS_ME * D;     // ellipsoid 0 of the pixel
-    if (lane == 0) { S.nell[p] = 1; S.elnv[(long)p * NS_ME] = lnv + grow; }
-    for (int e = lane; e < D * D; e += 64) {
+    if (tid == 0) { S.nell[p] = 1; S.elnv[(long)p * NS_ME] = lnvol_u; }
+    for (int e = tid; e < D * D; e += NT) {
         const int a = e / D, b = e - a * D;
         A[e] = b <= a ? sA[e] * scale : 0.0;
     }
-    for (int j = lane; j < D; j += 64) c[j] = sc[j];
+    for (int j = tid; j < D; j += NT) c[j] = sc[j];
     if (boxes) {
         // zz = A^-1 (u - c) = y / scale: the live points in the frame a proposal is drawn in (its unit-ball point);
         // their boxes in that frame and in the fixed rotations of it.  lanes = points, one (frame, coordinate) at a time
         const double inv = 1.0 / scale;
-        ssq = ns_wave_sum(ssq);
+        ssq = ns_block_sum(ssq, sred, tid, NT);
         const double sz = sqrt(ssq * inv * inv / ((double)(N - 1) * D));     // the spread of zz, the same in every direction
         const double mfloor = NS_MARGIN_FLOOR * sz, moff = NS_MARGIN_A * sz;
         // (zz in place first: one multiplication per coordinate instead of one per use)
-        for (int e = lane; e < N * D; e += 64) sd[e] *= inv;
-        wave_lds_sync();
+        for (int e = tid; e < N * D; e += NT) sd[e] *= inv;
+        __syncthreads();
         // lanes = (frame, coordinate) pairs, each walking all points: a lane keeps its column of the frame in registers
         // (up to NS_QCOL entries at a time) and its own minimum and maximum -- no wave reductions, and every point's
         // coordinates are one broadcast read for all lanes.  (The first version had lanes = points: 660 wave reductions
         // and a scalar load of the frame's entry inside the innermost loop made a refit 2 ms.)
         constexpr int NS_QCOL = 16;
         const int n_pair = (S.n_frames + 1) * D;
-        for (int e0 = 0; e0 < n_pair; e0 += 64) {
-            const int e = e0 + lane;
+        for (int e0 = 0; e0 < n_pair; e0 += NT) {
+            const int e = e0 + tid;
             const bool on = e < n_pair;
             const int k = on ? e / D : 0, j = on ? e - k * D : 0;
             double lo = INFINITY, hi = -INFINITY;
@@ -595,7 +840,7 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
             }
         }
     }
-    wave_lds_sync();
+    __syncthreads();
 }
 
 // ---- several ellipsoids ----------------------------------------------------------------------
@@ -783,21 +1028,37 @@ __device__ void ns_refit_multi(const NsDev &S, int p, long n_iter, double *su, i
     wave_lds_sync();
 }
 
-// ---- one wave per pixel: accept / replace / evidence / stop / refit ------------------------
+// ---- one workgroup per pixel: accept / replace / evidence / stop / refit -------------------
+// Wave 0 owns the pixel's state and does everything sequential (replacements in the candidates' order, walks); the other
+// waves help where a rejection round is wide: a segment of NS_UPD_SEG proposals has its flags, rows and likelihoods
+// fetched by all threads at once, and only the candidates above the threshold the segment started with -- the only ones
+// that can replace anything, the threshold never falls -- are handed to wave 0, in order.  (One wave walking 16 k flags
+// in chunks of 512, three dependent global loads per chunk, was ~0.6-1.1 ms per round of the boxes' runs.)
 // q indexes actlist
-__global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int Kr, long round) {
+#define NS_UPD_THREADS 256
+#define NS_UPD_SEG (4 * NS_UPD_THREADS)
+__host__ __device__ inline size_t ns_upd_lds(int N) {   // doubles: live lnL | survivors' lnL | their k, row, rank (ints) | counts | control
+    return (size_t)((N + 1) & ~1) + NS_UPD_SEG + (3 * NS_UPD_SEG) / 2 + 16 + 2;
+}
+__global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int n_act, int Kr, long round) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int q = blockIdx.x, lane = threadIdx.x;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (q >= n_act) return;
     const int p = S.actlist[q];
     const int N = ns_n(S, p), NS = S.N, D = S.D, K = Kr;      // live points of this pixel; stride of the live arrays
     const long cap = ns_cap(S, p);
     const double ln_shrink = S.nlive ? log1p(-exp(-1.0 / N)) : S.ln_shrink;
     double *sL = smem;                              // live log-likelihoods of the pixel
+    double *svL = sL + ((S.N + 1) & ~1);            // survivors of a segment: lnL ...
+    int *svK = (int *)(svL + NS_UPD_SEG), *svRow = svK + NS_UPD_SEG, *svRank = svRow + NS_UPD_SEG;   // ... proposal, compact row, rank among the valid
+    int *sCnt = svRank + NS_UPD_SEG;                // [2][4][4] valid / surviving proposals per (quarter of the segment, wave)
+    double *sCtl = (double *)(sCnt + 32);           // threshold and done flag after wave 0's pass
     if (!S.active[p]) return;
     double *Ll = S.Llive + (long)p * NS;
-    for (int i = lane; i < N; i += 64) sL[i] = Ll[i];
-    wave_lds_sync();
+    for (int i = tid; i < N; i += NS_UPD_THREADS) sL[i] = Ll[i];
+    __syncthreads();
+    const bool was_walking = S.walk[p] != 0;
+    if (was_walking && wave != 0) return;           // (a walk round is wave 0's alone: no barrier below on that path)
     auto worst_point = [&](double &lmin, int &w) {
         double mn = INFINITY;
         int ix = 0x7fffffff;
@@ -842,7 +1103,6 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         const double remain = Lmax - (double)it / N;
         done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= cap;
     };
-    const bool was_walking = S.walk[p] != 0;
     if (was_walking) {
         // ---- one Metropolis step of every walker (lane = walker), cycle end every n_steps rounds
         const int step = S.wstep[p];
@@ -897,45 +1157,67 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
         // goes stale by the factor exp(-replacements / N) in volume, far cheaper than throwing evaluated
         // points away.  The proposals are walked 64 at a time; only the valid ones cost anything.
         long scanned = 0, accepted = 0, n_valid = 0;
-        for (int kb = 0; kb < K && !done; kb += 512) {
-            // validity flags of 512 proposals at a time: eight independent loads per lane, so that a
-            // round of 16 k proposals costs 32 memory latencies, not 256
-            // (the rows and likelihoods of the valid ones are fetched lane-parallel as well: walking
-            // the candidates one by one through two dependent global loads each cost 3 us apiece)
-            unsigned long long masks[8];
-            int rows[8];
-            double Ls[8];
+        double Lseg = Lmin;                         // the threshold the segment starts with (wave 0's Lmin, shared below)
+        if (tid == 0) { sCtl[0] = Lmin; sCtl[1] = 0.0; }
+        __syncthreads();
+        Lseg = sCtl[0];
+        bool stop = false;                          // every thread's copy of `done`
+        for (int kb = 0; kb < K && !stop; kb += NS_UPD_SEG) {
+            unsigned long long mv[4], ms[4];
+            int rows[4];
+            double Ls[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int kk = kb + 64 * u + lane;
+            for (int u = 0; u < 4; ++u) {           // proposal kb + u * 256 + tid: coalesced flags, rows, likelihoods
+                const int kk = kb + u * NS_UPD_THREADS + tid;
                 const bool v = kk < K && S.valid[(long)q * K + kk] != 0;
-                masks[u] = __ballot(v);
+                mv[u] = __ballot(v);
                 rows[u] = v ? S.slot[(long)q * K + kk] : 0;
-                n_valid += __builtin_popcountll(masks[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool mine = (masks[u] >> lane) & 1ull;
+            for (int u = 0; u < 4; ++u) {
+                const bool mine = (mv[u] >> lane) & 1ull;
                 const double L = !mine ? 0.0 : S.part ? lnl_of_item(S.part, S.noise, (long)S.candpix[rows[u]], (long)rows[u], S.nspec) : S.candL[rows[u]];
                 Ls[u] = isfinite(L) ? L : S.log_zero;
+                ms[u] = __ballot(mine && Ls[u] > Lseg);
+                if (lane == 0) { sCnt[u * 4 + wave] = __builtin_popcountll(mv[u]); sCnt[16 + u * 4 + wave] = __builtin_popcountll(ms[u]); }
             }
+            __syncthreads();
+            int tot_v = 0, tot_s = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                unsigned long long mask = masks[u];
-                const int k0 = kb + 64 * u;
-                while (mask && !done) {
-                    const int src = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const long g = (long)q * K + k0 + src;
-                    const long row = __builtin_amdgcn_readlane(rows[u], src);
-                    evals += 1; scanned += 1;
-                    const double Lk = readlane_d(Ls[u], src);
-                    if (!(Lk > Lmin)) continue;
-                    accepted += 1;
-                    replace(S.candU + g * D, S.candT + row * S.DT, Lk);
+            for (int u = 0; u < 4; ++u) {
+                int base_v = 0, base_s = 0;         // valid / surviving proposals ahead of this (quarter, wave) in the segment
+                for (int e = 0; e < 16; ++e) {
+                    const int cv = sCnt[e], cs = sCnt[16 + e];
+                    if (e < u * 4 + wave) { base_v += cv; base_s += cs; }
+                    if (u == 0) { tot_v += cv; tot_s += cs; }
+                }
+                if ((ms[u] >> lane) & 1ull) {
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    const int e = base_s + __builtin_popcountll(ms[u] & lt);
+                    svL[e] = Ls[u];
+                    svK[e] = kb + u * NS_UPD_THREADS + tid;
+                    svRow[e] = rows[u];
+                    svRank[e] = base_v + __builtin_popcountll(mv[u] & lt) + 1;
                 }
             }
+            __syncthreads();
+            if (wave == 0) {
+                long seg_scanned = tot_v;
+                for (int i = 0; i < tot_s && !done; ++i) {
+                    const double Lk = svL[i];
+                    if (!(Lk > Lmin)) continue;
+                    accepted += 1;
+                    replace(S.candU + ((long)q * K + svK[i]) * D, S.candT + (long)svRow[i] * S.DT, Lk);
+                    if (done) seg_scanned = svRank[i];      // the candidates behind the last one are never looked at
+                }
+                scanned += seg_scanned; evals += seg_scanned; n_valid += tot_v;
+                if (lane == 0) { sCtl[0] = Lmin; sCtl[1] = done ? 1.0 : 0.0; }
+            }
+            __syncthreads();
+            Lseg = sCtl[0];
+            stop = sCtl[1] != 0.0;
         }
+        if (wave != 0) return;
         // Walk cycles of all pixels are kept in phase (they start at rounds that are multiples of
         // n_steps): the expensive cycle end then falls into the same launch for everybody instead of
         // making every launch wait for somebody's.
@@ -967,9 +1249,12 @@ __global__ void __launch_bounds__(64) ns_update_kernel(NsDev S, int n_act, int K
 }
 
 // The bounds of the pixels that are due (ns_update_kernel marks them; `direct`: all pixels, before the first round).
-// One wave per pixel.  LDS: [D*D][D][live points: N*D][fit slots][labels].
-__global__ void __launch_bounds__(64) ns_refit_kernel(NsDev S, int n_act, int direct) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+// One workgroup per pixel: one wave where the bound may be several ellipsoids, NS_REFIT_THREADS threads for the one-ellipsoid
+// fit with its shear and boxes (a lone wave's chain of LDS latencies was 2.2 ms per refit).
+// LDS: [8: reductions][D*D][D][live points: N*D][fit slots and labels | the shear's scratch].
+__global__ void __launch_bounds__(NS_REFIT_THREADS) ns_refit_kernel(NsDev S, int n_act, int direct) {
+    extern __shared__ __attribute__((aligned(16))) double smem_all[];
+    double *smem = smem_all + 8;
     const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= n_act) return;
     const int p = direct ? q : S.actlist[q];
@@ -991,7 +1276,7 @@ __global__ void __launch_bounds__(64) ns_refit_kernel(NsDev S, int n_act, int di
         default: ns_refit_multi<6>(S, p, it, sd, lab, wf, lane); break;
         }
     } else {
-        ns_refit(S, p, it, sA, sc, sd, lane);
+        ns_refit(S, p, it, sA, sc, sd, wf, (int)threadIdx.x, (int)blockDim.x, smem_all);     // (wf: the shear's scratch where the bound is one ellipsoid)
     }
     if (lane == 0) { S.since_fit[p] = 0; S.refit_due[p] = 0; }
 }
@@ -1028,6 +1313,9 @@ struct nfa_sampler {
     double *d_frames = nullptr;
     int set_frames = -2;        // nfa_sampler_set_boxes: -2 = the default (NS_FRAMES above NS_ME_MAXD sampled dimensions), -1 = no boxes
     double set_margin = 0.0;    // ... 0 = the default
+    double set_shear = -1.0;    // nfa_sampler_set_shear: < 0 = the default (engine option sampler_shear_pct), 0 = off, >= 1 = the safety factor
+    int *d_sh_mono = nullptr, *d_sh_start = nullptr;
+    std::vector<int> fm;        // the sampled dimensions' slots
     size_t k_alloc = 0;         // proposal rows allocated per pixel
     long raw_sum = 0, val_sum = 0;   // proposals drawn / evaluated since the last look at the active pixels
     std::vector<int> h_nlive;   // per-pixel live points (empty: d.N for everybody)
@@ -1051,7 +1339,8 @@ int nfa_sampler_destroy(nfa_sampler *s) {
                     d.since_fit, d.refit_due, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol, d.elnv, d.nell,
                     s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap, s->d_nlive, s->d_updp, s->d_capp,
-                    s->d_frames, d.ubox, d.fbox, d.rj_scan, d.rj_acc, d.rj_raw, d.rj_val, d.ln_pass};
+                    s->d_frames, d.ubox, d.fbox, d.rj_scan, d.rj_acc, d.rj_raw, d.rj_val, d.ln_pass,
+                    s->d_sh_mono, s->d_sh_start, d.sh_mu, d.sh_sg, d.sh_beta};
     for (void *p : ptrs) (void)hipFree(p);
     if (s->h_pub) (void)hipHostFree(s->h_pub);
     delete s;
@@ -1113,6 +1402,9 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.rj_scan, long, P); NS_ALLOC(d.rj_acc, long, P); NS_ALLOC(d.rj_raw, long, P); NS_ALLOC(d.rj_val, long, P);
     NS_ALLOC(d.ln_pass, double, P);
     NS_ALLOC(s->d_frames, double, (size_t)NS_FRAMES_MAX * D * D);
+    NS_ALLOC(s->d_sh_mono, int, NS_SHEAR_MMAX * 2); NS_ALLOC(s->d_sh_start, int, D);
+    NS_ALLOC(d.sh_mu, double, P * D); NS_ALLOC(d.sh_sg, double, P * D); NS_ALLOC(d.sh_beta, double, P * D * NS_SHEAR_MMAX);
+    s->fm = fm;
 #undef NS_ALLOC
     HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_fmap, fm.data(), sizeof(int) * D, hipMemcpyHostToDevice));
@@ -1158,6 +1450,16 @@ int nfa_sampler_set_boxes(nfa_sampler *s, int n_frames, double margin) {
     if (s->ran) return fail(NFA_ERR_STATE, "call nfa_sampler_set_boxes before nfa_sampler_begin");
     s->set_frames = n_frames;
     s->set_margin = margin;
+    return NFA_OK;
+}
+
+// The shear in front of a one-ellipsoid bound (10 or 15 sampled dimensions = all five free parameters of two or three
+// components; elsewhere the call is accepted and changes nothing): enlarge = the safety factor on the sheared ellipsoid's
+// enclosing volume (>= 1; NS_SHEAR_ENLARGE = 4 is the measured choice), 0 = off, < 0 = the default.  Before nfa_sampler_begin.
+int nfa_sampler_set_shear(nfa_sampler *s, double enlarge) {
+    if (!s || (enlarge > 0.0 && enlarge < 1.0) || enlarge > 1e6 || enlarge != enlarge) return fail(NFA_ERR_ARG, "shear: 0 (off), < 0 (default) or a safety factor >= 1");
+    if (s->ran) return fail(NFA_ERR_STATE, "call nfa_sampler_set_shear before nfa_sampler_begin");
+    s->set_shear = enlarge;
     return NFA_OK;
 }
 
@@ -1223,8 +1525,8 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemcpyAsync(d.n_evals, h_evals.data(), sizeof(long) * P, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d.lnZ, h_lnz.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d.active, s->h_active.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
-    s->lds = sizeof(double) * (size_t)((N + 1) & ~1);                       // the update wave: the live log-likelihoods
-    s->lds_refit = sizeof(double) * ((size_t)D * D + (size_t)((D + 1) & ~1));  // the refit wave: ...
+    s->lds = sizeof(double) * ns_upd_lds(N);                                // the update workgroup: the live log-likelihoods, a segment's survivors
+    s->lds_refit = sizeof(double) * (8 + (size_t)D * D + (size_t)((D + 1) & ~1));  // the refit workgroup: reductions, ...
     d.stage_live = (size_t)N * D * sizeof(double) <= 96 * 1024 ? 1 : 0;
     d.refit_every = g_eng.sampler_refit_every;
     // When does a pixel give up rejection sampling for constrained walks?  Measured on config 5 (profiles/r03/
@@ -1253,11 +1555,31 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
         d.frames = s->d_frames;
         s->raw_sum = s->val_sum = 0;
     }
+    {   // the shear: one-ellipsoid bounds of all five free parameters of two or three components
+        const double enl = s->set_shear >= 0.0 ? s->set_shear : 0.01 * g_eng.sampler_shear_pct;
+        const int nc = D / 5;
+        bool shape = (D == 10 || D == 15) && d.DT == 6 * nc;
+        for (int j = 0; shape && j < D; ++j) shape = (s->fm[(size_t)j] % nc) == (j % nc);
+        d.shear = (enl >= 1.0 && shape && !d.multi && d.stage_live) ? 1 : 0;
+        d.sh_M = 0;
+        if (d.shear) {
+            std::vector<int> mono, start;
+            ns_shear_monomials(D, nc, mono, start);
+            d.sh_M = (int)mono.size() / 2;
+            if (d.sh_M > NS_SHEAR_MMAX) return fail(NFA_ERR_STATE, "shear: too many monomials");
+            HIP_TRY(hipMemcpyAsync(s->d_sh_mono, mono.data(), sizeof(int) * mono.size(), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(s->d_sh_start, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            d.ln_enlarge_shear = log(enl);
+            s->lds_refit += sizeof(double) * ((size_t)d.sh_M * d.sh_M + (size_t)D * d.sh_M + 2 * (size_t)D);
+        }
+        d.sh_mono = s->d_sh_mono; d.sh_start = s->d_sh_start;
+    }
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));
     if (s->lds_refit > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_refit));
-    hipLaunchKernelGGL(ns_refit_kernel, dim3((unsigned)P), dim3(64), s->lds_refit, st, d, P, 1);   // first ellipsoids
+    hipLaunchKernelGGL(ns_refit_kernel, dim3((unsigned)P), dim3(d.multi ? 64 : NS_REFIT_THREADS), s->lds_refit, st, d, P, 1);   // first ellipsoids
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     s->rounds = 0;
@@ -1295,7 +1617,8 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
         long ratio = 1;
         if (d.boxes && s->raw_sum > 0) ratio = std::min<long>(NS_RATIO_MAX, std::max<long>(1, (s->raw_sum + s->val_sum / 2) / std::max<long>(s->val_sum, 1)));
         s->raw_sum = s->val_sum = 0;
-        const int Kr = (int)std::min<long>(NS_KMAX, std::max<long>(K, (s->b_target * ratio) / n_act));    // (n_act * Kr rows <= NS_RATIO_MAX * b_target: what nfa_sampler_create allocated)
+        const long kmax = g_eng.sampler_kmax > 0 ? g_eng.sampler_kmax : NS_KMAX;
+        const int Kr = (int)std::min<long>(kmax, std::max<long>(K, (s->b_target * ratio) / n_act));    // (n_act * Kr rows <= NS_RATIO_MAX * b_target: what nfa_sampler_create allocated)
         int n_pix_h[NS_PARTS];
         NsDev dh[NS_PARTS];
         {   // every part works on its own slices of the proposal / compact-row buffers
@@ -1319,10 +1642,10 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                 (void)B;
                 const dim3 pg((unsigned)((Kr + 127) / 128), (unsigned)std::min(n_pix_h[h], 65535), (unsigned)((n_pix_h[h] + 65534) / 65535));
                 switch (D) {                                        // compile-time dimensions where they are common
-                case 5: hipLaunchKernelGGL(ns_propose_kernel<5>, pg, dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
-                case 10: hipLaunchKernelGGL(ns_propose_kernel<10>, pg, dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
-                case 15: hipLaunchKernelGGL(ns_propose_kernel<15>, pg, dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
-                default: hipLaunchKernelGGL(ns_propose_kernel<0>, pg, dim3(128), 0, st, dh[h], n_pix_h[h], Kr); break;
+                case 5: hipLaunchKernelGGL(ns_propose_kernel<5>, pg, dim3(NS_PROPOSE_THREADS), 0, st, dh[h], n_pix_h[h], Kr); break;
+                case 10: hipLaunchKernelGGL(ns_propose_kernel<10>, pg, dim3(NS_PROPOSE_THREADS), 0, st, dh[h], n_pix_h[h], Kr); break;
+                case 15: hipLaunchKernelGGL(ns_propose_kernel<15>, pg, dim3(NS_PROPOSE_THREADS), 0, st, dh[h], n_pix_h[h], Kr); break;
+                default: hipLaunchKernelGGL(ns_propose_kernel<0>, pg, dim3(NS_PROPOSE_THREADS), 0, st, dh[h], n_pix_h[h], Kr); break;
                 }
                 hipLaunchKernelGGL(ns_publish_kernel, dim3(1), dim3(1), 0, st, dh[h], s->seq + 1);
                 HIP_TRY(hipGetLastError());
@@ -1353,12 +1676,12 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                     dh[h].part = r->d_part[h];                             // (after the batch: its buffers may have grown)
                     dh[h].noise = r->ss->dev.noise; dh[h].nspec = r->ss->dev.n_spec;
                 }
-                hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_pix_h[h]), dim3(64), s->lds, st, dh[h], n_pix_h[h], Kr, s->rounds);
+                hipLaunchKernelGGL(ns_update_kernel, dim3((unsigned)n_pix_h[h]), dim3(NS_UPD_THREADS), s->lds, st, dh[h], n_pix_h[h], Kr, s->rounds);
                 // the refit wave of the pixels the update marked, in the rounds where a pixel can be due: rejection-mode
                 // pixels every refit_every-th round, walking ones at a cycle's end -- and in a cycle's first round, where a
                 // pixel that has just turned to walks brings along what it collected before
                 if ((s->rounds + 1) % d.refit_every == 0 || (d.method != 0 && ((s->rounds + 1) % d.n_steps == 0 || s->rounds % d.n_steps == 0)))
-                    hipLaunchKernelGGL(ns_refit_kernel, dim3((unsigned)n_pix_h[h]), dim3(64), s->lds_refit, st, dh[h], n_pix_h[h], 0);
+                    hipLaunchKernelGGL(ns_refit_kernel, dim3((unsigned)n_pix_h[h]), dim3(dh[h].multi ? 64 : NS_REFIT_THREADS), s->lds_refit, st, dh[h], n_pix_h[h], 0);
                 HIP_TRY(hipGetLastError());
             }
             s->rounds += 1;

@@ -313,6 +313,85 @@ def _box_veto(cand, zz, ubox, fbox, frames):
     return ok
 
 
+# ---- a volume-preserving shear in front of the one-ellipsoid bound (ns_shear_fit / ns_shear_inv on the device) --------
+_NS_SHEAR_RIDGE = 1e-6                                                          # NS_SHEAR_RIDGE
+_NS_SHEAR_ENLARGE = 4.0                                                         # NS_SHEAR_ENLARGE
+
+
+def _shear_monomials(comp):
+    """The monomials (a, b) -> z_a z_b (-1 = the factor 1) of the shear of sampled dimensions with velocity components
+    comp[D], ordered by their largest coordinate: [1], then per coordinate j its own z_j, z_j^2 and z_k z_j for the earlier
+    coordinates k of the same component.  start[j] = monomials before coordinate j's own = the features z_j is regressed
+    on; mono[start[j]] is z_j itself.  (ns_shear_monomials on the host side of the device sampler.)"""
+    D = len(comp)
+    mono, start = [(-1, -1)], []
+    for j in range(D):
+        start.append(len(mono))
+        mono.append((j, -1))
+        mono.append((j, j))
+        for k in range(j):
+            if comp[k] == comp[j]:
+                mono.append((k, j))
+    return np.array(mono[:start[-1] + 1], dtype=np.int32), np.array(start, dtype=np.int32)
+
+
+def _shear_phi(Z, mono, n):
+    """The first n monomials of rows Z[K, D]."""
+    F = np.ones((Z.shape[0], n))
+    for m in range(1, n):
+        a, b = mono[m]
+        F[:, m] = Z[:, a] if b < 0 else Z[:, a] * Z[:, b]
+    return F
+
+
+def _fit_shear(U, mono, start):
+    """The shear of one pixel's live points U[n, D]: standardise, z = (u - mu) / sg, then regress every coordinate on
+    the monomials of the earlier ones (`_shear_monomials`): w_j = z_j - phi_j(z_<j) . beta_j.  An additive triangular map
+    has a unit Jacobian: a point uniform in a w-ellipsoid is uniform in u over the ellipsoid's curved image, whose volume
+    is the ellipsoid's times prod sg.  One Gram matrix of all monomials and ONE Cholesky factorisation of it serve every
+    coordinate: the factor of a leading block is the leading block of the factor, and row start[j] of the factor is the
+    forward substitution of coordinate j's normal equations.  Returns mu[D], sg[D], beta[D, M] (row j: start[j] numbers)."""
+    n, D = U.shape
+    M = mono.shape[0]
+    mu = U.sum(axis=0) / n
+    d = U - mu
+    sg = np.sqrt(np.einsum('ni,ni->i', d, d) / (n - 1))
+    sg = np.maximum(sg, 1e-300)
+    Z = d / sg
+    F = _shear_phi(Z, mono, M)
+    G = F.T @ F
+    G[np.diag_indices(M)] += _NS_SHEAR_RIDGE * n
+    Lc = np.linalg.cholesky(G)
+    beta = np.zeros((D, M))
+    for j in range(1, D):
+        pj = int(start[j])
+        y = Lc[pj, :pj]
+        b = np.zeros(pj)
+        for r in range(pj - 1, -1, -1):                                         # back substitution with the block's transpose
+            b[r] = (y[r] - Lc[r + 1:pj, r] @ b[r + 1:]) / Lc[r, r]
+        beta[j, :pj] = b
+    return mu, sg, beta
+
+
+def _shear_fwd(X, mu, sg, beta, mono, start):
+    """w of rows X[K, D] of the unit cube."""
+    Z = (X - mu) / sg
+    W = Z.copy()
+    for j in range(1, Z.shape[1]):
+        pj = int(start[j])
+        W[:, j] = Z[:, j] - _shear_phi(Z, mono, pj) @ beta[j, :pj]
+    return W
+
+
+def _shear_inv(W, mu, sg, beta, mono, start):
+    """Unit-cube rows of rows W[K, D]: coordinate by coordinate, each from the ones before it."""
+    Z = W.copy()
+    for j in range(1, W.shape[1]):
+        pj = int(start[j])
+        Z[:, j] = W[:, j] + _shear_phi(Z, mono, pj) @ beta[j, :pj]
+    return mu + sg * Z
+
+
 def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
     """NestedResult per pixel from dead points (theta, lnL, lnw per pixel) and final live points:
     every live point carries the mass X_final / nlive.  `nlive`: one number, or one per pixel (a pixel's live
@@ -374,7 +453,7 @@ def default_cap_iter(nlive):
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
                check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None, walkers=None,
-               progress=None, frames=None, margin=None, refit_every=4):
+               progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -410,6 +489,10 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     frames, margin : the free rejections of a one-ellipsoid bound (`_fit_boxes`): `frames` rotated frames beside the unit
         cube's axes and the ellipsoid's own (None or -1: no boxes, the default; 32 is the measured choice), `margin` the factor c of a face's distance beyond the extreme live point (1.75).
         With boxes the proposals per round are scaled by the last rounds' ratio of drawn to evaluated proposals (at most 8).
+    shear : None / 0 = off; a number > 1 = the one-ellipsoid bound is fitted to the live points AFTER a volume-preserving
+        polynomial shear (`_fit_shear`: every coordinate minus a quadratic function of the earlier ones, which straightens
+        the curved tex / ntot ridges), with this safety factor on the enclosing volume instead of `enlarge` (4 is the
+        measured choice).  Proposals are drawn in the sheared frame and mapped back; boxes, if on, live in that frame.
     refit_every : rejection-mode pixels refit their bound in rounds that are multiples of this (the device's engine option
         `sampler_refit_every`).
     enlarge : safety factor on the volume of the ellipsoid that just encloses the live points
@@ -474,11 +557,28 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     Qf = _frames(nd, max(n_frames, 0)) if boxes else None
     ubox = np.zeros((P, nd, 2))
     fbox = np.zeros((P, max(n_frames, 0) + 1, nd, 2))
+    # (the device's shapes: all five free parameters of two or three components, slot % ncomp = dimension % ncomp)
+    ncomp_s = max(1, nd // 5)
+    shear_on = (bool(shear) and (not multi) and nd in (10, 15) and ndim == 6 * ncomp_s and nlive * nd * 8 <= 96 * 1024
+                and bool(np.all(fmap % ncomp_s == np.arange(nd) % ncomp_s)))
+    if shear_on:
+        assert float(shear) >= 1.0
+        mono, mstart = _shear_monomials(fmap % ncomp_s)
+        sh_mu, sh_sg, sh_beta = np.zeros((P, nd)), np.ones((P, nd)), np.zeros((P, nd, mono.shape[0]))
 
     def refit(p, ln_x):
         n = int(nl[p])
         if multi:
             centre[p], axes[p], elnv[p], nell[p], lnvol[p], use_cube[p] = _fit_multi(Ulive[p, :n], efr, ln_x, enlarge, max_ell)
+        elif shear_on:
+            sh_mu[p], sh_sg[p], sh_beta[p] = _fit_shear(Ulive[p, :n], mono, mstart)
+            Wl = _shear_fwd(Ulive[p, :n], sh_mu[p], sh_sg[p], sh_beta[p], mono, mstart)
+            ln_jac = float(np.log(sh_sg[p]).sum())                  # ln |du / dw|: volumes in w units are smaller by this
+            c1, a1, _, v1 = _fit_ellipsoids(Wl[None], efr, np.array([ln_x - ln_jac]), float(shear))
+            centre[p, 0], axes[p, 0], lnvol[p], nell[p] = c1[0], a1[0], v1[0] + ln_jac, 1
+            use_cube[p], elnv[p, 0] = lnvol[p] >= 0.0, lnvol[p]
+            if boxes:
+                ubox[p], fbox[p] = _fit_boxes(Wl, c1[0], a1[0], Qf, margin_c)     # `ubox`: the box in the w axes
         else:
             c1, a1, u1, v1 = _fit_ellipsoids(Ulive[p:p + 1, :n], efr, np.array([ln_x]), enlarge)
             centre[p, 0], axes[p, 0], use_cube[p], lnvol[p], elnv[p, 0], nell[p] = c1[0], a1[0], u1[0], v1[0], v1[0], 1
@@ -542,7 +642,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             # with boxes most proposals are vetoed for free: draw so many more that a round still evaluates ~b_target
             ratio = min(_NS_RATIO_MAX, max(1, (raw_sum + val_sum // 2) // max(val_sum, 1))) if boxes and raw_sum else 1
             n_chunk = int(active.sum())                          # the pixels the device's list holds until the next look
-            Kr = int(min(16384, max(K, (b_target * ratio) // n_chunk)))
+            Kr = int(min(kmax if kmax else 16384, max(K, (b_target * ratio) // n_chunk)))
             raw_sum = val_sum = 0
         raw_sum += Kr * n_chunk
         idx = np.flatnonzero(active)
@@ -602,7 +702,16 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                     cand, zf = _candidates(seed, [p], cand_base[p:p + 1], Kr, centre[p:p + 1, 0], axes[p:p + 1, 0],
                                            use_cube[p:p + 1], with_ball=True)
                     cand, keep = cand[0], True
-                    if boxes:
+                    if shear_on:
+                        # the ellipsoid lives in the sheared frame: its draws are w, the unit cube's draws are u
+                        if use_cube[p]:
+                            wc = _shear_fwd(cand, sh_mu[p], sh_sg[p], sh_beta[p], mono, mstart)
+                        else:
+                            wc, cand = cand, _shear_inv(cand, sh_mu[p], sh_sg[p], sh_beta[p], mono, mstart)
+                        if boxes:
+                            zz = np.linalg.solve(axes[p, 0], (wc - centre[p, 0]).T).T if use_cube[p] else zf[0]
+                            keep = _box_veto(wc, zz, ubox[p], fbox[p], Qf)
+                    elif boxes:
                         # the proposal's coordinates in the ellipsoid's frame: the unit-ball point it was made from, or
                         # (drawn from the unit cube) A^-1 (u - c)
                         zz = np.linalg.solve(axes[p, 0], (cand - centre[p, 0]).T).T if use_cube[p] else zf[0]
@@ -659,7 +768,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
                       upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=262144,
                       enlarge=1.5, method='auto', n_steps=None, free_mask=None, progress=None, time_limit=None,
-                      ellipsoids=None, frames=None, margin=None):
+                      ellipsoids=None, frames=None, margin=None, shear=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
     work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive).  `progress`
@@ -692,6 +801,8 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
             _ffi.check(lib.nfa_sampler_set_ellipsoids(h, int(ellipsoids)))
         if frames is not None or margin is not None:
             _ffi.check(lib.nfa_sampler_set_boxes(h, -2 if frames is None else int(frames), 0.0 if margin is None else float(margin)))
+        if shear is not None:
+            _ffi.check(lib.nfa_sampler_set_shear(h, float(shear)))
         if per_pixel:
             nl32 = nl.astype(np.int32)
             upd32 = np.maximum(1, (upd_frac * nl).astype(np.int64)).astype(np.int32)

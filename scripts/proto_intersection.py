@@ -98,18 +98,76 @@ def os_box(P, margin):
     return lo - m, hi + m
 
 
+def shear_features(X, i, kind, blocks):
+    """Columns the coordinate i is regressed on: the earlier coordinates, their squares and (kind 'x') the products of
+    pairs of them inside one velocity component / (kind 'X') all pairs.  An additive triangular map w_i = u_i - g_i(u_<i)
+    has a unit Jacobian: uniform in w is uniform in u."""
+    cols = [np.ones(X.shape[0])]
+    for j in range(i):
+        cols.append(X[:, j])
+        cols.append(X[:, j] ** 2)
+    if kind in ('x', 'X'):
+        comp = np.zeros(X.shape[1], dtype=int)
+        for c, b in enumerate(blocks):
+            comp[b] = c
+        for j in range(i):
+            for k in range(j + 1, i):
+                if kind == 'X' or comp[j] == comp[k]:
+                    cols.append(X[:, j] * X[:, k])
+    return np.stack(cols, axis=1)
+
+
+class Shear:
+    def __init__(self, U, kind, blocks, ridge=1e-6):
+        n, D = U.shape
+        self.loo = kind.endswith('L')                     # the fit's own points by their leave-one-out residuals
+        kind = kind.rstrip('L')
+        self.kind, self.blocks, self.coef = kind, blocks, [None] * D
+        self.mu, self.sg = U.mean(axis=0), U.std(axis=0) + 1e-12
+        Z = (U - self.mu) / self.sg                       # standardised: conditioning of the normal equations
+        for i in range(1, D):
+            F = shear_features(Z, i, kind, blocks)
+            A = F.T @ F + ridge * n * np.eye(F.shape[1])
+            self.coef[i] = np.linalg.solve(A, F.T @ Z[:, i])
+            if self.loo:
+                h = np.einsum('ij,ij->i', F @ np.linalg.inv(A), F)
+                Wl = self.__dict__.setdefault('W_loo', Z.copy())
+                Wl[:, i] = (Z[:, i] - F @ self.coef[i]) / (1.0 - h)
+
+    def fwd(self, X):
+        Z = (X - self.mu) / self.sg
+        W = Z.copy()
+        for i in range(1, Z.shape[1]):
+            W[:, i] = Z[:, i] - shear_features(Z, i, self.kind, self.blocks) @ self.coef[i]
+        return W                                           # standardised and sheared: a constant Jacobian (prod 1 / sg)
+
+    def inv(self, W):
+        Z = W.copy()
+        for i in range(1, W.shape[1]):
+            Z[:, i] = W[:, i] + shear_features(Z, i, self.kind, self.blocks) @ self.coef[i]
+        return Z * self.sg + self.mu
+
+
 class Bound:
     def __init__(self, U, blocks, which, enlarge, efr, ln_x, margin, enlarge_main=1.5):
         n, D = U.shape
         self.which = which
+        self.shear = None
+        self.lo, self.hi = os_box(U, margin)
+        for tok in which.split('+'):
+            if tok.startswith('shear'):
+                self.shear = Shear(U, tok[5:], blocks)
+        if self.shear is not None:
+            self.ln_jac = float(np.log(self.shear.sg).sum())       # ln |du / dw|
+            U = self.shear.W_loo if self.shear.loo else self.shear.fwd(U)
+            ln_x = ln_x - self.ln_jac                               # the prior volume to hold, in w units
         enlarge, enlarge_f = enlarge_main, enlarge           # the sampling ellipsoid keeps its own factor; `enlarge` is the filters'
         c, L, r2, lnv, cov = fit_one(U, enlarge)
         grow = max((ln_x - math.log(efr)) - lnv, 0.0)
         self.c = c
         self.A = L * (math.sqrt(r2) * math.exp((grow + math.log(enlarge)) / D))
         self.lnv = lnv + grow
-        self.use_cube = self.lnv >= 0.0
-        self.lo, self.hi = os_box(U, margin)
+        self.use_cube = self.lnv + (self.ln_jac if self.shear is not None else 0.0) >= 0.0
         if 'pbox' in which:
             w, V = np.linalg.eigh(cov)
             self.V = V
@@ -151,6 +209,10 @@ class Bound:
         ok = np.ones(K, dtype=bool)
         if 'box' in self.which.split('+'):
             ok &= np.all((X >= self.lo) & (X <= self.hi), axis=1)
+        if self.shear is not None:
+            X = self.shear.fwd(X)
+            y = np.linalg.solve(self.A, (X - self.c).T).T
+            ok &= np.sum(y * y, axis=1) <= 1.0 + 1e-9
         if 'pbox' in self.which:
             P = (X - self.c) @ self.V
             ok &= np.all((P >= self.plo) & (P <= self.phi), axis=1)
@@ -190,6 +252,8 @@ class Bound:
             z = rng.normal(size=(K, D))
             z *= (rng.uniform(size=(K, 1)) ** (1.0 / D)) / np.linalg.norm(z, axis=1)[:, None]
             X = self.c + z @ self.A.T
+            if self.shear is not None:
+                X = self.shear.inv(X)
         ok = np.all((X >= 0) & (X < 1), axis=1)
         ok &= self.member(X)
         return X, ok
@@ -214,7 +278,7 @@ def nested(loglike, blocks, which, nlive=400, tol=0.5, efr=0.3, enlarge=1.5, see
                 trace.append((it, n_evals - ev_at))
             bound = Bound(U, blocks, which, fenlarge, efr, -it / nlive, margin, enlarge)
             if audit is not None:
-                abounds = [(name, Bound(U, blocks, 'ell+' + w, e, efr, -it / nlive, m, enlarge), w) for name, w, m, e in audit]
+                abounds = [(a[0], Bound(U, blocks, 'ell+' + a[1], a[3], efr, -it / nlive, a[2], a[4] if len(a) > 4 else enlarge), a[1]) for a in audit]
             since = 0
         X, ok = bound.draw(rng, 256)
         n_raw += X.shape[0]
@@ -280,6 +344,15 @@ if __name__ == '__main__':
     comp_of = np.array([f % ncomp for f in fmap])
     blocks = [np.flatnonzero(comp_of == c) for c in range(ncomp)]
     t0 = time.time()
+    if which == 'audit_shear':
+        audit = [(f'{k} e{e}', k, 0.04, 1.5, e) for k in ('shear', 'shearx', 'shearxL', 'shearX', 'shearXL') for e in (1.5, 2.5, 4.0)]
+        for seed in range(seed0, seed0 + n_seeds):
+            tr = {}
+            lnZ, it, ev, raw = nested(ll, blocks, sys.argv[8] if len(sys.argv) > 8 else 'ell', seed=seed, trace=tr, audit=audit, enlarge=float(sys.argv[9]) if len(sys.argv) > 9 else 1.5)
+            print(f'audit seed {seed}: lnZ {lnZ:.2f} iters {it} evals {ev}', flush=True)
+            for name, rec in tr.items():
+                print(f'   {name:14s} excluded / accepted by quarter of the run: ' + '  '.join(f'{int(b)}/{int(a)}' for a, b in rec) + f'   total {rec[:, 1].sum() / rec[:, 0].sum() * 100:.2f} %', flush=True)
+        sys.exit(0)
     if which == 'audit':
         audit = [('box k20x1.5', 'box', (20, 1.5), 1.5), ('box s1x1.5', 'box', ('s', 1.0, 1.5), 1.5), ('box s1.25x1.5', 'box', ('s', 1.25, 1.5), 1.5),
                  ('wbox k20x1.5', 'wbox', (20, 1.5), 1.5), ('wbox s1x1.5', 'wbox', ('s', 1.0, 1.5), 1.5), ('wbox s1.25x1.5', 'wbox', ('s', 1.25, 1.5), 1.5),
@@ -295,6 +368,6 @@ if __name__ == '__main__':
         sys.exit(0)
     for seed in range(seed0, seed0 + n_seeds):
         tr = []
-        lnZ, it, ev, raw = nested(ll, blocks, which, seed=seed, trace=tr, margin=margin, fenlarge=fenlarge)
+        lnZ, it, ev, raw = nested(ll, blocks, which, seed=seed, trace=tr, margin=margin, fenlarge=fenlarge, enlarge=float(sys.argv[8]) if len(sys.argv) > 8 else 1.5)
         print(f'{which:28s} ncomp {ncomp} ntot {ntot} seed {seed}: lnZ {lnZ:.2f} iters {it} evals {ev} ({ev / it:.1f} per iteration) '
               f'raw draws {raw} ({raw / ev:.1f} per evaluation)  [{time.time() - t0:.0f} s]', flush=True)

@@ -492,6 +492,86 @@ def test_box_vetoes_of_a_one_ellipsoid_bound():
     assert abs(g1.n_iter - g0.n_iter) < 0.01 * g0.n_iter and abs(g1.n_evals - g0.n_evals) < 0.05 * g0.n_evals and abs(g1.lnZ - g0.lnZ) < 0.1
 
 
+def test_shear_in_front_of_the_ellipsoid():
+    """shear=e: the bound is an ellipsoid around the live points AFTER a volume-preserving polynomial shear.  The map and
+    its inverse are each other's; one Cholesky factorisation of the monomials' Gram matrix gives every coordinate's
+    least-squares coefficients; a bent ridge comes out straight; and on a ten-dimensional likelihood whose ridge is a
+    parabola the sampler needs a fraction of the evaluations for the same evidence."""
+    rng = np.random.default_rng(5)
+    comp = np.arange(10) % 2
+    mono, start = sampler._shear_monomials(comp)
+    assert mono.shape == (36, 2) and list(start) == [1, 3, 5, 8, 11, 15, 19, 24, 29, 35]
+    assert all(tuple(mono[start[j]]) == (j, -1) for j in range(10))
+    U = rng.uniform(0.3, 0.7, size=(400, 10))
+    U[:, 6] = 0.5 + 8.0 * (U[:, 4] - 0.5) ** 2 + 0.004 * rng.normal(size=400)          # coordinate 6 bends with coordinate 4 (same component)
+    mu, sg, beta = sampler._fit_shear(U, mono, start)
+    W = sampler._shear_fwd(U, mu, sg, beta, mono, start)
+    np.testing.assert_allclose(sampler._shear_inv(W, mu, sg, beta, mono, start), U, atol=1e-13)
+    Z = (U - mu) / sg
+    for j in (3, 6, 9):                                                                 # = ridge regression, coordinate by coordinate
+        F = sampler._shear_phi(Z, mono, start[j])
+        ref = np.linalg.solve(F.T @ F + sampler._NS_SHEAR_RIDGE * 400 * np.eye(start[j]), F.T @ Z[:, j])
+        np.testing.assert_allclose(beta[j, :start[j]], ref, atol=1e-9)
+    assert W[:, 6].std() < 0.05 and abs(W[:, 4].std() - 1.0) < 0.05                     # the bend is gone, the rest untouched
+    # a unit Jacobian: the sheared image of a box has the box's volume (Monte Carlo over the unit cube)
+    X = rng.uniform(size=(200000, 10))
+    Wx = sampler._shear_fwd(X, mu, sg, beta, mono, start)
+    lo, hi = np.quantile(W, 0.1, axis=0), np.quantile(W, 0.9, axis=0)
+    inside = np.all((Wx[:, [4, 6]] >= lo[[4, 6]]) & (Wx[:, [4, 6]] <= hi[[4, 6]]), axis=1).mean()
+    assert inside == pytest.approx(np.prod((hi - lo)[[4, 6]] * sg[[4, 6]]), rel=0.05)
+
+    def ridge(pix, T):            # 12 slots, slots 10 and 11 dummies; slot 6 follows a parabola in slot 4, slot 7 in slot 5
+        U = T[:, :10] - 0.5
+        d = U.copy()
+        d[:, 6] -= 3.0 * U[:, 4] ** 2 - 0.05
+        d[:, 7] += 3.0 * U[:, 5] ** 2 - 0.05
+        s = np.full(10, 0.08)
+        s[[6, 7]] = 0.01
+        return -0.5 * ((d / s) ** 2).sum(axis=1)
+    fm = np.array([1] * 10 + [0, 0])
+    kw = dict(nlive=200, tol=0.5, efr=0.3, seed=3, method='reject', batch_target=512, free_mask=fm)
+    plain = sampler.run_nested(ridge, 12, 1, **kw)
+    bent = sampler.run_nested(ridge, 12, 1, shear=4.0, **kw)
+    truth = float(np.sum(np.log(np.sqrt(2 * np.pi) * np.array([0.08] * 8 + [0.01] * 2))))     # (the Gaussians fit into the cube)
+    for r in plain + bent:
+        assert abs(r.lnZ - truth) < 4 * r.lnZ_err + 0.3, (r.lnZ, truth, r.lnZ_err)
+    assert sum(r.n_evals for r in bent) < 0.5 * sum(r.n_evals for r in plain)
+    # shapes the device has no shear for run without it: the same result as shear=None
+    f5 = _gauss_problem(np.full(5, 0.5), 0.05)
+    a5, b5 = sampler.run_nested(f5, 5, 1, nlive=100, seed=2, ellipsoids=1)[0], sampler.run_nested(f5, 5, 1, nlive=100, seed=2, ellipsoids=1, shear=4.0)[0]
+    assert (a5.n_iter, a5.n_evals, a5.lnZ) == (b5.n_iter, b5.n_evals, b5.lnZ)
+
+
+@pytest.mark.gpu
+def test_shear_on_the_device_follows_the_twin(engine, nfo):
+    """Two velocity components, shear on (with and without boxes): device and twin take the same decisions."""
+    from nestfit_amd.cube import CubeRunner
+    n_pix, n, noise = 3, 128, 0.1
+    rng = np.random.default_rng(3)
+    axes = [freq_axis(1, n), freq_axis(2, n)]
+    ut = engine.get_irdc_priors(size=500, vsys=0.0)
+    truths = np.tile(np.array([-0.5, 1.0, 12.0, 15.0, 5.0, 6.0, 14.4, 14.6, 0.4, 0.4, 0.0, 0.0]), (n_pix, 1))
+    truths[:, 6] += np.array([0.0, -0.4, 0.2])
+    try:
+        engine.set_exp_mode('table')
+        probe = CubeRunner(axes, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=2)
+        model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
+        cube = CubeRunner(axes, (1, 2), model + rng.normal(0, noise, model.shape), np.full((n_pix, 2), noise), ut, ncomp=2)
+        for extra in (dict(shear=4.0, method='reject', maxiter=2400), dict(shear=4.0, frames=32, maxiter=1800), dict(shear=2.5, frames=8, n_steps=20)):
+            kw = dict(nlive=150, tol=0.5, efr=0.3, seed=7, batch_target=2048, **{'maxiter': 900, **extra})
+            dev = sampler.fit_pixels(cube, np.arange(n_pix), device=True, **kw)
+            twin = sampler.fit_pixels(cube, np.arange(n_pix), device=False, **kw)
+            for d, t in zip(dev, twin):
+                assert (d.n_iter, d.n_evals) == (t.n_iter, t.n_evals), (extra, d.n_iter, t.n_iter, d.n_evals, t.n_evals)
+                assert d.lnZ == pytest.approx(t.lnZ, rel=1e-10)
+        kw = dict(nlive=150, tol=0.5, efr=0.3, seed=7, maxiter=2400, batch_target=2048, method='reject')
+        with_shear = sampler.fit_pixels(cube, np.arange(n_pix), shear=4.0, **kw)
+        without = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
+        assert sum(r.n_evals for r in with_shear) < 0.8 * sum(r.n_evals for r in without)
+    finally:
+        engine.set_exp_mode('fast')
+
+
 @pytest.mark.gpu
 def test_box_vetoes_on_the_device_follow_the_twin(engine, nfo):
     """Two velocity components (ten sampled dimensions), boxes on: the device sampler and the numpy twin fed by the
