@@ -385,10 +385,13 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
             const double u1 = ns_uniform_of(strm, (uint64_t)m);
             const double u2 = ns_uniform_of(strm, (uint64_t)(m + 1));
             const double r = sqrt(-2.0 * log(u1));
-            const double ang = 6.283185307179586 * u2;
-            z[m] = r * cos(ang);
+            // (sine and cosine of 2 pi u2 in one call whose argument is in half turns: no reduction of a large angle, half
+            // the instructions of cos(ang) and sin(ang); against the twin's numpy the values differ in the last bit at most)
+            double sn, cs;
+            sincospi(2.0 * u2, &sn, &cs);
+            z[m] = r * cs;
             n2 += z[m] * z[m];
-            if (m + 1 < D) { z[m + 1] = r * sin(ang); n2 += z[m + 1] * z[m + 1]; }
+            if (m + 1 < D) { z[m + 1] = r * sn; n2 += z[m + 1] * z[m + 1]; }
         }
         const double ur = ns_uniform_of(strm, NS_B_RADIUS);
         const double f = exp(log(ur) / D) / sqrt(n2);               // uniform in the unit ball
@@ -453,9 +456,11 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
             // any of its lanes is alive: packed, a quarter of the waves do
             __shared__ double qbuf[2 * DM * NS_PROPOSE_THREADS];
             __shared__ int qk[NS_PROPOSE_THREADS];
+            __shared__ int qfail[NS_PROPOSE_THREADS];
             __shared__ int qn;
             const int tid = (int)threadIdx.x;
             if (tid == 0) qn = 0;
+            qfail[tid] = 0;
             __syncthreads();
             if (ok) {
                 const int e = atomicAdd(&qn, 1);
@@ -465,11 +470,48 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
                 S.valid[gid] = 0;
             }
             __syncthreads();
-            ok = tid < qn;
+            const int n_q = qn;
+            // The rotated frames, lanes = (frame, coordinate) pairs: a thread keeps the frame columns of its pairs in registers
+            // -- loaded once per workgroup -- and every queued proposal's ball point is one broadcast read per coordinate for
+            // all of them.  (With lanes = proposals the 100 entries of every frame came through the scalar cache for every
+            // wave: 480 cache lines per wave, more than the cache holds for the pixels of a CU, and the launch spent its
+            // time waiting for them -- 66 k cycles per wave of proposals.)
+            constexpr int R = DM <= 10 ? 3 : 2;                // pairs per thread and pass
+            const int n_pair = S.n_frames * DM;
+            for (int e0 = 0; e0 < n_pair && n_q > 0; e0 += R * NS_PROPOSE_THREADS) {
+                double qc[R][DM], lo[R], hi[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = e0 + r * NS_PROPOSE_THREADS + tid;
+                    const bool on = e < n_pair;
+                    const int kf = on ? e / DM : 0, j = on ? e - kf * DM : 0;
+                    const double *Q = S.frames + (long)kf * DM * DM;
+#pragma unroll
+                    for (int a2 = 0; a2 < DM; ++a2) qc[r][a2] = Q[a2 * DM + j];
+                    lo[r] = on ? S.fbox[((long)p * (S.n_frames + 1) + 1 + kf) * DM * 2 + 2 * j] : -INFINITY;
+                    hi[r] = on ? S.fbox[((long)p * (S.n_frames + 1) + 1 + kf) * DM * 2 + 2 * j + 1] : INFINITY;
+                }
+                for (int i = 0; i < n_q; ++i) {
+                    double zi[DM];
+#pragma unroll
+                    for (int j = 0; j < DM; ++j) zi[j] = qbuf[j * NS_PROPOSE_THREADS + i];
+                    bool bad = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        double w = 0.0;
+#pragma unroll
+                        for (int a2 = 0; a2 < DM; ++a2) w += zi[a2] * qc[r][a2];
+                        bad = bad || !((w >= lo[r]) && (w <= hi[r]));
+                    }
+                    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (tid & 63) == 0) qfail[i] = 1;
+                }
+            }
+            __syncthreads();
+            ok = tid < n_q;
             if (ok) {
-                for (int j = 0; j < DM; ++j) { zq[j] = qbuf[j * NS_PROPOSE_THREADS + tid]; x[j] = qbuf[(DM + j) * NS_PROPOSE_THREADS + tid]; }
+                for (int j = 0; j < DM; ++j) x[j] = qbuf[(DM + j) * NS_PROPOSE_THREADS + tid];
                 gid = (long)q * Kr + qk[tid];
-                ok = ns_in_frames<DD>(S, p, zq);
+                ok = qfail[tid] == 0;
                 S.valid[gid] = ok ? 1 : 0;
             }
         } else if (in_range) {
@@ -500,7 +542,7 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
 
 // grid: x = chunks of a pixel's Kr proposals, y = the active pixels of this part (z: beyond 65535 of them)
 template <int DD>
-__global__ void ns_propose_kernel(NsDev S, int n_act, int Kr) {
+__global__ void __launch_bounds__(NS_PROPOSE_THREADS) ns_propose_kernel(NsDev S, int n_act, int Kr) {
     const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int q = (int)(blockIdx.y + blockIdx.z * 65535u);
     if (q < n_act) ns_propose_one<DD>(S, q, k, n_act, Kr, k < Kr);
