@@ -95,7 +95,7 @@ int nfa_get_exp_mode(void);
  *   "sampler_frames"      rotated box frames of a one-ellipsoid bound (nfa_sampler_set_boxes): -2 (default) and -1
  *                   none, 0..64; "sampler_margin_pct": the boxes' margin factor in hundredths (0 = 175);
  *   "sampler_shear_pct"   the shear in front of one-ellipsoid bounds (nfa_sampler_set_shear): its safety factor in
- *                   hundredths, 0 = off, 100..100000 (400 is the measured choice);
+ *                   hundredths, -1 (default) = 400 where the shape allows, 0 = off, 100..100000;
  *   "sampler_refit_every" rejection-mode pixels refit their bound in rounds that are multiples of this (default 4);
  *                   the sampler_* keys are read when a sampler is created / begun, A/B knobs like the rest;
  *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid; the
@@ -361,7 +361,7 @@ int nfa_sampler_set_ellipsoids(nfa_sampler *s, int max_ellipsoids);
 /* Free rejections of a one-ellipsoid bound (between create and begin).  Above six sampled dimensions no ellipsoid bounds
  * the live region of a fit well; but every superset of the region may veto a proposal before its likelihood is evaluated:
  * the bounding boxes of the live points in the unit cube's axes, in the ellipsoid's own frame and in n_frames fixed
- * rotations of it (-2: the default = none; -1: none; 0..64, 32 being the measured choice).  margin: a face lies
+ * rotations of it (-2: the default = 32 where the bound is sheared, none elsewhere; -1: none; 0..64).  margin: a face lies
  * beyond the extreme live point by margin * max(0.1 s, extreme - mean - 1.5 s), s the spread along its direction
  * (0: the default, 1.75).  MultiNest has no counterpart; `efr` keeps its meaning for the ellipsoid the proposals are drawn
  * from (nestfit/core/core.pyx:727-732). */
@@ -372,7 +372,7 @@ int nfa_sampler_set_boxes(nfa_sampler *s, int n_frames, double margin);
  * inside one velocity component, products of the earlier coordinates): an additive triangular map has a unit Jacobian, so
  * a point drawn uniformly in the w-ellipsoid and mapped back is uniform over its curved image in the unit cube.  Boxes, if
  * on, are fitted and tested in the w frame.  enlarge: the safety factor on the sheared ellipsoid's enclosing volume (>= 1;
- * 4 is the measured choice), 0 = off, < 0 = the default (engine option "sampler_shear_pct", hundredths; 0 = off).  Applies
+ * 4 is the measured choice), 0 = off, < 0 = the default (engine option "sampler_shear_pct": 4 unless changed).  Applies
  * where all five free parameters of two or three components are sampled (10 or 15 dimensions); accepted and without effect
  * elsewhere.  MultiNest has no counterpart (its answer to curved regions is more ellipsoids: nestfit/core/core.pyx:727-760). */
 int nfa_sampler_set_shear(nfa_sampler *s, double enlarge);

@@ -84,6 +84,7 @@ static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for 
 // ellipsoid around straight things is small
 #define NS_SHEAR_RIDGE 1e-6        // on the Gram matrix's diagonal, times the live points
 #define NS_SHEAR_ENLARGE 4.0       // safety factor on the enclosing volume of the sheared ellipsoid
+#define NS_SHEAR_PIVOT 1e-9        // a Cholesky pivot below this fraction of its diagonal entry: the monomial is dropped
 #define NS_SHEAR_MMAX 64           // monomials at most
 #define NS_REFIT_THREADS 512       // of the workgroup that fits a one-ellipsoid bound
 #define NS_WALK_LOWD 6             // up to this many sampled dimensions ...
@@ -161,7 +162,9 @@ struct NsDev {
     const int *sh_start;                // [D] monomials before coordinate j's own = the features z_j is regressed on
     double *sh_mu, *sh_sg;              // [P][D] z = (u - mu) / sg
     double *sh_beta;                    // [P][D][sh_M] w_j = z_j - phi(z_<j) . beta_j
+    long   *dbg;                        // NFA_NS_TIMING=1: stage times of the update workgroup of the first listed pixel (100 MHz ticks)
 };
+#define NS_TICK(slot) do { if (timing) { const long t_ = (long)wall_clock64(); S.dbg[slot] += t_ - t_last; t_last = t_; } } while (0)
 
 // The monomials of the shear (host; the twin's _shear_monomials): [1], then per coordinate j its own z_j, z_j^2 and
 // z_k z_j for the earlier coordinates k of the same velocity component (k % nc == j % nc).
@@ -660,21 +663,28 @@ __device__ double ns_shear_fit(const NsDev &S, int p, int N, double *sd, double 
         sG[r * M + c] = acc + (r == c ? NS_SHEAR_RIDGE * N : 0.0);
     }
     __syncthreads();
-    // Cholesky in place, column by column: lane 0 the diagonal, lanes = rows below it
+    // Cholesky in place, column by column: lane 0 the diagonal, lanes = rows below it.  A monomial whose pivot has
+    // drowned in rounding (live points squeezed onto a line at ln X ~ -50: the ridge keeps the matrix positive definite
+    // on paper only) is dropped -- pivot = its own norm, nothing below it: its coefficient comes out as zero and the
+    // rest are those of the regression without it -- instead of dividing by a rounding error
     for (int j = 0; j < M; ++j) {
         if (tid == 0) {
-            double d = sG[j * M + j];
+            const double g = sG[j * M + j];
+            double d = g;
             for (int k = 0; k < j; ++k) d -= sG[j * M + k] * sG[j * M + k];
-            sG[j * M + j] = sqrt(fmax(d, 1e-300));
+            const bool keep = d > NS_SHEAR_PIVOT * g;
+            sG[j * M + j] = keep ? sqrt(d) : -sqrt(fmax(g, 1e-300));       // (the sign: the flag for the rows below)
         }
         __syncthreads();
         const double dj = sG[j * M + j];
         for (int i = j + 1 + tid; i < M; i += NT) {
             double v = sG[i * M + j];
             for (int k = 0; k < j; ++k) v -= sG[i * M + k] * sG[j * M + k];
-            sG[i * M + j] = v / dj;
+            sG[i * M + j] = dj > 0.0 ? v / dj : 0.0;
         }
         __syncthreads();
+        if (tid == 0 && dj < 0.0) sG[j * M + j] = -dj;
+        // (row j's own off-diagonal entries stay: they are the forward substitution of a coordinate whose monomial this is)
     }
     // coefficients: lanes = coordinates, back substitution with the transposed leading block
     for (int j = tid; j < D; j += NT) {
@@ -1096,6 +1106,8 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
     int *sCnt = svRank + NS_UPD_SEG;                // [2][4][4] valid / surviving proposals per (quarter of the segment, wave)
     double *sCtl = (double *)(sCnt + 32);           // threshold and done flag after wave 0's pass
     if (!S.active[p]) return;
+    const bool timing = S.dbg != nullptr && q == 0 && tid == 0;
+    long t_last = timing ? (long)wall_clock64() : 0;
     double *Ll = S.Llive + (long)p * NS;
     for (int i = tid; i < N; i += NS_UPD_THREADS) sL[i] = Ll[i];
     __syncthreads();
@@ -1125,23 +1137,28 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
     bool done = false;
     // a candidate above the threshold replaces the worst live point, which dies with prior mass
     // X_it - X_(it+1); returns nothing, updates the wave-uniform state above
-    auto replace = [&](const double *cU, const double *cT, double Lk) {
+    // (the rows travel in registers, lane j = entry j -- D, DT <= NS_MAXD <= 64: the candidate's are loaded by the caller
+    // ahead of time, the dying point's when it became the worst.  As three load-then-store copies through pointers a
+    // replacement was three memory latencies long, and a round lasts as long as its busiest pixel's replacements.)
+    double tw = lane < S.DT ? S.Tlive[((long)p * NS + w) * S.DT + lane] : 0.0;       // theta of the worst live point
+    NS_TICK(0);                                     // prologue
+    if (timing) S.dbg[8] += 1;
+    auto replace = [&](double cu, double ct, double Lk) {
         const double lnw = -(double)it / N + ln_shrink;
         lnZ = ns_logaddexp(lnZ, lnw + Lmin);
         if (it < cap) {
-            double *dT = S.deadT + ((long)p * S.cap + it) * S.DT;
-            const double *Tw = S.Tlive + ((long)p * NS + w) * S.DT;
-            for (int j = lane; j < S.DT; j += 64) dT[j] = Tw[j];
+            if (lane < S.DT) S.deadT[((long)p * S.cap + it) * S.DT + lane] = tw;
             if (lane == 0) { S.deadL[(long)p * S.cap + it] = Lmin; S.deadlnw[(long)p * S.cap + it] = lnw; }
         }
-        wave_lds_sync();
-        for (int j = lane; j < D; j += 64) S.Ulive[((long)p * NS + w) * D + j] = cU[j];
-        for (int j = lane; j < S.DT; j += 64) S.Tlive[((long)p * NS + w) * S.DT + j] = cT[j];
+        if (lane < D) S.Ulive[((long)p * NS + w) * D + lane] = cu;
+        if (lane < S.DT) S.Tlive[((long)p * NS + w) * S.DT + lane] = ct;
         if (lane == 0) { sL[w] = Lk; Ll[w] = Lk; }
         wave_lds_sync();
         it += 1; since += 1;
         Lmax = fmax(Lmax, Lk);                      // the point that left was the minimum
+        const int w_old = w;
         worst_point(Lmin, w);
+        tw = w == w_old ? ct : (lane < S.DT ? S.Tlive[((long)p * NS + w) * S.DT + lane] : 0.0);
         const double remain = Lmax - (double)it / N;
         done = (ns_logaddexp(lnZ, remain) - lnZ < S.tol) || it >= S.maxiter || it >= cap;
     };
@@ -1180,7 +1197,7 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
                 if (!moved) continue;               // never left its starting live point: not a new sample
                 const double Lk = __hip_atomic_load(&S.wL[(long)p * S.w_stride + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!(Lk > Lmin)) continue;
-                replace(S.wU + ((long)p * S.w_stride + k) * D, S.wT + ((long)p * S.w_stride + k) * S.DT, Lk);
+                replace(lane < D ? S.wU[((long)p * S.w_stride + k) * D + lane] : 0.0, lane < S.DT ? S.wT[((long)p * S.w_stride + k) * S.DT + lane] : 0.0, Lk);
             }
             // acceptance near one half (as dynesty's rwalk tunes it)
             if (tot_sum > 0) scale = fmin(1.0, scale * exp(((double)acc_sum / (double)tot_sum - NS_WALK_TARGET) / (0.5 * sqrt((double)D))));
@@ -1204,60 +1221,94 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
         __syncthreads();
         Lseg = sCtl[0];
         bool stop = false;                          // every thread's copy of `done`
-        for (int kb = 0; kb < K && !stop; kb += NS_UPD_SEG) {
-            unsigned long long mv[4], ms[4];
-            int rows[4];
-            double Ls[4];
+        // NS_UPD_U x 256 proposals have their flags, rows and likelihoods in flight together (three dependent loads each:
+        // fetched segment by segment they were the round); then segment by segment -- 4 x 256 proposals -- through the
+        // threshold, in order
+        constexpr int NS_UPD_U = 8;
+        for (int kb = 0; kb < K && !stop; kb += NS_UPD_U * NS_UPD_THREADS) {
+            unsigned vbits = 0;
+            int rows[NS_UPD_U];
+            double Ls[NS_UPD_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {           // proposal kb + u * 256 + tid: coalesced flags, rows, likelihoods
+            for (int u = 0; u < NS_UPD_U; ++u) {    // proposal kb + u * 256 + tid: coalesced
                 const int kk = kb + u * NS_UPD_THREADS + tid;
                 const bool v = kk < K && S.valid[(long)q * K + kk] != 0;
-                mv[u] = __ballot(v);
-                rows[u] = v ? S.slot[(long)q * K + kk] : 0;
+                vbits |= v ? (1u << u) : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool mine = (mv[u] >> lane) & 1ull;
+            for (int u = 0; u < NS_UPD_U; ++u) rows[u] = (vbits >> u) & 1u ? S.slot[(long)q * K + kb + u * NS_UPD_THREADS + tid] : 0;
+#pragma unroll
+            for (int u = 0; u < NS_UPD_U; ++u) {
+                const bool mine = (vbits >> u) & 1u;
                 const double L = !mine ? 0.0 : S.part ? lnl_of_item(S.part, S.noise, (long)S.candpix[rows[u]], (long)rows[u], S.nspec) : S.candL[rows[u]];
                 Ls[u] = isfinite(L) ? L : S.log_zero;
-                ms[u] = __ballot(mine && Ls[u] > Lseg);
-                if (lane == 0) { sCnt[u * 4 + wave] = __builtin_popcountll(mv[u]); sCnt[16 + u * 4 + wave] = __builtin_popcountll(ms[u]); }
             }
-            __syncthreads();
-            int tot_v = 0, tot_s = 0;
+            if (timing) { S.dbg[10] += (long)(Ls[0] != 12345.678); S.dbg[9] += 1; }      // (the loads have landed)
+            NS_TICK(1);                             // flags, rows, likelihoods of NS_UPD_U x 256 proposals
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int base_v = 0, base_s = 0;         // valid / surviving proposals ahead of this (quarter, wave) in the segment
-                for (int e = 0; e < 16; ++e) {
-                    const int cv = sCnt[e], cs = sCnt[16 + e];
-                    if (e < u * 4 + wave) { base_v += cv; base_s += cs; }
-                    if (u == 0) { tot_v += cv; tot_s += cs; }
+            for (int sub = 0; sub < NS_UPD_U / 4; ++sub) {
+                if (stop || kb + sub * NS_UPD_SEG >= K) break;          // (uniform over the workgroup)
+                unsigned long long mv[4], ms[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool mine = (vbits >> (4 * sub + u)) & 1u;
+                    mv[u] = __ballot(mine);
+                    ms[u] = __ballot(mine && Ls[4 * sub + u] > Lseg);
+                    if (lane == 0) { sCnt[u * 4 + wave] = __builtin_popcountll(mv[u]); sCnt[16 + u * 4 + wave] = __builtin_popcountll(ms[u]); }
                 }
-                if ((ms[u] >> lane) & 1ull) {
-                    const unsigned long long lt = (1ull << lane) - 1ull;
-                    const int e = base_s + __builtin_popcountll(ms[u] & lt);
-                    svL[e] = Ls[u];
-                    svK[e] = kb + u * NS_UPD_THREADS + tid;
-                    svRow[e] = rows[u];
-                    svRank[e] = base_v + __builtin_popcountll(mv[u] & lt) + 1;
+                __syncthreads();
+                int tot_v = 0, tot_s = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int base_v = 0, base_s = 0;     // valid / surviving proposals ahead of this (quarter, wave) in the segment
+                    for (int e = 0; e < 16; ++e) {
+                        const int cv = sCnt[e], cs = sCnt[16 + e];
+                        if (e < u * 4 + wave) { base_v += cv; base_s += cs; }
+                        if (u == 0) { tot_v += cv; tot_s += cs; }
+                    }
+                    if ((ms[u] >> lane) & 1ull) {
+                        const unsigned long long lt = (1ull << lane) - 1ull;
+                        const int e = base_s + __builtin_popcountll(ms[u] & lt);
+                        svL[e] = Ls[4 * sub + u];
+                        svK[e] = kb + (4 * sub + u) * NS_UPD_THREADS + tid;
+                        svRow[e] = rows[4 * sub + u];
+                        svRank[e] = base_v + __builtin_popcountll(mv[u] & lt) + 1;
+                    }
                 }
+                if (tot_s == 0) {                   // nobody above the threshold: the segment only counts
+                    if (wave == 0) { scanned += tot_v; evals += tot_v; n_valid += tot_v; }
+                    __syncthreads();                // (sCnt is rewritten by the next segment)
+                    NS_TICK(2);
+                    continue;
+                }
+                __syncthreads();
+                NS_TICK(2);                         // counts, compaction
+                if (wave == 0) {
+                    long seg_scanned = tot_v;
+                    // (the next survivor's rows are on their way while this one is dealt with)
+                    double cu_n = lane < D ? S.candU[((long)q * K + svK[0]) * D + lane] : 0.0;
+                    double ct_n = lane < S.DT ? S.candT[(long)svRow[0] * S.DT + lane] : 0.0;
+                    for (int i = 0; i < tot_s && !done; ++i) {
+                        const double Lk = svL[i], cu = cu_n, ct = ct_n;
+                        if (i + 1 < tot_s) {
+                            cu_n = lane < D ? S.candU[((long)q * K + svK[i + 1]) * D + lane] : 0.0;
+                            ct_n = lane < S.DT ? S.candT[(long)svRow[i + 1] * S.DT + lane] : 0.0;
+                        }
+                        if (!(Lk > Lmin)) continue;
+                        accepted += 1;
+                        replace(cu, ct, Lk);
+                        if (timing) S.dbg[11] += 1;
+                        if (done) seg_scanned = svRank[i];      // the candidates behind the last one are never looked at
+                    }
+                    scanned += seg_scanned; evals += seg_scanned; n_valid += tot_v;
+                    if (lane == 0) { sCtl[0] = Lmin; sCtl[1] = done ? 1.0 : 0.0; }
+                }
+                __syncthreads();
+                NS_TICK(3);                         // wave 0's pass over the survivors
+                if (timing) S.dbg[12] += tot_s;
+                Lseg = sCtl[0];
+                stop = sCtl[1] != 0.0;
             }
-            __syncthreads();
-            if (wave == 0) {
-                long seg_scanned = tot_v;
-                for (int i = 0; i < tot_s && !done; ++i) {
-                    const double Lk = svL[i];
-                    if (!(Lk > Lmin)) continue;
-                    accepted += 1;
-                    replace(S.candU + ((long)q * K + svK[i]) * D, S.candT + (long)svRow[i] * S.DT, Lk);
-                    if (done) seg_scanned = svRank[i];      // the candidates behind the last one are never looked at
-                }
-                scanned += seg_scanned; evals += seg_scanned; n_valid += tot_v;
-                if (lane == 0) { sCtl[0] = Lmin; sCtl[1] = done ? 1.0 : 0.0; }
-            }
-            __syncthreads();
-            Lseg = sCtl[0];
-            stop = sCtl[1] != 0.0;
         }
         if (wave != 0) return;
         // Walk cycles of all pixels are kept in phase (they start at rounds that are multiples of
@@ -1268,7 +1319,9 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
         if (lane == 0) {
             long ws = S.rj_scan[p] + scanned, wa = S.rj_acc[p] + accepted, wr = S.rj_raw[p] + K, wv = S.rj_val[p] + n_valid;
             if ((round + 1) % S.n_steps == 0) {
-                if (!done && (S.method == 2 || (S.method == 1 && ws >= 64 && S.walk_factor * wa * S.n_steps < ws))) {
+                // (a window that let fewer than 64 of at least 4096 proposals through has no bound worth the name: walk --
+                // and be back when a walk cycle's refit has made a new one)
+                if (!done && (S.method == 2 || (S.method == 1 && (ws >= 64 ? S.walk_factor * wa * S.n_steps < ws : wr >= 4096)))) {
                     S.walk[p] = 1; S.wstep[p] = 0; S.wscale[p] = 1.0; S.wacc_sum[p] = 0; S.wtot_sum[p] = 0;
                     S.ln_pass[p] = S.boxes ? log((double)(wv > 1 ? wv : 1) / (double)(wr > 1 ? wr : 1)) : 0.0;
                 }
@@ -1288,6 +1341,7 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
     // four times the registers of everything above, and a round's update should not carry them)
     const bool due = !done && since >= ns_upd(S, p) && (was_walking || (round + 1) % S.refit_every == 0);
     if (lane == 0) { S.since_fit[p] = since; S.refit_due[p] = due ? 1 : 0; }
+    NS_TICK(4);                                     // the tail
 }
 
 // The bounds of the pixels that are due (ns_update_kernel marks them; `direct`: all pixels, before the first round).
@@ -1377,6 +1431,14 @@ extern "C" {
 int nfa_sampler_destroy(nfa_sampler *s) {
     if (!s) return NFA_OK;
     NsDev &d = s->d;
+    if (d.dbg) {
+        long h[16];
+        if (hipMemcpy(h, d.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[ns timing, first listed pixel of part 0] update launches %ld: prologue %.1f us, loads %.1f us (%ld batches), counts+compaction %.1f us, "
+                    "wave-0 pass %.1f us (%ld survivors, %ld replacements), tail %.1f us per launch\n", h[8], 0.01 * h[0] / h[8], 0.01 * h[1] / h[8], h[9],
+                    0.01 * h[2] / h[8], 0.01 * h[3] / h[8], h[12], h[11], 0.01 * h[4] / h[8]);
+        (void)hipFree(d.dbg);
+    }
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
                     d.since_fit, d.refit_due, d.deadT, d.deadL, d.deadlnw, d.candU, d.candT, d.candL, d.candpix, d.valid, d.slot, d.count,
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol, d.elnv, d.nell,
@@ -1447,6 +1509,7 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(s->d_sh_mono, int, NS_SHEAR_MMAX * 2); NS_ALLOC(s->d_sh_start, int, D);
     NS_ALLOC(d.sh_mu, double, P * D); NS_ALLOC(d.sh_sg, double, P * D); NS_ALLOC(d.sh_beta, double, P * D * NS_SHEAR_MMAX);
     s->fm = fm;
+    if (getenv("NFA_NS_TIMING")) { NS_ALLOC(d.dbg, long, 16); HIP_TRY(hipMemset(d.dbg, 0, sizeof(long) * 16)); }
 #undef NS_ALLOC
     HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_fmap, fm.data(), sizeof(int) * D, hipMemcpyHostToDevice));
@@ -1581,24 +1644,8 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     d.max_ell = s->max_ell > 0 ? s->max_ell : (g_eng.sampler_ellipsoids == 1 ? 1 : NS_ME);
     d.multi = (d.stage_live && D <= NS_ME_MAXD && d.max_ell > 1) ? 1 : 0;
     if (d.multi) s->lds_refit += sizeof(double) * (size_t)((NS_ME + 2) * ns_me_slot(D)) + sizeof(int) * (size_t)((N + 3) & ~3);   // ... fit slots, labels
-    {   // free rejections by boxes: one-ellipsoid bounds whose live points are staged in LDS
-        // (off unless asked for: on BASELINE config 5 the boxes save a quarter of the evaluations of the two-component runs
-        // and cost more than that in longer rounds -- DESIGN section 10; a bright pixel alone needs a third of the walks' evaluations)
-        int nf = s->set_frames != -2 ? s->set_frames : g_eng.sampler_frames != -2 ? g_eng.sampler_frames : -1;
-        d.boxes = (!d.multi && d.stage_live && nf >= 0) ? 1 : 0;
-        d.n_frames = d.boxes ? nf : 0;
-        d.margin_c = s->set_margin > 0.0 ? s->set_margin : g_eng.sampler_margin_pct > 0 ? 0.01 * g_eng.sampler_margin_pct : NS_MARGIN_C;
-        if (d.boxes && d.n_frames > 0) {
-            std::vector<double> Q;
-            ns_make_frames(D, d.n_frames, Q);
-            HIP_TRY(hipMemcpyAsync(s->d_frames, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));                   // (Q goes out of scope)
-        }
-        d.frames = s->d_frames;
-        s->raw_sum = s->val_sum = 0;
-    }
     {   // the shear: one-ellipsoid bounds of all five free parameters of two or three components
-        const double enl = s->set_shear >= 0.0 ? s->set_shear : 0.01 * g_eng.sampler_shear_pct;
+        const double enl = s->set_shear >= 0.0 ? s->set_shear : g_eng.sampler_shear_pct >= 0 ? 0.01 * g_eng.sampler_shear_pct : NS_SHEAR_ENLARGE;
         const int nc = D / 5;
         bool shape = (D == 10 || D == 15) && d.DT == 6 * nc;
         for (int j = 0; shape && j < D; ++j) shape = (s->fm[(size_t)j] % nc) == (j % nc);
@@ -1616,6 +1663,24 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
             s->lds_refit += sizeof(double) * ((size_t)d.sh_M * d.sh_M + (size_t)D * d.sh_M + 2 * (size_t)D);
         }
         d.sh_mono = s->d_sh_mono; d.sh_start = s->d_sh_start;
+    }
+    {   // free rejections by boxes: one-ellipsoid bounds whose live points are staged in LDS
+        // (off unless asked for: on BASELINE config 5 the boxes save a quarter of the evaluations of the two-component runs
+        // and cost more than that in longer rounds -- DESIGN section 10; a bright pixel alone needs a third of the walks' evaluations)
+        // (by default: NS_FRAMES frames where the bound is sheared -- there the pair halves the evaluations of config 5's
+        // two-component runs in less time than the walks take -- and none elsewhere)
+        int nf = s->set_frames != -2 ? s->set_frames : g_eng.sampler_frames != -2 ? g_eng.sampler_frames : (d.shear ? NS_FRAMES : -1);
+        d.boxes = (!d.multi && d.stage_live && nf >= 0) ? 1 : 0;
+        d.n_frames = d.boxes ? nf : 0;
+        d.margin_c = s->set_margin > 0.0 ? s->set_margin : g_eng.sampler_margin_pct > 0 ? 0.01 * g_eng.sampler_margin_pct : NS_MARGIN_C;
+        if (d.boxes && d.n_frames > 0) {
+            std::vector<double> Q;
+            ns_make_frames(D, d.n_frames, Q);
+            HIP_TRY(hipMemcpyAsync(s->d_frames, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));                   // (Q goes out of scope)
+        }
+        d.frames = s->d_frames;
+        s->raw_sum = s->val_sum = 0;
     }
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));

@@ -315,6 +315,7 @@ def _box_veto(cand, zz, ubox, fbox, frames):
 
 # ---- a volume-preserving shear in front of the one-ellipsoid bound (ns_shear_fit / ns_shear_inv on the device) --------
 _NS_SHEAR_RIDGE = 1e-6                                                          # NS_SHEAR_RIDGE
+_NS_SHEAR_PIVOT = 1e-9                                                          # NS_SHEAR_PIVOT
 _NS_SHEAR_ENLARGE = 4.0                                                         # NS_SHEAR_ENLARGE
 
 
@@ -361,7 +362,15 @@ def _fit_shear(U, mono, start):
     F = _shear_phi(Z, mono, M)
     G = F.T @ F
     G[np.diag_indices(M)] += _NS_SHEAR_RIDGE * n
-    Lc = np.linalg.cholesky(G)
+    # Cholesky, column by column; a monomial whose pivot has drowned in rounding is dropped (ns_shear_fit): pivot = its own
+    # norm, nothing below it, so that its coefficient comes out as zero
+    Lc = np.zeros((M, M))
+    for j in range(M):
+        d = G[j, j] - Lc[j, :j] @ Lc[j, :j]
+        keep = d > _NS_SHEAR_PIVOT * G[j, j]
+        Lc[j, j] = math.sqrt(d) if keep else math.sqrt(max(G[j, j], 1e-300))
+        if keep and j + 1 < M:
+            Lc[j + 1:, j] = (G[j + 1:, j] - Lc[j + 1:, :j] @ Lc[j, :j]) / Lc[j, j]
     beta = np.zeros((D, M))
     for j in range(1, D):
         pj = int(start[j])
@@ -487,12 +496,13 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         duplicated parameters: `PriorTransformer.free_mask`).  They are not sampled -- a uniform dummy
         dimension integrates to one -- and stay at u = 0.5: fewer dimensions for the same evidence.
     frames, margin : the free rejections of a one-ellipsoid bound (`_fit_boxes`): `frames` rotated frames beside the unit
-        cube's axes and the ellipsoid's own (None or -1: no boxes, the default; 32 is the measured choice), `margin` the factor c of a face's distance beyond the extreme live point (1.75).
+        cube's axes and the ellipsoid's own (-1: no boxes; None: 32 where the bound is sheared, none elsewhere), `margin` the factor c of a face's distance beyond the extreme live point (1.75).
         With boxes the proposals per round are scaled by the last rounds' ratio of drawn to evaluated proposals (at most 8).
-    shear : None / 0 = off; a number > 1 = the one-ellipsoid bound is fitted to the live points AFTER a volume-preserving
+    shear : 0 = off; a number >= 1 = the one-ellipsoid bound is fitted to the live points AFTER a volume-preserving
         polynomial shear (`_fit_shear`: every coordinate minus a quadratic function of the earlier ones, which straightens
-        the curved tex / ntot ridges), with this safety factor on the enclosing volume instead of `enlarge` (4 is the
-        measured choice).  Proposals are drawn in the sheared frame and mapped back; boxes, if on, live in that frame.
+        the curved tex / ntot ridges), with this safety factor on the enclosing volume instead of `enlarge`; None = the
+        default, 4.  Proposals are drawn in the sheared frame and mapped back; boxes, if on, live in that frame.  Only
+        where all five free parameters of two or three components are sampled (10 or 15 dimensions): elsewhere ignored.
     refit_every : rejection-mode pixels refit their bound in rounds that are multiples of this (the device's engine option
         `sampler_refit_every`).
     enlarge : safety factor on the volume of the ellipsoid that just encloses the live points
@@ -551,16 +561,18 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     elnv, nell = np.full((P, _NS_ME), -np.inf), np.ones(P, dtype=np.int64)
     use_cube, lnvol = np.empty(P, dtype=bool), np.empty(P)
     # free rejections (one-ellipsoid bounds only): boxes in the unit cube's axes, the ellipsoid's frame and n_frames rotations
-    n_frames = -1 if frames is None else int(frames)            # (off unless asked for: DESIGN section 10)
+    # (the device's shapes for the shear: all five free parameters of two or three components, slot % ncomp = dimension % ncomp;
+    # there it is on by default, with NS_FRAMES box frames, like the device's -- shear=0 / frames=-1 turn them off)
+    ncomp_s = max(1, nd // 5)
+    shear = _NS_SHEAR_ENLARGE if shear is None else shear
+    shear_on = (bool(shear) and (not multi) and nd in (10, 15) and ndim == 6 * ncomp_s and nlive * nd * 8 <= 96 * 1024
+                and bool(np.all(fmap % ncomp_s == np.arange(nd) % ncomp_s)))
+    n_frames = (_NS_FRAMES if shear_on else -1) if frames is None else int(frames)
     boxes = (not multi) and n_frames >= 0 and nlive * nd * 8 <= 96 * 1024
     margin_c = _NS_MARGIN_C if margin is None else float(margin)
     Qf = _frames(nd, max(n_frames, 0)) if boxes else None
     ubox = np.zeros((P, nd, 2))
     fbox = np.zeros((P, max(n_frames, 0) + 1, nd, 2))
-    # (the device's shapes: all five free parameters of two or three components, slot % ncomp = dimension % ncomp)
-    ncomp_s = max(1, nd // 5)
-    shear_on = (bool(shear) and (not multi) and nd in (10, 15) and ndim == 6 * ncomp_s and nlive * nd * 8 <= 96 * 1024
-                and bool(np.all(fmap % ncomp_s == np.arange(nd) % ncomp_s)))
     if shear_on:
         assert float(shear) >= 1.0
         mono, mstart = _shear_monomials(fmap % ncomp_s)
@@ -735,7 +747,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                 # looks at all rejection rounds since the last one (a single round of a few hundred candidates is noise)
                 rj_scan[p] += scanned; rj_acc[p] += accepted; rj_raw[p] += Kr; rj_val[p] += int(vi.size)
                 if (rnd + 1) % n_steps == 0:
-                    if not done and (method == 2 or (method == 1 and rj_scan[p] >= 64 and walk_factor * rj_acc[p] * n_steps < rj_scan[p])):
+                    if not done and (method == 2 or (method == 1 and (walk_factor * rj_acc[p] * n_steps < rj_scan[p] if rj_scan[p] >= 64 else rj_raw[p] >= 4096))):
                         walk[p], wstep[p], wscale[p], wacc_sum[p], wtot_sum[p] = True, 0, 1.0, 0, 0
                         ln_pass[p] = math.log(max(int(rj_val[p]), 1) / max(int(rj_raw[p]), 1)) if boxes else 0.0
                     rj_scan[p] = rj_acc[p] = rj_raw[p] = rj_val[p] = 0
@@ -750,6 +762,9 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
         rnd += 1
         if progress is not None:
             progress(int(active.sum()), int(n_iter.max()))
+            if hasattr(progress, 'detail'):                     # (debugging aid: the round's state)
+                progress.detail(dict(rnd=rnd, n_iter=n_iter, n_evals=n_evals, walk=walk, use_cube=use_cube, lnvol=lnvol, Kr=Kr,
+                                     rj=(rj_scan, rj_acc, rj_raw, rj_val), ln_pass=ln_pass, Llive=Llive, Ulive=Ulive))
 
     dead_pix = np.concatenate(dead_pix) if dead_pix else np.zeros(0, dtype=np.int64)
     dead_T = np.concatenate(dead_T) if dead_T else np.zeros((0, ndim))
@@ -825,6 +840,10 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
             chunks = int(min(4096, max(1, chunks * (1.0 / max(dt, 1e-3)))))     # about a second per call
             if progress is not None:
                 progress(int(n_active.value), None)
+                if hasattr(progress, 'counts'):                                  # (debugging aid: the counters, chunk by chunk)
+                    ni, ne, rr = np.empty(P, dtype=np.int64), np.empty(P, dtype=np.int64), C.c_int64()
+                    _ffi.check(lib.nfa_sampler_counts(h, ni.ctypes.data_as(_ffi._lp), ne.ctypes.data_as(_ffi._lp), C.byref(rr)))
+                    chunks = progress.counts(ni, ne, int(rr.value)) or chunks
             if time_limit is not None and time.perf_counter() - t0 > time_limit:
                 break
         n_iter = np.empty(P, dtype=np.int64)

@@ -530,12 +530,14 @@ def test_shear_in_front_of_the_ellipsoid():
         return -0.5 * ((d / s) ** 2).sum(axis=1)
     fm = np.array([1] * 10 + [0, 0])
     kw = dict(nlive=200, tol=0.5, efr=0.3, seed=3, method='reject', batch_target=512, free_mask=fm)
-    plain = sampler.run_nested(ridge, 12, 1, **kw)
-    bent = sampler.run_nested(ridge, 12, 1, shear=4.0, **kw)
+    plain = sampler.run_nested(ridge, 12, 1, shear=0, **kw)
+    bent = sampler.run_nested(ridge, 12, 1, shear=4.0, frames=-1, **kw)
+    both = sampler.run_nested(ridge, 12, 1, **kw)                  # the default of this shape: shear 4 and 32 box frames
     truth = float(np.sum(np.log(np.sqrt(2 * np.pi) * np.array([0.08] * 8 + [0.01] * 2))))     # (the Gaussians fit into the cube)
-    for r in plain + bent:
+    for r in plain + bent + both:
         assert abs(r.lnZ - truth) < 4 * r.lnZ_err + 0.3, (r.lnZ, truth, r.lnZ_err)
     assert sum(r.n_evals for r in bent) < 0.5 * sum(r.n_evals for r in plain)
+    assert sum(r.n_evals for r in both) < sum(r.n_evals for r in bent)
     # shapes the device has no shear for run without it: the same result as shear=None
     f5 = _gauss_problem(np.full(5, 0.5), 0.05)
     a5, b5 = sampler.run_nested(f5, 5, 1, nlive=100, seed=2, ellipsoids=1)[0], sampler.run_nested(f5, 5, 1, nlive=100, seed=2, ellipsoids=1, shear=4.0)[0]
@@ -565,8 +567,8 @@ def test_shear_on_the_device_follows_the_twin(engine, nfo):
                 assert (d.n_iter, d.n_evals) == (t.n_iter, t.n_evals), (extra, d.n_iter, t.n_iter, d.n_evals, t.n_evals)
                 assert d.lnZ == pytest.approx(t.lnZ, rel=1e-10)
         kw = dict(nlive=150, tol=0.5, efr=0.3, seed=7, maxiter=2400, batch_target=2048, method='reject')
-        with_shear = sampler.fit_pixels(cube, np.arange(n_pix), shear=4.0, **kw)
-        without = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
+        with_shear = sampler.fit_pixels(cube, np.arange(n_pix), shear=4.0, frames=-1, **kw)
+        without = sampler.fit_pixels(cube, np.arange(n_pix), shear=0, **kw)
         assert sum(r.n_evals for r in with_shear) < 0.8 * sum(r.n_evals for r in without)
     finally:
         engine.set_exp_mode('fast')
@@ -590,14 +592,14 @@ def test_box_vetoes_on_the_device_follow_the_twin(engine, nfo):
         model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
         cube = CubeRunner(axes, (1, 2), model + rng.normal(0, noise, model.shape), np.full((n_pix, 2), noise), ut, ncomp=2)
         for extra in (dict(frames=8), dict(frames=32, margin=1.5, n_steps=20), dict(frames=0, method='reject')):
-            kw = dict(nlive=150, tol=0.5, efr=0.3, seed=7, maxiter=900, batch_target=2048, **extra)
+            kw = dict(nlive=150, tol=0.5, efr=0.3, seed=7, maxiter=900, batch_target=2048, shear=0, **extra)
             dev = sampler.fit_pixels(cube, np.arange(n_pix), device=True, **kw)
             twin = sampler.fit_pixels(cube, np.arange(n_pix), device=False, **kw)
             for d, t in zip(dev, twin):
                 assert (d.n_iter, d.n_evals) == (t.n_iter, t.n_evals), (extra, d.n_iter, t.n_iter, d.n_evals, t.n_evals)
                 assert d.lnZ == pytest.approx(t.lnZ, rel=1e-10)
         # and the vetoes do veto: fewer evaluations than the same run without them
-        kw = dict(nlive=150, tol=0.5, efr=0.3, seed=7, maxiter=900, batch_target=2048, method='reject')
+        kw = dict(nlive=150, tol=0.5, efr=0.3, seed=7, maxiter=900, batch_target=2048, method='reject', shear=0)
         with_boxes = sampler.fit_pixels(cube, np.arange(n_pix), frames=32, **kw)
         without = sampler.fit_pixels(cube, np.arange(n_pix), **kw)
         assert sum(r.n_evals for r in with_boxes) < 0.8 * sum(r.n_evals for r in without)
