@@ -37,10 +37,10 @@ def run(label, **kw):
 
 
 ref = run('walks of 140 steps', method='walk', n_steps=140)
-rows = [ref, run('shipped default (walks of 100 steps, automatic)')]
+rows = [ref, run('shipped default (shear 4, 32 box frames)')]
 for tok in sys.argv[3:]:
     f = tok.split(':')
-    kw = dict(shear=float(f[0]) or None, frames=int(f[1]) if int(f[1]) >= 0 else None)
+    kw = dict(shear=float(f[0]), frames=int(f[1]))
     if len(f) > 2 and f[2]:
         kw['margin'] = float(f[2])
     if len(f) > 3:
