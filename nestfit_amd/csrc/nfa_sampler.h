@@ -87,6 +87,7 @@ static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for 
 #define NS_SHEAR_PIVOT 1e-9        // a Cholesky pivot below this fraction of its diagonal entry: the monomial is dropped
 #define NS_SHEAR_MMAX 64           // monomials at most
 #define NS_REFIT_THREADS 512       // of the workgroup that fits a one-ellipsoid bound
+#define NS_K_TARGET 16             // replacements per pixel and rejection round the per-pixel share of proposals aims at
 #define NS_WALK_LOWD 6             // up to this many sampled dimensions ...
 #define NS_WALK_FACTOR_LOWD 64     // ... the switch to walks waits for an acceptance below 1 / (64 n_steps)
 #define NS_WALK_FACTOR 2           // above: 1 / (2 n_steps)
@@ -162,6 +163,11 @@ struct NsDev {
     const int *sh_start;                // [D] monomials before coordinate j's own = the features z_j is regressed on
     double *sh_mu, *sh_sg;              // [P][D] z = (u - mu) / sg
     double *sh_beta;                    // [P][D][sh_M] w_j = z_j - phi(z_<j) . beta_j
+    // proposals per pixel: a pixel whose rejection rounds accept far more than k_target candidates halves its share of the
+    // next round, one that accepts far fewer doubles it (up to the round's Kr): the round's longest update workgroup is the
+    // pixel with the most replacements, and a bound that has seen 100 of them in a round is stale
+    int    *Kp;                         // [P] 0 = the round's Kr
+    int     k_target;                   // 0 = everybody gets Kr
     long   *dbg;                        // NFA_NS_TIMING=1: stage times of the update workgroup of the first listed pixel (100 MHz ticks)
 };
 #define NS_TICK(slot) do { if (timing) { const long t_ = (long)wall_clock64(); S.dbg[slot] += t_ - t_last; t_last = t_; } } while (0)
@@ -206,6 +212,7 @@ static void ns_make_frames(int D, int K, std::vector<double> &Q) {
 __device__ __forceinline__ int  ns_n(const NsDev &S, int p)   { return S.nlive ? S.nlive[p] : S.N; }
 __device__ __forceinline__ long ns_cap(const NsDev &S, int p) { return S.capp ? S.capp[p] : S.cap; }
 __device__ __forceinline__ int  ns_upd(const NsDev &S, int p) { return S.updp ? S.updp[p] : S.upd; }
+__device__ __forceinline__ int  ns_kp(const NsDev &S, int p, int Kr) { const int k = S.k_target > 0 ? S.Kp[p] : 0; return k > 0 ? min(k, Kr) : Kr; }
 __device__ __forceinline__ int  ns_wmax(const NsDev &S, int p) { return min(S.w_stride, S.w_fixed > 0 ? S.w_fixed : ns_walkers_for(ns_n(S, p))); }
 
 // ---- live points -------------------------------------------------------------------------
@@ -320,8 +327,13 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
     // vetoes is never looked at again, and with no store ahead of them the loads of the bound (uniform over the
     // workgroup) go through the scalar cache -- as per-lane loads, 3200 of them per proposal, they were the kernel
     double x[DM], zq[DM];
-    bool ok = in_range;
     const bool walking = S.walk[p] != 0;
+    if (!walking) {                     // the pixel's own share of the round's proposals
+        const int kp = ns_kp(S, p, Kr);
+        if ((int)(blockIdx.x * blockDim.x) >= kp) return;          // (the whole workgroup: nothing to do)
+        in_range = in_range && k < kp;
+    }
+    bool ok = in_range;
     // the rotated frames' tests on packed survivors (compile-time dimensions: the queue's LDS is sized by them)
     const bool queued = DD > 0 && !walking && S.boxes && S.n_frames > 0;
     // (ONE branch per mode: stores of the walkers' branch ahead of the rejection branch on a common path -- a join
@@ -1108,10 +1120,12 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
     if (!S.active[p]) return;
     const bool timing = S.dbg != nullptr && q == 0 && tid == 0;
     long t_last = timing ? (long)wall_clock64() : 0;
+    const long t_wg = S.dbg != nullptr && tid == 0 ? (long)wall_clock64() : 0;      // every pixel's workgroup: sum and maximum of its time
     double *Ll = S.Llive + (long)p * NS;
     for (int i = tid; i < N; i += NS_UPD_THREADS) sL[i] = Ll[i];
     __syncthreads();
     const bool was_walking = S.walk[p] != 0;
+    int k_used = Kr;                                // what the pixel's random stream advanced by in this round
     if (was_walking && wave != 0) return;           // (a walk round is wave 0's alone: no barrier below on that path)
     auto worst_point = [&](double &lmin, int &w) {
         double mn = INFINITY;
@@ -1216,6 +1230,7 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
         // goes stale by the factor exp(-replacements / N) in volume, far cheaper than throwing evaluated
         // points away.  The proposals are walked 64 at a time; only the valid ones cost anything.
         long scanned = 0, accepted = 0, n_valid = 0;
+        const int K_scan = ns_kp(S, p, K);          // the proposals this pixel drew (the flags' stride stays K)
         double Lseg = Lmin;                         // the threshold the segment starts with (wave 0's Lmin, shared below)
         if (tid == 0) { sCtl[0] = Lmin; sCtl[1] = 0.0; }
         __syncthreads();
@@ -1225,14 +1240,14 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
         // fetched segment by segment they were the round); then segment by segment -- 4 x 256 proposals -- through the
         // threshold, in order
         constexpr int NS_UPD_U = 8;
-        for (int kb = 0; kb < K && !stop; kb += NS_UPD_U * NS_UPD_THREADS) {
+        for (int kb = 0; kb < K_scan && !stop; kb += NS_UPD_U * NS_UPD_THREADS) {
             unsigned vbits = 0;
             int rows[NS_UPD_U];
             double Ls[NS_UPD_U];
 #pragma unroll
             for (int u = 0; u < NS_UPD_U; ++u) {    // proposal kb + u * 256 + tid: coalesced
                 const int kk = kb + u * NS_UPD_THREADS + tid;
-                const bool v = kk < K && S.valid[(long)q * K + kk] != 0;
+                const bool v = kk < K_scan && S.valid[(long)q * K + kk] != 0;
                 vbits |= v ? (1u << u) : 0u;
             }
 #pragma unroll
@@ -1247,7 +1262,7 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
             NS_TICK(1);                             // flags, rows, likelihoods of NS_UPD_U x 256 proposals
 #pragma unroll
             for (int sub = 0; sub < NS_UPD_U / 4; ++sub) {
-                if (stop || kb + sub * NS_UPD_SEG >= K) break;          // (uniform over the workgroup)
+                if (stop || kb + sub * NS_UPD_SEG >= K_scan) break;     // (uniform over the workgroup)
                 unsigned long long mv[4], ms[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -1317,7 +1332,14 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
         // The decision looks at all rejection rounds since the last decision point: one round of a few hundred
         // candidates is noise (a pixel that a single unlucky round sent to the walks stayed there for thousands of rounds).
         if (lane == 0) {
-            long ws = S.rj_scan[p] + scanned, wa = S.rj_acc[p] + accepted, wr = S.rj_raw[p] + K, wv = S.rj_val[p] + n_valid;
+            long ws = S.rj_scan[p] + scanned, wa = S.rj_acc[p] + accepted, wr = S.rj_raw[p] + K_scan, wv = S.rj_val[p] + n_valid;
+            if (S.k_target > 0) {
+                int kn = K_scan;
+                if (accepted > 2 * S.k_target) kn = max(K_scan / 2, S.K);
+                else if (2 * accepted < S.k_target) kn = min(K_scan * 2, 1 << 20);
+                S.Kp[p] = kn;
+            }
+            k_used = K_scan;
             if ((round + 1) % S.n_steps == 0) {
                 // (a window that let fewer than 64 of at least 4096 proposals through has no bound worth the name: walk --
                 // and be back when a walk cycle's refit has made a new one)
@@ -1331,7 +1353,7 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
         }
     }
     if (lane == 0) {
-        S.n_iter[p] = it; S.n_evals[p] = evals; S.lnZ[p] = lnZ; S.cand_base[p] += Kr;
+        S.n_iter[p] = it; S.n_evals[p] = evals; S.lnZ[p] = lnZ; S.cand_base[p] += k_used;
         if (done) S.active[p] = 0;
     }
     // A refit costs ~100 us and pixels are in lock-step: rejection-mode pixels refit only in every
@@ -1342,6 +1364,19 @@ __global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int 
     const bool due = !done && since >= ns_upd(S, p) && (was_walking || (round + 1) % S.refit_every == 0);
     if (lane == 0) { S.since_fit[p] = since; S.refit_due[p] = due ? 1 : 0; }
     NS_TICK(4);                                     // the tail
+    if (S.dbg != nullptr && tid == 0) {
+        const long dt = (long)wall_clock64() - t_wg;
+        atomicAdd((unsigned long long *)&S.dbg[13], (unsigned long long)dt);
+        atomicAdd((unsigned long long *)&S.dbg[14], 1ull);
+        atomicMax((unsigned long long *)&S.dbg[15], (unsigned long long)dt);
+        if (was_walking) { atomicAdd((unsigned long long *)&S.dbg[5], (unsigned long long)dt); atomicAdd((unsigned long long *)&S.dbg[6], 1ull); }
+        int bin = 0;
+        while ((1l << bin) * 100 < dt && bin < 15) ++bin;                   // 1, 2, 4 ... us
+        atomicAdd((unsigned long long *)&S.dbg[16 + bin], 1ull);
+        atomicAdd((unsigned long long *)&S.dbg[32 + bin], (unsigned long long)dt);
+        const long nrep = it - S.n_iter[p] + 0;                             // (n_iter was written above: so this is 0; see dbg[48+])
+        (void)nrep;
+    }
 }
 
 // The bounds of the pixels that are due (ns_update_kernel marks them; `direct`: all pixels, before the first round).
@@ -1432,11 +1467,15 @@ int nfa_sampler_destroy(nfa_sampler *s) {
     if (!s) return NFA_OK;
     NsDev &d = s->d;
     if (d.dbg) {
-        long h[16];
+        long h[64];
         if (hipMemcpy(h, d.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[ns timing, first listed pixel of part 0] update launches %ld: prologue %.1f us, loads %.1f us (%ld batches), counts+compaction %.1f us, "
                     "wave-0 pass %.1f us (%ld survivors, %ld replacements), tail %.1f us per launch\n", h[8], 0.01 * h[0] / h[8], 0.01 * h[1] / h[8], h[9],
                     0.01 * h[2] / h[8], 0.01 * h[3] / h[8], h[12], h[11], 0.01 * h[4] / h[8]);
+        if (hipMemcpy(h, d.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[14] > 0)
+            fprintf(stderr, "[ns timing, all update workgroups] %ld: mean %.1f us, longest %.1f us; walking ones %ld: mean %.1f us\n", h[14], 0.01 * h[13] / h[14],
+                    0.01 * h[15], h[6], h[6] ? 0.01 * h[5] / h[6] : 0.0);
+        for (int b = 0; b < 16; ++b) if (h[16 + b]) fprintf(stderr, "    <= %5ld us: %9ld workgroups, %8.1f ms in all\n", 1l << b, h[16 + b], 1e-5 * h[32 + b]);
         (void)hipFree(d.dbg);
     }
     void *ptrs[] = {d.Ulive, d.Tlive, d.Llive, d.centre, d.axes, d.n_iter, d.n_evals, d.cand_base, d.lnZ, d.active, d.use_cube,
@@ -1444,7 +1483,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol, d.elnv, d.nell,
                     s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap, s->d_nlive, s->d_updp, s->d_capp,
                     s->d_frames, d.ubox, d.fbox, d.rj_scan, d.rj_acc, d.rj_raw, d.rj_val, d.ln_pass,
-                    s->d_sh_mono, s->d_sh_start, d.sh_mu, d.sh_sg, d.sh_beta};
+                    s->d_sh_mono, s->d_sh_start, d.sh_mu, d.sh_sg, d.sh_beta, d.Kp};
     for (void *p : ptrs) (void)hipFree(p);
     if (s->h_pub) (void)hipHostFree(s->h_pub);
     delete s;
@@ -1507,9 +1546,10 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.ln_pass, double, P);
     NS_ALLOC(s->d_frames, double, (size_t)NS_FRAMES_MAX * D * D);
     NS_ALLOC(s->d_sh_mono, int, NS_SHEAR_MMAX * 2); NS_ALLOC(s->d_sh_start, int, D);
+    NS_ALLOC(d.Kp, int, P);
     NS_ALLOC(d.sh_mu, double, P * D); NS_ALLOC(d.sh_sg, double, P * D); NS_ALLOC(d.sh_beta, double, P * D * NS_SHEAR_MMAX);
     s->fm = fm;
-    if (getenv("NFA_NS_TIMING")) { NS_ALLOC(d.dbg, long, 16); HIP_TRY(hipMemset(d.dbg, 0, sizeof(long) * 16)); }
+    if (getenv("NFA_NS_TIMING")) { NS_ALLOC(d.dbg, long, 64); HIP_TRY(hipMemset(d.dbg, 0, sizeof(long) * 64)); }
 #undef NS_ALLOC
     HIP_TRY(hipMemcpy(s->d_pixmap, pm.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_fmap, fm.data(), sizeof(int) * D, hipMemcpyHostToDevice));
@@ -1613,6 +1653,8 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemsetAsync(d.rj_raw, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.rj_val, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.ln_pass, 0, sizeof(double) * P, st));
+    HIP_TRY(hipMemsetAsync(d.Kp, 0, sizeof(int) * P, st));
+    d.k_target = g_eng.sampler_ktarget >= 0 ? g_eng.sampler_ktarget : NS_K_TARGET;
     {   // live points
         const long tot = (long)P * N;
         hipLaunchKernelGGL(ns_init_live_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, s->d_livepix);

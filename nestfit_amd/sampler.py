@@ -314,6 +314,7 @@ def _box_veto(cand, zz, ubox, fbox, frames):
 
 
 # ---- a volume-preserving shear in front of the one-ellipsoid bound (ns_shear_fit / ns_shear_inv on the device) --------
+_NS_K_TARGET = 16                                                               # NS_K_TARGET
 _NS_SHEAR_RIDGE = 1e-6                                                          # NS_SHEAR_RIDGE
 _NS_SHEAR_PIVOT = 1e-9                                                          # NS_SHEAR_PIVOT
 _NS_SHEAR_ENLARGE = 4.0                                                         # NS_SHEAR_ENLARGE
@@ -462,7 +463,7 @@ def default_cap_iter(nlive):
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
                check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None, walkers=None,
-               progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None):
+               progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None, k_target=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -627,6 +628,10 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     # what a pixel's rejection rounds did since the last decision point (every n_steps rounds): candidates scanned and
     # accepted, proposals drawn and evaluated; ln of the last window's evaluated / drawn (the boxes' share of the
     # ellipsoid: what the way back from the walks counts the bound's volume with)
+    # a pixel's own share of a rejection round's proposals (ns_kp / NS_K_TARGET): halved after a round with more than twice
+    # k_target replacements, doubled after one with fewer than half of it; 0 = the round's Kr
+    k_target = _NS_K_TARGET if k_target is None else int(k_target)
+    Kp = np.zeros(P, dtype=np.int64)
     rj_scan, rj_acc = np.zeros(P, dtype=np.int64), np.zeros(P, dtype=np.int64)
     rj_raw, rj_val = np.zeros(P, dtype=np.int64), np.zeros(P, dtype=np.int64)
     ln_pass = np.zeros(P)
@@ -663,6 +668,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             nlive = int(nl[p])
             done = False
             was_walking = bool(walk[p])
+            k_used = Kr                                         # what the pixel's random stream advances by in this round
             if walk[p]:
                 # one Metropolis step of every walker inside {L > threshold frozen at the cycle start}
                 step = int(wstep[p])
@@ -708,10 +714,11 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                     if method == 1 and (-n_iter[p] / nlive - min(lnvol[p] + ln_pass[p], 0.0)) > math.log(8.0 / (walk_factor * n_steps)):
                         walk[p] = False
             else:
+                k_used = int(min(Kp[p], Kr)) if (k_target > 0 and Kp[p] > 0) else Kr
                 if nell[p] > 1 and not use_cube[p]:
-                    cand, keep = _candidates_multi(seed, p, cand_base[p], Kr, centre[p], axes[p], elnv[p], int(nell[p]), lnvol[p])
+                    cand, keep = _candidates_multi(seed, p, cand_base[p], k_used, centre[p], axes[p], elnv[p], int(nell[p]), lnvol[p])
                 else:
-                    cand, zf = _candidates(seed, [p], cand_base[p:p + 1], Kr, centre[p:p + 1, 0], axes[p:p + 1, 0],
+                    cand, zf = _candidates(seed, [p], cand_base[p:p + 1], k_used, centre[p:p + 1, 0], axes[p:p + 1, 0],
                                            use_cube[p:p + 1], with_ball=True)
                     cand, keep = cand[0], True
                     if shear_on:
@@ -745,13 +752,20 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                                 break
                 # walk cycles of all pixels stay in phase: they start at rounds that are multiples of n_steps.  The decision
                 # looks at all rejection rounds since the last one (a single round of a few hundred candidates is noise)
-                rj_scan[p] += scanned; rj_acc[p] += accepted; rj_raw[p] += Kr; rj_val[p] += int(vi.size)
+                rj_scan[p] += scanned; rj_acc[p] += accepted; rj_raw[p] += k_used; rj_val[p] += int(vi.size)
+                if k_target > 0:
+                    if accepted > 2 * k_target:
+                        Kp[p] = max(k_used // 2, K)
+                    elif 2 * accepted < k_target:
+                        Kp[p] = min(k_used * 2, 1 << 20)
+                    else:
+                        Kp[p] = k_used
                 if (rnd + 1) % n_steps == 0:
                     if not done and (method == 2 or (method == 1 and (walk_factor * rj_acc[p] * n_steps < rj_scan[p] if rj_scan[p] >= 64 else rj_raw[p] >= 4096))):
                         walk[p], wstep[p], wscale[p], wacc_sum[p], wtot_sum[p] = True, 0, 1.0, 0, 0
                         ln_pass[p] = math.log(max(int(rj_val[p]), 1) / max(int(rj_raw[p]), 1)) if boxes else 0.0
                     rj_scan[p] = rj_acc[p] = rj_raw[p] = rj_val[p] = 0
-            cand_base[p] += Kr
+            cand_base[p] += k_used
             if done:
                 active[p] = False
             elif since_fit[p] >= updp[p] and (was_walking or (rnd + 1) % refit_every == 0):
