@@ -77,7 +77,7 @@ static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for 
 #define NS_MARGIN_C 1.75
 #define NS_MARGIN_A 1.5
 #define NS_MARGIN_FLOOR 0.1
-#define NS_RATIO_MAX 8             // proposals drawn per round: at most this multiple of the evaluations aimed for
+#define NS_RATIO_MAX 32            // proposals drawn per round: at most this multiple of the evaluations aimed for
 #define NS_FRAME_SEED 0x5EEDF00Dull
 // A volume-preserving shear in front of the one-ellipsoid bound (the twin's _fit_shear): every sampled coordinate minus a
 // quadratic function of the earlier ones -- the curved tex / ntot ridges of faint pixels come out straight, and an
@@ -1518,7 +1518,8 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     s->b_target = std::max<long>((long)n_pix * n_cand, (long)batch_target);
     // rows of the candidate buffers: n_act * Kr <= max(b_target, n_act * K) <= b_target -- times NS_RATIO_MAX where boxes
     // may veto proposals for free (one-ellipsoid bounds: more than NS_ME_MAXD sampled dimensions, or on request)
-    const size_t K = ((size_t)s->b_target * NS_RATIO_MAX + P - 1) / P;       // so that P * K >= NS_RATIO_MAX * b_target
+    const size_t ratio_alloc = g_eng.sampler_ratio_max > 0 ? g_eng.sampler_ratio_max : NS_RATIO_MAX;
+    const size_t K = ((size_t)s->b_target * ratio_alloc + P - 1) / P;       // so that P * K >= ratio_max * b_target
     s->k_alloc = K;
     std::vector<int> pm(P);
     for (size_t p = 0; p < P; ++p) pm[p] = pix ? pix[p] : 0;
@@ -1764,7 +1765,8 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
         const int n_act = s->n_act;
         // with boxes most proposals are vetoed for free: so many more are drawn that a round still evaluates ~b_target
         long ratio = 1;
-        if (d.boxes && s->raw_sum > 0) ratio = std::min<long>(NS_RATIO_MAX, std::max<long>(1, (s->raw_sum + s->val_sum / 2) / std::max<long>(s->val_sum, 1)));
+        const long ratio_max = g_eng.sampler_ratio_max > 0 ? g_eng.sampler_ratio_max : NS_RATIO_MAX;
+        if (d.boxes && s->raw_sum > 0) ratio = std::min<long>(ratio_max, std::max<long>(1, (s->raw_sum + s->val_sum / 2) / std::max<long>(s->val_sum, 1)));
         s->raw_sum = s->val_sum = 0;
         const long kmax = g_eng.sampler_kmax > 0 ? g_eng.sampler_kmax : NS_KMAX;
         const int Kr = (int)std::min<long>(kmax, std::max<long>(K, (s->b_target * ratio) / n_act));    // (n_act * Kr rows <= NS_RATIO_MAX * b_target: what nfa_sampler_create allocated)

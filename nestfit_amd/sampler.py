@@ -259,7 +259,7 @@ def _candidates_multi(seed, p, base, K, cs, As, lv, ne, lnvol):
 # bound cuts off, and the evaluations per iteration it saves).
 _FRAME_SEED = _U64(0x5EEDF00D)
 _NS_FRAMES, _NS_MARGIN_C, _NS_MARGIN_A, _NS_MARGIN_FLOOR = 32, 1.75, 1.5, 0.1     # NS_FRAMES, NS_MARGIN_C, NS_MARGIN_A, NS_MARGIN_FLOOR
-_NS_RATIO_MAX = 8                                                              # NS_RATIO_MAX
+_NS_RATIO_MAX = 32                                                             # NS_RATIO_MAX
 
 
 def _frames(D, K):
@@ -463,7 +463,7 @@ def default_cap_iter(nlive):
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
                check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None, walkers=None,
-               progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None, k_target=None):
+               progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None, k_target=None, ratio_max=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -657,7 +657,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     while active.any():
         if rnd % check_every == 0:                              # the device compacts its pixel list here
             # with boxes most proposals are vetoed for free: draw so many more that a round still evaluates ~b_target
-            ratio = min(_NS_RATIO_MAX, max(1, (raw_sum + val_sum // 2) // max(val_sum, 1))) if boxes and raw_sum else 1
+            ratio = min(int(ratio_max) if ratio_max else _NS_RATIO_MAX, max(1, (raw_sum + val_sum // 2) // max(val_sum, 1))) if boxes and raw_sum else 1
             n_chunk = int(active.sum())                          # the pixels the device's list holds until the next look
             Kr = int(min(kmax if kmax else 16384, max(K, (b_target * ratio) // n_chunk)))
             raw_sum = val_sum = 0

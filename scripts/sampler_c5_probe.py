@@ -28,7 +28,7 @@ for c in range(ncomp):
 probe = CubeRunner(axes, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=ncomp)
 model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
 cube = CubeRunner(axes, (1, 2), model + rng.normal(0, noise, model.shape), np.full((n_pix, 2), noise), ut, ncomp=ncomp)
-for key in ('walk_factor', 'refit_every', 'parts', 'kmax', 'ktarget'):
+for key in ('walk_factor', 'refit_every', 'parts', 'kmax', 'ktarget', 'ratio_max'):
     if key in kw:
         _ffi.set_option('sampler_' + key, kw.pop(key))
 _ffi.check(_ffi.load().nfa_device_synchronize())
