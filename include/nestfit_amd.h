@@ -96,6 +96,12 @@ int nfa_get_exp_mode(void);
  *                   none, 0..64; "sampler_margin_pct": the boxes' margin factor in hundredths (0 = 175);
  *   "sampler_shear_pct"   the shear in front of one-ellipsoid bounds (nfa_sampler_set_shear): its safety factor in
  *                   hundredths, -1 (default) = 400 where the shape allows, 0 = off, 100..100000;
+ *   "sampler_ktarget"     replacements per pixel and rejection round a pixel's own share of the round's proposals aims
+ *                   at: halved after a round with more than twice as many, doubled after one with fewer than half
+ *                   (-1 = the default, 16; 0 = every pixel the round's number); "sampler_ratio_max": proposals drawn
+ *                   per round with vetoes on, at most this multiple of the evaluations aimed for (0 = the default,
+ *                   32; the candidate buffers are sized by it when a sampler is created); "sampler_kmax": most
+ *                   proposals a pixel gets in a round (0 = 16384).  The twin: `k_target=`, `ratio_max=`, `kmax=`;
  *   "sampler_refit_every" rejection-mode pixels refit their bound in rounds that are multiples of this (default 4);
  *                   the sampler_* keys are read when a sampler is created / begun, A/B knobs like the rest;
  *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid; the
