@@ -641,9 +641,11 @@ __device__ __forceinline__ double ns_block_max(double v, double *sred, int tid, 
 // One Gram matrix of all monomials and ONE Cholesky factorisation serve every coordinate: the factor of a leading block is
 // the leading block of the factor, and row start[j] of the factor is the forward substitution of coordinate j's normal
 // equations (its right-hand side is the Gram column of the monomial z_j itself).
-__device__ double ns_shear_fit(const NsDev &S, int p, int N, double *sd, double *sh, int tid, int NT, double *sred) {
+#define NS_RTICK(slot) do { if (S.dbg && blockIdx.x == 0 && tid == 0) { const long t_ = (long)wall_clock64(); S.dbg[slot] += t_ - t_r; t_r = t_; } } while (0)
+__device__ double ns_shear_fit(const NsDev &S, int p, int N, double *sd, double *sh, int tid, int NT, double *sred, long &t_r) {
     const int D = S.D, M = S.sh_M;
-    double *sG = sh, *sB = sG + M * M, *smu = sB + D * M, *ssg = smu + D;
+    double *sG = sh, *sB = sG + M * M, *smu = sB + D * M, *ssg = smu + D, *sone = ssg + D;
+    if (tid == 0) sone[0] = 1.0;
     const int *mono = S.sh_mono, *start = S.sh_start;
     for (int j = tid; j < D; j += NT) {
         double acc = 0.0;
@@ -657,6 +659,7 @@ __device__ double ns_shear_fit(const NsDev &S, int p, int N, double *sd, double 
     __syncthreads();
     for (int e = tid; e < N * D; e += NT) { const int j = e % D; sd[e] = (sd[e] - smu[j]) / ssg[j]; }
     __syncthreads();
+    NS_RTICK(48);                                   // mean, spread, standardise
     // Gram matrix, lower triangle: lanes = entries, each walking all points
     const int n_ent = M * (M + 1) / 2;
     for (int e = tid; e < n_ent; e += NT) {
@@ -664,17 +667,26 @@ __device__ double ns_shear_fit(const NsDev &S, int p, int N, double *sd, double 
         while (r * (r + 1) / 2 > e) --r;
         while ((r + 1) * (r + 2) / 2 <= e) ++r;
         const int c = e - r * (r + 1) / 2;
-        const int a0 = mono[2 * r], a1 = mono[2 * r + 1], b0 = mono[2 * c], b1 = mono[2 * c + 1];
-        double acc = 0.0;
-        for (int i = 0; i < N; ++i) {
-            const double *z = sd + i * D;
-            const double fr = a0 < 0 ? 1.0 : (a1 < 0 ? z[a0] : z[a0] * z[a1]);
-            const double fc = b0 < 0 ? 1.0 : (b1 < 0 ? z[b0] : z[b0] * z[b1]);
-            acc += fr * fc;
+        // the entry's (up to) four factors as (address of the first point's value, stride): a missing factor reads the
+        // constant 1 with stride 0 -- no branches inside the walk over the points, four points in flight
+        const int f[4] = {mono[2 * r], mono[2 * r + 1], mono[2 * c], mono[2 * c + 1]};
+        const double *fp[4];
+        int fs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fp[t] = f[t] < 0 ? sone : sd + f[t]; fs[t] = f[t] < 0 ? 0 : D; }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int i = 0;
+        for (; i + 4 <= N; i += 4) {
+            a0 += (fp[0][(i + 0) * fs[0]] * fp[1][(i + 0) * fs[1]]) * (fp[2][(i + 0) * fs[2]] * fp[3][(i + 0) * fs[3]]);
+            a1 += (fp[0][(i + 1) * fs[0]] * fp[1][(i + 1) * fs[1]]) * (fp[2][(i + 1) * fs[2]] * fp[3][(i + 1) * fs[3]]);
+            a2 += (fp[0][(i + 2) * fs[0]] * fp[1][(i + 2) * fs[1]]) * (fp[2][(i + 2) * fs[2]] * fp[3][(i + 2) * fs[3]]);
+            a3 += (fp[0][(i + 3) * fs[0]] * fp[1][(i + 3) * fs[1]]) * (fp[2][(i + 3) * fs[2]] * fp[3][(i + 3) * fs[3]]);
         }
-        sG[r * M + c] = acc + (r == c ? NS_SHEAR_RIDGE * N : 0.0);
+        for (; i < N; ++i) a0 += (fp[0][i * fs[0]] * fp[1][i * fs[1]]) * (fp[2][i * fs[2]] * fp[3][i * fs[3]]);
+        sG[r * M + c] = ((a0 + a1) + (a2 + a3)) + (r == c ? NS_SHEAR_RIDGE * N : 0.0);
     }
     __syncthreads();
+    NS_RTICK(49);                                   // Gram matrix
     // Cholesky in place, column by column: lane 0 the diagonal, lanes = rows below it.  A monomial whose pivot has
     // drowned in rounding (live points squeezed onto a line at ln X ~ -50: the ridge keeps the matrix positive definite
     // on paper only) is dropped -- pivot = its own norm, nothing below it: its coefficient comes out as zero and the
@@ -698,6 +710,7 @@ __device__ double ns_shear_fit(const NsDev &S, int p, int N, double *sd, double 
         if (tid == 0 && dj < 0.0) sG[j * M + j] = -dj;
         // (row j's own off-diagonal entries stay: they are the forward substitution of a coordinate whose monomial this is)
     }
+    NS_RTICK(50);                                   // Cholesky
     // coefficients: lanes = coordinates, back substitution with the transposed leading block
     for (int j = tid; j < D; j += NT) {
         const int pj = j == 0 ? 0 : start[j];
@@ -710,6 +723,7 @@ __device__ double ns_shear_fit(const NsDev &S, int p, int N, double *sd, double 
         }
     }
     __syncthreads();
+    NS_RTICK(51);                                   // back substitutions
     for (int e = tid; e < D * M; e += NT) S.sh_beta[(long)p * D * M + e] = sB[e];
     for (int j = tid; j < D; j += NT) { S.sh_mu[(long)p * D + j] = smu[j]; S.sh_sg[(long)p * D + j] = ssg[j]; }
     // w in place: lanes = points, from the last coordinate down (a coordinate's features are the earlier z)
@@ -729,13 +743,43 @@ __device__ double ns_shear_fit(const NsDev &S, int p, int N, double *sd, double 
     double lj = 0.0;
     for (int j = 0; j < D; ++j) lj += log(ssg[j]);
     __syncthreads();
+    NS_RTICK(52);                                   // w in place
     return lj;
+}
+
+// Extent of the live points (rows of sd, DD coordinates each, in LDS) along column j of the frame Q: the column in
+// registers, four points in flight (a lone chain of broadcast read -> DD multiply-adds per point was most of a refit)
+template <int DD>
+__device__ __forceinline__ void ns_frame_extent(const double *sd, int N, const double *Q, int j, double &lo, double &hi) {
+    double qc[DD];
+#pragma unroll
+    for (int a = 0; a < DD; ++a) qc[a] = Q[a * DD + j];
+    int i = 0;
+    for (; i + 4 <= N; i += 4) {
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+#pragma unroll
+        for (int a = 0; a < DD; ++a) {          // (each sum in the order a = 0, 1, ...: the same bits as one point at a time)
+            w0 += sd[(i + 0) * DD + a] * qc[a];
+            w1 += sd[(i + 1) * DD + a] * qc[a];
+            w2 += sd[(i + 2) * DD + a] * qc[a];
+            w3 += sd[(i + 3) * DD + a] * qc[a];
+        }
+        lo = fmin(fmin(lo, w0), fmin(w1, fmin(w2, w3)));
+        hi = fmax(fmax(hi, w0), fmax(w1, fmax(w2, w3)));
+    }
+    for (; i < N; ++i) {
+        double w = 0.0;
+#pragma unroll
+        for (int a = 0; a < DD; ++a) w += sd[i * DD + a] * qc[a];
+        lo = fmin(lo, w); hi = fmax(hi, w);
+    }
 }
 
 __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double *sc, double *sd, double *sh, int tid, int NT, double *sred) {
     const int N = ns_n(S, p), D = S.D;
     const double *U = S.Ulive + (long)p * S.N * D;
     double tr = 0.0, ln_jac = 0.0, ln_enl = S.ln_enlarge;
+    long t_r = S.dbg && blockIdx.x == 0 && tid == 0 ? (long)wall_clock64() : 0;
     if (sd) {
         // the live points fit in LDS (N * D doubles): staged once with coalesced loads, then lanes =
         // dimensions for the mean and lanes = entries of the covariance matrix, each walking all
@@ -743,7 +787,7 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         // ~200 us per refit for D = 12
         for (int e = tid; e < N * D; e += NT) sd[e] = U[e];
         __syncthreads();
-        if (S.shear) { ln_jac = ns_shear_fit(S, p, N, sd, sh, tid, NT, sred); ln_enl = S.ln_enlarge_shear; }   // sd: w from here on
+        if (S.shear) { ln_jac = ns_shear_fit(S, p, N, sd, sh, tid, NT, sred, t_r); ln_enl = S.ln_enlarge_shear; }   // sd: w from here on
         for (int j = tid; j < D; j += NT) {
             double acc = 0.0;
             for (int i = 0; i < N; ++i) acc += sd[i * D + j];
@@ -758,9 +802,16 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
             while (a * (a + 1) / 2 > e) --a;
             while ((a + 1) * (a + 2) / 2 <= e) ++a;
             const int b = e - a * (a + 1) / 2;
-            double acc = 0.0;
-            for (int i = 0; i < N; ++i) acc += sd[i * D + a] * sd[i * D + b];
-            sA[a * D + b] = acc / (N - 1);
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;         // (four points in flight)
+            int i = 0;
+            for (; i + 4 <= N; i += 4) {
+                c0 += sd[(i + 0) * D + a] * sd[(i + 0) * D + b];
+                c1 += sd[(i + 1) * D + a] * sd[(i + 1) * D + b];
+                c2 += sd[(i + 2) * D + a] * sd[(i + 2) * D + b];
+                c3 += sd[(i + 3) * D + a] * sd[(i + 3) * D + b];
+            }
+            for (; i < N; ++i) c0 += sd[i * D + a] * sd[i * D + b];
+            sA[a * D + b] = ((c0 + c1) + (c2 + c3)) / (N - 1);
         }
         __syncthreads();
         for (int a = 0; a < D; ++a) tr += sA[a * D + a];
@@ -782,6 +833,7 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
             }
         __syncthreads();
     }
+    NS_RTICK(53);                                   // (stage,) mean, covariance
     if (tid == 0) {                    // Cholesky, lower triangle in place
         const double eps = 1e-12 * fmax(tr, 1e-30);
         for (int a = 0; a < D; ++a) sA[a * D + a] += eps;
@@ -814,6 +866,7 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         }
         __syncthreads();
     }
+    NS_RTICK(54);                                   // Cholesky of the covariance, the box in the w axes
     double r2 = 0.0, ssq = 0.0;
     for (int i = tid; i < N; i += NT) {           // y = L^-1 (u_i - c), forward substitution
         double s2 = 0.0;
@@ -838,6 +891,7 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         ssq += s2;
     }
     r2 = ns_block_max(r2, sred, tid, NT);
+    NS_RTICK(55);                                   // y of every point
     // the covariance ellipsoid scaled to enclose every live point, then MultiNest's rule: enlarged
     // until its volume is at least the expected prior volume over the target efficiency, X / efr
     double lnv = S.ln_vball + 0.5 * D * log(r2) + ln_enl;   // safety factor on the enclosing volume
@@ -878,6 +932,10 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
             double lo = INFINITY, hi = -INFINITY;
             if (k == 0) {
                 for (int i = 0; i < N; ++i) { const double w = sd[i * D + j]; lo = fmin(lo, w); hi = fmax(hi, w); }
+            } else if (D == 10) {
+                ns_frame_extent<10>(sd, N, S.frames + (long)(k - 1) * D * D, j, lo, hi);
+            } else if (D == 15) {
+                ns_frame_extent<15>(sd, N, S.frames + (long)(k - 1) * D * D, j, lo, hi);
             } else if (D <= NS_QCOL) {
                 double qc[NS_QCOL];
                 const double *Q = S.frames + (long)(k - 1) * D * D;
@@ -905,6 +963,8 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         }
     }
     __syncthreads();
+    NS_RTICK(56);                                   // the frames' boxes
+    if (S.dbg && blockIdx.x == 0 && tid == 0) S.dbg[57] += 1;
 }
 
 // ---- several ellipsoids ----------------------------------------------------------------------
@@ -1475,6 +1535,9 @@ int nfa_sampler_destroy(nfa_sampler *s) {
         if (hipMemcpy(h, d.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[14] > 0)
             fprintf(stderr, "[ns timing, all update workgroups] %ld: mean %.1f us, longest %.1f us; walking ones %ld: mean %.1f us\n", h[14], 0.01 * h[13] / h[14],
                     0.01 * h[15], h[6], h[6] ? 0.01 * h[5] / h[6] : 0.0);
+        if (h[57]) fprintf(stderr, "[ns timing, refit workgroup 0] %ld refits: standardise %.1f, Gram %.1f, Cholesky %.1f, back substitution %.1f, w %.1f, covariance %.1f, "
+                           "its Cholesky + axis box %.1f, y %.1f, frames' boxes %.1f us\n", h[57], 0.01 * h[48] / h[57], 0.01 * h[49] / h[57], 0.01 * h[50] / h[57], 0.01 * h[51] / h[57],
+                           0.01 * h[52] / h[57], 0.01 * h[53] / h[57], 0.01 * h[54] / h[57], 0.01 * h[55] / h[57], 0.01 * h[56] / h[57]);
         for (int b = 0; b < 16; ++b) if (h[16 + b]) fprintf(stderr, "    <= %5ld us: %9ld workgroups, %8.1f ms in all\n", 1l << b, h[16 + b], 1e-5 * h[32 + b]);
         (void)hipFree(d.dbg);
     }
@@ -1703,7 +1766,7 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
             HIP_TRY(hipMemcpyAsync(s->d_sh_start, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
             d.ln_enlarge_shear = log(enl);
-            s->lds_refit += sizeof(double) * ((size_t)d.sh_M * d.sh_M + (size_t)D * d.sh_M + 2 * (size_t)D);
+            s->lds_refit += sizeof(double) * ((size_t)d.sh_M * d.sh_M + (size_t)D * d.sh_M + 2 * (size_t)D + 2);
         }
         d.sh_mono = s->d_sh_mono; d.sh_start = s->d_sh_start;
     }
