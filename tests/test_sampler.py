@@ -576,6 +576,37 @@ def test_shear_on_the_device_follows_the_twin(engine, nfo):
 
 
 @pytest.mark.gpu
+def test_shear_with_three_components_follows_the_twin(engine, nfo):
+    """Fifteen sampled dimensions (three velocity components): the defaults -- shear, boxes, a pixel's own share of
+    proposals -- on the device and in the twin, decision for decision."""
+    from nestfit_amd.cube import CubeRunner
+    n_pix, n, noise = 2, 128, 0.1
+    rng = np.random.default_rng(4)
+    axes = [freq_axis(1, n), freq_axis(2, n)]
+    ut = engine.get_irdc_priors(size=500, vsys=0.0)
+    assert ut.free_mask(3).tolist() == [1] * 15 + [0] * 3
+    truths = np.tile(np.array([-1.5, 0.0, 1.6, 12.0, 14.0, 15.0, 5.0, 5.5, 6.0, 14.4, 14.5, 14.6, 0.35, 0.4, 0.35, 0.0, 0.0, 0.0]), (n_pix, 1))
+    truths[1, 9:12] -= 0.3
+    try:
+        engine.set_exp_mode('table')
+        probe = CubeRunner(axes, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=3)
+        model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
+        cube = CubeRunner(axes, (1, 2), model + rng.normal(0, noise, model.shape), np.full((n_pix, 2), noise), ut, ncomp=3)
+        for extra in (dict(method='reject', maxiter=2000),):        # (the twin's fifteen-dimensional rounds are slow in Python)
+            kw = dict(nlive=200, tol=0.5, efr=0.3, seed=11, batch_target=2048, **extra)
+            dev = sampler.fit_pixels(cube, np.arange(n_pix), device=True, **kw)
+            twin = sampler.fit_pixels(cube, np.arange(n_pix), device=False, **kw)
+            for d, t in zip(dev, twin):
+                assert (d.n_iter, d.n_evals) == (t.n_iter, t.n_evals), (extra, d.n_iter, t.n_iter, d.n_evals, t.n_evals)
+                assert d.lnZ == pytest.approx(t.lnZ, rel=1e-10)
+        kw = dict(nlive=200, tol=0.5, efr=0.3, seed=11, batch_target=2048, method='reject', maxiter=2600)
+        plain = sampler.fit_pixels(cube, np.arange(n_pix), shear=0, frames=-1, **kw)
+        assert sum(r.n_evals for r in dev) > 0 and sum(r.n_evals for r in sampler.fit_pixels(cube, np.arange(n_pix), **kw)) < 0.8 * sum(r.n_evals for r in plain)
+    finally:
+        engine.set_exp_mode('fast')
+
+
+@pytest.mark.gpu
 def test_box_vetoes_on_the_device_follow_the_twin(engine, nfo):
     """Two velocity components (ten sampled dimensions), boxes on: the device sampler and the numpy twin fed by the
     GPU's table-mode likelihood take the same decisions -- iteration and evaluation counts equal, lnZ to 1e-10 -- in
