@@ -382,6 +382,11 @@ int nfa_sampler_set_boxes(nfa_sampler *s, int n_frames, double margin);
  * where all five free parameters of two or three components are sampled (10 or 15 dimensions); accepted and without effect
  * elsewhere.  MultiNest has no counterpart (its answer to curved regions is more ellipsoids: nestfit/core/core.pyx:727-760). */
 int nfa_sampler_set_shear(nfa_sampler *s, double enlarge);
+/* With the shear and the boxes on: every pair (i, j) of the sheared coordinates has the bounding ellipse of the live points'
+ * projection onto (w_i, w_j) -- the covariance ellipse scaled to enclose them, its area times `enlarge` -- as one more free
+ * veto: the region lies inside the cylinder over each of its projections.  enlarge >= 1 (1.75 is the measured choice), 0 = off,
+ * < 0 = the default (engine option "sampler_pairs_pct", hundredths).  Between create and begin. */
+int nfa_sampler_set_pairs(nfa_sampler *s, double enlarge);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
 /* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the

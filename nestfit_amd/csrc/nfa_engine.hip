@@ -65,6 +65,7 @@ struct Engine {
     int    sampler_frames = -2;      // rotated box frames of a one-ellipsoid bound: -2 = by the sampled dimensions, -1 = no boxes, 0..64
     int    sampler_margin_pct = 0;   // the boxes' margin factor c in hundredths (0 = NS_MARGIN_C)
     int    sampler_ktarget = -1;     // replacements per pixel and rejection round its share of proposals aims at (-1 = NS_K_TARGET, 0 = everybody the round's Kr)
+    int    sampler_pairs_pct = -1;   // the pair ellipses' safety factor in hundredths (-1 = NS_PAIRS_ENLARGE where the bound is sheared and boxed, 0 = off)
     int    sampler_ratio_max = 0;    // proposals drawn per round: at most this multiple of the evaluations aimed for (0 = NS_RATIO_MAX)
     int    sampler_kmax = 0;         // most proposals one pixel gets in a round (0 = NS_KMAX)
     int    sampler_shear_pct = -1;   // the shear's safety factor in hundredths (-1 = the default, NS_SHEAR_ENLARGE where the shape allows; 0 = no shear)
@@ -307,6 +308,7 @@ int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "sampler_frames") && value >= -2 && value <= 64) { g_eng.sampler_frames = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_margin_pct") && value >= 0 && value <= 1000) { g_eng.sampler_margin_pct = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_ktarget") && value >= -1 && value <= 4096) { g_eng.sampler_ktarget = value; return NFA_OK; }
+    if (key && !strcmp(key, "sampler_pairs_pct") && (value == -1 || value == 0 || (value >= 100 && value <= 100000))) { g_eng.sampler_pairs_pct = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_ratio_max") && value >= 0 && value <= 64) { g_eng.sampler_ratio_max = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_kmax") && (value == 0 || (value >= 64 && value <= 16384))) { g_eng.sampler_kmax = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_shear_pct") && (value == -1 || value == 0 || (value >= 100 && value <= 100000))) { g_eng.sampler_shear_pct = value; return NFA_OK; }

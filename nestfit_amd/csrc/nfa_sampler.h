@@ -87,6 +87,7 @@ static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for 
 #define NS_SHEAR_PIVOT 1e-9        // a Cholesky pivot below this fraction of its diagonal entry: the monomial is dropped
 #define NS_SHEAR_MMAX 64           // monomials at most
 #define NS_REFIT_THREADS 512       // of the workgroup that fits a one-ellipsoid bound
+#define NS_PAIRS_ENLARGE 1.75      // safety factor on the area of a pair ellipse
 #define NS_K_TARGET 16             // replacements per pixel and rejection round the per-pixel share of proposals aims at
 #define NS_WALK_LOWD 6             // up to this many sampled dimensions ...
 #define NS_WALK_FACTOR_LOWD 64     // ... the switch to walks waits for an acceptance below 1 / (64 n_steps)
@@ -163,6 +164,11 @@ struct NsDev {
     const int *sh_start;                // [D] monomials before coordinate j's own = the features z_j is regressed on
     double *sh_mu, *sh_sg;              // [P][D] z = (u - mu) / sg
     double *sh_beta;                    // [P][D][sh_M] w_j = z_j - phi(z_<j) . beta_j
+    // pair ellipses (with the shear and the boxes): every pair of sheared coordinates has the bounding ellipse of the live
+    // points' projection as one more free veto
+    int     pairs;
+    double  pairs_enlarge;              // safety factor on an ellipse's area
+    double *pair_tab;                   // [P][D (D - 1) / 2][5] c_i, c_j, L00, L10, L11
     // proposals per pixel: a pixel whose rejection rounds accept far more than k_target candidates halves its share of the
     // next round, one that accepts far fewer doubles it (up to the round's Kr): the round's longest update workgroup is the
     // pixel with the most replacements, and a bound that has seen 100 of them in a round is stale
@@ -253,6 +259,23 @@ __device__ __forceinline__ bool ns_in_axis_boxes(const NsDev &S, int p, const do
     if (!ok) return false;
     const k_dbl_p fb = (k_dbl_p)(S.fbox + (long)p * (S.n_frames + 1) * D * 2);
     for (int j = 0; j < D; ++j) ok = ok && (zz[j] >= fb[2 * j]) && (zz[j] <= fb[2 * j + 1]);
+    return ok;
+}
+// inside every pair ellipse?  x = the proposal in the sheared coordinates
+template <int DD>
+__device__ __forceinline__ bool ns_in_pairs(const NsDev &S, int p, const double *x) {
+    const k_dbl_p pt = (k_dbl_p)(S.pair_tab + (long)p * (DD * (DD - 1) / 2) * 5);
+    bool ok = true;
+    int e = 0;
+#pragma unroll
+    for (int j = 1; j < DD; ++j)
+#pragma unroll
+        for (int i = 0; i < j; ++i) {
+            const double y0 = (x[i] - pt[5 * e]) / pt[5 * e + 2];
+            const double y1 = ((x[j] - pt[5 * e + 1]) - pt[5 * e + 3] * y0) / pt[5 * e + 4];
+            ok = ok && (y0 * y0 + y1 * y1 <= 1.0);
+            ++e;
+        }
     return ok;
 }
 template <int DD>
@@ -391,6 +414,7 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
                 zz[j] = v / A[j * D + j];
             }
             ok = ok && ns_in_axis_boxes<DD>(S, p, w, zz);
+            if constexpr (DD == 10 || DD == 15) { if (S.pairs) ok = ok && ns_in_pairs<DD>(S, p, w); }
             if (!queued) ok = ok && ns_in_frames<DD>(S, p, zz);
         }
     } else {
@@ -434,6 +458,7 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
             x[j] = v;
         }
         if (ok && S.boxes) ok = ns_in_axis_boxes<DD>(S, p, x, z);   // (one ellipsoid: the ball point IS A^-1 (x - c))
+        if constexpr (DD == 10 || DD == 15) { if (ok && S.pairs) ok = ns_in_pairs<DD>(S, p, x); }     // (x: still the sheared point)
         if (queued) { for (int j = 0; j < D; ++j) zq[j] = z[j]; }
         else if (ok && S.boxes) ok = ns_in_frames<DD>(S, p, z);
         if constexpr (DD == 10 || DD == 15) {
@@ -834,6 +859,51 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
         __syncthreads();
     }
     NS_RTICK(53);                                   // (stage,) mean, covariance
+    if (S.pairs && sd && sh) {
+        // The pair ellipses (the twin's _fit_pairs): for every pair i < j the ellipse around the live points' projection
+        // onto (w_i, w_j) -- its covariance is three entries of the matrix just formed.  Threads = (pair, slice of the
+        // points) for the largest Mahalanobis distance, combined through an integer maximum on the (non-negative) bits.
+        const int n_pr = D * (D - 1) / 2;
+        double *sp = sh;                            // [n_pr][4]: L00, L10, L11, r2 (the shear's scratch is free again)
+        for (int e = tid; e < n_pr; e += NT) {
+            int j = (int)((sqrt(8.0 * e + 1.0) + 1.0) * 0.5);          // pairs in the order j = 1.., i = 0..j-1
+            while (j * (j - 1) / 2 > e) --j;
+            while ((j + 1) * j / 2 <= e) ++j;
+            const int i = e - j * (j - 1) / 2;
+            const double l00 = sqrt(fmax(sA[i * D + i], 1e-300));
+            const double l10 = sA[j * D + i] / l00;
+            const double l11 = sqrt(fmax(sA[j * D + j] - l10 * l10, 1e-300));
+            sp[4 * e] = l00; sp[4 * e + 1] = l10; sp[4 * e + 2] = l11; sp[4 * e + 3] = 0.0;
+        }
+        __syncthreads();
+        const int n_sl = max(1, NT / n_pr);
+        if (tid < n_pr * n_sl) {
+            const int e = tid % n_pr, sl = tid / n_pr;
+            int j = (int)((sqrt(8.0 * e + 1.0) + 1.0) * 0.5);
+            while (j * (j - 1) / 2 > e) --j;
+            while ((j + 1) * j / 2 <= e) ++j;
+            const int i = e - j * (j - 1) / 2;
+            const double l00 = sp[4 * e], l10 = sp[4 * e + 1], l11 = sp[4 * e + 2];
+            double r2 = 0.0;
+            for (int n = sl; n < N; n += n_sl) {
+                const double y0 = sd[n * D + i] / l00;
+                const double y1 = (sd[n * D + j] - l10 * y0) / l11;
+                r2 = fmax(r2, y0 * y0 + y1 * y1);
+            }
+            atomicMax((unsigned long long *)&sp[4 * e + 3], (unsigned long long)__double_as_longlong(r2));
+        }
+        __syncthreads();
+        for (int e = tid; e < n_pr; e += NT) {
+            int j = (int)((sqrt(8.0 * e + 1.0) + 1.0) * 0.5);
+            while (j * (j - 1) / 2 > e) --j;
+            while ((j + 1) * j / 2 <= e) ++j;
+            const int i = e - j * (j - 1) / 2;
+            const double sc2 = sqrt(sp[4 * e + 3] * S.pairs_enlarge);
+            double *pt = S.pair_tab + ((long)p * n_pr + e) * 5;
+            pt[0] = sc[i]; pt[1] = sc[j]; pt[2] = sp[4 * e] * sc2; pt[3] = sp[4 * e + 1] * sc2; pt[4] = sp[4 * e + 2] * sc2;
+        }
+        __syncthreads();
+    }
     if (tid == 0) {                    // Cholesky, lower triangle in place
         const double eps = 1e-12 * fmax(tr, 1e-30);
         for (int a = 0; a < D; ++a) sA[a * D + a] += eps;
@@ -1504,6 +1574,7 @@ struct nfa_sampler {
     double *d_frames = nullptr;
     int set_frames = -2;        // nfa_sampler_set_boxes: -2 = the default (NS_FRAMES above NS_ME_MAXD sampled dimensions), -1 = no boxes
     double set_margin = 0.0;    // ... 0 = the default
+    double set_pairs = -1.0;    // nfa_sampler_set_pairs: < 0 = the default, 0 = off, >= 1 = the safety factor on the ellipses' areas
     double set_shear = -1.0;    // nfa_sampler_set_shear: < 0 = the default (engine option sampler_shear_pct), 0 = off, >= 1 = the safety factor
     int *d_sh_mono = nullptr, *d_sh_start = nullptr;
     std::vector<int> fm;        // the sampled dimensions' slots
@@ -1546,7 +1617,7 @@ int nfa_sampler_destroy(nfa_sampler *s) {
                     d.walk, d.wstep, d.wW, d.wscale, d.wLthr, d.wacc_sum, d.wtot_sum, d.wU, d.wT, d.wL, d.wnacc, d.lnvol, d.elnv, d.nell,
                     s->d_pixmap, s->d_actlist, s->d_livepix, s->d_fmap, s->d_nlive, s->d_updp, s->d_capp,
                     s->d_frames, d.ubox, d.fbox, d.rj_scan, d.rj_acc, d.rj_raw, d.rj_val, d.ln_pass,
-                    s->d_sh_mono, s->d_sh_start, d.sh_mu, d.sh_sg, d.sh_beta, d.Kp};
+                    s->d_sh_mono, s->d_sh_start, d.sh_mu, d.sh_sg, d.sh_beta, d.Kp, d.pair_tab};
     for (void *p : ptrs) (void)hipFree(p);
     if (s->h_pub) (void)hipHostFree(s->h_pub);
     delete s;
@@ -1610,7 +1681,7 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     NS_ALLOC(d.ln_pass, double, P);
     NS_ALLOC(s->d_frames, double, (size_t)NS_FRAMES_MAX * D * D);
     NS_ALLOC(s->d_sh_mono, int, NS_SHEAR_MMAX * 2); NS_ALLOC(s->d_sh_start, int, D);
-    NS_ALLOC(d.Kp, int, P);
+    NS_ALLOC(d.Kp, int, P); NS_ALLOC(d.pair_tab, double, P * (D * (D - 1) / 2 + 1) * 5);
     NS_ALLOC(d.sh_mu, double, P * D); NS_ALLOC(d.sh_sg, double, P * D); NS_ALLOC(d.sh_beta, double, P * D * NS_SHEAR_MMAX);
     s->fm = fm;
     if (getenv("NFA_NS_TIMING")) { NS_ALLOC(d.dbg, long, 64); HIP_TRY(hipMemset(d.dbg, 0, sizeof(long) * 64)); }
@@ -1669,6 +1740,15 @@ int nfa_sampler_set_shear(nfa_sampler *s, double enlarge) {
     if (!s || (enlarge > 0.0 && enlarge < 1.0) || enlarge > 1e6 || enlarge != enlarge) return fail(NFA_ERR_ARG, "shear: 0 (off), < 0 (default) or a safety factor >= 1");
     if (s->ran) return fail(NFA_ERR_STATE, "call nfa_sampler_set_shear before nfa_sampler_begin");
     s->set_shear = enlarge;
+    return NFA_OK;
+}
+
+// The pair ellipses (with the shear and the boxes): enlarge = the safety factor on their areas (>= 1; NS_PAIRS_ENLARGE = 1.75),
+// 0 = off, < 0 = the default.  Before nfa_sampler_begin.
+int nfa_sampler_set_pairs(nfa_sampler *s, double enlarge) {
+    if (!s || (enlarge > 0.0 && enlarge < 1.0) || enlarge > 1e6 || enlarge != enlarge) return fail(NFA_ERR_ARG, "pairs: 0 (off), < 0 (default) or a safety factor >= 1");
+    if (s->ran) return fail(NFA_ERR_STATE, "call nfa_sampler_set_pairs before nfa_sampler_begin");
+    s->set_pairs = enlarge;
     return NFA_OK;
 }
 
@@ -1787,6 +1867,10 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
         }
         d.frames = s->d_frames;
         s->raw_sum = s->val_sum = 0;
+        const double pe = s->set_pairs >= 0.0 ? s->set_pairs : g_eng.sampler_pairs_pct >= 0 ? 0.01 * g_eng.sampler_pairs_pct : NS_PAIRS_ENLARGE;
+        d.pairs = (d.shear && d.boxes && pe >= 1.0) ? 1 : 0;
+        d.pairs_enlarge = pe;
+        if (d.pairs && (size_t)(D * (D - 1) / 2) * 4 > (size_t)d.sh_M * d.sh_M) d.pairs = 0;      // (they are fitted in the shear's scratch)
     }
     if (s->lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)ns_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));

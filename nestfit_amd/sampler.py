@@ -402,6 +402,48 @@ def _shear_inv(W, mu, sg, beta, mono, start):
     return mu + sg * Z
 
 
+_NS_PAIRS_ENLARGE = 1.75                                                        # NS_PAIRS_ENLARGE
+
+
+def _fit_pairs(W, enlarge):
+    """The pair ellipses of one pixel (ns_refit): for every pair i < j of the sheared coordinates the ellipse around the live
+    points' projection onto (w_i, w_j) -- covariance ellipse scaled to enclose every point, its area times `enlarge`.  The
+    region lies inside the cylinder over every one of its projections: D (D - 1) / 2 more free vetoes, five numbers each:
+    rows [c_i, c_j, L00, L10, L11] with {c + L y : |y| <= 1}."""
+    n, D = W.shape
+    c = W.sum(axis=0) / n
+    d = W - c
+    cov = (d.T @ d) / (n - 1)
+    out = np.empty((D * (D - 1) // 2, 5))
+    e = 0
+    for j in range(1, D):
+        for i in range(j):
+            l00 = math.sqrt(max(cov[i, i], 1e-300))
+            l10 = cov[j, i] / l00
+            l11 = math.sqrt(max(cov[j, j] - l10 * l10, 1e-300))
+            y0 = d[:, i] / l00
+            y1 = (d[:, j] - l10 * y0) / l11
+            s = math.sqrt(float(np.max(y0 * y0 + y1 * y1)) * enlarge)
+            out[e] = (c[i], c[j], l00 * s, l10 * s, l11 * s)
+            e += 1
+    return out
+
+
+def _pair_veto(W, pairs):
+    """Flags of the rows W[K, D] (sheared coordinates) inside every pair ellipse."""
+    D = W.shape[1]
+    ok = np.ones(W.shape[0], dtype=bool)
+    e = 0
+    for j in range(1, D):
+        for i in range(j):
+            ci, cj, l00, l10, l11 = pairs[e]
+            y0 = (W[:, i] - ci) / l00
+            y1 = ((W[:, j] - cj) - l10 * y0) / l11
+            ok &= (y0 * y0 + y1 * y1) <= 1.0
+            e += 1
+    return ok
+
+
 def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
     """NestedResult per pixel from dead points (theta, lnL, lnw per pixel) and final live points:
     every live point carries the mass X_final / nlive.  `nlive`: one number, or one per pixel (a pixel's live
@@ -463,7 +505,7 @@ def default_cap_iter(nlive):
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
                check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None, walkers=None,
-               progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None, k_target=None, ratio_max=None):
+               progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None, k_target=None, ratio_max=None, pairs=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -574,6 +616,10 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     Qf = _frames(nd, max(n_frames, 0)) if boxes else None
     ubox = np.zeros((P, nd, 2))
     fbox = np.zeros((P, max(n_frames, 0) + 1, nd, 2))
+    # the pair ellipses (`_fit_pairs`): with the shear and the boxes, unless pairs=0; `pairs` = the safety factor on their areas
+    pairs_enl = _NS_PAIRS_ENLARGE if pairs is None else float(pairs)
+    pairs_on = shear_on and boxes and pairs_enl >= 1.0
+    pair_tab = np.zeros((P, nd * (nd - 1) // 2, 5)) if pairs_on else None
     if shear_on:
         assert float(shear) >= 1.0
         mono, mstart = _shear_monomials(fmap % ncomp_s)
@@ -592,6 +638,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             use_cube[p], elnv[p, 0] = lnvol[p] >= 0.0, lnvol[p]
             if boxes:
                 ubox[p], fbox[p] = _fit_boxes(Wl, c1[0], a1[0], Qf, margin_c)     # `ubox`: the box in the w axes
+            if pairs_on:
+                pair_tab[p] = _fit_pairs(Wl, pairs_enl)
         else:
             c1, a1, u1, v1 = _fit_ellipsoids(Ulive[p:p + 1, :n], efr, np.array([ln_x]), enlarge)
             centre[p, 0], axes[p, 0], use_cube[p], lnvol[p], elnv[p, 0], nell[p] = c1[0], a1[0], u1[0], v1[0], v1[0], 1
@@ -730,6 +778,8 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
                         if boxes:
                             zz = np.linalg.solve(axes[p, 0], (wc - centre[p, 0]).T).T if use_cube[p] else zf[0]
                             keep = _box_veto(wc, zz, ubox[p], fbox[p], Qf)
+                            if pairs_on:
+                                keep &= _pair_veto(wc, pair_tab[p])
                     elif boxes:
                         # the proposal's coordinates in the ellipsoid's frame: the unit-ball point it was made from, or
                         # (drawn from the unit cube) A^-1 (u - c)
@@ -797,7 +847,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
                       upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=262144,
                       enlarge=1.5, method='auto', n_steps=None, free_mask=None, progress=None, time_limit=None,
-                      ellipsoids=None, frames=None, margin=None, shear=None):
+                      ellipsoids=None, frames=None, margin=None, shear=None, pairs=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
     work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive).  `progress`
@@ -832,6 +882,8 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
             _ffi.check(lib.nfa_sampler_set_boxes(h, -2 if frames is None else int(frames), 0.0 if margin is None else float(margin)))
         if shear is not None:
             _ffi.check(lib.nfa_sampler_set_shear(h, float(shear)))
+        if pairs is not None:
+            _ffi.check(lib.nfa_sampler_set_pairs(h, float(pairs)))
         if per_pixel:
             nl32 = nl.astype(np.int32)
             upd32 = np.maximum(1, (upd_frac * nl).astype(np.int64)).astype(np.int32)

@@ -12,7 +12,7 @@ side = int(sys.argv[1])
 kw = {}
 for a in sys.argv[2:]:
     k, v = a.split('=')
-    kw[k] = v if k == 'method' else float(v) if k == 'margin' else int(v)
+    kw[k] = v if k == 'method' else float(v) if k in ('margin', 'pairs', 'shear') else int(v)
 n, noise, nlive, ncomp = 512, 0.1, 400, 2
 n_pix = side * side
 rng = np.random.default_rng(0)
@@ -33,7 +33,7 @@ for key in ('walk_factor', 'refit_every', 'parts', 'kmax', 'ktarget', 'ratio_max
         _ffi.set_option('sampler_' + key, kw.pop(key))
 _ffi.check(_ffi.load().nfa_device_synchronize())
 t0 = time.perf_counter()
-res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=nlive, tol=0.5, efr=0.3, seed=1, **kw)
+res = sampler.fit_pixels(cube, np.arange(n_pix), nlive=nlive, tol=0.5, efr=0.3, **{"seed": 1, **kw})
 dt = time.perf_counter() - t0
 ev = np.array([x.n_evals for x in res]); it = np.array([x.n_iter for x in res]); lz = np.array([x.lnZ for x in res])
 print(f'{side}x{side} {kw}: {dt:.2f} s, evals/pixel {ev.mean():.0f} (min {ev.min()} max {ev.max()}), iterations {it.mean():.0f}, '

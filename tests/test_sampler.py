@@ -539,6 +539,13 @@ def test_shear_in_front_of_the_ellipsoid():
         assert abs(r.lnZ - truth) < 4 * r.lnZ_err + 0.3, (r.lnZ, truth, r.lnZ_err)
     assert sum(r.n_evals for r in bent) < 0.5 * sum(r.n_evals for r in plain)
     assert sum(r.n_evals for r in both) < sum(r.n_evals for r in bent)
+    # the pair ellipses: every live point inside every one of them, a point half as far again outside some
+    Wp = rng.normal(size=(300, 10)) @ rng.normal(size=(10, 10))
+    pt = sampler._fit_pairs(Wp, 1.75)
+    assert pt.shape == (45, 5) and sampler._pair_veto(Wp, pt).all() and not sampler._pair_veto(1.6 * (Wp - Wp.mean(axis=0)) + Wp.mean(axis=0), pt).all()
+    fewer = sampler.run_nested(ridge, 12, 1, pairs=1.75, **kw)
+    none = sampler.run_nested(ridge, 12, 1, pairs=0, **kw)
+    assert fewer[0].n_evals < none[0].n_evals and abs(fewer[0].lnZ - truth) < 4 * fewer[0].lnZ_err + 0.3
     # shapes the device has no shear for run without it: the same result as shear=None
     f5 = _gauss_problem(np.full(5, 0.5), 0.05)
     a5, b5 = sampler.run_nested(f5, 5, 1, nlive=100, seed=2, ellipsoids=1)[0], sampler.run_nested(f5, 5, 1, nlive=100, seed=2, ellipsoids=1, shear=4.0)[0]
