@@ -96,6 +96,8 @@ int nfa_get_exp_mode(void);
  *                   none, 0..64; "sampler_margin_pct": the boxes' margin factor in hundredths (0 = 175);
  *   "sampler_shear_pct"   the shear in front of one-ellipsoid bounds (nfa_sampler_set_shear): its safety factor in
  *                   hundredths, -1 (default) = 400 where the shape allows, 0 = off, 100..100000;
+ *   "sampler_pairs_pct"   the pair ellipses of a sheared and boxed bound (nfa_sampler_set_pairs): their safety factor in
+ *                   hundredths, -1 (default) = 175, 0 = off, 100..100000;
  *   "sampler_ktarget"     replacements per pixel and rejection round a pixel's own share of the round's proposals aims
  *                   at: halved after a round with more than twice as many, doubled after one with fewer than half
  *                   (-1 = the default, 16; 0 = every pixel the round's number); "sampler_ratio_max": proposals drawn

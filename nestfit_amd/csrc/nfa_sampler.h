@@ -168,7 +168,7 @@ struct NsDev {
     // points' projection as one more free veto
     int     pairs;
     double  pairs_enlarge;              // safety factor on an ellipse's area
-    double *pair_tab;                   // [P][D (D - 1) / 2][5] c_i, c_j, L00, L10, L11
+    double *pair_tab;                   // [P][D (D - 1) / 2][5] c_i, c_j, 1 / L00, L10, 1 / L11
     // proposals per pixel: a pixel whose rejection rounds accept far more than k_target candidates halves its share of the
     // next round, one that accepts far fewer doubles it (up to the round's Kr): the round's longest update workgroup is the
     // pixel with the most replacements, and a bound that has seen 100 of them in a round is stale
@@ -271,8 +271,8 @@ __device__ __forceinline__ bool ns_in_pairs(const NsDev &S, int p, const double 
     for (int j = 1; j < DD; ++j)
 #pragma unroll
         for (int i = 0; i < j; ++i) {
-            const double y0 = (x[i] - pt[5 * e]) / pt[5 * e + 2];
-            const double y1 = ((x[j] - pt[5 * e + 1]) - pt[5 * e + 3] * y0) / pt[5 * e + 4];
+            const double y0 = (x[i] - pt[5 * e]) * pt[5 * e + 2];         // (the table holds 1 / L00, L10, 1 / L11: no divisions here)
+            const double y1 = ((x[j] - pt[5 * e + 1]) - pt[5 * e + 3] * y0) * pt[5 * e + 4];
             ok = ok && (y0 * y0 + y1 * y1 <= 1.0);
             ++e;
         }
@@ -900,7 +900,7 @@ __device__ void ns_refit(const NsDev &S, int p, long n_iter, double *sA, double 
             const int i = e - j * (j - 1) / 2;
             const double sc2 = sqrt(sp[4 * e + 3] * S.pairs_enlarge);
             double *pt = S.pair_tab + ((long)p * n_pr + e) * 5;
-            pt[0] = sc[i]; pt[1] = sc[j]; pt[2] = sp[4 * e] * sc2; pt[3] = sp[4 * e + 1] * sc2; pt[4] = sp[4 * e + 2] * sc2;
+            pt[0] = sc[i]; pt[1] = sc[j]; pt[2] = 1.0 / (sp[4 * e] * sc2); pt[3] = sp[4 * e + 1] * sc2; pt[4] = 1.0 / (sp[4 * e + 2] * sc2);
         }
         __syncthreads();
     }

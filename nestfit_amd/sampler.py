@@ -409,7 +409,7 @@ def _fit_pairs(W, enlarge):
     """The pair ellipses of one pixel (ns_refit): for every pair i < j of the sheared coordinates the ellipse around the live
     points' projection onto (w_i, w_j) -- covariance ellipse scaled to enclose every point, its area times `enlarge`.  The
     region lies inside the cylinder over every one of its projections: D (D - 1) / 2 more free vetoes, five numbers each:
-    rows [c_i, c_j, L00, L10, L11] with {c + L y : |y| <= 1}."""
+    rows [c_i, c_j, 1 / L00, L10, 1 / L11] with {c + L y : |y| <= 1}."""
     n, D = W.shape
     c = W.sum(axis=0) / n
     d = W - c
@@ -424,7 +424,7 @@ def _fit_pairs(W, enlarge):
             y0 = d[:, i] / l00
             y1 = (d[:, j] - l10 * y0) / l11
             s = math.sqrt(float(np.max(y0 * y0 + y1 * y1)) * enlarge)
-            out[e] = (c[i], c[j], l00 * s, l10 * s, l11 * s)
+            out[e] = (c[i], c[j], 1.0 / (l00 * s), l10 * s, 1.0 / (l11 * s))
             e += 1
     return out
 
@@ -436,9 +436,9 @@ def _pair_veto(W, pairs):
     e = 0
     for j in range(1, D):
         for i in range(j):
-            ci, cj, l00, l10, l11 = pairs[e]
-            y0 = (W[:, i] - ci) / l00
-            y1 = ((W[:, j] - cj) - l10 * y0) / l11
+            ci, cj, r00, l10, r11 = pairs[e]
+            y0 = (W[:, i] - ci) * r00
+            y1 = ((W[:, j] - cj) - l10 * y0) * r11
             ok &= (y0 * y0 + y1 * y1) <= 1.0
             e += 1
     return ok
