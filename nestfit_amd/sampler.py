@@ -396,10 +396,13 @@ def _shear_fwd(X, mu, sg, beta, mono, start):
 def _shear_inv(W, mu, sg, beta, mono, start):
     """Unit-cube rows of rows W[K, D]: coordinate by coordinate, each from the ones before it."""
     Z = W.copy()
-    for j in range(1, W.shape[1]):
-        pj = int(start[j])
-        Z[:, j] = W[:, j] + _shear_phi(Z, mono, pj) @ beta[j, :pj]
-    return mu + sg * Z
+    # (a draw from the far end of an ellipsoid whose coefficients are large can run away through the products: it ends as
+    # inf or nan, fails the unit cube's test like any other point outside, and is dropped -- on the device as here)
+    with np.errstate(over='ignore', invalid='ignore'):
+        for j in range(1, W.shape[1]):
+            pj = int(start[j])
+            Z[:, j] = W[:, j] + _shear_phi(Z, mono, pj) @ beta[j, :pj]
+        return mu + sg * Z
 
 
 _NS_PAIRS_ENLARGE = 1.75                                                        # NS_PAIRS_ENLARGE
