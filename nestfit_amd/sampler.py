@@ -507,7 +507,7 @@ def default_cap_iter(nlive):
 
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
-               check_every=8, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None, walkers=None,
+               check_every=32, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None, walkers=None,
                progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None, k_target=None, ratio_max=None, pairs=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
@@ -848,7 +848,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 
 
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
-                      upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=8, batch_target=262144,
+                      upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=32, batch_target=262144,
                       enlarge=1.5, method='auto', n_steps=None, free_mask=None, progress=None, time_limit=None,
                       ellipsoids=None, frames=None, margin=None, shear=None, pairs=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a

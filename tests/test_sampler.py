@@ -261,7 +261,7 @@ def test_sampler_on_gpu_matches_the_same_sampler_on_the_oracle(engine, nfo):
             got = sampler.fit_pixels(cube, np.arange(n_pix), device=device, **kw)
             for g, r in zip(got, ref):
                 assert g.n_iter == r.n_iter and g.n_evals == r.n_evals, (device, g.n_iter, r.n_iter)
-                assert 0 <= g.rounds - r.rounds < 8            # the device looks up every 8 rounds
+                assert 0 <= g.rounds - r.rounds < 32           # the device looks up every 32 rounds (check_every)
                 assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
                 np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
         # constrained random walks from the first round on: twin and device take the same steps
