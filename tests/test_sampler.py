@@ -583,6 +583,31 @@ def test_shear_on_the_device_follows_the_twin(engine, nfo):
 
 
 @pytest.mark.gpu
+def test_live_points_that_do_not_fit_in_lds(engine, nfo):
+    """1300 live points in ten dimensions are 104 KB: the refit workgroup reads them from global memory (block-wide sums
+    instead of the staged passes), shear and boxes stay off -- device and twin alike."""
+    from nestfit_amd.cube import CubeRunner
+    n_pix, n, noise = 2, 128, 0.1
+    rng = np.random.default_rng(6)
+    axes = [freq_axis(1, n), freq_axis(2, n)]
+    ut = engine.get_irdc_priors(size=500, vsys=0.0)
+    truths = np.tile(np.array([-0.5, 1.0, 12.0, 15.0, 5.0, 6.0, 14.4, 14.6, 0.4, 0.4, 0.0, 0.0]), (n_pix, 1))
+    try:
+        engine.set_exp_mode('table')
+        probe = CubeRunner(axes, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=2)
+        model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
+        cube = CubeRunner(axes, (1, 2), model + rng.normal(0, noise, model.shape), np.full((n_pix, 2), noise), ut, ncomp=2)
+        kw = dict(nlive=1300, tol=0.5, efr=0.3, seed=3, maxiter=14000, batch_target=4096, method='reject')      # (well past the rounds in which the unit cube is the bound)
+        dev = sampler.fit_pixels(cube, np.arange(n_pix), device=True, **kw)
+        twin = sampler.fit_pixels(cube, np.arange(n_pix), device=False, **kw)
+        for d, t in zip(dev, twin):
+            assert (d.n_iter, d.n_evals) == (t.n_iter, t.n_evals), (d.n_iter, t.n_iter, d.n_evals, t.n_evals)
+            assert d.lnZ == pytest.approx(t.lnZ, rel=1e-10)
+    finally:
+        engine.set_exp_mode('fast')
+
+
+@pytest.mark.gpu
 def test_shear_with_three_components_follows_the_twin(engine, nfo):
     """Fifteen sampled dimensions (three velocity components): the defaults -- shear, boxes, a pixel's own share of
     proposals -- on the device and in the twin, decision for decision."""
