@@ -103,7 +103,7 @@ int nfa_get_exp_mode(void);
  *                   (-1 = the default, 16; 0 = every pixel the round's number); "sampler_ratio_max": proposals drawn
  *                   per round with vetoes on, at most this multiple of the evaluations aimed for (0 = the default,
  *                   32; the candidate buffers are sized by it when a sampler is created); "sampler_kmax": most
- *                   proposals a pixel gets in a round (0 = 16384).  The twin: `k_target=`, `ratio_max=`, `kmax=`;
+ *                   proposals a pixel gets in a round (0 = 65536).  The twin: `k_target=`, `ratio_max=`, `kmax=`;
  *   "sampler_refit_every" rejection-mode pixels refit their bound in rounds that are multiples of this (default 4);
  *                   the sampler_* keys are read when a sampler is created / begun, A/B knobs like the rest;
  *   "ablate"        only in builds with -DNFA_ABLATE (timing experiments, results invalid; the

@@ -313,7 +313,7 @@ int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "sampler_ktarget") && value >= -1 && value <= 4096) { g_eng.sampler_ktarget = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_pairs_pct") && (value == -1 || value == 0 || (value >= 100 && value <= 100000))) { g_eng.sampler_pairs_pct = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_ratio_max") && value >= 0 && value <= 64) { g_eng.sampler_ratio_max = value; return NFA_OK; }
-    if (key && !strcmp(key, "sampler_kmax") && (value == 0 || (value >= 64 && value <= 16384))) { g_eng.sampler_kmax = value; return NFA_OK; }
+    if (key && !strcmp(key, "sampler_kmax") && (value == 0 || (value >= 64 && value <= 262144))) { g_eng.sampler_kmax = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_shear_pct") && (value == -1 || value == 0 || (value >= 100 && value <= 100000))) { g_eng.sampler_shear_pct = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb_table") && value >= 0 && value <= 16) { g_eng.wpb_table = value; return NFA_OK; }
     if (key && !strcmp(key, "wpb") && value >= 1 && value <= 16) { g_eng.wpb = value; return NFA_OK; }

@@ -88,6 +88,7 @@ static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for 
 #define NS_SHEAR_MMAX 64           // monomials at most
 #define NS_REFIT_THREADS 512       // of the workgroup that fits a one-ellipsoid bound
 #define NS_PAIRS_ENLARGE 1.75      // safety factor on the area of a pair ellipse
+#define NS_KP_START 256            // a pixel's share of proposals in its first rejection round
 #define NS_K_TARGET 16             // replacements per pixel and rejection round the per-pixel share of proposals aims at
 #define NS_WALK_LOWD 6             // up to this many sampled dimensions ...
 #define NS_WALK_FACTOR_LOWD 64     // ... the switch to walks waits for an acceptance below 1 / (64 n_steps)
@@ -1561,7 +1562,7 @@ __global__ void ns_pack_dead_kernel(NsDev S, const long *__restrict__ off, doubl
 
 // ---- host side -----------------------------------------------------------------------------
 #ifndef NS_KMAX
-#define NS_KMAX 16384           // most proposals one pixel gets in a round
+#define NS_KMAX 65536           // most proposals one pixel gets in a round
 #endif
 #define NS_PARTS 4              // at most this many groups of pixels, each on its own stream lane
 struct nfa_sampler {
@@ -1797,7 +1798,9 @@ int nfa_sampler_begin(nfa_sampler *s, double tol, double efr, int64_t seed, int6
     HIP_TRY(hipMemsetAsync(d.rj_raw, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.rj_val, 0, sizeof(long) * P, st));
     HIP_TRY(hipMemsetAsync(d.ln_pass, 0, sizeof(double) * P, st));
-    HIP_TRY(hipMemsetAsync(d.Kp, 0, sizeof(int) * P, st));
+    // (a pixel starts with a small share and doubles it while its rounds accept little: started at the round's Kr, a run of
+    // two pixels drew 65 k proposals per pixel in its first round, where every second one is accepted, and halved from there)
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d.Kp, NS_KP_START, P, st));
     d.k_target = g_eng.sampler_ktarget >= 0 ? g_eng.sampler_ktarget : NS_K_TARGET;
     {   // live points
         const long tot = (long)P * N;

@@ -314,6 +314,7 @@ def _box_veto(cand, zz, ubox, fbox, frames):
 
 
 # ---- a volume-preserving shear in front of the one-ellipsoid bound (ns_shear_fit / ns_shear_inv on the device) --------
+_NS_KP_START = 256                                                              # NS_KP_START
 _NS_K_TARGET = 16                                                               # NS_K_TARGET
 _NS_SHEAR_RIDGE = 1e-6                                                          # NS_SHEAR_RIDGE
 _NS_SHEAR_PIVOT = 1e-9                                                          # NS_SHEAR_PIVOT
@@ -523,7 +524,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     n_cand : candidates per pixel and round (default ceil(2 / efr)), at least: every
         `check_every` rounds the number is raised so that the round's batch stays near
         max(n_pix * n_cand, batch_target) proposals however few pixels are still running (at most
-        16384 per pixel); only proposals inside the unit cube are evaluated.
+        65536 per pixel); only proposals inside the unit cube are evaluated.
         They are scanned in order and every one above the pixel's current threshold replaces its
         worst live point.
     upd_frac : the ellipsoids are refitted at the end of a round once this fraction of nlive
@@ -682,7 +683,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     # a pixel's own share of a rejection round's proposals (ns_kp / NS_K_TARGET): halved after a round with more than twice
     # k_target replacements, doubled after one with fewer than half of it; 0 = the round's Kr
     k_target = _NS_K_TARGET if k_target is None else int(k_target)
-    Kp = np.zeros(P, dtype=np.int64)
+    Kp = np.full(P, _NS_KP_START, dtype=np.int64)                # (a small share first, doubled while little is accepted)
     rj_scan, rj_acc = np.zeros(P, dtype=np.int64), np.zeros(P, dtype=np.int64)
     rj_raw, rj_val = np.zeros(P, dtype=np.int64), np.zeros(P, dtype=np.int64)
     ln_pass = np.zeros(P)
@@ -710,7 +711,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
             # with boxes most proposals are vetoed for free: draw so many more that a round still evaluates ~b_target
             ratio = min(int(ratio_max) if ratio_max else _NS_RATIO_MAX, max(1, (raw_sum + val_sum // 2) // max(val_sum, 1))) if boxes and raw_sum else 1
             n_chunk = int(active.sum())                          # the pixels the device's list holds until the next look
-            Kr = int(min(kmax if kmax else 16384, max(K, (b_target * ratio) // n_chunk)))
+            Kr = int(min(kmax if kmax else 65536, max(K, (b_target * ratio) // n_chunk)))
             raw_sum = val_sum = 0
         raw_sum += Kr * n_chunk
         idx = np.flatnonzero(active)
