@@ -389,6 +389,12 @@ int nfa_sampler_set_shear(nfa_sampler *s, double enlarge);
  * veto: the region lies inside the cylinder over each of its projections.  enlarge >= 1 (1.75 is the measured choice), 0 = off,
  * < 0 = the default (engine option "sampler_pairs_pct", hundredths).  Between create and begin. */
 int nfa_sampler_set_pairs(nfa_sampler *s, double enlarge);
+/* After a run: every pixel's table of posterior samples in one copy (what MultiNest leaves in its post files and mn_dump
+ * reads back, nestfit/core/core.pyx:627-687) -- rows [offsets[p], offsets[p+1]) of out[offsets[P]][ndim + 2] are pixel p's
+ * dead points (min(n_iter[p], cap) of them) followed by its live points; a row = theta[ndim], -2 lnL, ln(prior mass x
+ * likelihood): lnw + lnL of a dead point, lnL + live_off[p] of a live one (live_off[p] = -n_iter / nlive - ln nlive, given by
+ * the caller, who normalises the last column into weights). */
+int nfa_sampler_posterior_packed(nfa_sampler *s, const int64_t *offsets, const double *live_off, double *out);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
 /* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the

@@ -1560,6 +1560,33 @@ __global__ void ns_pack_dead_kernel(NsDev S, const long *__restrict__ off, doubl
     }
 }
 
+// The posterior samples of every pixel in the layout of the result (the reference's post_equal_weights-like table,
+// core.pyx:627-687): rows [off[p], off[p + 1]) of out = pixel p's dead points (the first off[p+1] - off[p] - nlive_p of
+// them) followed by its live points; a row = theta[DT], -2 lnL, ln(prior mass x likelihood) -- lnw + lnL for a dead point,
+// lnL + live_off[p] for a live one (live_off[p] = -n_iter / nlive - ln nlive, from the host: the host turns the last
+// column into weights).  One copy off the device and no copy on the host: a pixel's table is a view into `out`.
+__global__ void ns_pack_post_kernel(NsDev S, const long *__restrict__ off, const double *__restrict__ live_off, double *__restrict__ out) {
+    const int DT = S.DT, W = DT + 2;
+    for (long p = blockIdx.y; p < S.P; p += gridDim.y) {
+        const long n = off[p + 1] - off[p], nl = ns_n(S, (int)p), nd = n - nl;
+        double *o = out + off[p] * W;
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n * W; e += (long)gridDim.x * blockDim.x) {
+            const long r = e / W;
+            const int c = (int)(e - r * W);
+            double v;
+            if (r < nd) {
+                const double L = S.deadL[p * S.cap + r];
+                v = c < DT ? S.deadT[(p * S.cap + r) * DT + c] : c == DT ? -2.0 * L : S.deadlnw[p * S.cap + r] + L;
+            } else {
+                const long i = r - nd;
+                const double L = S.Llive[p * S.N + i];
+                v = c < DT ? S.Tlive[(p * S.N + i) * DT + c] : c == DT ? -2.0 * L : L + live_off[p];
+            }
+            o[e] = v;
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------
 #ifndef NS_KMAX
 #define NS_KMAX 65536           // most proposals one pixel gets in a round
@@ -2056,6 +2083,38 @@ int nfa_sampler_dead_packed(nfa_sampler *s, const int64_t *offsets, double *thet
     ok = ok && hipStreamSynchronize(st) == hipSuccess;
     release();
     return ok ? NFA_OK : fail(NFA_ERR_DEVICE, "copying the dead points failed");
+}
+
+// The posterior tables of every pixel at once (ns_pack_post_kernel): offsets[P + 1] (host; rows of pixel p =
+// min(n_iter[p], cap) dead points + its live points), live_off[P] (host), out[offsets[P]][DT + 2] (host).
+int nfa_sampler_posterior_packed(nfa_sampler *s, const int64_t *offsets, const double *live_off, double *out) {
+    if (!s || !s->ran || !offsets || !live_off || !out) return fail(NFA_ERR_ARG, "bad argument");
+    const NsDev &d = s->d;
+    const int P = d.P;
+    if (offsets[0] != 0) return fail(NFA_ERR_ARG, "offsets must start at 0");
+    for (int p = 0; p < P; ++p) {
+        const int64_t nl = s->h_nlive.empty() ? d.N : s->h_nlive[(size_t)p];
+        if (offsets[p + 1] - offsets[p] < nl || offsets[p + 1] - offsets[p] - nl > d.cap) return fail(NFA_ERR_ARG, "bad offsets");
+    }
+    const int64_t total = offsets[P];
+    long *d_off = nullptr;
+    double *d_lo = nullptr, *d_out = nullptr;
+    auto release = [&]() { (void)hipFree(d_off); (void)hipFree(d_lo); (void)hipFree(d_out); };
+    if (hipMalloc((void **)&d_off, sizeof(long) * (P + 1)) != hipSuccess || hipMalloc((void **)&d_lo, sizeof(double) * P) != hipSuccess
+        || hipMalloc((void **)&d_out, sizeof(double) * total * (d.DT + 2)) != hipSuccess) {
+        release();
+        return fail(NFA_ERR_DEVICE, "out of device memory for the packed posterior tables");
+    }
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    hipStream_t st = s->r->lanes[0];
+    bool ok = hipMemcpyAsync(d_off, offsets, sizeof(long) * (P + 1), hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d_lo, live_off, sizeof(double) * P, hipMemcpyHostToDevice, st) == hipSuccess;
+    hipLaunchKernelGGL(ns_pack_post_kernel, dim3(16, (unsigned)std::min(P, 32768)), dim3(256), 0, st, d, (const long *)d_off, (const double *)d_lo, d_out);
+    ok = ok && hipGetLastError() == hipSuccess;
+    ok = ok && hipMemcpyAsync(out, d_out, sizeof(double) * total * (d.DT + 2), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    release();
+    return ok ? NFA_OK : fail(NFA_ERR_DEVICE, "copying the posterior tables failed");
 }
 
 // final live points: theta[P][N][D], lnL[P][N]

@@ -52,7 +52,9 @@ class NestedResult:
         w = posterior[:, -1]
         th = posterior[:, :-2]
         mean = w @ th
-        var = np.maximum(w @ (th - mean) ** 2, 0.0)
+        # (the weighted second moment about the mean from the raw one -- one (n_samples, n_params) temporary instead of the two
+        # of (th - mean) ** 2: a map of a thousand pixels builds a thousand of these)
+        var = np.maximum(w @ (th * th) - 2.0 * mean * mean + mean * mean * w.sum(), 0.0)
         best = th[np.argmin(posterior[:, -2])]      # max likelihood
         mapp = th[np.argmax(w)]                     # largest posterior mass
         self.param_constr = np.stack([mean, np.sqrt(var), best, mapp])    # (4, n_params)
@@ -493,6 +495,35 @@ def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
     return results
 
 
+def _assemble_packed(ndim, nlive, n_iter, n_evals, n_dead, off, table, tol=None):
+    """`_assemble` for tables the device has laid out (nfa_sampler_posterior_packed): rows off[p] .. off[p + 1] of `table` are
+    pixel p's dead points followed by its live points, columns theta, -2 lnL, ln(prior mass x likelihood); the last column
+    becomes the weight here, in place."""
+    results = []
+    for p in range(len(n_iter)):
+        nl, nd = int(nlive[p]), int(n_dead[p])
+        post = table[off[p]:off[p + 1]]
+        lw = post[:, ndim + 1]
+        L = -0.5 * post[:, ndim]
+
+        def lse(x):
+            if x.size == 0:
+                return -np.inf
+            m = x.max()
+            return m if not np.isfinite(m) else m + math.log(np.exp(x - m).sum())
+        lnZ_dead = lse(lw[:nd])
+        lnZ_tot = np.logaddexp(lnZ_dead, lse(lw[nd:]))
+        wt = np.exp(lw - lnZ_tot)
+        with np.errstate(invalid='ignore'):
+            Hp = float(np.sum(np.where(wt > 0, wt * (L - lnZ_tot), 0.0)))
+        post[:, ndim + 1] = wt
+        results.append(NestedResult(post, lnZ_tot, np.sqrt(max(Hp, 0.0) / nl), L.max(), nl, n_evals[p], n_iter[p], Hp))
+        if tol is not None:
+            remain = L[nd:].max() - n_iter[p] / nl
+            results[-1].truncated = bool(not (np.logaddexp(lnZ_dead, remain) - lnZ_dead < tol))
+    return results
+
+
 def _resolve_seed(seed):
     if seed is None or seed < 0:                                # like MultiNest: from the system
         return int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> np.uint64(1))
@@ -900,6 +931,7 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
                                          else int(method), int(n_steps) if n_steps else 10 * nd))
         n_active = C.c_int64(P)
         t0 = time.perf_counter()
+        t_created = t0
         chunks = 16
         while True:
             t1 = time.perf_counter()
@@ -916,26 +948,29 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
                     chunks = progress.counts(ni, ne, int(rr.value)) or chunks
             if time_limit is not None and time.perf_counter() - t0 > time_limit:
                 break
+        t_rounds = time.perf_counter()
         n_iter = np.empty(P, dtype=np.int64)
         n_evals = np.empty(P, dtype=np.int64)
         rounds = C.c_int64()
         _ffi.check(lib.nfa_sampler_counts(h, n_iter.ctypes.data_as(_ffi._lp), n_evals.ctypes.data_as(_ffi._lp),
                                           C.byref(rounds)))
-        Tlive = np.empty((P, nlive, ndim))
-        Llive = np.empty((P, nlive))
-        _ffi.check(lib.nfa_sampler_live(h, _ffi.dptr(Tlive), _ffi.dptr(Llive)))
-        # the dead points of all pixels in one packed copy; a pixel's arrays are views into it
+        # every pixel's table of posterior samples, laid out by the device (dead points, then live points; theta, -2 lnL,
+        # ln(prior mass x likelihood)): one copy, and a pixel's table is a view into it
+        n_dead = np.minimum(n_iter, capp)
         off = np.zeros(P + 1, dtype=np.int64)
-        np.cumsum(np.minimum(n_iter, capp), out=off[1:])
-        tot = int(off[-1])
-        allT, allL, allw = np.empty((tot, ndim)), np.empty(tot), np.empty(tot)
-        _ffi.check(lib.nfa_sampler_dead_packed(h, off.ctypes.data_as(_ffi._lp), _ffi.dptr(allT), _ffi.dptr(allL), _ffi.dptr(allw)))
-        dead = [(allT[off[p]:off[p + 1]], allL[off[p]:off[p + 1]], allw[off[p]:off[p + 1]]) for p in range(P)]
+        np.cumsum(n_dead + nl, out=off[1:])
+        live_off = -n_iter / nl - np.log(nl)
+        table = np.empty((int(off[-1]), ndim + 2))
+        _ffi.check(lib.nfa_sampler_posterior_packed(h, off.ctypes.data_as(_ffi._lp), _ffi.dptr(live_off), _ffi.dptr(table)))
     finally:
         lib.nfa_sampler_destroy(h)
-    res = _assemble(ndim, nl, n_iter, n_evals, dead, Tlive, Llive, tol)
+    t_read = time.perf_counter()
+    res = _assemble_packed(ndim, nl, n_iter, n_evals, n_dead, off, table, tol)
     for r in res:
         r.rounds = int(rounds.value)
+    # where the call's time went (seconds): the rounds on the device, the read-back of live and dead points, the assembly of
+    # the results on the host
+    res[0].timings = {'rounds': t_rounds - t_created, 'read_back': t_read - t_rounds, 'assemble': time.perf_counter() - t_read}
     return res
 
 

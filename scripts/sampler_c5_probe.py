@@ -38,5 +38,6 @@ dt = time.perf_counter() - t0
 ev = np.array([x.n_evals for x in res]); it = np.array([x.n_iter for x in res]); lz = np.array([x.lnZ for x in res])
 print(f'{side}x{side} {kw}: {dt:.2f} s, evals/pixel {ev.mean():.0f} (min {ev.min()} max {ev.max()}), iterations {it.mean():.0f}, '
       f'evals/iteration {ev.sum() / it.sum():.1f}, rounds {res[0].rounds}, mean lnZ {lz.mean():.3f}')
+print('   timings', {k: round(v, 3) for k, v in getattr(res[0], 'timings', {}).items()})
 import os; os.makedirs('gpurun_out/r04', exist_ok=True)
 np.save(f'gpurun_out/r04/c5probe_lnZ_{side}_' + '_'.join(f'{k}{v}' for k, v in kw.items()) + '.npy', lz)
