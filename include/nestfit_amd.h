@@ -393,8 +393,11 @@ int nfa_sampler_set_pairs(nfa_sampler *s, double enlarge);
  * reads back, nestfit/core/core.pyx:627-687) -- rows [offsets[p], offsets[p+1]) of out[offsets[P]][ndim + 2] are pixel p's
  * dead points (min(n_iter[p], cap) of them) followed by its live points; a row = theta[ndim], -2 lnL, ln(prior mass x
  * likelihood): lnw + lnL of a dead point, lnL + live_off[p] of a live one (live_off[p] = -n_iter / nlive - ln nlive, given by
- * the caller, who normalises the last column into weights). */
-int nfa_sampler_posterior_packed(nfa_sampler *s, const int64_t *offsets, const double *live_off, double *out);
+ * the caller, who normalises the last column into weights) -- or, with stats[P][6 + 4 ndim] given, the device does: the
+ * last column comes back as weights exp(. - lnZ) and stats[p] = lnZ, lnZ of the dead points alone, information H, largest
+ * lnL, largest lnL of the live points, sum of the weights, then weighted mean[ndim], weighted raw second moment[ndim],
+ * theta of the largest likelihood[ndim], theta of the largest weight[ndim] (what mn_dump derives from MultiNest's files). */
+int nfa_sampler_posterior_packed(nfa_sampler *s, const int64_t *offsets, const double *live_off, double *out, double *stats);
 int nfa_sampler_run(nfa_sampler *s, double tol, double efr, int64_t seed, int64_t maxiter, int upd,
                     double log_zero, int check_every);
 /* method: how a pixel finds its next point above the threshold.  0 = rejection sampling in the

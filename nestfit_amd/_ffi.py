@@ -108,7 +108,7 @@ SIGNATURES = {
     'nfa_sampler_set_boxes': (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     'nfa_sampler_set_shear': (C.c_int, [C.c_void_p, C.c_double]),
     'nfa_sampler_set_pairs': (C.c_int, [C.c_void_p, C.c_double]),
-    'nfa_sampler_posterior_packed': (C.c_int, [C.c_void_p, _lp, _dp, _dp]),
+    'nfa_sampler_posterior_packed': (C.c_int, [C.c_void_p, _lp, _dp, _dp, _dp]),
     'nfa_sampler_run': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int,
                                   C.c_double, C.c_int]),
     'nfa_sampler_begin': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int,

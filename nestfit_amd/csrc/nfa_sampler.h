@@ -1587,6 +1587,89 @@ __global__ void ns_pack_post_kernel(NsDev S, const long *__restrict__ off, const
     }
 }
 
+// What a result needs from a pixel's table, formed where the table is: the last column turned into weights in place
+// (exp(ln(prior mass x likelihood) - lnZ)), and per pixel stats[p] = [lnZ, lnZ of the dead points alone, information H,
+// largest lnL, largest lnL of the live points, sum of the weights] + weighted mean[DT] + weighted raw second moment[DT] +
+// theta of the largest likelihood[DT] + theta of the largest weight[DT].  One workgroup per pixel.
+#define NS_FIN_THREADS 256
+__device__ __forceinline__ double ns_fin_sum(double v, double *sred) {
+    v = ns_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < NS_FIN_THREADS / 64; ++k) t += sred[k];
+    return t;
+}
+__device__ __forceinline__ double ns_fin_max(double v, double *sred) {
+    v = ns_wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = sred[0];
+    for (int k = 1; k < NS_FIN_THREADS / 64; ++k) t = fmax(t, sred[k]);
+    return t;
+}
+__global__ void __launch_bounds__(NS_FIN_THREADS) ns_finish_kernel(NsDev S, const long *__restrict__ off, double *__restrict__ out, double *__restrict__ stats) {
+    __shared__ double sred[NS_FIN_THREADS / 64];
+    __shared__ unsigned long long sarg[2];
+    const int DT = S.DT, W = DT + 2, tid = (int)threadIdx.x;
+    const long p = blockIdx.x;
+    const long n = off[p + 1] - off[p], nl = ns_n(S, (int)p), nd = n - nl;
+    double *o = out + off[p] * W;
+    double *st = stats + p * (6 + 4 * DT);
+    // maxima of the log weights (dead, live) and of lnL
+    double md = -INFINITY, ml = -INFINITY, lmax = -INFINITY, llive = -INFINITY;
+    for (long r = tid; r < n; r += NS_FIN_THREADS) {
+        const double lw = o[r * W + DT + 1], L = -0.5 * o[r * W + DT];
+        if (r < nd) md = fmax(md, lw); else { ml = fmax(ml, lw); llive = fmax(llive, L); }
+        lmax = fmax(lmax, L);
+    }
+    md = ns_fin_max(md, sred); ml = ns_fin_max(ml, sred); lmax = ns_fin_max(lmax, sred); llive = ns_fin_max(llive, sred);
+    double sd = 0.0, sl = 0.0;
+    for (long r = tid; r < n; r += NS_FIN_THREADS) {
+        const double lw = o[r * W + DT + 1];
+        if (r < nd) sd += isfinite(md) ? exp(lw - md) : 0.0; else sl += isfinite(ml) ? exp(lw - ml) : 0.0;
+    }
+    sd = ns_fin_sum(sd, sred); sl = ns_fin_sum(sl, sred);
+    const double lnz_dead = nd > 0 ? (isfinite(md) ? md + log(sd) : md) : -INFINITY;
+    const double lnz_live = isfinite(ml) ? ml + log(sl) : ml;
+    const double lnz = ns_logaddexp(lnz_dead, lnz_live);
+    // weights in place, information, sum of the weights; rows of the largest likelihood and of the largest weight
+    double H = 0.0, sw = 0.0, bestL = -INFINITY, bestw = -1.0;
+    long ibest = 0, imap = 0;
+    for (long r = tid; r < n; r += NS_FIN_THREADS) {
+        const double lw = o[r * W + DT + 1], L = -0.5 * o[r * W + DT];
+        const double w = exp(lw - lnz);
+        o[r * W + DT + 1] = w;
+        if (w > 0.0) H += w * (L - lnz);
+        sw += w;
+        if (L > bestL) { bestL = L; ibest = r; }
+        if (w > bestw) { bestw = w; imap = r; }
+    }
+    H = ns_fin_sum(H, sred); sw = ns_fin_sum(sw, sred);
+    // (arg-maxima over the workgroup: the value's bits -- order-preserving for the finite values that matter -- with the row packed below)
+    if (tid == 0) { sarg[0] = 0ull; sarg[1] = 0ull; }
+    __syncthreads();
+    const double gL = ns_fin_max(bestL, sred), gw = ns_fin_max(bestw, sred);
+    if (bestL == gL) atomicMax(&sarg[0], ~(unsigned long long)ibest);        // the FIRST row among equals: largest complement
+    if (bestw == gw) atomicMax(&sarg[1], ~(unsigned long long)imap);
+    __syncthreads();
+    const long rb = (long)~sarg[0], rm = (long)~sarg[1];
+    if (tid == 0) { st[0] = lnz; st[1] = lnz_dead; st[2] = H; st[3] = lmax; st[4] = llive; st[5] = sw; }
+    for (int j = tid; j < DT; j += NS_FIN_THREADS) { st[6 + 2 * DT + j] = o[rb * W + j]; st[6 + 3 * DT + j] = o[rm * W + j]; }
+    // weighted first and second moments of every column
+    for (int j = 0; j < DT; ++j) {
+        double m1 = 0.0, m2 = 0.0;
+        for (long r = tid; r < n; r += NS_FIN_THREADS) {
+            const double w = o[r * W + DT + 1], t = o[r * W + j];
+            m1 += w * t; m2 += w * (t * t);
+        }
+        m1 = ns_fin_sum(m1, sred); m2 = ns_fin_sum(m2, sred);
+        if (tid == 0) { st[6 + j] = m1; st[6 + DT + j] = m2; }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------
 #ifndef NS_KMAX
 #define NS_KMAX 65536           // most proposals one pixel gets in a round
@@ -2087,7 +2170,7 @@ int nfa_sampler_dead_packed(nfa_sampler *s, const int64_t *offsets, double *thet
 
 // The posterior tables of every pixel at once (ns_pack_post_kernel): offsets[P + 1] (host; rows of pixel p =
 // min(n_iter[p], cap) dead points + its live points), live_off[P] (host), out[offsets[P]][DT + 2] (host).
-int nfa_sampler_posterior_packed(nfa_sampler *s, const int64_t *offsets, const double *live_off, double *out) {
+int nfa_sampler_posterior_packed(nfa_sampler *s, const int64_t *offsets, const double *live_off, double *out, double *stats) {
     if (!s || !s->ran || !offsets || !live_off || !out) return fail(NFA_ERR_ARG, "bad argument");
     const NsDev &d = s->d;
     const int P = d.P;
@@ -2098,10 +2181,12 @@ int nfa_sampler_posterior_packed(nfa_sampler *s, const int64_t *offsets, const d
     }
     const int64_t total = offsets[P];
     long *d_off = nullptr;
-    double *d_lo = nullptr, *d_out = nullptr;
-    auto release = [&]() { (void)hipFree(d_off); (void)hipFree(d_lo); (void)hipFree(d_out); };
+    double *d_lo = nullptr, *d_out = nullptr, *d_st = nullptr;
+    const size_t n_st = (size_t)P * (6 + 4 * d.DT);
+    auto release = [&]() { (void)hipFree(d_off); (void)hipFree(d_lo); (void)hipFree(d_out); (void)hipFree(d_st); };
     if (hipMalloc((void **)&d_off, sizeof(long) * (P + 1)) != hipSuccess || hipMalloc((void **)&d_lo, sizeof(double) * P) != hipSuccess
-        || hipMalloc((void **)&d_out, sizeof(double) * total * (d.DT + 2)) != hipSuccess) {
+        || hipMalloc((void **)&d_out, sizeof(double) * total * (d.DT + 2)) != hipSuccess
+        || (stats && hipMalloc((void **)&d_st, sizeof(double) * n_st) != hipSuccess)) {
         release();
         return fail(NFA_ERR_DEVICE, "out of device memory for the packed posterior tables");
     }
@@ -2111,6 +2196,11 @@ int nfa_sampler_posterior_packed(nfa_sampler *s, const int64_t *offsets, const d
     ok = ok && hipMemcpyAsync(d_lo, live_off, sizeof(double) * P, hipMemcpyHostToDevice, st) == hipSuccess;
     hipLaunchKernelGGL(ns_pack_post_kernel, dim3(16, (unsigned)std::min(P, 32768)), dim3(256), 0, st, d, (const long *)d_off, (const double *)d_lo, d_out);
     ok = ok && hipGetLastError() == hipSuccess;
+    if (stats) {            // weights, evidence, information and moments formed where the tables are
+        hipLaunchKernelGGL(ns_finish_kernel, dim3((unsigned)P), dim3(NS_FIN_THREADS), 0, st, d, (const long *)d_off, d_out, d_st);
+        ok = ok && hipGetLastError() == hipSuccess;
+        ok = ok && hipMemcpyAsync(stats, d_st, sizeof(double) * n_st, hipMemcpyDeviceToHost, st) == hipSuccess;
+    }
     ok = ok && hipMemcpyAsync(out, d_out, sizeof(double) * total * (d.DT + 2), hipMemcpyDeviceToHost, st) == hipSuccess;
     ok = ok && hipStreamSynchronize(st) == hipSuccess;
     release();

@@ -59,6 +59,27 @@ class NestedResult:
         mapp = th[np.argmax(w)]                     # largest posterior mass
         self.param_constr = np.stack([mean, np.sqrt(var), best, mapp])    # (4, n_params)
 
+    @classmethod
+    def from_stats(cls, posterior, stats, n_live, n_evals, n_iter):
+        """The same result from what the device has already formed of the table (nfa_sampler_posterior_packed with `stats`:
+        lnZ, lnZ of the dead points, H, largest lnL, largest live lnL, sum of the weights, mean, raw second moment, theta of
+        the largest likelihood, theta of the largest weight): no pass over the table on the host."""
+        self = cls.__new__(cls)
+        nd = int(posterior.shape[1] - 2)
+        self.posterior = posterior
+        self.n_samples = int(posterior.shape[0])
+        self.n_params = nd
+        self.lnZ = float(stats[0])
+        self.information = float(stats[2])
+        self.lnZ_err = float(np.sqrt(max(self.information, 0.0) / n_live))
+        self.max_loglike = float(stats[3])
+        self.n_live, self.n_evals, self.n_iter = int(n_live), int(n_evals), int(n_iter)
+        self.truncated = False
+        mean, m2 = stats[6:6 + nd], stats[6 + nd:6 + 2 * nd]
+        var = np.maximum(m2 - 2.0 * mean * mean + mean * mean * stats[5], 0.0)
+        self.param_constr = np.stack([mean, np.sqrt(var), stats[6 + 2 * nd:6 + 3 * nd], stats[6 + 3 * nd:6 + 4 * nd]])
+        return self
+
 
 # ---- counter-based random numbers, shared bit for bit with csrc/nfa_sampler.h -------------
 _U64 = np.uint64
@@ -495,14 +516,22 @@ def _assemble(ndim, nlive, n_iter, n_evals, dead, Tlive, Llive, tol=None):
     return results
 
 
-def _assemble_packed(ndim, nlive, n_iter, n_evals, n_dead, off, table, tol=None):
+def _assemble_packed(ndim, nlive, n_iter, n_evals, n_dead, off, table, tol=None, stats=None):
     """`_assemble` for tables the device has laid out (nfa_sampler_posterior_packed): rows off[p] .. off[p + 1] of `table` are
     pixel p's dead points followed by its live points, columns theta, -2 lnL, ln(prior mass x likelihood); the last column
-    becomes the weight here, in place."""
+    becomes the weight here, in place -- or has become it on the device, which then also hands over `stats` (evidence,
+    information, moments: `NestedResult.from_stats`)."""
     results = []
     for p in range(len(n_iter)):
         nl, nd = int(nlive[p]), int(n_dead[p])
         post = table[off[p]:off[p + 1]]
+        if stats is not None:
+            r = NestedResult.from_stats(post, stats[p], nl, n_evals[p], n_iter[p])
+            if tol is not None:
+                remain = stats[p, 4] - n_iter[p] / nl
+                r.truncated = bool(not (np.logaddexp(stats[p, 1], remain) - stats[p, 1] < tol))
+            results.append(r)
+            continue
         lw = post[:, ndim + 1]
         L = -0.5 * post[:, ndim]
 
@@ -961,11 +990,12 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
         np.cumsum(n_dead + nl, out=off[1:])
         live_off = -n_iter / nl - np.log(nl)
         table = np.empty((int(off[-1]), ndim + 2))
-        _ffi.check(lib.nfa_sampler_posterior_packed(h, off.ctypes.data_as(_ffi._lp), _ffi.dptr(live_off), _ffi.dptr(table)))
+        stats = np.empty((P, 6 + 4 * ndim))
+        _ffi.check(lib.nfa_sampler_posterior_packed(h, off.ctypes.data_as(_ffi._lp), _ffi.dptr(live_off), _ffi.dptr(table), _ffi.dptr(stats)))
     finally:
         lib.nfa_sampler_destroy(h)
     t_read = time.perf_counter()
-    res = _assemble_packed(ndim, nl, n_iter, n_evals, n_dead, off, table, tol)
+    res = _assemble_packed(ndim, nl, n_iter, n_evals, n_dead, off, table, tol, stats)
     for r in res:
         r.rounds = int(rounds.value)
     # where the call's time went (seconds): the rounds on the device, the read-back of live and dead points, the assembly of
