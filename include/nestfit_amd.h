@@ -95,7 +95,7 @@ int nfa_get_exp_mode(void);
  *   "sampler_frames"      rotated box frames of a one-ellipsoid bound (nfa_sampler_set_boxes): -2 (default) and -1
  *                   none, 0..64; "sampler_margin_pct": the boxes' margin factor in hundredths (0 = 175);
  *   "sampler_shear_pct"   the shear in front of one-ellipsoid bounds (nfa_sampler_set_shear): its safety factor in
- *                   hundredths, -1 (default) = 300 where the shape allows, 0 = off, 100..100000;
+ *                   hundredths, -1 (default) = 250 where the shape allows, 0 = off, 100..100000;
  *   "sampler_pairs_pct"   the pair ellipses of a sheared and boxed bound (nfa_sampler_set_pairs): their safety factor in
  *                   hundredths, -1 (default) = 175, 0 = off, 100..100000;
  *   "sampler_ktarget"     replacements per pixel and rejection round a pixel's own share of the round's proposals aims
@@ -380,7 +380,7 @@ int nfa_sampler_set_boxes(nfa_sampler *s, int n_frames, double margin);
  * inside one velocity component, products of the earlier coordinates): an additive triangular map has a unit Jacobian, so
  * a point drawn uniformly in the w-ellipsoid and mapped back is uniform over its curved image in the unit cube.  Boxes, if
  * on, are fitted and tested in the w frame.  enlarge: the safety factor on the sheared ellipsoid's enclosing volume (>= 1;
- * 3 is the measured choice), 0 = off, < 0 = the default (engine option "sampler_shear_pct": 3 unless changed).  Applies
+ * 2.5 is the measured choice), 0 = off, < 0 = the default (engine option "sampler_shear_pct": 2.5 unless changed).  Applies
  * where all five free parameters of two or three components are sampled (10 or 15 dimensions); accepted and without effect
  * elsewhere.  MultiNest has no counterpart (its answer to curved regions is more ellipsoids: nestfit/core/core.pyx:727-760). */
 int nfa_sampler_set_shear(nfa_sampler *s, double enlarge);

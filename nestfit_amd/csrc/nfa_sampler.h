@@ -83,7 +83,7 @@ static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for 
 // quadratic function of the earlier ones -- the curved tex / ntot ridges of faint pixels come out straight, and an
 // ellipsoid around straight things is small
 #define NS_SHEAR_RIDGE 1e-6        // on the Gram matrix's diagonal, times the live points
-#define NS_SHEAR_ENLARGE 3.0       // safety factor on the enclosing volume of the sheared ellipsoid
+#define NS_SHEAR_ENLARGE 2.5       // safety factor on the enclosing volume of the sheared ellipsoid
 #define NS_SHEAR_PIVOT 1e-9        // a Cholesky pivot below this fraction of its diagonal entry: the monomial is dropped
 #define NS_SHEAR_MMAX 64           // monomials at most
 #define NS_REFIT_THREADS 512       // of the workgroup that fits a one-ellipsoid bound
@@ -1846,7 +1846,7 @@ int nfa_sampler_set_boxes(nfa_sampler *s, int n_frames, double margin) {
 
 // The shear in front of a one-ellipsoid bound (10 or 15 sampled dimensions = all five free parameters of two or three
 // components; elsewhere the call is accepted and changes nothing): enlarge = the safety factor on the sheared ellipsoid's
-// enclosing volume (>= 1; NS_SHEAR_ENLARGE = 3 is the measured choice), 0 = off, < 0 = the default.  Before nfa_sampler_begin.
+// enclosing volume (>= 1; NS_SHEAR_ENLARGE = 2.5 is the measured choice), 0 = off, < 0 = the default.  Before nfa_sampler_begin.
 int nfa_sampler_set_shear(nfa_sampler *s, double enlarge) {
     if (!s || (enlarge > 0.0 && enlarge < 1.0) || enlarge > 1e6 || enlarge != enlarge) return fail(NFA_ERR_ARG, "shear: 0 (off), < 0 (default) or a safety factor >= 1");
     if (s->ran) return fail(NFA_ERR_STATE, "call nfa_sampler_set_shear before nfa_sampler_begin");

@@ -341,7 +341,7 @@ _NS_KP_START = 256                                                              
 _NS_K_TARGET = 16                                                               # NS_K_TARGET
 _NS_SHEAR_RIDGE = 1e-6                                                          # NS_SHEAR_RIDGE
 _NS_SHEAR_PIVOT = 1e-9                                                          # NS_SHEAR_PIVOT
-_NS_SHEAR_ENLARGE = 3.0                                                         # NS_SHEAR_ENLARGE
+_NS_SHEAR_ENLARGE = 2.5                                                         # NS_SHEAR_ENLARGE
 
 
 def _shear_monomials(comp):
@@ -608,7 +608,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     shear : 0 = off; a number >= 1 = the one-ellipsoid bound is fitted to the live points AFTER a volume-preserving
         polynomial shear (`_fit_shear`: every coordinate minus a quadratic function of the earlier ones, which straightens
         the curved tex / ntot ridges), with this safety factor on the enclosing volume instead of `enlarge`; None = the
-        default, 3.  Proposals are drawn in the sheared frame and mapped back; boxes, if on, live in that frame.  Only
+        default, 2.5.  Proposals are drawn in the sheared frame and mapped back; boxes, if on, live in that frame.  Only
         where all five free parameters of two or three components are sampled (10 or 15 dimensions): elsewhere ignored.
     refit_every : rejection-mode pixels refit their bound in rounds that are multiples of this (the device's engine option
         `sampler_refit_every`).

@@ -37,7 +37,7 @@ def run(label, **kw):
 
 
 ref = run('walks of 140 steps', method='walk', n_steps=140)
-rows = [ref, run('shipped default (shear 3, 32 box frames, pairs 1.75)')]
+rows = [ref, run('shipped default (shear 2.5, 32 box frames, pairs 1.75)')]
 for tok in sys.argv[3:]:
     f = tok.split(':')
     kw = dict(shear=float(f[0]), frames=int(f[1]))

@@ -533,7 +533,7 @@ def test_shear_in_front_of_the_ellipsoid():
     kw = dict(nlive=200, tol=0.5, efr=0.3, seed=3, method='reject', batch_target=512, free_mask=fm)
     plain = sampler.run_nested(ridge, 12, 1, shear=0, **kw)
     bent = sampler.run_nested(ridge, 12, 1, shear=4.0, frames=-1, **kw)
-    both = sampler.run_nested(ridge, 12, 1, **kw)                  # the default of this shape: shear 3, 32 box frames, pair ellipses
+    both = sampler.run_nested(ridge, 12, 1, **kw)                  # the default of this shape: shear 2.5, 32 box frames, pair ellipses
     truth = float(np.sum(np.log(np.sqrt(2 * np.pi) * np.array([0.08] * 8 + [0.01] * 2))))     # (the Gaussians fit into the cube)
     for r in plain + bent + both:
         assert abs(r.lnZ - truth) < 4 * r.lnZ_err + 0.3, (r.lnZ, truth, r.lnZ_err)
