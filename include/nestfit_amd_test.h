@@ -35,6 +35,13 @@ typedef void (*nfa_loglike_callback_fn)(double *cube, int *ndim, int *npars, dou
 int nfa_test_callback_latency(nfa_loglike_callback_fn callback, void *runner, int ndim, const double *u,
                               int n_calls, double *lnew_out, double *seconds_out);
 
+/* Timeline of the queue form of the table-mode likelihood kernel (csrc/nfa_device.h, lnl_kernel_queue): on = 1 attaches
+ * a buffer (and clears it), 0 frees it; with it attached every wave of a launch records up to 8 units as
+ * {start, end, item * nspec + spectrum, position in the launch's order}, ticks of 10 ns.  `out` takes
+ * 8192 waves x 8 records x 4 words of the last launch. */
+int nfa_test_queue_trace(int on);
+int nfa_test_queue_trace_read(unsigned long long *out);
+
 #ifdef __cplusplus
 }
 #endif

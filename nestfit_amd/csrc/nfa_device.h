@@ -148,6 +148,15 @@ struct LnlGeom {
     unsigned inv_nspec; // floor(2^32 / nspec) + 1: unit / nspec = mulhi(unit, inv_nspec) for unit < 2^28; 0: nspec == 1
     unsigned inv_nhf;   // floor(2^32 / nhf_max) + 1: p / nhf_max = mulhi(p, inv_nhf) for the few hundred (component, line) slots; 0: nhf_max == 1
     int split;          // waves that share one (item, spectrum) unit (1, 2, 4), each taking LNL_PARTS / split row parts
+#ifdef NFA_TEST_HOOKS
+    unsigned long long *trace;   // measurement (test library): per wave of the queue kernel 8 records {start, end, unit, position} in 10 ns ticks
+#endif
+    int qmode;          // experiments: 2 = the queue kernel with static strides instead of draws (timing only)
+    const int *order;   // the queue kernel's order of the items: item of class c and rank k at order[c * order_cap + k], the
+    long order_cap;     // classes' counts behind the queue's counters (set-up stage, setup_order); nullptr: as they come
+    unsigned *queue;    // table mode, split == 1, launches of several units per wave slot (lnl_kernel_queue): the launch's
+                        // chunk counter and, a 128-byte line behind it, its count of workgroups that have left
+                        // (NFA_QUEUE_WORDS words, zero between launches); nullptr: one unit per wave (lnl_kernel)
     int ablate;        // timing experiments only: 1 skip Tb, 2 skip the line loop, 4 skip rows, 8 skip line set-up
 };
 
@@ -558,6 +567,7 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
 // the extractions inside the shifts: seven address instructions (round 3: nine -- a bit-field extract and a shift-add
 // per index).  A lane below 2^-5 (u negative; its value comes from the Taylor form) forms an A address far beyond the
 // workgroup's LDS: such a read returns nothing and faults nothing; its B and C addresses stay inside row 15's reach.
+#define NFA_TABLE_GATHER_LINE(X, G0, G1, G2) NFA_TABLE_GATHER(X, G0, G1, G2)
 #define NFA_TABLE_GATHER(X, G0, G1, G2)                                                                    \
         "v_add_u32 %[t0], 0xc3000000, %[" #X "]\n\t"              /* bits - (122 << 23) */                 \
         "v_lshlrev_b32_sdwa %[t1], 3, %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* (l, j0) * 8 */ \
@@ -569,12 +579,43 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
         "v_lshlrev_b32_sdwa %[t1], 3, %[" #X "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" /* j2 * 8 */ \
         "v_lshl_add_u32 %[t1], %[t0], 11, %[t1]\n\t"                                                       \
         "ds_read_b64 %[" #G2 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_C) "\n\t"
+#ifdef NFA_CGATHER_VMEM
+// experiment (profiles/r05/ab_table_cgather_vmem.txt): the C factor gathered from the global copy of the tables through
+// the vector-memory path (its own counter, vmcnt) instead of the LDS; issued first, it has the longest way
+#undef NFA_TABLE_GATHER_LINE
+#define NFA_TABLE_GATHER_LINE(X, G0, G1, G2)                                                               \
+        "v_add_u32 %[t0], 0xc3000000, %[" #X "]\n\t"                                                       \
+        "v_lshlrev_b32_sdwa %[t1], 3, %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+        "v_bfe_u32 %[t0], %[t0], 23, 4\n\t"                                                                \
+        "ds_read_b64 %[" #G0 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_A) "\n\t"                              \
+        "v_lshlrev_b32_sdwa %[t1], 3, %[" #X "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshl_add_u32 %[t1], %[t0], 11, %[t1]\n\t"                                                       \
+        "global_load_dwordx2 %[" #G2 "], %[t1], %[gc]\n\t"                                                 \
+        "v_lshlrev_b32_sdwa %[t1], 3, %[" #X "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshl_add_u32 %[t1], %[t0], 11, %[t1]\n\t"                                                       \
+        "ds_read_b64 %[" #G1 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_B) "\n\t"
+#define NFA_W_A01 "s_waitcnt lgkmcnt(2)\n\t"
+#define NFA_W_A2  "s_waitcnt vmcnt(1)\n\t"
+#define NFA_W_B01 "s_waitcnt lgkmcnt(0)\n\t"
+#define NFA_W_B2  "s_waitcnt vmcnt(0)\n\t"
+#define NFA_W_S01 "s_waitcnt lgkmcnt(0)\n\t"
+#define NFA_W_S2  "s_waitcnt vmcnt(0)\n\t"
+#define NFA_GC_OPERAND , [gc] "s"(gC)
+#else
+#define NFA_W_A01 "s_waitcnt lgkmcnt(4)\n\t"
+#define NFA_W_A2  "s_waitcnt lgkmcnt(3)\n\t"
+#define NFA_W_B01 "s_waitcnt lgkmcnt(1)\n\t"
+#define NFA_W_B2  "s_waitcnt lgkmcnt(0)\n\t"
+#define NFA_W_S01 "s_waitcnt lgkmcnt(1)\n\t"
+#define NFA_W_S2  "s_waitcnt lgkmcnt(0)\n\t"
+#define NFA_GC_OPERAND
+#endif
 #define NFA_TABLE_LOOKUP(X, G0, G1, G2, NUC, ID)                                                           \
         "v_add_f64 %[" #G0 "], %[xj], -%[" #NUC "]\n\t"                                                    \
         "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #G0 "]\n\t"                                                 \
         "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #ID "]\n\t"                                                 \
         "v_cvt_f32_f64 %[" #X "], %[" #G0 "]\n\t"                 /* math.pxd:17 narrowing */             \
-        NFA_TABLE_GATHER(X, G0, G1, G2)
+        NFA_TABLE_GATHER_LINE(X, G0, G1, G2)
 // FastExp's Taylor form (fastexp.c:264-270: 1 - t (1 - t/2 (1 - t/3)), one IEEE operation per operation of the
 // reference) for the lanes in VCC.  The middle step 1 - (t ty) 0.5 is ONE fused multiply-add: a product with 0.5 is
 // exact, so fma(t ty, -0.5, 1) rounds once, where the reference's multiplication and subtraction round once too.
@@ -601,7 +642,8 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
 // condition there across the block).
 __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj,
                                                 double nucA, double idA, double wA, float midA, float halfA,
-                                                double nucB, double idB, double wB, float midB, float halfB) {
+                                                double nucB, double idB, double wB, float midB, float halfB,
+                                                const double *gC = nullptr) {
     float xA, xB;
     uint32_t t0, t1;
     double a0, a1, a2, b0, b1, b2;
@@ -618,9 +660,9 @@ __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj
         // line A: the product as its gathers land, the Taylor form where x < 2^-5, tau += w e
         "s_mov_b64 exec, %[mA]\n\t"
         "v_cmp_gt_f32 vcc, 0x3d000000, %[xA]\n\t"
-        "s_waitcnt lgkmcnt(4)\n\t"
+        NFA_W_A01
         "v_mul_f64 %[a0], %[a0], %[a1]\n\t"
-        "s_waitcnt lgkmcnt(3)\n\t"
+        NFA_W_A2
         "v_mul_f64 %[a0], %[a0], %[a2]\n\t"
         NFA_TABLE_TAYLOR(xA, a0, a1, a2, ".Lnfa_tpa_")
         "s_mov_b64 exec, %[mA]\n\t"
@@ -628,9 +670,9 @@ __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj
         // line B
         "s_mov_b64 exec, %[mB]\n\t"
         "v_cmp_gt_f32 vcc, 0x3d000000, %[xB]\n\t"
-        "s_waitcnt lgkmcnt(1)\n\t"
+        NFA_W_B01
         "v_mul_f64 %[b0], %[b0], %[b1]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
+        NFA_W_B2
         "v_mul_f64 %[b0], %[b0], %[b2]\n\t"
         NFA_TABLE_TAYLOR(xB, b0, b1, b2, ".Lnfa_tpb_")
         "s_mov_b64 exec, %[mB]\n\t"
@@ -641,13 +683,14 @@ __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj
           [mA] "=&s"(mA), [mB] "=&s"(mB)
         : [jf] "v"(jf), [xj] "v"(xj), [nucA] "v"(nucA), [idA] "v"(idA), [wA] "v"(wA), [midA] "v"(midA), [halfA] "v"(halfA),
           [nucB] "v"(nucB), [idB] "v"(idB), [wB] "v"(wB), [midB] "v"(midB), [halfB] "v"(halfB),
-          [nthird] "s"(-(1.0 / 3.0))
+          [nthird] "s"(-(1.0 / 3.0)) NFA_GC_OPERAND
         : "vcc");
 }
 
 // One line x row step of the table mode (the odd line of a run), the same arithmetic.
 __device__ __forceinline__ void line_single_table(double &tau, float jf, double xj,
-                                                  double nucA, double idA, double wA, float midA, float halfA) {
+                                                  double nucA, double idA, double wA, float midA, float halfA,
+                                                  const double *gC = nullptr) {
     float xA;
     uint32_t t0, t1;
     double a0, a1, a2;
@@ -658,9 +701,9 @@ __device__ __forceinline__ void line_single_table(double &tau, float jf, double 
         "s_mov_b64 exec, %[mA]\n\t"
         NFA_TABLE_LOOKUP(xA, a0, a1, a2, nucA, idA)
         "v_cmp_gt_f32 vcc, 0x3d000000, %[xA]\n\t"
-        "s_waitcnt lgkmcnt(1)\n\t"
+        NFA_W_S01
         "v_mul_f64 %[a0], %[a0], %[a1]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
+        NFA_W_S2
         "v_mul_f64 %[a0], %[a0], %[a2]\n\t"
         NFA_TABLE_TAYLOR(xA, a0, a1, a2, ".Lnfa_tps_")
         "s_mov_b64 exec, %[mA]\n\t"
@@ -669,7 +712,7 @@ __device__ __forceinline__ void line_single_table(double &tau, float jf, double 
         : [tau] "+v"(tau), [xA] "=&v"(xA), [t0] "=&v"(t0), [t1] "=&v"(t1),
           [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [mA] "=&s"(mA)
         : [jf] "v"(jf), [xj] "v"(xj), [nucA] "v"(nucA), [idA] "v"(idA), [wA] "v"(wA), [midA] "v"(midA), [halfA] "v"(halfA),
-          [nthird] "s"(-(1.0 / 3.0))
+          [nthird] "s"(-(1.0 / 3.0)) NFA_GC_OPERAND
         : "vcc");
 }
 
@@ -710,12 +753,12 @@ __device__ __forceinline__ double one_minus_fastexp_table_row(double tau) {
 // The body of the likelihood kernel for workgroup `block_id` of a launch (lnl_kernel: the hardware's
 // workgroup; point_kernel: the one workgroup walks the few of a single point).  `sm` = the staged
 // exponential tables (n_shared doubles at the start of smem), the line tables follow them.
-template <int MODE, bool WRITE_SPEC, bool WIDE, int NCOMP>
+template <int MODE, bool WRITE_SPEC, bool WIDE, int NCOMP, bool DYN = false>
 __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict__ pix, const double *__restrict__ D,
                                          double *__restrict__ part, double *__restrict__ spec_out, long B,
                                          const LnlGeom &G, const double *__restrict__ g_tabs, double *smem,
                                          const double *sm, int n_shared, unsigned block_id,
-                                         const BatchGroup *grp = nullptr) {
+                                         const BatchGroup *grp = nullptr, long unit_dyn = -1) {
     typedef typename std::conditional<MODE == 2, float, double>::type tau_t;
     constexpr int NC = NCOMP > 0 ? NCOMP : 1;
     // the fast mode's narrow form: at most 26 lines per transition (32-bit line masks), fp32 optical depth, the
@@ -731,7 +774,11 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
 #else
     const int ablate = 0;
 #endif
-    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    int lane_ = threadIdx.x & 63;
+    // the queue form runs this body in a loop: what depends only on the lane must not move out of it (the row loop has
+    // no registers to spare for values of the unit's prologue)
+    if (DYN) asm volatile("" : "+v"(lane_));
+    const int lane = lane_, waves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ncomp = NCOMP > 0 ? NCOMP : S.ncomp, nspec = S.n_spec;
     const int drec = drec_size(ncomp, nspec);
@@ -745,18 +792,20 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // The grid covers all units (the host keeps B * nspec * split below 2^28).  Waves
     // of a workgroup land on the SIMDs of a CU in order, so the unit -> wave assignment is rotated per
     // workgroup: otherwise one SIMD would only ever see the spectrum with the most hyperfine lines.
-    const int split = G.split;
+    const int split = DYN ? 1 : G.split;                            // (the queue form: one wave per unit)
     const unsigned units = (unsigned)B * (unsigned)nspec;
     const unsigned rot = __builtin_amdgcn_readfirstlane((block_id * 0x9E3779B1u) >> 28);
     const unsigned wsel0 = (unsigned)wave + rot;
     // (no integer division in here: the compiler builds one from two dozen vector instructions, and a wave
     // of the metric shape is only ~2200 long; split is 1, 2 or 4, the waves of a workgroup mostly a power of two)
-    const unsigned wsel = (waves & (waves - 1)) == 0 ? (wsel0 & (unsigned)(waves - 1)) : wsel0 % (unsigned)waves;
+    // (unit_dyn >= 0: the unit was drawn from the workgroup's queue, lnl_kernel; the wave keeps its own LDS slice)
+    const unsigned wsel = DYN ? (unsigned)wave
+                        : (waves & (waves - 1)) == 0 ? (wsel0 & (unsigned)(waves - 1)) : wsel0 % (unsigned)waves;
     const int split_log2 = split >> 1;                              // 1, 2, 4 -> 0, 1, 2
     const unsigned upw = (unsigned)waves >> split_log2;             // units per workgroup
     const unsigned ulocal = wsel >> split_log2;
     const int rpart = (int)(wsel & (unsigned)(split - 1));
-    const unsigned unit = block_id * upw + ulocal;
+    const unsigned unit = DYN ? (unsigned)unit_dyn : block_id * upw + ulocal;
     LineRec *w_line = (LineRec *)(smem + n_shared + (size_t)ulocal * G.wave_doubles);
     int2 *w_win = (int2 *)(w_line + (NCOMP > 0 ? NCOMP : S.ncomp) * G.nhf_max);   // the windows [lo, hi) follow the table
     // split > 1: the parts' per-lane sums meet here, [unit of the workgroup][part][lane]
@@ -982,7 +1031,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         if constexpr (MODE == 0 && FWIN) {
                             const v2d wm = rec_ab(va + 16);
                             line_single_table(tau, jf, xj, ab.x, ab.y, wm.x, __int_as_float(__double2loint(wm.y)),
-                                              __int_as_float(__double2hiint(wm.y)));
+                                              __int_as_float(__double2hiint(wm.y)), g_tabs + SM_FEC);
                         } else {
                             const v4i hw = rec_hw(va);
                             step(ab, hw, wi);
@@ -999,7 +1048,8 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                             const v2d wm0 = rec_ab(va + 16), wm1 = rec_ab(va + 48);
                             line_pair_table(tau, jf, xj, ab0.x, ab0.y, wm0.x, __int_as_float(__double2loint(wm0.y)),
                                             __int_as_float(__double2hiint(wm0.y)), ab1.x, ab1.y, wm1.x,
-                                            __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)));
+                                            __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)),
+                                            g_tabs + SM_FEC);
                         } else {
                             const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
                             step(ab0, hw0, wi);
@@ -1117,6 +1167,125 @@ lnl_kernel(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__re
     const double *sm = smem;
     if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);   // fast: no tables
     lnl_body<MODE, WRITE_SPEC, WIDE, NCOMP>(S, nullptr, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x, &grp);
+}
+
+// Table mode, one wave per unit, the units drawn from a queue.  A workgroup of the table mode is sixteen waves behind one
+// 51 KB copy of the product tables, and in lnl_kernel the wave slots of the waves that are done stay empty until the
+// longest of the sixteen is: units differ by the widths of their lines, and at the metric's shape 4.5 of 8 waves per
+// SIMD were resident on average (profiles/r04/pmc_lnl_table.json).  Here the launch is as many workgroups as the device
+// holds at once (two per CU), each stages the tables once, and every wave takes units one at a time until none is
+// left.  The launch is cut into chunks of NFA_QUEUE_CHUNK units that a workgroup draws from the launch's counter in global memory (one returning
+// atomic per chunk: a unit per wave and draw there stands in line, ~11 ns per atomic on one word, profiles/r05) and
+// hands out to its waves from a word in LDS: {first unit of the chunk, units handed out} as ONE 64-bit word, so that a
+// wave's returning add is a snapshot of both.  The wave whose add finds the chunk just used up draws the next one and
+// rewrites the word; waves that come while it does wait on the word.  Every unit is computed exactly once; which wave
+// computes it does not enter its result.  The last workgroup to leave zeroes the launch's counters for the next launch
+// on this stream lane.
+#define NFA_QUEUE_CHUNK  16u
+#define NFA_QUEUE_END    0xffffffffu
+#define NFA_QUEUE_STRIDE 32                                   // words between the two counters: a 128-byte line each
+#define NFA_ORDER_CLASSES 32                                  // cost classes of the items (a 128-byte line of counts behind the counters)
+#define NFA_QUEUE_WORDS  (2 * NFA_QUEUE_STRIDE + NFA_ORDER_CLASSES)
+template <bool WRITE_SPEC, int NCOMP>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) __attribute__((amdgpu_waves_per_eu(8, 8)))
+lnl_kernel_queue(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__restrict__ part,
+                 double *__restrict__ spec_out, long B, LnlGeom G, const double *__restrict__ g_tabs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int n_shared = 0;
+    // the workgroup's queue word and its count of waves that have left, behind the waves' line tables (the barrier of
+    // the staging publishes them)
+    unsigned long long *const wq = (unsigned long long *)(smem + (SM_END_TABLE - SM_EXP2) + (size_t)(blockDim.x >> 6) * G.wave_doubles);
+    unsigned *const left = (unsigned *)(wq + 1);
+    if (threadIdx.x == 0) { *wq = (unsigned long long)NFA_QUEUE_CHUNK; *left = 0u; }      // "used up": the first comer draws
+    const double *sm = stage_exp_tables<0>(smem, g_tabs, &n_shared);
+    const unsigned units = (unsigned)B * (unsigned)S.n_spec;
+    // (every unit comes from the queue, a wave's first one too: a workgroup that becomes resident late -- the launch
+    // shares the device with another lane's -- finds what is left, or nothing, and does not hold units of its own)
+    const unsigned queued = units;
+    const int lane_q = threadIdx.x & 63;
+    unsigned *const q = G.queue;
+    unsigned unit = 0;
+    bool have = false, first_draw = true;
+#ifdef NFA_TEST_HOOKS
+    int n_rec = 0;
+#endif
+    const unsigned nspec_q = (unsigned)S.n_spec;
+    const unsigned inv_nspec_q = G.inv_nspec;
+#pragma nounroll
+    while (have || first_draw) {
+      if (!first_draw) {
+        // Position `unit` of the launch's order -> (item, spectrum).  The set-up stage has put the items into classes of
+        // like cost, the dearest class first (setup_order): the units that take longest start first and the launch
+        // ends on its shortest ones, with every wave slot still at work.  Lane c holds the number of items in the
+        // classes from c on; the class of position p is the last one whose number exceeds p.
+        unsigned u_item = unit;
+        if (G.order) {
+            const unsigned p = inv_nspec_q ? __umulhi(unit, inv_nspec_q) : unit, sp = unit - p * nspec_q;
+            unsigned cnt = lane_q < NFA_ORDER_CLASSES ? q[2 * NFA_QUEUE_STRIDE + lane_q] : 0u;
+#pragma unroll
+            for (int d = 1; d < NFA_ORDER_CLASSES; d <<= 1) {          // suffix sums over lanes 0..31
+                const unsigned o = __shfl_down(cnt, d, 64);
+                cnt += (lane_q + d < NFA_ORDER_CLASSES) ? o : 0u;
+            }
+            const unsigned long long above = __builtin_amdgcn_ballot_w64(lane_q < NFA_ORDER_CLASSES && cnt > p);
+            const int cls = 63 - __builtin_clzll(above | 1ull);     // (p < B: lane 0's number is B, the mask is never empty)
+            const unsigned behind = cls + 1 < NFA_ORDER_CLASSES ? __shfl(cnt, cls + 1, 64) : 0u;
+            const int item = G.order[(long)cls * G.order_cap + (p - behind)];
+            u_item = (unsigned)__builtin_amdgcn_readfirstlane(item) * nspec_q + sp;
+        }
+#ifdef NFA_TEST_HOOKS
+        const unsigned long long t_start = wall_clock64();
+#endif
+        lnl_body<0, WRITE_SPEC, false, NCOMP, true>(S, nullptr, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x,
+                                                    &grp, (long)u_item);
+#ifdef NFA_TEST_HOOKS
+        if (G.trace && lane_q == 0 && n_rec < 8) {
+            unsigned long long *t = G.trace + ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + n_rec) * 4;
+            t[0] = t_start; t[1] = wall_clock64(); t[2] = u_item; t[3] = unit;
+        }
+        n_rec += 1;
+#endif
+      }
+        first_draw = false;
+        have = false;
+#pragma nounroll
+        for (;;) {
+            unsigned long long old = 0;
+            if (lane_q == 0) old = __hip_atomic_fetch_add(wq, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned first = __builtin_amdgcn_readfirstlane((unsigned)(old >> 32));
+            const unsigned k = __builtin_amdgcn_readfirstlane((unsigned)old);
+            if (first == NFA_QUEUE_END) break;
+            if (k < NFA_QUEUE_CHUNK) {
+                if (first + k >= queued) continue;                 // beyond the launch's last unit: the next draw ends it
+                unit = first + k; have = true;
+                break;
+            }
+            if (k == NFA_QUEUE_CHUNK) {                              // this wave draws the workgroup's next chunk
+                unsigned g = 0;
+                if (lane_q == 0) g = __hip_atomic_fetch_add(q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned nf = __builtin_amdgcn_readfirstlane(g) * NFA_QUEUE_CHUNK;
+                have = nf < queued;                                  // and takes the chunk's first unit itself
+                if (lane_q == 0)
+                    __hip_atomic_store(wq, have ? ((unsigned long long)nf << 32) | 1ull : (unsigned long long)NFA_QUEUE_END << 32,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unit = nf;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);                             // a chunk is being drawn
+        }
+    }
+    if (lane_q == 0) {
+        const unsigned w = blockDim.x >> 6;
+        if (__hip_atomic_fetch_add(left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == w - 1) {
+            unsigned *const out = q + NFA_QUEUE_STRIDE;
+            if (__hip_atomic_fetch_add(out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+                __hip_atomic_store(q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(out, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < NFA_ORDER_CLASSES; ++i)
+                    __hip_atomic_store(q + 2 * NFA_QUEUE_STRIDE + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // chi^2 parts of one item -> its log-likelihood: the sum over the spectra, in order (ammonia.pyx:425-432), of

@@ -53,6 +53,11 @@ struct Engine {
                                      // 0 = by launch size (resolve_split).  The chi^2 of a unit is a sum of LNL_PARTS
                                      // row blocks in a fixed order whatever the split, so every evaluation is bitwise
                                      // independent of it and of the batch it travels in (the sampler twin relies on that)
+    int    lnl_queue = 1;            // table mode: launches of two and more units per wave slot run as resident workgroups
+                                     // whose waves draw the units from a queue (lnl_kernel_queue); 0 = one unit per wave always
+    unsigned long long *d_trace = nullptr;   // test library: the queue kernel's per-wave records (nfa_test_queue_trace)
+    int    lnl_queue_wg = 0;         // A/B: workgroups per CU of a queue launch (0 = 2)
+    int    lnl_order = 1;            // the queue takes the items in the order of their cost classes (setup_order); 0 = as they come
     int    lnl_cap = 0;              // fast / poly mode: workgroups of the likelihood kernel resident per CU at most
                                      // (LDS padding; 0 = no cap).  A/B knob: leaving one slot per CU to the set-up
                                      // kernels of the next batch paid off (+7 %) until those kernels got a raised wave
@@ -209,6 +214,8 @@ struct nfa_runner {
     hipStream_t lanes[NFA_MAX_LANES] = {};
     double     *d_D[NFA_MAX_LANES] = {};
     double     *d_part[NFA_MAX_LANES] = {};  // per (item, spectrum) log-likelihood terms
+    int        *d_order[NFA_MAX_LANES] = {}; // the items of the lane's launch by cost class (setup_order): NFA_ORDER_CLASSES x cap_D
+    unsigned   *d_queue[NFA_MAX_LANES] = {}; // unit counters of the lane's table-mode launches (lnl_kernel_queue), zero between launches
     int64_t     cap_D[NFA_MAX_LANES] = {};
     hipStream_t stream = nullptr;            // lane 0: also the stream of the host-pointer entry points
     uint64_t    n_calls = 0;
@@ -295,6 +302,9 @@ int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 
 int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "lnl_cap") && value >= 0 && value <= 8) { g_eng.lnl_cap = value; return NFA_OK; }
+    if (key && !strcmp(key, "lnl_queue_wg") && value >= 0 && value <= 2) { g_eng.lnl_queue_wg = value; return NFA_OK; }
+    if (key && !strcmp(key, "lnl_order") && (value == 0 || value == 1)) { g_eng.lnl_order = value; return NFA_OK; }
+    if (key && !strcmp(key, "lnl_queue") && value >= 0 && value <= 2) { g_eng.lnl_queue = value; return NFA_OK; }
     if (key && !strcmp(key, "lnl_split") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_eng.lnl_split = value; return NFA_OK; }
     if (key && !strcmp(key, "graph") && (value == 0 || value == 1)) { g_eng.graph = value; return NFA_OK; }
     if (key && !strcmp(key, "point") && (value == 0 || value == 1)) { g_eng.point = value; return NFA_OK; }
@@ -662,7 +672,7 @@ int nfa_runner_destroy(nfa_runner *r) {
     { RUNNER_LOCK(r); r->pending.n = 0; }
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamSynchronize(r->lanes[k]);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
-    for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_part[k]); }
+    for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_part[k]); (void)hipFree(r->d_queue[k]); (void)hipFree(r->d_order[k]); }
     if (r->g1) (void)hipGraphExecDestroy(r->g1);
     if (r->h_pin) (void)hipHostFree(r->h_pin);
     if (r->h_point) (void)hipHostFree(r->h_point);
@@ -741,11 +751,16 @@ static int reserve_lane(nfa_runner *r, int slot, int64_t B) {
     const int n_spec = r->ss->dev.n_spec;
     if (slot == 0 && r->g1) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
     HIP_TRY(hipStreamSynchronize(r->lanes[slot]));
-    (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_part[slot]);
-    r->d_D[slot] = nullptr; r->d_part[slot] = nullptr; r->cap_D[slot] = 0;
+    (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_part[slot]); (void)hipFree(r->d_order[slot]);
+    r->d_D[slot] = nullptr; r->d_part[slot] = nullptr; r->d_order[slot] = nullptr; r->cap_D[slot] = 0;
     const int64_t cap = std::max<int64_t>(B, 4096);
     HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec_size(r->ncomp, n_spec)));
     HIP_TRY(hipMalloc(&r->d_part[slot], sizeof(double) * cap * n_spec));
+    HIP_TRY(hipMalloc(&r->d_order[slot], sizeof(int) * cap * NFA_ORDER_CLASSES));
+    if (!r->d_queue[slot]) {
+        HIP_TRY(hipMalloc(&r->d_queue[slot], sizeof(unsigned) * NFA_QUEUE_WORDS));
+        HIP_TRY(hipMemset(r->d_queue[slot], 0, sizeof(unsigned) * NFA_QUEUE_WORDS));
+    }
     r->cap_D[slot] = cap;
     return NFA_OK;
 }
@@ -758,10 +773,15 @@ static size_t setup_lds_bytes(const nfa_runner *r, int mode, bool has_prior) {
     return sizeof(double) * ((setup_uses_tables(r, mode) ? (SM_END_TABLE - SM_EXP2) : NFA_EXP2_N) + work);
 }
 
+static bool lnl_uses_queue(const nfa_runner *r, const SpecDev &S, int64_t B, int mode);
 static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot, int mode) {
     const SpecDev S = runner_specdev(r);
     hipStream_t st = r->lanes[slot];
     int rc = reserve_lane(r, slot, B); if (rc) return rc;
+    // the likelihood launch behind this one draws its units from a queue: the items' order by cost is formed here
+    SetupOrder order = {nullptr, nullptr, 0};
+    if (g_eng.lnl_order && lnl_uses_queue(r, S, B, mode) && r->d_order[slot])
+        order = SetupOrder{r->d_queue[slot] + 2 * NFA_QUEUE_STRIDE, r->d_order[slot], (long)r->cap_D[slot]};
     if (has_prior && !r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     const PriorProg *prog = has_prior ? (const PriorProg *)r->pr->d_prog : nullptr;
     // items per workgroup and waves per workgroup (options setup_ti, setup_threads: A/B knobs)
@@ -776,10 +796,10 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     (void)d_U;                                               // the batches' arrays travel in r->cur_group
     if (r->ev_cur)      // profiling: the events ride on the dispatch itself -- its own start and stop, as a tracer sees them
         hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, r->ev_cur[0], r->ev_cur[1], 0, prog, S, r->cur_group, r->d_D[slot], (long)B,
-                              has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti);
+                              has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti, order);
     else
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, prog, S, r->cur_group, r->d_D[slot], (long)B,
-                           has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti);
+                           has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti, order);
     HIP_TRY(hipGetLastError());
     return NFA_OK;
 }
@@ -798,6 +818,21 @@ static int lnl_wave_doubles(const nfa_runner *r) {
     return (r->ncomp * r->ss->nhf_max * per_line + 1) & ~1;          // 16-byte records: an even number of doubles
 }
 
+// waves per workgroup of a table-mode launch with one wave per unit: the workgroup stages 51 KB of product tables, so it
+// is made as fat as keeps the most waves resident per CU (ties: more workgroups, so that one stages while another computes)
+static int table_waves(const nfa_runner *r) {
+    if (r->wpb_table > 0) return r->wpb_table;
+    const int n_shared = SM_END_TABLE - SM_EXP2, wave_doubles = lnl_wave_doubles(r);
+    int best = -1, best_blocks = 0, waves = 16;
+    for (int w = 4; w <= 16; w += 2) {
+        const size_t need = sizeof(double) * ((size_t)n_shared + (size_t)wave_doubles * w);
+        const int blocks = (int)((160 * 1024) / need);
+        const int resident = std::min(32, blocks * w);
+        if (resident > best || (resident == best && blocks > best_blocks)) { best = resident; best_blocks = blocks; waves = w; }
+    }
+    return waves;
+}
+
 // waves per unit of a launch of B items (runner option lnl_split; 0 = by the size of the launch)
 static int resolve_split(const nfa_runner *r, const SpecDev &S, int64_t B) {
     int split = r->lnl_split;
@@ -810,6 +845,14 @@ static int resolve_split(const nfa_runner *r, const SpecDev &S, int64_t B) {
     for (int k = 0; k < S.n_spec; ++k) min_rows = std::min(min_rows, (S.size[k] + 63) / 64);
     while (split > 1 && split > min_rows) split /= 2;
     return split;
+}
+
+// table mode, one wave per unit, at least two units per wave slot of the device: as many workgroups as are resident at
+// once, the units drawn from the launch's queue (lnl_kernel_queue)
+static bool lnl_uses_queue(const nfa_runner *r, const SpecDev &S, int64_t B, int mode) {
+    if (mode != 0 || g_eng.lnl_queue == 0 || lnl_wide(r)) return false;
+    if (resolve_split(r, S, B) != 1 || table_waves(r) != 16) return false;
+    return B * S.n_spec >= 2 * ((int64_t)g_eng.n_cu * 2) * 16;
 }
 
 template <int MODE, bool WS, bool WIDE, int NCOMP>
@@ -836,28 +879,29 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     waves = std::max(waves, split);
     waves -= waves % split;
     if (MODE == 0 && split > 1) waves = std::max(8, split);
-    if (MODE == 0 && split == 1) {
-        waves = r->wpb_table;
-        if (waves <= 0) {
-            int best = -1, best_blocks = 0;
-            for (int w = 4; w <= 16; w += 2) {
-                const size_t need = sizeof(double) * ((size_t)n_shared + (size_t)G.wave_doubles * w);
-                const int blocks = (int)((160 * 1024) / need);
-                const int resident = std::min(32, blocks * w);
-                if (resident > best || (resident == best && blocks > best_blocks)) { best = resident; best_blocks = blocks; waves = w; }
-            }
-        }
+    if (MODE == 0 && split == 1) waves = table_waves(r);
+    G.queue = nullptr; G.order = nullptr; G.order_cap = 0;
+    G.qmode = g_eng.lnl_queue;
+#ifdef NFA_TEST_HOOKS
+    G.trace = g_eng.d_trace;
+#endif
+    const int64_t n_units = B * S.n_spec, wg_resident = (int64_t)g_eng.n_cu * (g_eng.lnl_queue_wg > 0 ? g_eng.lnl_queue_wg : 2);
+    if (MODE == 0 && !WIDE && r->d_queue[slot] && lnl_uses_queue(r, S, B, 0)) {
+        G.queue = r->d_queue[slot];
+        if (g_eng.lnl_order && r->d_order[slot]) { G.order = r->d_order[slot]; G.order_cap = (long)r->cap_D[slot]; }
     }
-    size_t lds = sizeof(double) * ((size_t)n_shared + ((size_t)G.wave_doubles + (split > 1 ? LNL_PARTS * 64 : 0)) * (waves / split));
+    size_t lds = sizeof(double) * ((size_t)n_shared + ((size_t)G.wave_doubles + (split > 1 ? LNL_PARTS * 64 : 0)) * (waves / split))
+               + (G.queue ? 16 : 0);
     if (MODE == 0) lds = std::max(lds, sizeof(double) * (size_t)(n_shared + SM_TABLE_TAIL));
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "ncomp too large for the LDS line table");
     if (MODE != 0 && r->lnl_cap > 0 && waves * r->lnl_cap < 32)      // residency cap: see Engine::lnl_cap
         lds = std::max(lds, (size_t)((160 * 1024) / r->lnl_cap) & ~(size_t)15);
     void (*kern)(SpecDev, BatchGroup, const double *, double *, double *, long, LnlGeom, const double *) = lnl_kernel<MODE, WS, WIDE, NCOMP>;
+    if constexpr (MODE == 0 && !WIDE) { if (G.queue) kern = lnl_kernel_queue<WS, NCOMP>; }
     { int rc2 = ensure_dynamic_lds((const void *)kern, lds); if (rc2) return rc2; }
     const int64_t units = B * S.n_spec;
     const int64_t upw = waves / split;
-    const int64_t blocks = (units + upw - 1) / upw;
+    const int64_t blocks = G.queue ? wg_resident : (units + upw - 1) / upw;
     if (blocks > 0x7fffffffLL) return fail(NFA_ERR_ARG, "batch too large for one launch");
     hipStream_t st = r->lanes[slot];
     (void)d_pix;

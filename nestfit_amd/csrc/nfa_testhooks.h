@@ -200,3 +200,25 @@ int nfa_test_callback_latency(nfa_loglike_callback_fn callback, void *runner, in
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+//  timeline of the queue form of the table-mode likelihood kernel (lnl_kernel_queue): with a buffer attached every
+//  wave of a launch records {start, end, item * nspec + spectrum, position in the order} of up to 8 units, in ticks of
+//  10 ns (s_memrealtime); the buffer holds the last launch
+// ---------------------------------------------------------------------------
+#define NFA_TRACE_WAVES 8192
+int nfa_test_queue_trace(int on) {
+    int rc0 = engine_init(); if (rc0) return rc0;
+    if (on && !g_eng.d_trace) {
+        HIP_TRY(hipMalloc(&g_eng.d_trace, sizeof(unsigned long long) * NFA_TRACE_WAVES * 8 * 4));
+    }
+    if (on) HIP_TRY(hipMemset(g_eng.d_trace, 0, sizeof(unsigned long long) * NFA_TRACE_WAVES * 8 * 4));
+    if (!on && g_eng.d_trace) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(g_eng.d_trace); g_eng.d_trace = nullptr; }
+    return NFA_OK;
+}
+int nfa_test_queue_trace_read(unsigned long long *out) {
+    if (!g_eng.d_trace) return fail(NFA_ERR_STATE, "no trace buffer");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, g_eng.d_trace, sizeof(unsigned long long) * NFA_TRACE_WAVES * 8 * 4, hipMemcpyDeviceToHost));
+    return NFA_OK;
+}

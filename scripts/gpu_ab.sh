@@ -6,7 +6,7 @@ rounds=$1; shift
 args=()
 while [ "$1" != "--" ]; do args+=("$1"); shift; done
 shift
-out=gpurun_out/r04/ab; mkdir -p $out
+out=gpurun_out/${NFA_ROUND:-r05}/ab; mkdir -p $out
 for r in $(seq $rounds); do
   for lib in "$@"; do
     tag=$(basename $lib .so)
@@ -14,11 +14,11 @@ for r in $(seq $rounds); do
   done
 done
 python - "$@" <<'P'
-import json, sys, glob, statistics as st
+import json, sys, glob, os, statistics as st
 for lib in sys.argv[1:]:
     tag = lib.split('/')[-1][:-3]
     v, k, s = [], [], []
-    for f in sorted(glob.glob(f'gpurun_out/r04/ab/{tag}_[0-9].json')):
+    for f in sorted(glob.glob(f"gpurun_out/{os.environ.get('NFA_ROUND', 'r05')}/ab/{tag}_[0-9].json")):
         d = json.loads(open(f).read().strip().splitlines()[-1])
         m = d['modes'][d['config']['exp_mode']]
         v.append(d['value'] / 1e6); k.append(m.get('lnl_kernel_us', 0)); s.append(m.get('setup_kernel_us', 0))
