@@ -538,7 +538,6 @@ def main():
     ap.add_argument('--wpb-table', type=int, default=0, help='engine A/B knob: waves per workgroup in table mode (0 = chosen per spectra set)')
     ap.add_argument('--lnl-cap', type=int, default=-1, help='engine A/B knob: likelihood workgroups per CU (0 = no cap)')
     ap.add_argument('--lnl-split', type=int, default=-1, help='engine A/B knob: waves per (item, spectrum) unit (0 = by launch size)')
-    ap.add_argument('--lnl-order', type=int, default=-1, help='engine A/B knob (table mode): 0 = the queue takes the items as they come, 1 = by cost class')
     ap.add_argument('--lnl-queue-wg', type=int, default=0, help='engine A/B knob (table mode): workgroups per CU of a queue launch')
     ap.add_argument('--lnl-queue', type=int, default=-1, help='engine A/B knob (table mode): 0 = one unit per wave always, 1 = large launches draw their units from a queue')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
@@ -588,8 +587,6 @@ def main():
         _ffi.set_option('lnl_split', args.lnl_split)
     if args.lnl_queue >= 0:
         _ffi.set_option('lnl_queue', args.lnl_queue)
-    if args.lnl_order >= 0:
-        _ffi.set_option('lnl_order', args.lnl_order)
     if args.lnl_queue_wg > 0:
         _ffi.set_option('lnl_queue_wg', args.lnl_queue_wg)
     if args.prior_stage >= 0:

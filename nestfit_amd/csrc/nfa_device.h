@@ -129,7 +129,9 @@ __host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncom
 // Up to NFA_GROUP_MAX batches of `each` rows that a caller enqueues one after the other travel as ONE launch (the
 // engine coalesces them, nfa_engine.hip): item b of the launch is row b - c * each of batch c = b / each, and every
 // batch keeps its own pixel, unit-cube and result arrays.
+#ifndef NFA_GROUP_MAX
 #define NFA_GROUP_MAX 4
+#endif
 struct BatchGroup {
     const int *pix[NFA_GROUP_MAX];
     double    *U[NFA_GROUP_MAX];
@@ -138,7 +140,12 @@ struct BatchGroup {
     int        n;
 };
 __device__ __forceinline__ int group_of(const BatchGroup &g, long b) {
-    return g.n > 1 ? (int)(b >= g.each) + (int)(b >= 2 * g.each) + (int)(b >= 3 * g.each) : 0;
+    if (g.n <= 1) return 0;
+    int c = (int)(b >= g.each) + (int)(b >= 2 * g.each) + (int)(b >= 3 * g.each);
+#if NFA_GROUP_MAX > 4
+    for (int k = 4; k < NFA_GROUP_MAX; ++k) c += (int)(b >= k * g.each);
+#endif
+    return c;
 }
 
 #define LNL_PARTS 4      // row parts of a unit: the fixed shape of its chi^2 sum
@@ -151,9 +158,6 @@ struct LnlGeom {
 #ifdef NFA_TEST_HOOKS
     unsigned long long *trace;   // measurement (test library): per wave of the queue kernel 8 records {start, end, unit, position} in 10 ns ticks
 #endif
-    int qmode;          // experiments: 2 = the queue kernel with static strides instead of draws (timing only)
-    const int *order;   // the queue kernel's order of the items: item of class c and rank k at order[c * order_cap + k], the
-    long order_cap;     // classes' counts behind the queue's counters (set-up stage, setup_order); nullptr: as they come
     unsigned *queue;    // table mode, split == 1, launches of several units per wave slot (lnl_kernel_queue): the launch's
                         // chunk counter and, a 128-byte line behind it, its count of workgroups that have left
                         // (NFA_QUEUE_WORDS words, zero between launches); nullptr: one unit per wave (lnl_kernel)
@@ -877,7 +881,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // 0..31 the first component's lines, lanes 32..63 the second's -- two compares per row instead of four
     // (a compare costs as much as an fp64 operation, profiles/r02/ubench_valu.txt)
     constexpr bool PACK2 = MODE == 2 && !WIDE && NCOMP == 2;
-    constexpr bool HOISTX = MODE != 2;                         // exact modes: a component's Tb constants are read once per unit
+    constexpr bool HOISTX = false;                             // (round 4: the exact modes' Tb constants hoisted per unit; round 5: the cell form below needs none)
     int wlo2 = 0, whi2 = 0;
     double ck_kind[NC], ck_a0x[NC], ck_b0x[NC];
     // exact modes: the constants of a component's Tb pass (excitation temperature, its reciprocal, the band's cell of
@@ -954,12 +958,10 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             const unsigned jo = (unsigned)(valid ? j : N - 1) * 8u;           // byte offset of the lane's channel
             const double xj = *(const double *)((const char *)xs + jo);
             const double dj = *(const double *)((const char *)ds + jo);
-            double p3, T0, tbg;                        // read only where the branches below have set them
-            if (MODE == 2) p3 = *(const double *)((const char *)p3s + jo);
-            // exact modes: T0 and tbg of the channel for every Tb pass; the fast mode reads them inside the rare pass
-            // that needs them (y(T0) not a single table cell): carried through the row as "maybe loaded" values they
-            // cost two register copies per row
-            if (MODE != 2) { T0 = *(const double *)((const char *)t0s + jo); tbg = *(const double *)((const char *)tbgs + jo); }
+            double p3;
+            // T0 tbg of the channel; T0 and tbg themselves are read inside the rare pass that needs them (y(T0) not a single
+            // table cell): carried through the row as "maybe loaded" values they cost two register copies per row
+            p3 = *(const double *)((const char *)p3s + jo);
             double pred = 0.0;
             // one component: the lines in `mask` add their optical depths, then the Tb pass
             auto component = [&](int c, unsigned long long mask, double kind, double a0x, double b0x) {
@@ -1097,7 +1099,23 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         g = T0 * (y - tbg);
                     }
                     pred = __builtin_fma(g, one_minus_fastexp_f32((float)tau, livem), pred);
+                } else if (kind == 1.0) {
+                    // The band lies in ONE cell of the 1/(e^x - 1) table (hyperfine.pyx:23-45; the usual case): the cell's
+                    // straight line in x = T0 / tex is a straight line in the channel's frequency, and
+                    //     T0 (y - tbg) = B0x x^2 + A0x x - T0 tbg
+                    // with the two coefficients formed once per (item, component, spectrum) by the set-up stage -- two
+                    // fused multiply-adds per channel where the reference's order of operations (division, cell, slope,
+                    // difference, product: eight here, with the quotient by Markstein's step) rounds differently in the
+                    // sixteenth digit; the reference itself is built with -ffast-math and differs from its own strict
+                    // build by 1e-11.  FastExp of the optical depth, the factor with the table indices, is
+                    // the reference's to the bit.  Lanes with tau == 0 (skipped by the reference, hyperfine.pyx:104-105)
+                    // get g * (1 - 1) = +-0.
+                    const double g = __builtin_fma(xj, __builtin_fma(b0x, xj, a0x), -p3);
+                    pred = __builtin_fma(g, MODE == 0 ? one_minus_fastexp_table_row((double)tau) : nf_one_minus_fastexp_row<MODE>((double)tau, sm), pred);
                 } else {
+                    unsigned jr = jo;
+                    asm volatile("" : "+v"(jr));                      // the two addresses are formed here, not in every row's head
+                    const double T0 = *(const double *)((const char *)t0s + jr), tbg = *(const double *)((const char *)tbgs + jr);
                     // x = T0 / tex (hyperfine.pyx:107) without a division per channel: from the correctly rounded
                     // reciprocal the set-up stage left in the record, q = T0 r, e = T0 - tex q (exact, fused),
                     // x = q + e r is the correctly rounded quotient (Markstein's final step; the one exception,
@@ -1184,8 +1202,7 @@ lnl_kernel(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__re
 #define NFA_QUEUE_CHUNK  16u
 #define NFA_QUEUE_END    0xffffffffu
 #define NFA_QUEUE_STRIDE 32                                   // words between the two counters: a 128-byte line each
-#define NFA_ORDER_CLASSES 32                                  // cost classes of the items (a 128-byte line of counts behind the counters)
-#define NFA_QUEUE_WORDS  (2 * NFA_QUEUE_STRIDE + NFA_ORDER_CLASSES)
+#define NFA_QUEUE_WORDS  (2 * NFA_QUEUE_STRIDE)
 template <bool WRITE_SPEC, int NCOMP>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) __attribute__((amdgpu_waves_per_eu(8, 8)))
 lnl_kernel_queue(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__restrict__ part,
@@ -1209,30 +1226,10 @@ lnl_kernel_queue(SpecDev S, BatchGroup grp, const double *__restrict__ D, double
 #ifdef NFA_TEST_HOOKS
     int n_rec = 0;
 #endif
-    const unsigned nspec_q = (unsigned)S.n_spec;
-    const unsigned inv_nspec_q = G.inv_nspec;
 #pragma nounroll
     while (have || first_draw) {
       if (!first_draw) {
-        // Position `unit` of the launch's order -> (item, spectrum).  The set-up stage has put the items into classes of
-        // like cost, the dearest class first (setup_order): the units that take longest start first and the launch
-        // ends on its shortest ones, with every wave slot still at work.  Lane c holds the number of items in the
-        // classes from c on; the class of position p is the last one whose number exceeds p.
-        unsigned u_item = unit;
-        if (G.order) {
-            const unsigned p = inv_nspec_q ? __umulhi(unit, inv_nspec_q) : unit, sp = unit - p * nspec_q;
-            unsigned cnt = lane_q < NFA_ORDER_CLASSES ? q[2 * NFA_QUEUE_STRIDE + lane_q] : 0u;
-#pragma unroll
-            for (int d = 1; d < NFA_ORDER_CLASSES; d <<= 1) {          // suffix sums over lanes 0..31
-                const unsigned o = __shfl_down(cnt, d, 64);
-                cnt += (lane_q + d < NFA_ORDER_CLASSES) ? o : 0u;
-            }
-            const unsigned long long above = __builtin_amdgcn_ballot_w64(lane_q < NFA_ORDER_CLASSES && cnt > p);
-            const int cls = 63 - __builtin_clzll(above | 1ull);     // (p < B: lane 0's number is B, the mask is never empty)
-            const unsigned behind = cls + 1 < NFA_ORDER_CLASSES ? __shfl(cnt, cls + 1, 64) : 0u;
-            const int item = G.order[(long)cls * G.order_cap + (p - behind)];
-            u_item = (unsigned)__builtin_amdgcn_readfirstlane(item) * nspec_q + sp;
-        }
+        const unsigned u_item = unit;
 #ifdef NFA_TEST_HOOKS
         const unsigned long long t_start = wall_clock64();
 #endif
@@ -1281,8 +1278,6 @@ lnl_kernel_queue(SpecDev S, BatchGroup grp, const double *__restrict__ D, double
             if (__hip_atomic_fetch_add(out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
                 __hip_atomic_store(q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(out, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int i = 0; i < NFA_ORDER_CLASSES; ++i)
-                    __hip_atomic_store(q + 2 * NFA_QUEUE_STRIDE + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

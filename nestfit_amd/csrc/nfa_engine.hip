@@ -57,7 +57,6 @@ struct Engine {
                                      // whose waves draw the units from a queue (lnl_kernel_queue); 0 = one unit per wave always
     unsigned long long *d_trace = nullptr;   // test library: the queue kernel's per-wave records (nfa_test_queue_trace)
     int    lnl_queue_wg = 0;         // A/B: workgroups per CU of a queue launch (0 = 2)
-    int    lnl_order = 1;            // the queue takes the items in the order of their cost classes (setup_order); 0 = as they come
     int    lnl_cap = 0;              // fast / poly mode: workgroups of the likelihood kernel resident per CU at most
                                      // (LDS padding; 0 = no cap).  A/B knob: leaving one slot per CU to the set-up
                                      // kernels of the next batch paid off (+7 %) until those kernels got a raised wave
@@ -214,7 +213,6 @@ struct nfa_runner {
     hipStream_t lanes[NFA_MAX_LANES] = {};
     double     *d_D[NFA_MAX_LANES] = {};
     double     *d_part[NFA_MAX_LANES] = {};  // per (item, spectrum) log-likelihood terms
-    int        *d_order[NFA_MAX_LANES] = {}; // the items of the lane's launch by cost class (setup_order): NFA_ORDER_CLASSES x cap_D
     unsigned   *d_queue[NFA_MAX_LANES] = {}; // unit counters of the lane's table-mode launches (lnl_kernel_queue), zero between launches
     int64_t     cap_D[NFA_MAX_LANES] = {};
     hipStream_t stream = nullptr;            // lane 0: also the stream of the host-pointer entry points
@@ -303,8 +301,7 @@ int nfa_get_exp_mode(void) { return g_eng.exp_mode; }
 int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "lnl_cap") && value >= 0 && value <= 8) { g_eng.lnl_cap = value; return NFA_OK; }
     if (key && !strcmp(key, "lnl_queue_wg") && value >= 0 && value <= 2) { g_eng.lnl_queue_wg = value; return NFA_OK; }
-    if (key && !strcmp(key, "lnl_order") && (value == 0 || value == 1)) { g_eng.lnl_order = value; return NFA_OK; }
-    if (key && !strcmp(key, "lnl_queue") && value >= 0 && value <= 2) { g_eng.lnl_queue = value; return NFA_OK; }
+    if (key && !strcmp(key, "lnl_queue") && (value == 0 || value == 1)) { g_eng.lnl_queue = value; return NFA_OK; }
     if (key && !strcmp(key, "lnl_split") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_eng.lnl_split = value; return NFA_OK; }
     if (key && !strcmp(key, "graph") && (value == 0 || value == 1)) { g_eng.graph = value; return NFA_OK; }
     if (key && !strcmp(key, "point") && (value == 0 || value == 1)) { g_eng.point = value; return NFA_OK; }
@@ -672,7 +669,7 @@ int nfa_runner_destroy(nfa_runner *r) {
     { RUNNER_LOCK(r); r->pending.n = 0; }
     for (int k = 0; k < r->n_lanes; ++k) (void)hipStreamSynchronize(r->lanes[k]);
     (void)hipFree(r->d_U); (void)hipFree(r->d_lnL); (void)hipFree(r->d_pix); (void)hipFree(r->d_spec);
-    for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_part[k]); (void)hipFree(r->d_queue[k]); (void)hipFree(r->d_order[k]); }
+    for (int k = 0; k < r->n_lanes; ++k) { (void)hipFree(r->d_D[k]); (void)hipFree(r->d_part[k]); (void)hipFree(r->d_queue[k]); }
     if (r->g1) (void)hipGraphExecDestroy(r->g1);
     if (r->h_pin) (void)hipHostFree(r->h_pin);
     if (r->h_point) (void)hipHostFree(r->h_point);
@@ -751,12 +748,11 @@ static int reserve_lane(nfa_runner *r, int slot, int64_t B) {
     const int n_spec = r->ss->dev.n_spec;
     if (slot == 0 && r->g1) { (void)hipGraphExecDestroy(r->g1); r->g1 = nullptr; }
     HIP_TRY(hipStreamSynchronize(r->lanes[slot]));
-    (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_part[slot]); (void)hipFree(r->d_order[slot]);
-    r->d_D[slot] = nullptr; r->d_part[slot] = nullptr; r->d_order[slot] = nullptr; r->cap_D[slot] = 0;
+    (void)hipFree(r->d_D[slot]); (void)hipFree(r->d_part[slot]);
+    r->d_D[slot] = nullptr; r->d_part[slot] = nullptr; r->cap_D[slot] = 0;
     const int64_t cap = std::max<int64_t>(B, 4096);
     HIP_TRY(hipMalloc(&r->d_D[slot], sizeof(double) * cap * drec_size(r->ncomp, n_spec)));
     HIP_TRY(hipMalloc(&r->d_part[slot], sizeof(double) * cap * n_spec));
-    HIP_TRY(hipMalloc(&r->d_order[slot], sizeof(int) * cap * NFA_ORDER_CLASSES));
     if (!r->d_queue[slot]) {
         HIP_TRY(hipMalloc(&r->d_queue[slot], sizeof(unsigned) * NFA_QUEUE_WORDS));
         HIP_TRY(hipMemset(r->d_queue[slot], 0, sizeof(unsigned) * NFA_QUEUE_WORDS));
@@ -773,15 +769,10 @@ static size_t setup_lds_bytes(const nfa_runner *r, int mode, bool has_prior) {
     return sizeof(double) * ((setup_uses_tables(r, mode) ? (SM_END_TABLE - SM_EXP2) : NFA_EXP2_N) + work);
 }
 
-static bool lnl_uses_queue(const nfa_runner *r, const SpecDev &S, int64_t B, int mode);
 static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, int slot, int mode) {
     const SpecDev S = runner_specdev(r);
     hipStream_t st = r->lanes[slot];
     int rc = reserve_lane(r, slot, B); if (rc) return rc;
-    // the likelihood launch behind this one draws its units from a queue: the items' order by cost is formed here
-    SetupOrder order = {nullptr, nullptr, 0};
-    if (g_eng.lnl_order && lnl_uses_queue(r, S, B, mode) && r->d_order[slot])
-        order = SetupOrder{r->d_queue[slot] + 2 * NFA_QUEUE_STRIDE, r->d_order[slot], (long)r->cap_D[slot]};
     if (has_prior && !r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     const PriorProg *prog = has_prior ? (const PriorProg *)r->pr->d_prog : nullptr;
     // items per workgroup and waves per workgroup (options setup_ti, setup_threads: A/B knobs)
@@ -796,10 +787,10 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     (void)d_U;                                               // the batches' arrays travel in r->cur_group
     if (r->ev_cur)      // profiling: the events ride on the dispatch itself -- its own start and stop, as a tracer sees them
         hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, r->ev_cur[0], r->ev_cur[1], 0, prog, S, r->cur_group, r->d_D[slot], (long)B,
-                              has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti, order);
+                              has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti);
     else
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, prog, S, r->cur_group, r->d_D[slot], (long)B,
-                           has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti, order);
+                           has_prior ? 1 : 0, (const double *)g_eng.d_tabs, g_eng.ablate, ti);
     HIP_TRY(hipGetLastError());
     return NFA_OK;
 }
@@ -880,16 +871,12 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     waves -= waves % split;
     if (MODE == 0 && split > 1) waves = std::max(8, split);
     if (MODE == 0 && split == 1) waves = table_waves(r);
-    G.queue = nullptr; G.order = nullptr; G.order_cap = 0;
-    G.qmode = g_eng.lnl_queue;
+    G.queue = nullptr;
 #ifdef NFA_TEST_HOOKS
     G.trace = g_eng.d_trace;
 #endif
     const int64_t n_units = B * S.n_spec, wg_resident = (int64_t)g_eng.n_cu * (g_eng.lnl_queue_wg > 0 ? g_eng.lnl_queue_wg : 2);
-    if (MODE == 0 && !WIDE && r->d_queue[slot] && lnl_uses_queue(r, S, B, 0)) {
-        G.queue = r->d_queue[slot];
-        if (g_eng.lnl_order && r->d_order[slot]) { G.order = r->d_order[slot]; G.order_cap = (long)r->cap_D[slot]; }
-    }
+    if (MODE == 0 && !WIDE && r->d_queue[slot] && lnl_uses_queue(r, S, B, 0)) G.queue = r->d_queue[slot];
     size_t lds = sizeof(double) * ((size_t)n_shared + ((size_t)G.wave_doubles + (split > 1 ? LNL_PARTS * 64 : 0)) * (waves / split))
                + (G.queue ? 16 : 0);
     if (MODE == 0) lds = std::max(lds, sizeof(double) * (size_t)(n_shared + SM_TABLE_TAIL));
@@ -1059,14 +1046,14 @@ int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_
     const int64_t units = B * r->ss->dev.n_spec, slots = (int64_t)g_eng.n_cu * 32;
     BatchGroup &p = r->pending;
     const int group = g_eng.coalesce;                  // read per call: a knob, not part of a runner's identity
-    const bool fits = group > 1 && !r->profiling && B % ti == 0 && 2 * units <= 4 * slots;   // (a group stays below 4 waves per slot)
+    const bool fits = group > 1 && !r->profiling && B % ti == 0 && 2 * units <= NFA_GROUP_MAX * slots;   // (a group stays below NFA_GROUP_MAX waves per slot)
     if (p.n > 0 && (!fits || p.each != (long)B || (p.pix[0] == nullptr) != (d_pix == nullptr) ||
-                    (int64_t)(p.n + 1) * units > 4 * slots)) {
+                    (int64_t)(p.n + 1) * units > NFA_GROUP_MAX * slots)) {
         int rc = flush_pending(r); if (rc) return rc;
     }
     if (!fits) return run_batch(r, d_pix, d_U, d_lnL, nullptr, B, true, -1, nullptr);
     p.pix[p.n] = d_pix; p.U[p.n] = d_U; p.lnL[p.n] = d_lnL; p.each = (long)B; p.n += 1;
-    if (p.n >= group || (int64_t)(p.n + 1) * units > 4 * slots) return flush_pending(r);
+    if (p.n >= group || (int64_t)(p.n + 1) * units > NFA_GROUP_MAX * slots) return flush_pending(r);
     return NFA_OK;
 }
 

@@ -68,9 +68,9 @@ __global__ void __launch_bounds__(POINT_THREADS) ring_serve_kernel(const PriorPr
     unsigned turn = 0;
     for (;;) {
         // One turn: wave 0 looks at ONE slot -- lane 0 reads its state word, a trip over the bus; a posted point then
-        // costs one more trip for everything the request holds: lane j reads coordinate j, the last two lanes the pixel and
-        // the point count, all in flight together.  CLAIMED is a plain (posted) store: this workgroup is the only server
-        // of its slots.  Then the whole workgroup meets at the barrier and, with nothing posted, sleeps a microsecond.
+        // costs the claim (below) and one more trip for everything the request holds: lane j reads coordinate j, the last two
+        // lanes the pixel and the point count, all in flight together.  Then the whole workgroup meets at the barrier and,
+        // with nothing posted, sleeps a microsecond.
         // (A polling wave that spins by itself while the others wait at the barrier looks cheaper and is not: 14
         // workgroups served 164 k points/s that way against 390 k with a barrier per turn -- flags left in the
         // experiment's place, profiles/r04/ring.txt.)  The stop word and the clock are looked at every 16th turn.
@@ -90,8 +90,20 @@ __global__ void __launch_bounds__(POINT_THREADS) ring_serve_kernel(const PriorPr
                 unsigned state = 0;
                 if (tid == 0) state = rs_load_u32(s + RS_STATE);            // (one lane: 64 lanes at system scope are 64 trips)
                 state = __builtin_amdgcn_readfirstlane(state);
+                // A posted point is claimed by compare-and-swap, like every other server of a ring claims (nfa_ring_serve's
+                // threads, a second resident kernel, nfa_ring_poll: nothing makes this workgroup the only server of its slots,
+                // and the client may take its request back -- POSTED -> FREE -- at any moment): one more trip over the bus, on
+                // a hit only.  The request is read behind the successful claim (acquire).
                 if (state == (unsigned)RING_POSTED) {
-                    if (tid == 0) __hip_atomic_store((unsigned *)(s + RS_STATE), (unsigned)RING_CLAIMED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    unsigned got = 0u;
+                    if (tid == 0) {
+                        unsigned expect = (unsigned)RING_POSTED;
+                        got = __hip_atomic_compare_exchange_strong((unsigned *)(s + RS_STATE), &expect, (unsigned)RING_CLAIMED, __ATOMIC_ACQUIRE,
+                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 1u : 0u;
+                    }
+                    state = __builtin_amdgcn_readfirstlane(got) ? (unsigned)RING_POSTED : (unsigned)RING_FREE;
+                }
+                if (state == (unsigned)RING_POSTED) {
                     const unsigned char *s_cube = s + RS_DATA + 8ull * A.max_points;
                     double v = 0.0;
                     unsigned w = 0;
@@ -221,8 +233,10 @@ int nfa_ring_serve_device(nfa_ring *ring, nfa_runner *run, int lifetime_ms, int 
     }
     unsigned long long *d_cnt = nullptr;
     HIP_TRY(hipMalloc((void **)&d_cnt, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(d_cnt, 0, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipDeviceSynchronize());
+    if (hipMemset(d_cnt, 0, 2 * sizeof(unsigned long long)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(d_cnt);
+        return fail(NFA_ERR_DEVICE, "the resident kernel's counters could not be cleared");
+    }
     RingServeArgs A;
     A.base = (unsigned char *)ring->dev_base;
     A.slot0 = sizeof(RingHeader); A.stride = h->slot_stride;
@@ -260,7 +274,11 @@ int nfa_ring_serve_device(nfa_ring *ring, nfa_runner *run, int lifetime_ms, int 
             nanosleep(&ts, nullptr);
         }
         if (q != hipSuccess) { (void)hipGetLastError(); rc_out = fail(NFA_ERR_DEVICE, "the resident serving kernel failed"); nfa_ring_stop(ring); break; }
-        HIP_TRY(hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost));
+        // (a device error from here on leaves through the common exit below: the ring must not go on advertising a
+        // server -- clients only give up on a ring with n_servers == 0 -- and is stopped for everybody)
+        if (hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError(); rc_out = fail(NFA_ERR_DEVICE, "the resident kernel's counters could not be read"); nfa_ring_stop(ring); break;
+        }
         const unsigned long long served = h_cnt[0] + h_cnt[1];
         const int64_t now = ring_now_us();
         if (served != served_before) {

@@ -430,50 +430,11 @@ __device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const doubl
 #define SETUP_THREADS 256
 // the set-up stage of the 64 items of workgroup `block_id`, by the blockDim.x threads of the workgroup (`sm` =
 // the staged exponential tables, n_shared doubles at the start of smem)
-// The order in which the queue form of the table-mode likelihood kernel (lnl_kernel_queue) takes the items of a launch:
-// classes of like cost, the dearest first.  What a unit costs is its line x row steps, and those go with the widths of
-// its components' lines: a line's window is ten sigma wide (hyperfine.pyx:77-81), i.e. 10 sigma nu / (c nu_chan)
-// channels.  The class of an item is twice the number of 64-channel rows its windows span in the first spectrum, summed
-// over the components (capped); an item takes the next free place of its class -- one returning add per wave and class
-// present in it -- and writes its number there.  Lanes = the workgroup's items (wave 0).
-struct SetupOrder { unsigned *counts; int *items; long cap; };
-__device__ __forceinline__ void setup_order(const SetupOrder &O, const SpecDev &S, const double *th_all, long b0, int n_it, int tid) {
-    if (tid >= 64) return;
-    const int ncomp = S.ncomp;
-    const int sig0 = S.model == NFA_MODEL_AMMONIA ? 4 * ncomp : S.model == NFA_MODEL_GAUSSIAN ? ncomp : 3 * ncomp;
-    const double per_kms = 10.0 / NFA_CKMS * S.rest[0] / S.nu_chan[0] / 64.0;       // rows per km/s of sigma
-    int cls = -1;
-    if (tid < n_it) {
-        double rows = 0.0;
-        for (int c = 0; c < ncomp; ++c) {
-            const double sg = th_all[(sig0 + c) * 64 + tid];
-            rows += (sg > 0.0 && sg < 1e30 ? sg * per_kms : 0.0) + 1.0;
-        }
-        const double k = 2.0 * rows;
-        cls = k < (double)(NFA_ORDER_CLASSES - 1) ? (int)k : NFA_ORDER_CLASSES - 1;
-    }
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(cls >= 0);
-    const unsigned long long below = (1ull << tid) - 1ull;
-    int place = 0;
-    while (todo) {
-        const int c0 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(todo));
-        const unsigned long long same = __builtin_amdgcn_ballot_w64(cls == c0);
-        unsigned first = 0;
-        if (tid == __builtin_ctzll(same))
-            first = __hip_atomic_fetch_add(O.counts + c0, (unsigned)__builtin_popcountll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        first = __builtin_amdgcn_readlane(first, __builtin_ctzll(same));
-        if (cls == c0) place = (int)first + __builtin_popcountll(same & below);
-        todo &= ~same;
-    }
-    if (cls >= 0) O.items[(long)cls * O.cap + place] = (int)(b0 + tid);
-}
-
 template <int MODE, bool FAST = false>
 __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, const SpecDev &S,
                                            double *__restrict__ U, double *__restrict__ D, long B, int has_prior,
                                            const double *__restrict__ g_tabs, int ablate_in, double *smem,
-                                           const double *sm, int n_shared, unsigned block_id, int ti = SETUP_TI,
-                                           const SetupOrder *order = nullptr) {
+                                           const double *sm, int n_shared, unsigned block_id, int ti = SETUP_TI) {
 #ifdef NFA_ABLATE
     const int ablate = ablate_in;      // timing experiments: 16 skip the priors, 32 the partition sums, 64 the derive phase
 #else
@@ -527,7 +488,6 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
             const int it = q / ndim, k = q - it * ndim;
             U[b0 * ndim + q] = th_all[k * 64 + it];
         }
-    if (order && order->items) setup_order(*order, S, th_all, b0, n_it, tid);
     const bool ammonia = S.model == NFA_MODEL_AMMONIA;
     // ---- phase 2: lanes = (item, component, J mod 16)
     if (ammonia && !(ablate & 32)) {
@@ -558,7 +518,7 @@ template <int MODE, bool FAST = false>
 __global__ void __launch_bounds__(512) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
                                                     BatchGroup grp, double *__restrict__ D,
                                                     long B, int has_prior,
-                                                    const double *__restrict__ g_tabs, int ablate_in, int ti, SetupOrder order) {
+                                                    const double *__restrict__ g_tabs, int ablate_in, int ti) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // the workgroup's items belong to one batch of the group (the host sees to it that `each` is a multiple of ti):
     // its unit-cube array, shifted so that the body can go on indexing it with the item's number in the launch
@@ -567,7 +527,7 @@ __global__ void __launch_bounds__(512) setup_kernel(const PriorProg *__restrict_
     __builtin_amdgcn_s_setprio(3);
     int n_shared;
     const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
-    setup_body<MODE, FAST>(ppp, S, U, D, B, has_prior, g_tabs, ablate_in, smem, sm, n_shared, blockIdx.x, ti, &order);
+    setup_body<MODE, FAST>(ppp, S, U, D, B, has_prior, g_tabs, ablate_in, smem, sm, n_shared, blockIdx.x, ti);
 }
 
 // ---------------------------------------------------------------------------

@@ -122,7 +122,8 @@ class CubeFitter:
                     over = np.flatnonzero(nlive > SAMPLER_MAX_NLIVE)
                     print(f'-- {over.size} pixel(s) ask for more than {SAMPLER_MAX_NLIVE} live points (up to {int(nlive.max())}): clamped')
                     nlive = np.minimum(nlive, SAMPLER_MAX_NLIVE)
-                groups = [(sel, nlive) for sel in _runs_within_a_factor(nlive, 2.0)] if np.ndim(nlive) else [(np.arange(lon.size), nlive)]
+                # (each run carries the counts of ITS pixels: _fit_group indexes them by the pixel's place in the run)
+                groups = [(sel, nlive[sel]) for sel in _runs_within_a_factor(nlive, 2.0)] if np.ndim(nlive) else [(np.arange(lon.size), nlive)]
             else:
                 groups = [(np.flatnonzero(nlive == nl), int(nl)) for nl in np.unique(nlive)]
             workers = min(len(groups), self.group_workers) if self.fit_backend is None else 1
@@ -135,7 +136,7 @@ class CubeFitter:
                         f.result()
             else:
                 for sel, nl in groups:
-                    self._fit_group(hdf, lon[sel], lat[sel], nl if np.ndim(nl) == 0 else np.asarray(nl)[sel], kw)
+                    self._fit_group(hdf, lon[sel], lat[sel], nl, kw)
         hdf.close()                                  # saves the file (once)
         return hdf
 
@@ -163,6 +164,7 @@ class CubeFitter:
 
     def _fit_group(self, hdf, lon, lat, nlive, kw):
         """`nlive`: the group's number of live points, or one per pixel of the group."""
+        assert np.ndim(nlive) == 0 or np.shape(nlive) == (lon.size,), 'one live-point count per pixel of the group'
         old_lnZ = None
         nbest = np.zeros(lon.size, dtype=np.int64)
         alive = np.arange(lon.size)                      # pixels still adding components

@@ -1,6 +1,6 @@
 """Timeline of one table-mode launch of the metric's shape through the unit queue (lnl_kernel_queue): when the waves
 start and stop, how many are at work over the launch, how long a unit takes by its place in the order.
-Test library only (nfa_test_queue_trace).  usage: python scripts/queue_timeline.py [order 0|1] [rows]"""
+Test library only (nfa_test_queue_trace).  usage: python scripts/queue_timeline.py [rows]"""
 import ctypes as C
 import os
 import sys
@@ -13,11 +13,9 @@ import nestfit_amd as na
 from nestfit_amd import _ffi
 from nestfit_amd.synth import freq_axis
 
-order = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 12288
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
 lib = _ffi.load()
 na.set_exp_mode('table')
-_ffi.set_option('lnl_order', order)
 rng = np.random.default_rng(5)
 n = 1024
 spec_data = [[freq_axis(t, n), rng.normal(0, 0.2, n), 0.2, t] for t in (1, 2)]
@@ -35,7 +33,7 @@ t0 = rec[:, :, 0][used].min()
 start = (rec[:, :, 0] - t0) * 0.01
 end = (rec[:, :, 1] - t0) * 0.01                      # microseconds
 dur = (end - start)[used]
-print(f'order {order}, {B} rows x 2 spectra = {2 * B} units on {used.any(1).sum()} waves; units recorded {used.sum()}')
+print(f'{B} rows x 2 spectra = {2 * B} units on {used.any(1).sum()} waves; units recorded {used.sum()}')
 print(f'launch (first start to last end) {end[used].max():.1f} us; unit duration mean {dur.mean():.1f} us, sd {dur.std():.1f}, min {dur.min():.1f}, max {dur.max():.1f}')
 first = np.where(used.any(1), start[:, 0], np.nan)
 print(f'waves start {np.nanmin(first):.1f} .. {np.nanpercentile(first, 50):.1f} (median) .. {np.nanmax(first):.1f} us')

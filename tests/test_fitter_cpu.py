@@ -184,3 +184,31 @@ def test_lock_step_runs_are_cut_by_the_spread_of_live_points():
     for r in runs:
         assert nl[r].max() <= 2 * nl[r].min()
     assert len(_runs_within_a_factor(np.arange(100, 181), 2.0)) == 1
+
+
+@pytest.mark.parametrize('workers', [1, 3])
+def test_every_pixel_of_a_run_gets_its_own_live_points(tmp_path, workers):
+    """Pixels whose counts differ by more than a factor of two are fitted in several lock-step runs, side by side on
+    worker threads on the device path: whichever branch submits them, a run's pixels must arrive with THEIR counts (the
+    parallel branch once handed every run the whole stripe's array, so that all runs but the first took the first
+    pixels' counts).  The device path is stood in for by a stub that records what it is given."""
+    import nestfit_amd.fitter as fmod
+    stack = _stack(n_lon=7)
+    fit = _fitter(stack)
+    fit.nlive_snr_fact = 5
+    fit.fit_backend = None                                   # the device path's branch (threads), with the stub below
+    fit.group_workers = workers
+    want = {0: 24, 1: 500, 2: 30, 3: 40, 4: 1200, 5: 26}     # three runs: {24, 26, 30, 40}, {500}, {1200}
+    fit._nlive = lambda lon, lat: np.array([want[int(i)] for i in lon], dtype=np.int64)
+    seen = {}
+
+    def stub(lon, lat, ncomp, nlive, kw):
+        assert np.shape(nlive) == (lon.size,)
+        for i, n in zip(lon.tolist(), np.asarray(nlive).tolist()):
+            seen.setdefault(i, set()).add(n)
+        return _oracle_backend(fit, lon, lat, ncomp, np.minimum(nlive, 24), kw)
+    fit._fit_on_device = stub
+    lon, lat = np.arange(7), np.zeros(7, dtype=int)
+    fit.fit((lon, lat), tmp_path / 'chunk0.npz')
+    assert seen == {i: {n} for i, n in want.items()}
+    assert len(fmod._runs_within_a_factor(np.array(list(want.values())), 2.0)) == 3
