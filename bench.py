@@ -20,11 +20,13 @@ back `repeats_per_block` times (chosen so that a block lasts >= 20 ms whatever K
 between barrier + device synchronisation on both sides; its time is the maximum over ranks and `ms_per_step` =
 block time / (K x repeats).  `--blocks` blocks are timed; `value` is the median block (whole-job evaluations /
 block time), `spread` holds min / max; `k_steps_alone` is the same for blocks of exactly K steps.
-The three numerical modes are timed in the same run (`modes`); `value` is the fast mode, whose
-arithmetic `dtype` states.  `roofline`: algorithmic bytes per launch / the average duration of
-lnl_kernel, measured live with HIP events on a one-lane runner (launches do not overlap there, so
+Both numerical modes are timed in the same run (`modes`); `value`, `ms_per_step`, `dtype` and `roofline` are the
+TABLE mode's -- the reference's own arithmetic (core/fastexp.c:234-283: float-narrowed argument, f64 product of three
+table entries; models/hyperfine.pyx:93-96: tau summed in f64) --, the fast mode (f32 exponentials, <= 1e-6 on Tb) is
+the `fast_*` keys of `roofline` and `modes.fast`.  `roofline`: algorithmic bytes per launch / the average duration of
+the likelihood kernel, measured live with HIP events on a one-lane runner (launches do not overlap there, so
 the interval is what `rocprofv3 --kernel-trace --stats -- python bench.py --streams 1` reports for
-the kernel: profiles/r02/); the pipelined rate of the timed blocks is given beside it.
+the kernel: profiles/r05/); the pipelined rate of the timed blocks is given beside it.
 
 Rank 0 prints ONE JSON line (DESIGN.md "Measurement" explains every field).
 """
@@ -57,10 +59,12 @@ WORKLOADS = {
     'C4': ((1, 2, 3), 2048, 40.0, 3, 'TRUTH_3COMP', 4096),
     'C1': ((1,), 256, 30.0, 1, 'TRUTH_1COMP', 4096),
 }
-PROFILE_DIRS = [ROOT / 'profiles' / 'r04', ROOT / 'profiles' / 'r03', ROOT / 'profiles' / 'r02']
+PROFILE_DIRS = [ROOT / 'profiles' / 'r05', ROOT / 'profiles' / 'r04', ROOT / 'profiles' / 'r03', ROOT / 'profiles' / 'r02']
 MIN_BLOCK_S = 0.025            # length a timed block is sized for from a lone K-step probe (>= 20 ms in effect)
 MAX_BLOCK_STEPS = 4096
-LNL_KERNEL_NAME = {'fast': 'void lnl_kernel<2, false, false, 2>', 'table': 'void lnl_kernel<0, false, false, 2>'}
+# (table mode: launches of two and more units per wave slot -- the engine's coalesced steps -- run as lnl_kernel_queue)
+LNL_KERNEL_NAME = {'fast': 'void lnl_kernel<2, false, false, 2>', 'table': 'void lnl_kernel_queue<false, 2>'}
+OTHER_MODE = {'table': 'fast', 'fast': 'table'}
 
 
 def profile_file(name):
@@ -518,7 +522,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--blocks', type=int, default=61, help='timed blocks of --steps steps (value = the median block)')
+    ap.add_argument('--blocks', type=int, default=121, help='timed blocks of --steps steps (value = the median block)')
     ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS) + ['C5'],
                     help='C2 (default) is the headline metric; C5 = nested sampling of a 32x32 cube (not a "step" bench)')
     ap.add_argument('--side', type=int, default=128, help='pixels per side of the synthetic cube (C3: 128)')
@@ -526,7 +530,7 @@ def main():
     ap.add_argument('--pixels-per-step', default='1', choices=['1', 'B'],
                     help="1: the B rows of a step share one pixel (C2, the metric); B: every row has its own pixel "
                          "(one evaluation per pixel: the shape whose data really stream from HBM)")
-    ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', 'fast'), choices=list(MODES),
+    ap.add_argument('--exp-mode', default=os.environ.get('NFA_EXP_MODE', REFERENCE_PRECISION_MODE), choices=list(MODES),
                     help='the mode `value` is quoted in (both are timed)')
     ap.add_argument('--modes', default='all', choices=['all', 'one'], help='time both numerical modes or only --exp-mode')
     ap.add_argument('--spectra-out', default='auto', choices=['auto', 'on', 'off', 'only'],
@@ -645,9 +649,10 @@ def main():
     allrec = nfcomm.gather_pixel_records(rec, comm)
     assert allrec.shape == (world, 5) and (allrec[:, 0] % world == allrec[:, 2]).all()
 
-    # the spectra-out mode (the HBM-bound form of the path) on the same stripe, in the headline's mode
+    # the spectra-out mode (the HBM-bound form of the path) on the same stripe, in the fast mode (the form whose store
+    # counts: in the table mode the same rows are arithmetic for twice as long)
     if args.spectra_out == 'on' or (args.spectra_out == 'auto' and default_run):
-        spectra = M.run_spectra_out(na, args.exp_mode, max(5, args.blocks // 4))
+        spectra = M.run_spectra_out(na, 'fast', max(5, args.blocks // 8))
     spec0, ut, U_host = M.spec0, M.ut, M.U_host
     M.close()
     # BASELINE config 4 (three transitions x 2048 channels x 3 components: the LDS hyperfine-table stress), a short block
@@ -677,9 +682,18 @@ def main():
         head = per_mode[args.exp_mode]
         value = head['value']
         step_s = head['ms_per_step'] * 1e-3
+        # (key order: what reads this line keeps the first twenty scalars of `roofline` -- the headline mode's figures
+        # first, then the other mode's as other_*)
+        other = OTHER_MODE[args.exp_mode]
+        po = per_mode.get(other)
         roof = {'bound': 'valu', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
-                'kernel': 'lnl_kernel', 'algorithmic_bytes_per_eval': bytes_eval, 'evals_per_launch': B * steps_per_launch,
-                'steps_per_launch': steps_per_launch}
+                'kernel': LNL_KERNEL_NAME[args.exp_mode] if ncomp == 2 else 'lnl_kernel', 'mode': args.exp_mode,
+                'algorithmic_bytes_per_eval': bytes_eval, 'evals_per_launch': B * steps_per_launch,
+                'steps_per_launch': steps_per_launch, 'avg_launch_us': None, 'rocprof_avg_launch_us': None, 'rocprof_frac': None,
+                'pipeline_frac': None, 'valu_busy_frac': None, 'valu_instructions_per_eval': None}
+        if po:
+            roof.update({f'{other}_value': po['value'], f'{other}_frac': po.get('roofline_frac'), f'{other}_ms_per_step': po['ms_per_step'],
+                         f'{other}_avg_launch_us': po.get('lnl_kernel_us')})
         if 'lnl_kernel_us' in head:
             ach = bytes_eval * B * steps_per_launch / (head['lnl_kernel_us'] * 1e-6) / 1e9
             roof.update({'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'avg_launch_us': head['lnl_kernel_us'],

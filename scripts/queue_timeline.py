@@ -50,3 +50,11 @@ for a, b in ((0, 8192), (8192, 16384), (16384, 24576), (24576, 1 << 30)):
     m = (pos >= a) & (pos < b)
     if m.any():
         print(f'positions {a:6d}..{min(b, 2 * B):6d}: {m.sum():6d} units, duration mean {dur[m].mean():6.1f} us, start mean {s_[m].mean():6.1f} us')
+# who is slow: the first unit's duration by the wave's place in its workgroup, and by the workgroup's number
+w_in_wg = np.arange(8192) % 16
+d0 = np.where(used[:, 0], end[:, 0] - start[:, 0], np.nan)
+print('first unit, mean duration by wave of the workgroup: ' + ' '.join(f'{np.nanmean(d0[w_in_wg == k]):5.0f}' for k in range(16)))
+wg = np.arange(8192) // 16
+print('first unit, mean duration by workgroup number (eighths of the grid): ' + ' '.join(f'{np.nanmean(d0[(wg >= a) & (wg < a + 64)]):5.0f}' for a in range(0, 512, 64)))
+n_units = used.sum(1)
+print('units per wave by wave of the workgroup: ' + ' '.join(f'{n_units[w_in_wg == k].mean():4.1f}' for k in range(16)))
