@@ -161,10 +161,84 @@ def cpu_baseline(spec_data, program, ncomp, U, budget_s=12.0):
     }
 
 
+def c5_specified(na, mode, side=32, n=1024, seed=5):
+    """BASELINE config 5 as SURVEY.md 8d specifies it, through the cube driver: side x side pixels of config 3's generator
+    (two-component truths of the ParamSampler ranges, NH3 (1,1)+(2,2), n channels each, 0.2 K noise), 400 live points,
+    tol 0.5, efr 0.3, fixed seed, ncomp_max = 2 with the lnZ_thresh = 11 loop of nestfit/main.py:452-469
+    (CubeFitter.fit_cube into a store in a temporary directory), on the built-in device sampler (libmultinest is not
+    available here).  {seconds, evaluations, nbest histogram, mean lnZ_err ...} of the run in numerical mode `mode`."""
+    import tempfile
+    from nestfit_amd import _ffi
+    from nestfit_amd.fitter import CubeFitter
+    from nestfit_amd.store import HdfStore
+    from nestfit_amd.synth import c5_stack
+    stack, truths, model, data, axes, ut = c5_stack(side, n, 0.2)
+    n_pix = side * side
+    na.set_exp_mode(mode)
+    fitter = CubeFitter(stack, ut, na.AmmoniaRunner, lnZ_thresh=11, ncomp_max=2, nlive_snr_fact=0,
+                        mn_kwargs={'nlive': 400, 'tol': 0.5, 'efr': 0.3, 'seed': seed})
+    stages = {}
+    inner = fitter._fit_on_device
+
+    def counted(lon, lat, ncomp, nlive, kw):
+        t0 = time.perf_counter()
+        res, null_lnZ, n_chan_tot = inner(lon, lat, ncomp, nlive, kw)
+        st = stages.setdefault(int(ncomp), {'pixels': 0, 'seconds': 0.0, 'likelihood_evals': 0, 'iterations': 0, 'lnZ_err': []})
+        st['pixels'] += len(res); st['seconds'] += time.perf_counter() - t0
+        st['likelihood_evals'] += int(sum(r.n_evals for r in res)); st['iterations'] += int(sum(r.n_iter for r in res))
+        st['lnZ_err'] += [float(r.lnZ_err) for r in res]
+        return res, null_lnZ, n_chan_tot
+    fitter._fit_on_device = counted
+    with tempfile.TemporaryDirectory() as tmp:
+        _ffi.check(_ffi.load().nfa_device_synchronize())
+        t0 = time.perf_counter()
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):          # (the driver's progress lines)
+            fitter.fit_cube(os.path.join(tmp, 'c5'), nproc=1)
+        seconds = time.perf_counter() - t0
+        with HdfStore(os.path.join(tmp, 'c5')) as store:
+            nbest = np.array([int(g.attrs['nbest']) for g in store.iter_pix_groups()])
+    evals = sum(st['likelihood_evals'] for st in stages.values())
+    out = {'mode': mode, 'dtype': DTYPES[mode], 'seconds': seconds, 'pixels': n_pix, 'pixels_per_s': n_pix / seconds,
+           'likelihood_evals': evals, 'evals_per_pixel': evals / n_pix, 'evals_per_s': evals / seconds,
+           'nbest_histogram': {str(k): int((nbest == k).sum()) for k in (0, 1, 2)},
+           'mean_lnZ_err': float(np.mean(sum((st['lnZ_err'] for st in stages.values()), [])))}
+    for ncomp, st in sorted(stages.items()):
+        out[f'ncomp_{ncomp}'] = {'pixels': st['pixels'], 'seconds': st['seconds'], 'evals_per_pixel': st['likelihood_evals'] / max(st['pixels'], 1),
+                                 'iterations_per_pixel': st['iterations'] / max(st['pixels'], 1), 'mean_lnZ_err': float(np.mean(st['lnZ_err']))}
+    return out
+
+
+C5_WORKLOAD = ('C5: 32x32 pixels of the C3 generator (two-component truths, NH3 (1,1)+(2,2), 1024 channels each, 0.2 K), nlive 400, '
+               'tol 0.5, efr 0.3, seed 5, ncomp_max 2 / lnZ_thresh 11 through CubeFitter.fit_cube (nestfit/main.py:452-469); built-in '
+               'device sampler (libmultinest is not available), store written')
+
+
 def bench_c5(args):
-    """BASELINE config 5 on the built-in device sampler (one GPU): nested sampling with 400 live
-    points of every pixel of a 32x32 synthetic NH3 (1,1)+(2,2) cube, with one and with two velocity
-    components.  Not the headline metric: one JSON line of its own shape."""
+    """BASELINE config 5 as specified on one GPU, both numerical modes (or --modes one): one JSON line of
+    its own shape -- not the headline metric."""
+    import nestfit_amd as na
+    from nestfit_amd import _ffi
+    for key, val in (('setup_ti', args.setup_ti), ('setup_threads', args.setup_threads), ('wpb', args.wpb), ('streams', args.streams),
+                     ('sampler_parts', args.sampler_parts), ('sampler_refit_every', args.sampler_refit_every), ('sampler_walk_factor', args.sampler_walk_factor), ('sampler_ellipsoids', args.sampler_ellipsoids), ('sampler_walkers', args.sampler_walkers), ('lnl_cap', max(args.lnl_cap, 0))):
+        if val:
+            _ffi.set_option(key, val)
+    modes = list(MODES) if args.modes == 'all' else [args.exp_mode]
+    c5_specified(na, 'fast', side=8, n=256)                     # (code objects, streams and buffers come up outside the clock)
+    out = {m: c5_specified(na, m) for m in modes}
+    head = out[modes[0]]
+    print(json.dumps({
+        'metric': 'seconds, nested-sampling fit of the 32x32 NH3(1,1)+(2,2) cube of BASELINE config 5 (400 live points, ncomp_max 2)',
+        'value': head['seconds'], 'unit': 's', 'n_gpus': 1, 'higher_is_better': False,
+        'vs_baseline': None, 'dtype': DTYPES[modes[0]], 'data': 'synthetic',
+        'config': {'workload': C5_WORKLOAD, 'exp_mode': modes[0]}, 'modes': out}))
+
+
+def bench_c5_round4_shape(args):
+    """The cube rounds 2-4 timed as "C5" (--workload C5r4; kept so that the sampler's numbers stay comparable across
+    rounds): nested sampling with 400 live points of every pixel of a 32x32 synthetic NH3 (1,1)+(2,2) cube of 512 channels
+    with ONE-component truths, fitted with one and with two velocity components in two lock-step runs (no component
+    loop, no store).  BASELINE config 5 as SURVEY specifies it is --workload C5 (c5_specified)."""
     import nestfit_amd as na
     from nestfit_amd import _ffi, sampler
     from nestfit_amd.cube import CubeRunner
@@ -216,8 +290,8 @@ def bench_c5(args):
         'metric': 'pixels/sec, nested sampling (400 live points) of a 32x32 NH3(1,1)+(2,2) cube, 1 component',
         'value': out[1]['pixels_per_s'], 'unit': 'pixels/s', 'n_gpus': 1, 'higher_is_better': True,
         'vs_baseline': None, 'dtype': DTYPES[args.exp_mode], 'data': 'synthetic',
-        'config': {'workload': 'C5: 32x32 pixels x 2 spectra x 512 channels, built-in device sampler '
-                               '(libmultinest is not available), tol 0.5, efr 0.3', 'exp_mode': args.exp_mode},
+        'config': {'workload': 'C5r4 (rounds 2-4 shape, NOT the specified config 5): 32x32 pixels x 2 spectra x 512 channels, one-component '
+                               'truths, built-in device sampler (libmultinest is not available), tol 0.5, efr 0.3', 'exp_mode': args.exp_mode},
         'one_component': out[1], 'two_components': out[2]}))
 
 
@@ -523,7 +597,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--blocks', type=int, default=121, help='timed blocks of --steps steps (value = the median block)')
-    ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS) + ['C5'],
+    ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS) + ['C5', 'C5r4'],
                     help='C2 (default) is the headline metric; C5 = nested sampling of a 32x32 cube (not a "step" bench)')
     ap.add_argument('--side', type=int, default=128, help='pixels per side of the synthetic cube (C3: 128)')
     ap.add_argument('--batch', type=int, default=0, help='rows per step (default: workload B)')
@@ -565,6 +639,8 @@ def main():
 
     if args.workload == 'C5':
         return bench_c5(args)
+    if args.workload == 'C5r4':
+        return bench_c5_round4_shape(args)
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         relaunch_one_rank_per_gpu(args)
@@ -667,6 +743,11 @@ def main():
             **{m: {k: e.get(k) for k in ('value', 'ms_per_step', 'blocks', 'repeats_per_block', 'lnl_kernel_us', 'evals_per_launch',
                                           'roofline_frac', 'min', 'max', 'dtype')} for m, e in pm4.items()}}
         M4.close()
+        # BASELINE config 5 as specified (the cube driver's component loop on the device sampler, a store written), in the
+        # fast mode (`python bench.py --workload C5` runs it in both)
+        if rank == 0 and world == 1:
+            c5_specified(na, 'fast', side=8, n=256)             # (code objects, streams and buffers come up outside the clock)
+            configs['C5'] = {'workload': C5_WORKLOAD, **c5_specified(na, 'fast')}
 
     # which device every rank computes on (two ranks on one GPU, or a silent fallback, show on the line)
     ubuf = C.create_string_buffer(40)
@@ -780,9 +861,12 @@ def main():
                 roof['spectra_out_traffic_frac_of_peak'] = spectra['traffic_frac_of_peak']
             except Exception:
                 pass
+        if 'C5' in configs:
+            roof['C5_seconds'] = configs['C5']['seconds']
+            roof['C5_evals_per_pixel'] = configs['C5']['evals_per_pixel']
         for cname, cfg in configs.items():
             for m in MODES:
-                if m in cfg:
+                if m in cfg and isinstance(cfg[m], dict):
                     roof[f'{cname}_{m}_value'] = cfg[m]['value']
                     roof[f'{cname}_{m}_frac'] = cfg[m].get('roofline_frac')
         roof['note'] = ('achieved / frac: algorithmic bytes (SURVEY 8d) per launch / lnl_kernel time per launch -- the launch the '

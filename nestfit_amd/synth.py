@@ -28,3 +28,41 @@ def param_sampler_draw(rng, vsep=(0.16, 3), trot=(3, 30), tex=(2.8, 12), ntot=(1
     return np.concatenate([
         [0.0, v], rng.uniform(*trot, size=2), rng.uniform(*tex, size=2),
         rng.uniform(*ntot, size=2), rng.uniform(*sigm, size=2), rng.uniform(*orth, size=2)])
+
+
+def c5_stack(side=32, n=1024, noise=0.2, seed=11, exp_mode='table'):
+    """BASELINE config 5 as SURVEY.md 8d defines it: `side` x `side` pixels of config 3's generator (two-component
+    truths from the ParamSampler ranges, default_rng(11), sigma = 0.2 K), NH3 (1,1)+(2,2) on `n` channels each, as
+    the `CubeStack` of two `DataCube`s the cube driver takes (frequency axes from FITS-style headers).  The model
+    spectra come from the engine (`exp_mode`; the mode in force before the call is put back).
+    Returns (stack, truths, model, data, axes_hz, utrans)."""
+    import nestfit_amd as na
+    from .cube import CubeRunner
+    from .cubeio import CubeStack, DataCube, SimpleCube
+    n_pix = side * side
+    rng = np.random.default_rng(seed)
+    truths = np.array([param_sampler_draw(rng) for _ in range(n_pix)])
+    ut = na.get_irdc_priors(size=500, vsys=0.0)
+    headers, cubes_hz = [], []
+    for t in (1, 2):
+        f = freq_axis(t, n)
+        hdr = {'BUNIT': 'K', 'CTYPE3': 'FREQ', 'CUNIT3': 'Hz', 'CRVAL3': float(f[0]), 'CDELT3': float((f[-1] - f[0]) / (n - 1)),
+               'CRPIX3': 1.0, 'RESTFRQ': NU0[t], 'CTYPE1': 'RA---SIN', 'CTYPE2': 'DEC--SIN', 'CRVAL1': 270.0, 'CRVAL2': -20.0,
+               'CDELT1': -1e-3, 'CDELT2': 1e-3, 'CRPIX1': 1.0, 'CRPIX2': 1.0, 'CUNIT1': 'deg', 'CUNIT2': 'deg',
+               'NAXIS1': side, 'NAXIS2': side, 'NAXIS3': n, 'NAXIS': 3}
+        headers.append(hdr)
+        cubes_hz.append(SimpleCube(hdr, np.zeros((n, side, side))).spectral_axis_hz())
+    before = na.get_exp_mode()
+    na.set_exp_mode(exp_mode)
+    try:
+        probe = CubeRunner(cubes_hz, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=2)
+        model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
+    finally:
+        na.set_exp_mode(before)
+    data = model + rng.normal(0, noise, model.shape)
+    dcubes = []
+    for k, t in enumerate((1, 2)):
+        # SimpleCube data are (chan, lat, lon); pixel p = i_lon * side + i_lat
+        arr = data[:, k * n:(k + 1) * n].reshape(side, side, n).transpose(2, 1, 0)
+        dcubes.append(DataCube(SimpleCube(headers[k], arr), noise, trans_id=t))
+    return CubeStack(dcubes), truths, model, data, cubes_hz, ut

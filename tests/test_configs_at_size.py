@@ -155,51 +155,39 @@ def test_config5_sampler_at_size(engine, nfo):
 
 
 def _c5_stack(engine, side, n, noise):
-    """BASELINE config 5 as SURVEY.md 8d defines it: `side` x `side` pixels of config 3's generator (two-component
-    truths from the ParamSampler ranges, default_rng(11), sigma = 0.2 K), NH3 (1,1)+(2,2) on `n` channels each, as
-    the `CubeStack` of two `DataCube`s the cube driver takes (frequency axes from FITS-style headers)."""
-    from nestfit_amd.cube import CubeRunner
-    from nestfit_amd.cubeio import CubeStack, DataCube, SimpleCube
-    from nestfit_amd.synth import NU0
-    n_pix = side * side
-    rng = np.random.default_rng(11)
-    truths = np.array([param_sampler_draw(rng) for _ in range(n_pix)])
-    ut = engine.get_irdc_priors(size=500, vsys=0.0)
-    headers, cubes_hz = [], []
-    for t in (1, 2):
-        f = freq_axis(t, n)
-        hdr = {'BUNIT': 'K', 'CTYPE3': 'FREQ', 'CUNIT3': 'Hz', 'CRVAL3': float(f[0]), 'CDELT3': float((f[-1] - f[0]) / (n - 1)),
-               'CRPIX3': 1.0, 'RESTFRQ': NU0[t], 'CTYPE1': 'RA---SIN', 'CTYPE2': 'DEC--SIN', 'CRVAL1': 270.0, 'CRVAL2': -20.0,
-               'CDELT1': -1e-3, 'CDELT2': 1e-3, 'CRPIX1': 1.0, 'CRPIX2': 1.0, 'CUNIT1': 'deg', 'CUNIT2': 'deg',
-               'NAXIS1': side, 'NAXIS2': side, 'NAXIS3': n, 'NAXIS': 3}
-        headers.append(hdr)
-        cubes_hz.append(SimpleCube(hdr, np.zeros((n, side, side))).spectral_axis_hz())
-    engine.set_exp_mode('table')
-    probe = CubeRunner(cubes_hz, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=2)
-    model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
-    data = model + rng.normal(0, noise, model.shape)
-    dcubes = []
-    for k, t in enumerate((1, 2)):
-        # SimpleCube data are (chan, lat, lon); pixel p = i_lon * side + i_lat
-        arr = data[:, k * n:(k + 1) * n].reshape(side, side, n).transpose(2, 1, 0)
-        dcubes.append(DataCube(SimpleCube(headers[k], arr), noise, trans_id=t))
-    return CubeStack(dcubes), truths, model, data, cubes_hz, ut
+    """BASELINE config 5 as SURVEY.md 8d defines it (the generator bench.py --workload C5 uses: nestfit_amd/synth.py)."""
+    from nestfit_amd.synth import c5_stack
+    return c5_stack(side, n, noise)
 
 
-def test_config5_as_specified(engine, nfo, tmp_path):
-    """SURVEY.md 8d C5 through the cube driver: 32 x 32 pixels of the C3 generator (1024 channels, two-component truths),
-    400 live points, tol 0.5, efr 0.3, fixed seed, ncomp_max = 2 with the lnZ_thresh = 11 loop of main.py:452-469, in
-    the bit-faithful table mode.  The nested-sampling runs of both component counts are replayed by the numpy twin
-    whose likelihood for 8 pixels is the CPU oracle (first 1200 iterations: the oracle needs ~40 us per evaluation);
-    the stored evidences say how many components every pixel needs."""
-    from nestfit_amd import sampler
+@pytest.fixture(scope='module')
+def c5(engine):
+    return _c5_stack(engine, 32, 1024, 0.2)
+
+
+def _c5_component_snr(truths, axes, ut, n, noise):
+    """Peak brightness of every true component alone against the noise, per pixel: how many components are there to find."""
     from nestfit_amd.cube import CubeRunner
+    n_pix = truths.shape[0]
+    single = np.zeros((n_pix, 2))
+    probe = CubeRunner(axes, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=1)
+    for c in range(2):
+        one, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), np.ascontiguousarray(truths[:, c::2]))
+        single[:, c] = one.max(axis=1) / noise
+    return single
+
+
+def test_config5_as_specified(engine, c5, tmp_path):
+    """SURVEY.md 8d C5 through the cube driver, at size: 32 x 32 pixels of the C3 generator (1024 channels, two-component
+    truths), 400 live points, tol 0.5, efr 0.3, fixed seed, ncomp_max = 2 with the lnZ_thresh = 11 loop of
+    main.py:452-469, in the table mode (the reference's arithmetic).  The stored evidences say how many components
+    every pixel needs.  (The device sampler against the oracle-fed twin: the next test, on a quarter of the cube.)"""
     from nestfit_amd.fitter import CubeFitter
     from nestfit_amd.store import HdfStore
     side, n, noise, nlive = 32, 1024, 0.2, 400
     n_pix = side * side
     try:
-        stack, truths, model, data, axes, ut = _c5_stack(engine, side, n, noise)
+        stack, truths, model, data, axes, ut = c5
         engine.set_exp_mode('table')
         fitter = CubeFitter(stack, ut, engine.AmmoniaRunner, lnZ_thresh=11, ncomp_max=2, nlive_snr_fact=0,
                             mn_kwargs={'nlive': nlive, 'tol': 0.5, 'efr': 0.3, 'seed': 5})
@@ -222,12 +210,7 @@ def test_config5_as_specified(engine, nfo, tmp_path):
                     assert g['2']['posteriors'].shape[1] == 14 and g['2'].attrs['n_params'] == 12
                 else:
                     assert nbest[p] == 0
-        # how many components are there to find: peak brightness of every true component alone against the noise
-        single = np.zeros((n_pix, 2))
-        probe = CubeRunner(axes, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=1)
-        for c in range(2):
-            one, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), np.ascontiguousarray(truths[:, c::2]))
-            single[:, c] = one.max(axis=1) / noise
+        single = _c5_component_snr(truths, axes, ut, n, noise)
         # The generator's ranges (ntot 13..16, tex 2.8..12 K, separations down to 0.16 km/s) leave about half of the
         # pixels with a second component that is faint or blended: nbest = 2 is asserted where two components are
         # there to be found -- both clear of the noise and further apart than their blended width -- and nbest >= 1
@@ -243,34 +226,52 @@ def test_config5_as_specified(engine, nfo, tmp_path):
         want2 = (single.min(axis=1) >= 8) & (dv >= 1.0 * fwhm_blend)
         assert want2.sum() >= 40 and (nbest[want2] == 2).mean() >= 0.9
         assert (nbest[single.max(axis=1) >= 8] >= 1).mean() >= 0.99
-        # ---- device sampler against the numpy twin fed by the oracle, both component counts
-        pix = np.arange(n_pix)
+    finally:
+        engine.set_exp_mode('fast')
+
+
+@pytest.mark.parametrize('ncomp', [1, 2])
+def test_config5_device_sampler_against_the_oracle_fed_twin(engine, nfo, c5, ncomp):
+    """The nested-sampling runs of config 5's first 256 pixels (a quarter of the cube: the numpy twin is the slow side),
+    one and two components, table mode: the device sampler against the numpy twin whose likelihood for 8 two-component
+    pixels is the CPU oracle, over the first 1000 iterations (the oracle needs ~40 us per evaluation) -- the same
+    decisions (iteration and evaluation counts equal for EVERY pixel), lnZ to 1e-10, posteriors to 1e-8."""
+    from nestfit_amd import sampler
+    from nestfit_amd.cube import CubeRunner
+    n, noise, nlive, n_sub = 1024, 0.2, 400, 256
+    try:
+        stack, truths, model, data, axes, ut = c5
+        engine.set_exp_mode('table')
+        single = _c5_component_snr(truths[:n_sub], axes, ut, n, noise)
+        fwhm_blend = 2.355 * np.sqrt(truths[:n_sub, 8] * truths[:n_sub, 9])
+        want2 = (single.min(axis=1) >= 8) & (np.abs(truths[:n_sub, 1] - truths[:n_sub, 0]) >= fwhm_blend)
         check = np.random.default_rng(5).choice(np.flatnonzero(want2), 8, replace=False)
         ps = nfo.PriorSet(ut.lower())
-        for ncomp in (1, 2):
-            cube = CubeRunner(axes, (1, 2), data, np.full((n_pix, 2), noise), ut, ncomp=ncomp)
-            oracle = {int(p): nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(axes[k], data[p, k * n:(k + 1) * n], noise, t, native=False)
-                                                 for k, t in enumerate((1, 2))], ps, ncomp=ncomp) for p in check}
+        pix = np.arange(n_sub)
+        sub = np.ascontiguousarray(data[:n_sub])
+        cube = CubeRunner(axes, (1, 2), sub, np.full((n_sub, 2), noise), ut, ncomp=ncomp)
+        oracle = {int(p): nfo.AmmoniaRunner([nfo.AmmoniaSpectrum(axes[k], sub[p, k * n:(k + 1) * n], noise, t, native=False)
+                                             for k, t in enumerate((1, 2))], ps, ncomp=ncomp) for p in check}
 
-            def loglike_hybrid(px, U):
-                U0 = U.copy()
-                out = cube.loglikelihood_batch(px.astype(np.int32), U)          # transforms U in place
-                for p, run in oracle.items():
-                    m = px == p
-                    if m.any():
-                        sub = U0[m]
-                        out[m] = run.loglikelihood_batch(sub)
-                        U[m] = sub
-                return out
+        def loglike_hybrid(px, U):
+            U0 = U.copy()
+            out = cube.loglikelihood_batch(px.astype(np.int32), U)          # transforms U in place
+            for p, run in oracle.items():
+                m = px == p
+                if m.any():
+                    rows = U0[m]
+                    out[m] = run.loglikelihood_batch(rows)
+                    U[m] = rows
+            return out
 
-            kw = dict(nlive=nlive, tol=0.5, efr=0.3, seed=5, maxiter=1200, free_mask=cube.utrans.free_mask(ncomp))
-            dev = sampler.fit_pixels(cube, pix, **kw)
-            twin = sampler.run_nested(loglike_hybrid, cube.ndim, n_pix, **kw)
-            for p in check:
-                g, r = dev[p], twin[p]
-                assert g.n_iter == r.n_iter == 1200 and g.n_evals == r.n_evals, (ncomp, p, g.n_evals, r.n_evals)
-                assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
-                np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
-            assert all(a.n_evals == b.n_evals and a.n_iter == b.n_iter for a, b in zip(dev, twin))
+        kw = dict(nlive=nlive, tol=0.5, efr=0.3, seed=5, maxiter=1000, free_mask=cube.utrans.free_mask(ncomp))
+        dev = sampler.fit_pixels(cube, pix, **kw)
+        twin = sampler.run_nested(loglike_hybrid, cube.ndim, n_sub, **kw)
+        for p in check:
+            g, r = dev[p], twin[p]
+            assert g.n_iter == r.n_iter == 1000 and g.n_evals == r.n_evals, (ncomp, p, g.n_evals, r.n_evals)
+            assert g.lnZ == pytest.approx(r.lnZ, rel=1e-10)
+            np.testing.assert_allclose(g.posterior, r.posterior, rtol=1e-8, atol=1e-12)
+        assert all(a.n_evals == b.n_evals and a.n_iter == b.n_iter for a, b in zip(dev, twin))
     finally:
         engine.set_exp_mode('fast')
