@@ -237,8 +237,9 @@ def bench_c5(args):
 def bench_c5_round4_shape(args):
     """The cube rounds 2-4 timed as "C5" (--workload C5r4; kept so that the sampler's numbers stay comparable across
     rounds): nested sampling with 400 live points of every pixel of a 32x32 synthetic NH3 (1,1)+(2,2) cube of 512 channels
-    with ONE-component truths, fitted with one and with two velocity components in two lock-step runs (no component
-    loop, no store).  BASELINE config 5 as SURVEY specifies it is --workload C5 (c5_specified)."""
+    (nestfit_amd.synth.c5r4_cube: smooth maps of as many components as are fitted, not the C3 generator), with one and
+    with two velocity components in two lock-step runs (no component loop, no store), margins of rounds 2-4
+    (precision='speed').  BASELINE config 5 as SURVEY specifies it is --workload C5 (c5_specified)."""
     import nestfit_amd as na
     from nestfit_amd import _ffi, sampler
     from nestfit_amd.cube import CubeRunner
@@ -250,31 +251,19 @@ def bench_c5_round4_shape(args):
             _ffi.set_option(key, val)
     if args.prior_stage >= 0:
         _ffi.set_option('prior_stage', args.prior_stage)
+    from nestfit_amd.synth import c5r4_cube
     side, n, noise, nlive = 32, 512, 0.1, 400
     n_pix = side * side
-    rng = np.random.default_rng(0)
-    axes = [freq_axis(1, n), freq_axis(2, n)]
-    ut = na.get_irdc_priors(size=500, vsys=0.0)
-    lon, lat = np.indices((side, side))
-    r = np.hypot(lon - side / 2, lat - side / 2) / (side / 2)
     out = {}
     for ncomp in (1, 2):
         if args.c5_ncomp and ncomp != args.c5_ncomp:
-            rng.normal(0, noise, (n_pix, 2 * n))               # (the other run's noise draw: the cubes stay the same)
             out[ncomp] = {'seconds': float('nan'), 'pixels_per_s': float('nan'), 'evals_per_pixel': float('nan'), 'mean_lnZ_err': float('nan')}
             continue
-        truths = np.zeros((n_pix, 6 * ncomp))
-        for c in range(ncomp):
-            truths[:, c] = (-1.0 + 2.0 * lon.ravel() / side) + 1.5 * c
-            truths[:, ncomp + c], truths[:, 2 * ncomp + c] = 12.0 + 3 * c, 5.0 + c
-            truths[:, 3 * ncomp + c], truths[:, 4 * ncomp + c] = 14.6 - 0.6 * r.ravel(), 0.4
-        probe = CubeRunner(axes, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=ncomp)
-        model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
-        cube = CubeRunner(axes, (1, 2), model + rng.normal(0, noise, model.shape), np.full((n_pix, 2), noise), ut,
-                          ncomp=ncomp)
+        axes, data, noise, ut = c5r4_cube(ncomp, side, n, noise)
+        cube = CubeRunner(axes, (1, 2), data, np.full((n_pix, 2), noise), ut, ncomp=ncomp)
         _ffi.check(_ffi.load().nfa_device_synchronize())
         t0 = time.perf_counter()
-        knobs = {}
+        knobs = {'precision': 'speed'}                    # rounds 2-4's margins: what their numbers were measured with
         if args.sampler_batch_target:
             knobs['batch_target'] = args.sampler_batch_target
         if args.sampler_upd_frac:
@@ -290,8 +279,8 @@ def bench_c5_round4_shape(args):
         'metric': 'pixels/sec, nested sampling (400 live points) of a 32x32 NH3(1,1)+(2,2) cube, 1 component',
         'value': out[1]['pixels_per_s'], 'unit': 'pixels/s', 'n_gpus': 1, 'higher_is_better': True,
         'vs_baseline': None, 'dtype': DTYPES[args.exp_mode], 'data': 'synthetic',
-        'config': {'workload': 'C5r4 (rounds 2-4 shape, NOT the specified config 5): 32x32 pixels x 2 spectra x 512 channels, one-component '
-                               'truths, built-in device sampler (libmultinest is not available), tol 0.5, efr 0.3', 'exp_mode': args.exp_mode},
+        'config': {'workload': 'C5r4 (rounds 2-4 shape, NOT the specified config 5): 32x32 pixels x 2 spectra x 512 channels, smooth truth maps '
+                               '(synth.c5r4_cube), precision speed, built-in device sampler (libmultinest is not available), tol 0.5, efr 0.3', 'exp_mode': args.exp_mode},
         'one_component': out[1], 'two_components': out[2]}))
 
 

@@ -146,6 +146,8 @@ TEST_SIGNATURES = {
     'nfa_test_windows': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _ip, _ip]),
     'nfa_test_broker_storm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp]),
     'nfa_test_callback_latency': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, C.c_int, _dp, _dp]),
+    'nfa_test_queue_trace': (C.c_int, [C.c_int]),
+    'nfa_test_queue_trace_read': (C.c_int, [C.POINTER(C.c_ulonglong)]),
 }
 TEST_LIB_PATH = HERE / 'lib' / 'libnestfit_amd_test.so'
 

@@ -74,7 +74,7 @@ static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for 
 // numpy twin's _fit_boxes / _box_veto hold the same arithmetic.
 #define NS_FRAMES 32               // rotated frames a caller gets who asks for boxes without naming a number
 #define NS_FRAMES_MAX 64
-#define NS_MARGIN_C 1.75
+#define NS_MARGIN_C 2.5            // (round 4: 1.75, sampler.py precision='speed')
 #define NS_MARGIN_A 1.5
 #define NS_MARGIN_FLOOR 0.1
 #define NS_RATIO_MAX 32            // proposals drawn per round: at most this multiple of the evaluations aimed for
@@ -83,11 +83,11 @@ static_assert(NS_ME_MAXD <= 6, "ns_refit_kernel dispatches the cluster fits for 
 // quadratic function of the earlier ones -- the curved tex / ntot ridges of faint pixels come out straight, and an
 // ellipsoid around straight things is small
 #define NS_SHEAR_RIDGE 1e-6        // on the Gram matrix's diagonal, times the live points
-#define NS_SHEAR_ENLARGE 2.5       // safety factor on the enclosing volume of the sheared ellipsoid
+#define NS_SHEAR_ENLARGE 3.0       // safety factor on the enclosing volume of the sheared ellipsoid (round 4: 2.5, sampler.py precision='speed')
 #define NS_SHEAR_PIVOT 1e-9        // a Cholesky pivot below this fraction of its diagonal entry: the monomial is dropped
 #define NS_SHEAR_MMAX 64           // monomials at most
 #define NS_REFIT_THREADS 512       // of the workgroup that fits a one-ellipsoid bound
-#define NS_PAIRS_ENLARGE 1.75      // safety factor on the area of a pair ellipse
+#define NS_PAIRS_ENLARGE 2.0       // safety factor on the area of a pair ellipse (round 4: 1.75, sampler.py precision='speed')
 #define NS_KP_START 256            // a pixel's share of proposals in its first rejection round
 #define NS_K_TARGET 16             // replacements per pixel and rejection round the per-pixel share of proposals aims at
 #define NS_WALK_LOWD 6             // up to this many sampled dimensions ...

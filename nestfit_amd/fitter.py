@@ -108,7 +108,8 @@ class CubeFitter:
                 print(f'-- ({i_lon}, {i_lat}) SKIP: has NaN values')
         if lon.size:
             nlive = self._nlive(lon, lat)
-            kw = {k: self.mn_kwargs[k] for k in ('tol', 'efr', 'seed', 'maxiter') if k in self.mn_kwargs}
+            # ('precision': not one of MultiNest's arguments -- the built-in sampler's named setting, sampler.PRECISION)
+            kw = {k: self.mn_kwargs[k] for k in ('tol', 'efr', 'seed', 'maxiter', 'precision') if k in self.mn_kwargs}
             if self.one_group:
                 # every pixel keeps its own number of live points inside ONE lock-step run (the device sampler's
                 # per-pixel counts, nfa_sampler_set_pixel_nlive): no group per count, no rounding of the counts

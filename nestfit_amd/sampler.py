@@ -281,7 +281,7 @@ def _candidates_multi(seed, p, base, K, cs, As, lv, ne, lnvol):
 # spacing of the extreme order statistics would give (scripts/proto_intersection.py: the fraction of the true region a
 # bound cuts off, and the evaluations per iteration it saves).
 _FRAME_SEED = _U64(0x5EEDF00D)
-_NS_FRAMES, _NS_MARGIN_C, _NS_MARGIN_A, _NS_MARGIN_FLOOR = 32, 1.75, 1.5, 0.1     # NS_FRAMES, NS_MARGIN_C, NS_MARGIN_A, NS_MARGIN_FLOOR
+_NS_FRAMES, _NS_MARGIN_C, _NS_MARGIN_A, _NS_MARGIN_FLOOR = 32, 2.5, 1.5, 0.1      # NS_FRAMES, NS_MARGIN_C (round 4: 1.75 = precision='speed'), NS_MARGIN_A, NS_MARGIN_FLOOR
 _NS_RATIO_MAX = 32                                                             # NS_RATIO_MAX
 
 
@@ -341,7 +341,7 @@ _NS_KP_START = 256                                                              
 _NS_K_TARGET = 16                                                               # NS_K_TARGET
 _NS_SHEAR_RIDGE = 1e-6                                                          # NS_SHEAR_RIDGE
 _NS_SHEAR_PIVOT = 1e-9                                                          # NS_SHEAR_PIVOT
-_NS_SHEAR_ENLARGE = 2.5                                                         # NS_SHEAR_ENLARGE
+_NS_SHEAR_ENLARGE = 3.0                                                         # NS_SHEAR_ENLARGE (round 4: 2.5 = precision='speed')
 
 
 def _shear_monomials(comp):
@@ -429,7 +429,7 @@ def _shear_inv(W, mu, sg, beta, mono, start):
         return mu + sg * Z
 
 
-_NS_PAIRS_ENLARGE = 1.75                                                        # NS_PAIRS_ENLARGE
+_NS_PAIRS_ENLARGE = 2.0                                                         # NS_PAIRS_ENLARGE (round 4: 1.75 = precision='speed')
 
 
 def _fit_pairs(W, enlarge):
@@ -566,10 +566,32 @@ def default_cap_iter(nlive):
     return 60 * int(nlive)
 
 
+# Named settings of a sheared one-ellipsoid bound (two and three components) and its free rejections: the safety factor on
+# the ellipsoid's volume and the margins of the boxes and the pair ellipses trade evaluations for a cut of prior mass that
+# shows in the evidence.  Measured on 256 pixels of the two-component test cube against bound-free rejection
+# (tests/test_sampler_bias.py pins them; tests/golden/sampler_bias_reference.json, scripts/sampler_bias_reference.py;
+# a pixel's own lnZ_err is 0.25; profiles/r05/sampler_bias.txt):
+#   'speed'     shear 2.5, margin 1.75, pairs 1.75 (round 4's default)         +0.075 in lnZ, 408 k evaluations per pixel
+#   'default'   shear 3,   margin 2.5,  pairs 2.0                              +0.031, 699 k
+#   'evidence'  shear 4,   margin 3.5,  pairs 2.5, rejection only (no walks)   +0.018, 1180 k
+# (the sheared ellipsoid alone at 2.5, no boxes, no pairs: +0.029 at 5.6 M -- the factor on its volume, not the margins,
+# carries the last 0.03)
+PRECISION = {'speed': {'shear': 2.5, 'margin': 1.75, 'pairs': 1.75}, 'default': {},
+             'evidence': {'shear': 4.0, 'margin': 3.5, 'pairs': 2.5, 'method': 'reject'}}
+
+
+def resolve_precision(precision, margin=None, pairs=None, method='auto', shear=None):
+    """(margin, pairs, method, shear) of the named setting `precision` (None = 'default'); values given explicitly win."""
+    knobs = PRECISION[precision or 'default']
+    return (knobs.get('margin') if margin is None else margin, knobs.get('pairs') if pairs is None else pairs,
+            knobs.get('method', method) if method == 'auto' else method, knobs.get('shear') if shear is None else shear)
+
+
 def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6),
                n_cand=None, upd_frac=0.1, log_zero=LOG_ZERO, chunk=1 << 18, cap_iter=None,
                check_every=32, batch_target=262144, enlarge=1.5, method='auto', n_steps=None, free_mask=None, walk_factor=None, ellipsoids=None, walkers=None,
-               progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None, k_target=None, ratio_max=None, pairs=None):
+               progress=None, frames=None, margin=None, refit_every=4, shear=None, kmax=None, k_target=None, ratio_max=None, pairs=None,
+               precision=None):
     """Nested sampling of `n_pix` independent problems in lock-step: the host twin of the
     device-resident sampler (csrc/nfa_sampler.h), same random numbers, same decisions.
 
@@ -602,13 +624,14 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     free_mask : ndim flags, 0 for unit-cube slots the likelihood does not depend on (constant or
         duplicated parameters: `PriorTransformer.free_mask`).  They are not sampled -- a uniform dummy
         dimension integrates to one -- and stay at u = 0.5: fewer dimensions for the same evidence.
+    precision : 'speed' / 'default' / 'evidence': named settings of `shear`, `margin`, `pairs` and `method` (`PRECISION`).
     frames, margin : the free rejections of a one-ellipsoid bound (`_fit_boxes`): `frames` rotated frames beside the unit
-        cube's axes and the ellipsoid's own (-1: no boxes; None: 32 where the bound is sheared, none elsewhere), `margin` the factor c of a face's distance beyond the extreme live point (1.75).
+        cube's axes and the ellipsoid's own (-1: no boxes; None: 32 where the bound is sheared, none elsewhere), `margin` the factor c of a face's distance beyond the extreme live point (2.5).
         With boxes the proposals per round are scaled by the last rounds' ratio of drawn to evaluated proposals (at most 8).
     shear : 0 = off; a number >= 1 = the one-ellipsoid bound is fitted to the live points AFTER a volume-preserving
         polynomial shear (`_fit_shear`: every coordinate minus a quadratic function of the earlier ones, which straightens
         the curved tex / ntot ridges), with this safety factor on the enclosing volume instead of `enlarge`; None = the
-        default, 2.5.  Proposals are drawn in the sheared frame and mapped back; boxes, if on, live in that frame.  Only
+        default, 3.  Proposals are drawn in the sheared frame and mapped back; boxes, if on, live in that frame.  Only
         where all five free parameters of two or three components are sampled (10 or 15 dimensions): elsewhere ignored.
     refit_every : rejection-mode pixels refit their bound in rounds that are multiples of this (the device's engine option
         `sampler_refit_every`).
@@ -623,6 +646,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
     nl = np.broadcast_to(np.asarray(nlive, dtype=np.int64), (P,)).copy()
     nlive = int(nl.max())
     assert ndim > 0 and nl.min() > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
+    margin, pairs, method, shear = resolve_precision(precision, margin, pairs, method, shear)
     seed = _resolve_seed(seed)
     K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
     if cap_iter is None:
@@ -911,7 +935,7 @@ def run_nested(loglike, ndim, n_pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxit
 def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter=int(1e6), n_cand=None,
                       upd_frac=0.1, log_zero=LOG_ZERO, cap_iter=None, check_every=32, batch_target=262144,
                       enlarge=1.5, method='auto', n_steps=None, free_mask=None, progress=None, time_limit=None,
-                      ellipsoids=None, frames=None, margin=None, shear=None, pairs=None):
+                      ellipsoids=None, frames=None, margin=None, shear=None, pairs=None, precision=None):
     """The same algorithm with its whole state on the GPU (``nfa_sampler_*``): pixels `pix` of a
     `CubeRunner` (or pixel 0 of a single-pixel runner) in lock-step rounds, no per-round host
     work.  Options as `run_nested`; `cap_iter` defaults to min(maxiter, 60 nlive).  `progress`
@@ -928,6 +952,7 @@ def run_nested_device(runner, pix, nlive=400, tol=0.5, efr=0.3, seed=-1, maxiter
     per_pixel = bool((nl != nl[0]).any())
     nlive = int(nl.max())
     assert nl.min() > ndim + 1 and tol > 0 and 0 < efr <= 1 and maxiter >= 0
+    margin, pairs, method, shear = resolve_precision(precision, margin, pairs, method, shear)
     seed = _resolve_seed(seed)
     K = int(n_cand) if n_cand else int(np.ceil(2.0 / efr))
     capp = np.array([int(cap_iter) if cap_iter else int(max(1, min(maxiter, default_cap_iter(int(n))))) for n in nl], dtype=np.int64)
@@ -1139,13 +1164,14 @@ class Dumper:
 def run_multinest(runner, dumper, IS=False, mmodal=True, ceff=False, nlive=400, tol=0.5, efr=0.3,
                   nClsPar=None, maxModes=100, updInt=10, Ztol=-1e90, root='results', seed=-1,
                   pWrap=None, fb=False, resume=False, initMPI=False, outfile=False, logZero=-1e100,
-                  maxiter=int(1e6)):
+                  maxiter=int(1e6), precision=None):
     """Signature of the reference's ``run_multinest`` (core.pyx:727-823) on the built-in sampler,
     for one runner (one pixel).  `mmodal` / `maxModes`: clusters of live points get bounding ellipsoids of
     their own (at most min(maxModes, 4), and only where at most six dimensions are sampled; mmodal = False: one
     ellipsoid); the evidence is the global one either way (the reference's dumper stores no per-mode values).
     Options that concern importance sampling, constant efficiency, the clustering parameters or MultiNest's output
-    files are accepted and ignored; the argument checks are the reference's."""
+    files are accepted and ignored; the argument checks are the reference's.  `precision` (not MultiNest's): the
+    built-in sampler's named setting, `PRECISION`."""
     assert runner.ndim > 0
     assert nlive > 0
     assert tol > 0
@@ -1165,13 +1191,13 @@ def run_multinest(runner, dumper, IS=False, mmodal=True, ceff=False, nlive=400, 
     ellipsoids = min(int(maxModes), _NS_ME) if mmodal else 1
     if hasattr(runner, '_run'):          # engine runner: the whole run stays on the device
         res = run_nested_device(runner, np.zeros(1, dtype=np.int32), nlive=nlive, tol=tol, efr=efr, seed=seed,
-                                maxiter=maxiter, log_zero=logZero, free_mask=free_mask, ellipsoids=ellipsoids)[0]
+                                maxiter=maxiter, log_zero=logZero, free_mask=free_mask, ellipsoids=ellipsoids, precision=precision)[0]
     else:                                # any object with loglikelihood_batch(U): the numpy twin
         def loglike(pix, U):
             return runner.loglikelihood_batch(U)
 
         res = run_nested(loglike, runner.ndim, 1, nlive=nlive, tol=tol, efr=efr, seed=seed,
-                         maxiter=maxiter, log_zero=logZero, free_mask=free_mask, ellipsoids=ellipsoids)[0]
+                         maxiter=maxiter, log_zero=logZero, free_mask=free_mask, ellipsoids=ellipsoids, precision=precision)[0]
     dumper.dump(runner, res)
     return res
 

@@ -418,6 +418,8 @@ class HdfStore:
     def insert_fitter_pars(self, fitter):
         assert self.is_open
         self.hdf.attrs.update({name: get(fitter) for name, get in FITTER_ATTRS})
+        # the built-in sampler's named setting (sampler.PRECISION: margins of its bound's free rejections), where the results are
+        self.hdf.attrs['sampler_precision'] = str(getattr(fitter, 'mn_kwargs', {}).get('precision') or 'default')
         quantum = getattr(fitter, 'nlive_quantum', 1)
         if quantum != 1:                 # a deviation from main.py:445-447 is written down where the results are
             self.hdf.attrs['nlive_quantum'] = int(quantum)

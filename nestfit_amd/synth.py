@@ -66,3 +66,29 @@ def c5_stack(side=32, n=1024, noise=0.2, seed=11, exp_mode='table'):
         arr = data[:, k * n:(k + 1) * n].reshape(side, side, n).transpose(2, 1, 0)
         dcubes.append(DataCube(SimpleCube(headers[k], arr), noise, trans_id=t))
     return CubeStack(dcubes), truths, model, data, cubes_hz, ut
+
+
+def c5r4_cube(ncomp, side=32, n=512, noise=0.1, seed=0):
+    """The cube rounds 2-4 timed as "config 5" (bench.py --workload C5r4) and the sampler's evidence bias is measured
+    on (tests/test_sampler_bias.py): side x side pixels, NH3 (1,1)+(2,2) on n channels, `ncomp` velocity components
+    whose centre moves across the cube and whose column density falls from its middle, normal noise.
+    Returns (axes, data[n_pix, 2 n], noise, utrans).  The noise of the two-component cube is the generator's SECOND
+    draw (the first belongs to the one-component cube), as in the rounds that used it."""
+    import nestfit_amd as na
+    from .cube import CubeRunner
+    n_pix = side * side
+    rng = np.random.default_rng(seed)
+    axes = [freq_axis(1, n), freq_axis(2, n)]
+    ut = na.get_irdc_priors(size=500, vsys=0.0)
+    lon, lat = np.indices((side, side))
+    r = np.hypot(lon - side / 2, lat - side / 2) / (side / 2)
+    for nc in range(1, ncomp):
+        rng.normal(0, noise, (n_pix, 2 * n))                  # (the other cubes' noise draws)
+    truths = np.zeros((n_pix, 6 * ncomp))
+    for c in range(ncomp):
+        truths[:, c] = (-1.0 + 2.0 * lon.ravel() / side) + 1.5 * c
+        truths[:, ncomp + c], truths[:, 2 * ncomp + c] = 12.0 + 3 * c, 5.0 + c
+        truths[:, 3 * ncomp + c], truths[:, 4 * ncomp + c] = 14.6 - 0.6 * r.ravel(), 0.4
+    probe = CubeRunner(axes, (1, 2), np.zeros((1, 2 * n)), np.full((1, 2), noise), ut, ncomp=ncomp)
+    model, _ = probe.predict_batch(np.zeros(n_pix, dtype=np.int32), truths)
+    return axes, model + rng.normal(0, noise, model.shape), noise, ut

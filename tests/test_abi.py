@@ -33,7 +33,7 @@ def test_test_hooks_live_in_the_test_library_only():
     from nestfit_amd import _ffi
     product = _ffi.load()
     hooks = _declared('nestfit_amd_test.h')
-    assert sorted(_ffi.TEST_SIGNATURES) == hooks and len(hooks) == 6
+    assert sorted(_ffi.TEST_SIGNATURES) == hooks and len(hooks) == 8
     test_lib = C.CDLL(str(_ffi.TEST_LIB_PATH))
     for n in hooks:
         assert hasattr(test_lib, n), f'{n} declared in include/nestfit_amd_test.h but not exported'
