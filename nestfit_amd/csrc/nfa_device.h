@@ -925,6 +925,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const int n_rows = (ablate & 4) ? 0 : (N + 63) >> 6;
     const int parts_per_wave = LNL_PARTS >> split_log2;
     double tot = 0.0;
+    constexpr bool SPEC_DEFER = WRITE_SPEC && MODE == 2;
+    double pend_v = 0.0;                                           // spectra out: the row whose store is still to be issued
+    int pend_j = -1;
     for (int hp = 0; hp < parts_per_wave; ++hp) {
     const int h = rpart * parts_per_wave + hp;                 // part h = rows h, h + LNL_PARTS, h + 2 LNL_PARTS, ...
     acc = 0.0;
@@ -953,7 +956,13 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                 any = __builtin_amdgcn_ballot_w64((lo < r0 + 64) & (hi > r0) & (hi > lo)) != 0ull;
             }
         }
-        if (any || WRITE_SPEC) {
+        // Spectra out (main.py:1106-1113, 1182-1188): a row no line window touches is zeros, written without reading the row
+        // (write-once data, past the caches: non-temporal).
+        if (WRITE_SPEC && !any) {
+            if (j < N) __builtin_nontemporal_store(0.0, spec_out + b * S.chan_tot + off + j);
+            continue;
+        }
+        if (any) {
             const bool valid = j < N;
             const unsigned jo = (unsigned)(valid ? j : N - 1) * 8u;           // byte offset of the lane's channel
             const double xj = *(const double *)((const char *)xs + jo);
@@ -962,6 +971,18 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             // T0 tbg of the channel; T0 and tbg themselves are read inside the rare pass that needs them (y(T0) not a single
             // table cell): carried through the row as "maybe loaded" values they cost two register copies per row
             p3 = *(const double *)((const char *)p3s + jo);
+            // Spectra out: the PREVIOUS row's store is issued here, behind this row's loads.  Vector-memory operations of a
+            // wave complete in order (one counter, vmcnt): issued at the end of its own row, a store stood between the next
+            // row's loads and their first use, and every row waited for the acknowledgement of 512 bytes written to HBM
+            // (round 4: 43 us per 4096 rows with the store against 28 without).  Behind the loads it has the whole row to
+            // complete.
+            // (Fast mode; the table mode's sixteen-wave workgroups have no registers for the held row -- 64 for two of them
+            // per CU -- and store where the row ends.)
+            if (SPEC_DEFER) {
+                asm volatile("" ::: "memory");                        // (the loads above stay above, the store below)
+                if (pend_j >= 0) __builtin_nontemporal_store(pend_v, spec_out + b * S.chan_tot + off + pend_j);
+                asm volatile("" ::: "memory");
+            }
             double pred = 0.0;
             // one component: the lines in `mask` add their optical depths, then the Tb pass
             auto component = [&](int c, unsigned long long mask, double kind, double a0x, double b0x) {
@@ -1159,12 +1180,14 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     component(c, mask, Dk[dko + DK_KIND], Dk[dko + DK_A0X], Dk[dko + DK_B0X]);
                 }
             }
-            if (WRITE_SPEC) { if (valid) spec_out[b * S.chan_tot + off + j] = pred; }
+            if (SPEC_DEFER) { pend_v = pred; pend_j = valid ? j : -1; }
+            else if (WRITE_SPEC) { if (valid) __builtin_nontemporal_store(pred, spec_out + b * S.chan_tot + off + j); }
             if (any) acc = __builtin_fma(pred, __builtin_fma(-2.0, dj, pred), acc);       // lanes beyond N: pred = 0
         }
     }
     if (split == 1) tot += acc; else w_part[h * 64 + lane] = acc;
     }
+    if (SPEC_DEFER && pend_j >= 0) __builtin_nontemporal_store(pend_v, spec_out + b * S.chan_tot + off + pend_j);
     if (split > 1) {
         __syncthreads();
         if (rpart != 0) return;
@@ -1184,6 +1207,19 @@ lnl_kernel(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__re
     int n_shared = 0;
     const double *sm = smem;
     if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);   // fast: no tables
+    lnl_body<MODE, WRITE_SPEC, WIDE, NCOMP>(S, nullptr, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x, &grp);
+}
+
+// lnl_kernel held to 64 vector registers (eight waves per SIMD = two sixteen-wave workgroups of the table mode per CU): the
+// table mode with spectra out asks for 66 left alone.
+template <int MODE, bool WRITE_SPEC, bool WIDE, int NCOMP>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) __attribute__((amdgpu_waves_per_eu(8, 8)))
+lnl_kernel_w8(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__restrict__ part,
+              double *__restrict__ spec_out, long B, LnlGeom G, const double *__restrict__ g_tabs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int n_shared = 0;
+    const double *sm = smem;
+    if (MODE != 2) sm = stage_exp_tables<MODE == 2 ? 1 : MODE>(smem, g_tabs, &n_shared);
     lnl_body<MODE, WRITE_SPEC, WIDE, NCOMP>(S, nullptr, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x, &grp);
 }
 

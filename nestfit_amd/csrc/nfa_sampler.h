@@ -334,6 +334,12 @@ __device__ __forceinline__ void ns_shear_apply(const k_dbl_p beta, int M, double
 // slow pixels does not cost one launch per handful of candidates)
 // DD > 0: the number of sampled dimensions at compile time (loops unroll, the proposal's coordinates live in registers)
 #define NS_PROPOSE_THREADS 128
+#ifndef NFA_PROPOSE_ATTR
+#define NFA_PROPOSE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+#ifndef NFA_UPD_ATTR
+#define NFA_UPD_ATTR            // (held to 128 registers -- four workgroups per CU, every pixel of a launch resident -- it spills 296 B and the two-component run takes 3.70 s against 3.42: profiles/r05/ab_sampler_registers.txt)
+#endif
 // in_range: the thread has a proposal of its own (k < Kr); the others of a pixel's last workgroup go along to the barriers
 template <int DD>
 __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int n_act, int Kr, bool in_range) {
@@ -584,6 +590,14 @@ __device__ __forceinline__ void ns_propose_one(const NsDev &S, int q, int k, int
 // grid: x = chunks of a pixel's Kr proposals, y = the active pixels of this part (z: beyond 65535 of them)
 template <int DD>
 __global__ void __launch_bounds__(NS_PROPOSE_THREADS) ns_propose_kernel(NsDev S, int n_act, int Kr) {
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int q = (int)(blockIdx.y + blockIdx.z * 65535u);
+    if (q < n_act) ns_propose_one<DD>(S, q, k, n_act, Kr, k < Kr);
+}
+
+// the same held to 128 vector registers: four waves per SIMD where the ten-dimensional form asked for 129 (and three)
+template <int DD>
+__global__ void __launch_bounds__(NS_PROPOSE_THREADS) NFA_PROPOSE_ATTR ns_propose_kernel_v128(NsDev S, int n_act, int Kr) {
     const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int q = (int)(blockIdx.y + blockIdx.z * 65535u);
     if (q < n_act) ns_propose_one<DD>(S, q, k, n_act, Kr, k < Kr);
@@ -1235,7 +1249,7 @@ __device__ void ns_refit_multi(const NsDev &S, int p, long n_iter, double *su, i
 __host__ __device__ inline size_t ns_upd_lds(int N) {   // doubles: live lnL | survivors' lnL | their k, row, rank (ints) | counts | control
     return (size_t)((N + 1) & ~1) + NS_UPD_SEG + (3 * NS_UPD_SEG) / 2 + 16 + 2;
 }
-__global__ void __launch_bounds__(NS_UPD_THREADS) ns_update_kernel(NsDev S, int n_act, int Kr, long round) {
+__global__ void __launch_bounds__(NS_UPD_THREADS) NFA_UPD_ATTR ns_update_kernel(NsDev S, int n_act, int Kr, long round) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (q >= n_act) return;
@@ -2054,7 +2068,7 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
                 const dim3 pg((unsigned)((Kr + 127) / 128), (unsigned)std::min(n_pix_h[h], 65535), (unsigned)((n_pix_h[h] + 65534) / 65535));
                 switch (D) {                                        // compile-time dimensions where they are common
                 case 5: hipLaunchKernelGGL(ns_propose_kernel<5>, pg, dim3(NS_PROPOSE_THREADS), 0, st, dh[h], n_pix_h[h], Kr); break;
-                case 10: hipLaunchKernelGGL(ns_propose_kernel<10>, pg, dim3(NS_PROPOSE_THREADS), 0, st, dh[h], n_pix_h[h], Kr); break;
+                case 10: hipLaunchKernelGGL(ns_propose_kernel_v128<10>, pg, dim3(NS_PROPOSE_THREADS), 0, st, dh[h], n_pix_h[h], Kr); break;
                 case 15: hipLaunchKernelGGL(ns_propose_kernel<15>, pg, dim3(NS_PROPOSE_THREADS), 0, st, dh[h], n_pix_h[h], Kr); break;
                 default: hipLaunchKernelGGL(ns_propose_kernel<0>, pg, dim3(NS_PROPOSE_THREADS), 0, st, dh[h], n_pix_h[h], Kr); break;
                 }
