@@ -1672,15 +1672,17 @@ __global__ void __launch_bounds__(NS_FIN_THREADS) ns_finish_kernel(NsDev S, cons
     const long rb = (long)~sarg[0], rm = (long)~sarg[1];
     if (tid == 0) { st[0] = lnz; st[1] = lnz_dead; st[2] = H; st[3] = lmax; st[4] = llive; st[5] = sw; }
     for (int j = tid; j < DT; j += NS_FIN_THREADS) { st[6 + 2 * DT + j] = o[rb * W + j]; st[6 + 3 * DT + j] = o[rm * W + j]; }
-    // weighted first and second moments of every column
+    // weighted first and second moments of every column, taken about the row of the largest weight (a point inside the
+    // posterior's bulk: raw moments cancel where |mean| >> sigma): stored are the mean, sum w t, and sum w (t - c)^2
     for (int j = 0; j < DT; ++j) {
+        const double c = o[rm * W + j];
         double m1 = 0.0, m2 = 0.0;
         for (long r = tid; r < n; r += NS_FIN_THREADS) {
-            const double w = o[r * W + DT + 1], t = o[r * W + j];
-            m1 += w * t; m2 += w * (t * t);
+            const double w = o[r * W + DT + 1], d = o[r * W + j] - c;
+            m1 += w * d; m2 += w * (d * d);
         }
         m1 = ns_fin_sum(m1, sred); m2 = ns_fin_sum(m2, sred);
-        if (tid == 0) { st[6 + j] = m1; st[6 + DT + j] = m2; }
+        if (tid == 0) { st[6 + j] = m1 + c * sw; st[6 + DT + j] = m2; }
     }
 }
 
@@ -1704,6 +1706,7 @@ struct nfa_sampler {
     int *d_sh_mono = nullptr, *d_sh_start = nullptr;
     std::vector<int> fm;        // the sampled dimensions' slots
     size_t k_alloc = 0;         // proposal rows allocated per pixel
+    long ratio_max = NS_RATIO_MAX, kmax = NS_KMAX;   // options sampler_ratio_max / sampler_kmax as they stood at creation
     long raw_sum = 0, val_sum = 0;   // proposals drawn / evaluated since the last look at the active pixels
     std::vector<int> h_nlive;   // per-pixel live points (empty: d.N for everybody)
     int max_ell = 0;            // nfa_sampler_set_ellipsoids (0: the default)
@@ -1777,7 +1780,11 @@ int nfa_sampler_create(nfa_sampler **out, nfa_runner *r, const int32_t *pix, int
     s->b_target = std::max<long>((long)n_pix * n_cand, (long)batch_target);
     // rows of the candidate buffers: n_act * Kr <= max(b_target, n_act * K) <= b_target -- times NS_RATIO_MAX where boxes
     // may veto proposals for free (one-ellipsoid bounds: more than NS_ME_MAXD sampled dimensions, or on request)
+    // (the two process options are read ONCE, here: the buffers are sized for them, and a value changed while the sampler
+    // lives must not outrun the buffers)
     const size_t ratio_alloc = g_eng.sampler_ratio_max > 0 ? g_eng.sampler_ratio_max : NS_RATIO_MAX;
+    s->ratio_max = (long)ratio_alloc;
+    s->kmax = g_eng.sampler_kmax > 0 ? g_eng.sampler_kmax : NS_KMAX;
     const size_t K = ((size_t)s->b_target * ratio_alloc + P - 1) / P;       // so that P * K >= ratio_max * b_target
     s->k_alloc = K;
     std::vector<int> pm(P);
@@ -2039,10 +2046,10 @@ int nfa_sampler_advance(nfa_sampler *s, int64_t max_chunks, int64_t *n_active_ou
         const int n_act = s->n_act;
         // with boxes most proposals are vetoed for free: so many more are drawn that a round still evaluates ~b_target
         long ratio = 1;
-        const long ratio_max = g_eng.sampler_ratio_max > 0 ? g_eng.sampler_ratio_max : NS_RATIO_MAX;
+        const long ratio_max = s->ratio_max;
         if (d.boxes && s->raw_sum > 0) ratio = std::min<long>(ratio_max, std::max<long>(1, (s->raw_sum + s->val_sum / 2) / std::max<long>(s->val_sum, 1)));
         s->raw_sum = s->val_sum = 0;
-        const long kmax = g_eng.sampler_kmax > 0 ? g_eng.sampler_kmax : NS_KMAX;
+        const long kmax = s->kmax;
         const int Kr = (int)std::min<long>(kmax, std::max<long>(K, (s->b_target * ratio) / n_act));    // (n_act * Kr rows <= NS_RATIO_MAX * b_target: what nfa_sampler_create allocated)
         int n_pix_h[NS_PARTS];
         NsDev dh[NS_PARTS];

@@ -151,8 +151,12 @@ class CubeFitter:
         ndim = self.n_model * ncomp
         nl_max = int(np.max(nlive))
         cap = min(int(kw.get('maxiter', 10**6)), sampler.default_cap_iter(nl_max))
-        per_pixel = 8 * (cap * (ndim + 2) + nl_max * (2 * ndim + 2))
-        n_pass = max(1, SAMPLER_MEMORY_BUDGET // per_pixel)
+        # per pixel: the dead points, the live points, and the packed copy of both the read-back makes at the end of the run
+        # (nfa_sampler_posterior_packed); per sampler, whatever the pixels: the proposal buffers, 32 x 262144 rows of the
+        # unit-cube point, theta, lnL and three integers (1.8 GB in twelve dimensions)
+        per_pixel = 8 * (2 * cap * (ndim + 2) + nl_max * (3 * ndim + 4))
+        fixed = 32 * 262144 * (8 * (2 * ndim + 1) + 12)
+        n_pass = max(1, (SAMPLER_MEMORY_BUDGET - fixed) // per_pixel)
         res = []
         for a in range(0, lon.size, n_pass):
             kw_pass = dict(kw)

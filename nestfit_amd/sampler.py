@@ -51,19 +51,21 @@ class NestedResult:
         self.truncated = False
         w = posterior[:, -1]
         th = posterior[:, :-2]
-        mean = w @ th
-        # (the weighted second moment about the mean from the raw one -- one (n_samples, n_params) temporary instead of the two
-        # of (th - mean) ** 2: a map of a thousand pixels builds a thousand of these)
-        var = np.maximum(w @ (th * th) - 2.0 * mean * mean + mean * mean * w.sum(), 0.0)
         best = th[np.argmin(posterior[:, -2])]      # max likelihood
         mapp = th[np.argmax(w)]                     # largest posterior mass
-        self.param_constr = np.stack([mean, np.sqrt(var), best, mapp])    # (4, n_params)
+        # the weighted moments about the row of the largest weight, a point inside the posterior's bulk (raw second moments
+        # cancel where |mean| >> sigma); one (n_samples, n_params) temporary, like the device's ns_finish_kernel
+        d = th - mapp
+        m1 = w @ d
+        d *= d
+        mean = m1 + mapp * w.sum()
+        self.param_constr = np.stack([mean, np.sqrt(_var_about(w @ d, mean, mapp, w.sum())), best, mapp])    # (4, n_params)
 
     @classmethod
     def from_stats(cls, posterior, stats, n_live, n_evals, n_iter):
         """The same result from what the device has already formed of the table (nfa_sampler_posterior_packed with `stats`:
-        lnZ, lnZ of the dead points, H, largest lnL, largest live lnL, sum of the weights, mean, raw second moment, theta of
-        the largest likelihood, theta of the largest weight): no pass over the table on the host."""
+        lnZ, lnZ of the dead points, H, largest lnL, largest live lnL, sum of the weights, mean, second moment about the row of
+        the largest weight, theta of the largest likelihood, theta of the largest weight): no pass over the table on the host."""
         self = cls.__new__(cls)
         nd = int(posterior.shape[1] - 2)
         self.posterior = posterior
@@ -75,10 +77,15 @@ class NestedResult:
         self.max_loglike = float(stats[3])
         self.n_live, self.n_evals, self.n_iter = int(n_live), int(n_evals), int(n_iter)
         self.truncated = False
-        mean, m2 = stats[6:6 + nd], stats[6 + nd:6 + 2 * nd]
-        var = np.maximum(m2 - 2.0 * mean * mean + mean * mean * stats[5], 0.0)
-        self.param_constr = np.stack([mean, np.sqrt(var), stats[6 + 2 * nd:6 + 3 * nd], stats[6 + 3 * nd:6 + 4 * nd]])
+        mean, m2, mapp = stats[6:6 + nd], stats[6 + nd:6 + 2 * nd], stats[6 + 3 * nd:6 + 4 * nd]      # (m2: about the row of the largest weight)
+        self.param_constr = np.stack([mean, np.sqrt(_var_about(m2, mean, mapp, stats[5])), stats[6 + 2 * nd:6 + 3 * nd], mapp])
         return self
+
+
+def _var_about(s2, mean, c, wsum):
+    """sum w (t - mean)^2 from s2 = sum w (t - c)^2, mean = sum w t and wsum = sum w (the weights add up to one to rounding)."""
+    delta = mean - c
+    return np.maximum(s2 - 2.0 * delta * (mean - c * wsum) + delta * delta * wsum, 0.0)
 
 
 # ---- counter-based random numbers, shared bit for bit with csrc/nfa_sampler.h -------------

@@ -212,3 +212,24 @@ def test_every_pixel_of_a_run_gets_its_own_live_points(tmp_path, workers):
     fit.fit((lon, lat), tmp_path / 'chunk0.npz')
     assert seen == {i: {n} for i, n in want.items()}
     assert len(fmod._runs_within_a_factor(np.array(list(want.values())), 2.0)) == 3
+
+
+def test_posterior_spread_survives_a_large_offset():
+    """The posterior standard deviation of a parameter whose mean is 1e7 times its spread (raw second moments cancel
+    there: round 4's form gave 0 or noise): moments are taken about the sample of the largest weight."""
+    rng = np.random.default_rng(1)
+    n = 4000
+    t = 1.0e7 + rng.normal(0, 1.0, n)
+    w = rng.uniform(0.5, 1.5, n)
+    w /= w.sum()
+    post = np.column_stack([t, 3.0 + 0.1 * rng.normal(size=n), np.zeros(n), w])
+    r = sampler.NestedResult(post, 0.0, 0.1, 0.0, 400, n, n, 1.0)
+    want = np.sqrt(w @ (post[:, :2] - w @ post[:, :2]) ** 2)
+    np.testing.assert_allclose(r.param_constr[1], want, rtol=1e-6)
+    np.testing.assert_allclose(r.param_constr[0], w @ post[:, :2], rtol=1e-14)
+    # ... and the device's statistics (mean, second moment about the MAP row, MAP row) give the same through from_stats
+    imap = int(np.argmax(w))
+    c = post[imap, :2]
+    stats = np.concatenate([[0.0, 0.0, 1.0, 0.0, 0.0, w.sum()], w @ post[:, :2], w @ (post[:, :2] - c) ** 2, post[0, :2], c])
+    r2 = sampler.NestedResult.from_stats(post, stats, 400, n, n)
+    np.testing.assert_allclose(r2.param_constr[1], want, rtol=1e-6)
