@@ -760,7 +760,7 @@ def main():
                 'kernel': LNL_KERNEL_NAME[args.exp_mode] if ncomp == 2 else 'lnl_kernel', 'mode': args.exp_mode,
                 'algorithmic_bytes_per_eval': bytes_eval, 'evals_per_launch': B * steps_per_launch,
                 'steps_per_launch': steps_per_launch, 'avg_launch_us': None, 'rocprof_avg_launch_us': None, 'rocprof_frac': None,
-                'pipeline_frac': None, 'valu_busy_frac': None, 'valu_instructions_per_eval': None}
+                'pipeline_frac': None}
         if po:
             roof.update({f'{other}_value': po['value'], f'{other}_frac': po.get('roofline_frac'), f'{other}_ms_per_step': po['ms_per_step'],
                          f'{other}_avg_launch_us': po.get('lnl_kernel_us')})

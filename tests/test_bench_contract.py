@@ -31,18 +31,25 @@ def test_default_line_has_the_contract_keys():
     assert d['n_gpus'] == 1 and d['steps'] == 6 and d['warmup'] == 2 and d['unit'] == 'evals/s'
     assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
     assert 'workload' in d['config'] and 'model' not in d['config']
-    assert set(d['modes']) == {'table', 'fast'} and d['modes']['fast']['value'] == d['value']
+    # the headline is the table mode: the reference's own arithmetic (fastexp.c:234-283, hyperfine.pyx:93-96)
+    assert set(d['modes']) == {'table', 'fast'} and d['modes']['table']['value'] == d['value'] and d['dtype'].startswith('f64 (reference FastExp')
     r = d['roofline']
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert key in r, key
     assert r['frac'] == pytest.approx(r['achieved'] / r['peak']) and 0 < r['frac'] < 1
     # value = evaluations of the timed block / its time
     assert d['value'] == pytest.approx(4096 / (d['ms_per_step'] * 1e-3), rel=1e-6)
-    assert d['modes']['table']['value'] < d['value']
-    # the like-for-like number (the reference's own f64 arithmetic) travels inside `roofline`, as a block and as flat keys
+    assert d['modes']['fast']['value'] > d['value']
+    # ... its figures lead `roofline`, the fast mode's follow as fast_* inside the first twenty keys (what reads the line
+    # keeps that many scalars)
+    keys = list(r)
+    assert r['mode'] == 'table' and r['kernel'].startswith('void lnl_kernel')
+    for key in ('avg_launch_us', 'pipeline_frac', 'fast_value', 'fast_frac', 'fast_ms_per_step', 'fast_avg_launch_us'):
+        assert key in keys[:20], (key, keys[:24])
+    assert r['fast_value'] == d['modes']['fast']['value'] and 0 < r['frac'] < r['fast_frac'] < 1
     rp = r['reference_precision']
-    assert rp['mode'] == 'table' and rp['dtype'].startswith('f64') and rp['value'] == d['modes']['table']['value']
-    assert r['reference_precision_value'] == rp['value'] and 0 < r['reference_precision_frac'] < r['frac']
+    assert rp['mode'] == 'table' and rp['dtype'].startswith('f64') and rp['value'] == d['value']
+    assert r['reference_precision_value'] == rp['value'] and r['reference_precision_frac'] == pytest.approx(r['frac'])
     assert d['config']['reference_precision_value'] == rp['value']
     # the spectra-out mode and the short C4 block of the default command
     so = d['spectra_out']
@@ -51,6 +58,11 @@ def test_default_line_has_the_contract_keys():
     c4 = d['configs']['C4']
     assert c4['algorithmic_bytes_per_eval'] == 49448 and c4['table']['value'] < c4['fast']['value']
     assert r['C4_fast_value'] == c4['fast']['value'] and r['C4_table_frac'] == c4['table']['roofline_frac']
+    # BASELINE config 5 as specified, through the cube driver
+    c5 = d['configs']['C5']
+    assert 'ncomp_max 2' in c5['workload'] and c5['pixels'] == 1024 and c5['seconds'] > 0
+    assert sum(c5['nbest_histogram'].values()) == 1024 and c5['nbest_histogram']['2'] > 300
+    assert c5['evals_per_pixel'] > 1e5 and 0.1 < c5['mean_lnZ_err'] < 0.5 and r['C5_seconds'] == c5['seconds']
 
 
 def test_two_ranks_on_one_gpu_report_the_whole_job():
