@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """usage: fourlane_summary.py <kernel_trace.csv> <bench line json>
 
-The headline's own command (four stream lanes, fast mode only) under `rocprofv3 --kernel-trace`: what the kernels of
+The headline's own command (four stream lanes, one mode) under `rocprofv3 --kernel-trace`: what the kernels of
 the timed blocks add up to against the wall time the bench line reports -- the isolated launch (one lane) against the
 pipelined rate, shown instead of argued."""
 import csv, json, sys, collections
@@ -17,7 +17,8 @@ for r in rows:
 m = line['modes'][line['config']['exp_mode']]
 spl = line['config']['steps_per_launch']
 B = 4096
-lnl = [d for n, v in dur.items() if 'lnl_kernel<' in n for d in v if d[2] >= spl * B * 2 * 64]      # the launches of `spl` coalesced steps
+# the launches of `spl` coalesced steps: one wave per unit (grid = units x 64), or the table mode's queue form (resident workgroups)
+lnl = [d for n, v in dur.items() if 'lnl_kernel' in n and 'lnl_sum' not in n for d in v if d[2] >= spl * B * 2 * 64 or 'lnl_kernel_queue' in n]
 tot = sum(b - a for a, b, g in lnl)
 ivs = sorted((a, b) for a, b, g in lnl)
 union, ca, cb = 0, None, None

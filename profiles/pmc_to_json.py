@@ -40,6 +40,11 @@ if 'SQ_ACTIVE_INST_VALU' in mean and 'GRBM_GUI_ACTIVE' in mean:
     res['valu_busy_frac'] = busy / elapsed
     if 'SQ_ACTIVE_INST_SCA' in mean:
         res['scalar_busy_frac'] = mean['SQ_ACTIVE_INST_SCA'] * 4 / simds / elapsed      # per wave slot, like VALU
+if 'SQ_WAVE_CYCLES' in mean and 'GRBM_GUI_ACTIVE' in mean:
+    # waves resident per SIMD, averaged over the launch (SQ_WAVE_CYCLES: quad-cycles summed over the waves)
+    res['avg_waves_per_simd'] = mean['SQ_WAVE_CYCLES'] * 4 / 1024 / (mean['GRBM_GUI_ACTIVE'] / 8)
+if 'SQ_LDS_IDX_ACTIVE' in mean and 'GRBM_GUI_ACTIVE' in mean:
+    res['lds_idx_active_frac'] = mean['SQ_LDS_IDX_ACTIVE'] / 256 / (mean['GRBM_GUI_ACTIVE'] / 8)     # per CU
 if 'SQ_ACTIVE_INST_LDS' in mean and 'GRBM_GUI_ACTIVE' in mean:
     res['lds_inst_busy_frac'] = mean['SQ_ACTIVE_INST_LDS'] * 4 / 1024 / (mean['GRBM_GUI_ACTIVE'] / 8)      # like valu_busy_frac
 if 'SQ_LDS_BANK_CONFLICT' in mean and mean.get('SQ_LDS_IDX_ACTIVE'):
