@@ -18,7 +18,9 @@ for k in sys.argv[1:]:
     tot = collections.defaultdict(float); n = collections.defaultdict(int)
     for f in glob.glob(f'{base}/k{k}_*/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
-            if 'lnl_kernel' not in row['Kernel_Name'] or int(row['Grid_Size']) < 500000: continue
+            name, grid = row['Kernel_Name'], int(row['Grid_Size'])
+            # the table mode's launches of four steps: the queue form (resident grid), or one wave per unit
+            if not ('lnl_kernel_queue<false' in name or ('lnl_kernel<0, false' in name and grid >= 2000000)): continue
             tot[row['Counter_Name']] += float(row['Counter_Value']); n[row['Counter_Name']] += 1
     c = {a: tot[a] / n[a] for a in tot}
     if not c: print('queue', k, 'no rows'); continue
