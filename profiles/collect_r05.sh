@@ -67,7 +67,7 @@ c5)
   cp $out/c5r4_stats/*/*kernel_stats.csv $out/sampler_kernel_stats.csv; rm -rf $out/c5r4_stats
   ;;
 ring)
-  python3 scripts/measure_ring.py native > $out/ring.txt 2> $out/ring.err || exit 5
+  python3 scripts/measure_ring.py native 1:dev 4:dev 8:dev 14:dev 16:dev 14:1:1 > $out/ring.txt 2> $out/ring.err || exit 5
   ;;
 esac
 echo "collect_r05 $1 done"
