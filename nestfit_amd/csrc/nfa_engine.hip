@@ -840,10 +840,19 @@ static int resolve_split(const nfa_runner *r, const SpecDev &S, int64_t B) {
 
 // table mode, one wave per unit, at least two units per wave slot of the device: as many workgroups as are resident at
 // once, the units drawn from the launch's queue (lnl_kernel_queue)
+// workgroups of `waves` waves of the table mode that a CU holds at once (LDS: the tables, the waves' line tables, the queue's words)
+static int table_wg_per_cu(const nfa_runner *r, int waves) {
+    const size_t need = sizeof(double) * ((size_t)(SM_END_TABLE - SM_EXP2) + (size_t)lnl_wave_doubles(r) * waves) + 16;
+    return std::max(1, std::min((int)((160 * 1024) / need), 32 / waves));
+}
 static bool lnl_uses_queue(const nfa_runner *r, const SpecDev &S, int64_t B, int mode) {
     if (mode != 0 || g_eng.lnl_queue == 0 || lnl_wide(r)) return false;
-    if (resolve_split(r, S, B) != 1 || table_waves(r) != 16) return false;
-    return B * S.n_spec >= 2 * ((int64_t)g_eng.n_cu * 2) * 16;
+    if (resolve_split(r, S, B) != 1) return false;
+    // (short units -- config 1's 256 channels are four rows -- finish before the draw has paid: 348 M evaluations/s one
+    // unit per wave against 335 M through the queue; from eight rows per spectrum on)
+    for (int k = 0; k < S.n_spec; ++k) if (S.size[k] < 512) return false;
+    const int waves = table_waves(r);
+    return B * S.n_spec >= 2 * ((int64_t)g_eng.n_cu * table_wg_per_cu(r, waves)) * waves;     // two units per resident wave and more
 }
 
 template <int MODE, bool WS, bool WIDE, int NCOMP>
@@ -875,7 +884,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
 #ifdef NFA_TEST_HOOKS
     G.trace = g_eng.d_trace;
 #endif
-    const int64_t n_units = B * S.n_spec, wg_resident = (int64_t)g_eng.n_cu * (g_eng.lnl_queue_wg > 0 ? g_eng.lnl_queue_wg : 2);
+    const int64_t n_units = B * S.n_spec, wg_resident = (int64_t)g_eng.n_cu * (g_eng.lnl_queue_wg > 0 ? g_eng.lnl_queue_wg : table_wg_per_cu(r, waves));
     if (MODE == 0 && !WIDE && r->d_queue[slot] && lnl_uses_queue(r, S, B, 0)) G.queue = r->d_queue[slot];
     size_t lds = sizeof(double) * ((size_t)n_shared + ((size_t)G.wave_doubles + (split > 1 ? LNL_PARTS * 64 : 0)) * (waves / split))
                + (G.queue ? 16 : 0);

@@ -23,8 +23,11 @@ fetch, write = rows(fcsv, 'FETCH_SIZE'), rows(wcsv, 'WRITE_SIZE')
 cal = [v for k, g, v in fetch if 'null_lnz_kernel' in k and g >= 16384 * 2 * 64]
 cal_bytes = 16384 * 2048 * 8
 factor = cal_bytes / (max(cal) * 1024.0)
+import re
 def spectra_out(k):
-    return ', true, ' in k.split('lnl_kernel<')[1][:20] if 'lnl_kernel<' in k else False
+    # lnl_kernel<MODE, WRITE_SPEC, ...>, lnl_kernel_w8<MODE, WRITE_SPEC, ...>, lnl_kernel_queue<WRITE_SPEC, NCOMP>
+    m = re.search(r'lnl_kernel_queue<(true|false)', k) or re.search(r'lnl_kernel(?:_w8)?<\d+, (true|false)', k)
+    return bool(m) and m.group(1) == 'true'
 lnl_f = [v for k, g, v in fetch if 'lnl_kernel' in k and g >= 4096 * 64 and not spectra_out(k)]
 lnl_w = [v for k, g, v in write if 'lnl_kernel' in k and g >= 4096 * 64 and not spectra_out(k)]
 spec_f = [v for k, g, v in fetch if 'lnl_kernel' in k and g >= 4096 * 64 and spectra_out(k)]

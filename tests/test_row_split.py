@@ -45,7 +45,7 @@ def test_row_split_matches_one_wave_per_unit(engine, nfo, mode):
         engine.set_exp_mode('fast')
 
 
-@pytest.mark.parametrize('trans,n,ncomp', [((1, 2), 1024, 2), ((1,), 256, 1), ((1, 2, 3), 512, 3)])
+@pytest.mark.parametrize('trans,n,ncomp', [((1, 2), 1024, 2), ((1,), 512, 1), ((1, 2, 3), 512, 3)])
 def test_unit_queue_matches_one_unit_per_wave(engine, nfo, trans, n, ncomp):
     """Table mode, launches of two and more units per wave slot of the device: resident workgroups whose waves draw
     the units from a queue (lnl_kernel_queue) against the one-wave-per-unit launch of the same rows -- the same bits,
