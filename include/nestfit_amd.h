@@ -62,6 +62,11 @@ int nfa_get_exp_mode(void);
  *                   instructions.  The chi^2 of a unit is always the sum of four interleaved row parts (rows h,
  *                   h + 4, ...) taken in order, whoever computed them, so log-likelihoods are bitwise independent
  *                   of this option and of the batch an evaluation travels in;
+ *   "lnl_queue"     1 (default) / 0: table mode, launches of two and more (item, spectrum) units per wave slot of the
+ *                   device (the coalesced steps of nfa_runner_loglike_batch_dev; spectra of 512 channels and more) run as
+ *                   resident workgroups whose waves draw their units from a queue, or every wave owns one unit.
+ *                   Bitwise the same results; "lnl_queue_wg" 1 / 2 (0 = as many as fit): workgroups per CU of such a
+ *                   launch (A/B knob);
  *   "lnl_cap"       workgroups of the likelihood kernel resident per CU at most (fast and poly mode,
  *                   0 = no cap, the default; 1..8): A/B knob, see DESIGN.md;
  *   "streams"       number of HIP streams ("lanes", 1..8) that runners created afterwards spread consecutive
@@ -93,11 +98,12 @@ int nfa_get_exp_mode(void);
  *   "sampler_walkers"     walkers per pixel of a walk cycle, 64 / 128 / 192 / 256; 0 (default): by the live points
  *                   (128 from 384, 256 from 768);
  *   "sampler_frames"      rotated box frames of a one-ellipsoid bound (nfa_sampler_set_boxes): -2 (default) and -1
- *                   none, 0..64; "sampler_margin_pct": the boxes' margin factor in hundredths (0 = 175);
+ *                   none, 0..64; "sampler_margin_pct": the boxes' margin factor in hundredths (0 = 250);
  *   "sampler_shear_pct"   the shear in front of one-ellipsoid bounds (nfa_sampler_set_shear): its safety factor in
- *                   hundredths, -1 (default) = 250 where the shape allows, 0 = off, 100..100000;
+ *                   hundredths, -1 (default) = 300 where the shape allows, 0 = off, 100..100000;
  *   "sampler_pairs_pct"   the pair ellipses of a sheared and boxed bound (nfa_sampler_set_pairs): their safety factor in
- *                   hundredths, -1 (default) = 175, 0 = off, 100..100000;
+ *                   hundredths, -1 (default) = 200, 0 = off, 100..100000 (the host side names sets of these three:
+ *                   nestfit_amd.sampler.PRECISION, 'speed' = 250 / 175 / 175, round 4's defaults);
  *   "sampler_ktarget"     replacements per pixel and rejection round a pixel's own share of the round's proposals aims
  *                   at: halved after a round with more than twice as many, doubled after one with fewer than half
  *                   (-1 = the default, 16; 0 = every pixel the round's number); "sampler_ratio_max": proposals drawn

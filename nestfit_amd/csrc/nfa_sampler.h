@@ -1867,7 +1867,7 @@ int nfa_sampler_set_boxes(nfa_sampler *s, int n_frames, double margin) {
 
 // The shear in front of a one-ellipsoid bound (10 or 15 sampled dimensions = all five free parameters of two or three
 // components; elsewhere the call is accepted and changes nothing): enlarge = the safety factor on the sheared ellipsoid's
-// enclosing volume (>= 1; NS_SHEAR_ENLARGE = 2.5 is the measured choice), 0 = off, < 0 = the default.  Before nfa_sampler_begin.
+// enclosing volume (>= 1; NS_SHEAR_ENLARGE = 3: profiles/r05/sampler_bias.txt), 0 = off, < 0 = the default.  Before nfa_sampler_begin.
 int nfa_sampler_set_shear(nfa_sampler *s, double enlarge) {
     if (!s || (enlarge > 0.0 && enlarge < 1.0) || enlarge > 1e6 || enlarge != enlarge) return fail(NFA_ERR_ARG, "shear: 0 (off), < 0 (default) or a safety factor >= 1");
     if (s->ran) return fail(NFA_ERR_STATE, "call nfa_sampler_set_shear before nfa_sampler_begin");
@@ -1875,7 +1875,7 @@ int nfa_sampler_set_shear(nfa_sampler *s, double enlarge) {
     return NFA_OK;
 }
 
-// The pair ellipses (with the shear and the boxes): enlarge = the safety factor on their areas (>= 1; NS_PAIRS_ENLARGE = 1.75),
+// The pair ellipses (with the shear and the boxes): enlarge = the safety factor on their areas (>= 1; NS_PAIRS_ENLARGE = 2),
 // 0 = off, < 0 = the default.  Before nfa_sampler_begin.
 int nfa_sampler_set_pairs(nfa_sampler *s, double enlarge) {
     if (!s || (enlarge > 0.0 && enlarge < 1.0) || enlarge > 1e6 || enlarge != enlarge) return fail(NFA_ERR_ARG, "pairs: 0 (off), < 0 (default) or a safety factor >= 1");
