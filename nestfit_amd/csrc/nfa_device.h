@@ -1239,6 +1239,11 @@ lnl_kernel_w8(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *_
 #define NFA_QUEUE_END    0xffffffffu
 #define NFA_QUEUE_STRIDE 32                                   // words between the two counters: a 128-byte line each
 #define NFA_QUEUE_WORDS  (2 * NFA_QUEUE_STRIDE)
+struct QueueArgs { SpecDev S; BatchGroup grp; const double *D; double *part; double *spec_out; long B; LnlGeom G; const double *g_tabs; };
+// (the argument segment places every argument at the next multiple of its alignment: 8 for all of these, so the struct's
+// layout is the segment's -- .offset of the kernel's .args in the code object: 0, 896, 1008, 1016, 1024, 1032, 1040, 1080)
+static_assert(sizeof(SpecDev) % 8 == 0 && sizeof(BatchGroup) % 8 == 0 && sizeof(LnlGeom) % 8 == 0 && alignof(SpecDev) == 8 &&
+              alignof(BatchGroup) == 8 && alignof(LnlGeom) == 8, "QueueArgs must mirror the kernel argument segment");
 template <bool WRITE_SPEC, int NCOMP>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) __attribute__((amdgpu_waves_per_eu(8, 8)))
 lnl_kernel_queue(SpecDev S, BatchGroup grp, const double *__restrict__ D, double *__restrict__ part,
@@ -1269,8 +1274,17 @@ lnl_kernel_queue(SpecDev S, BatchGroup grp, const double *__restrict__ D, double
 #ifdef NFA_TEST_HOOKS
         const unsigned long long t_start = wall_clock64();
 #endif
-        lnl_body<0, WRITE_SPEC, false, NCOMP, true>(S, nullptr, D, part, spec_out, B, G, g_tabs, smem, sm, n_shared, blockIdx.x,
-                                                    &grp, (long)u_item);
+        // The kernel's arguments are read where the unit needs them, through the scalar cache, from the kernel's
+        // argument segment: through an address the compiler cannot see through, so that it does not
+        // load the unit-independent fields ONCE before the loop -- they then live in scalar registers across the whole
+        // body, overflow the 80 the launch may have, and come back from lanes of a vector register with ~85 v_readlane
+        // per unit, vector instructions on the pipe that bounds the kernel.
+        // (QueueArgs: the kernel's arguments as the segment holds them -- every one of them 8-byte aligned.)
+        typedef const __attribute__((address_space(4))) QueueArgs *k_args_p;
+        k_args_p A = (k_args_p)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(A));
+        lnl_body<0, WRITE_SPEC, false, NCOMP, true>(*(const SpecDev *)&A->S, nullptr, A->D, A->part, A->spec_out, A->B, *(const LnlGeom *)&A->G,
+                                                    A->g_tabs, smem, sm, n_shared, blockIdx.x, (const BatchGroup *)&A->grp, (long)u_item);
 #ifdef NFA_TEST_HOOKS
         if (G.trace && lane_q == 0 && n_rec < 8) {
             unsigned long long *t = G.trace + ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + n_rec) * 4;
