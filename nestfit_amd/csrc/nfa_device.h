@@ -770,7 +770,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     constexpr bool FASTN = MODE == 2 && !WIDE;
     // the window test in fp32 (LineRec.mid / half); the wide form may hold spectra of 2^22 channels and more and
     // tests the integers of the window array instead
-    constexpr bool FWIN = !WIDE;
+    constexpr bool FWIN = MODE == 0 || !WIDE;      // (the table mode's line blocks test the window in fp32 whatever the line count)
     const double *g_t0x = g_tabs + SM_T0X, *g_t0y = g_tabs + SM_T0Y;
 
 #ifdef NFA_ABLATE
@@ -880,7 +880,9 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     // fast mode, two components (at most 26 lines each): both components' windows in one register pair, lanes
     // 0..31 the first component's lines, lanes 32..63 the second's -- two compares per row instead of four
     // (a compare costs as much as an fp64 operation, profiles/r02/ubench_valu.txt)
-    constexpr bool PACK2 = MODE == 2 && !WIDE && NCOMP == 2;
+    // (round 5: the table mode too, where no transition has more than 26 lines -- WIDE is then the host's word for "more" --:
+    // two compares per row less of the ~80 a row costs)
+    constexpr bool PACK2 = (MODE == 2 || MODE == 0) && !WIDE && NCOMP == 2;
     constexpr bool HOISTX = false;                             // (round 4: the exact modes' Tb constants hoisted per unit; round 5: the cell form below needs none)
     int wlo2 = 0, whi2 = 0;
     double ck_kind[NC], ck_a0x[NC], ck_b0x[NC];

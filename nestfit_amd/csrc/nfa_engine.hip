@@ -893,7 +893,7 @@ static int launch_lnl_t(nfa_runner *r, const int *d_pix, int slot, double *d_lnL
     if (MODE != 0 && r->lnl_cap > 0 && waves * r->lnl_cap < 32)      // residency cap: see Engine::lnl_cap
         lds = std::max(lds, (size_t)((160 * 1024) / r->lnl_cap) & ~(size_t)15);
     void (*kern)(SpecDev, BatchGroup, const double *, double *, double *, long, LnlGeom, const double *) = lnl_kernel<MODE, WS, WIDE, NCOMP>;
-    if constexpr (MODE == 0 && WS && !WIDE) kern = lnl_kernel_w8<MODE, WS, WIDE, NCOMP>;
+    if constexpr (MODE == 0 && WS) kern = lnl_kernel_w8<MODE, WS, WIDE, NCOMP>;
     if constexpr (MODE == 0 && !WIDE) { if (G.queue) kern = lnl_kernel_queue<WS, NCOMP>; }
     { int rc2 = ensure_dynamic_lds((const void *)kern, lds); if (rc2) return rc2; }
     const int64_t units = B * S.n_spec;
@@ -935,6 +935,9 @@ static int launch_lnl(nfa_runner *r, const int *d_pix, int slot, double *d_lnL, 
                       int mode) {
     switch (mode) {
     case 0:
+        if (lnl_wide(r))                // more than 26 lines in a transition (N2H+ 2-1, 3-2): 64-bit line masks, a mask per component
+            return d_spec ? launch_lnl_n<0, true, true>(r, d_pix, slot, d_lnL, d_spec, B)
+                          : launch_lnl_n<0, false, true>(r, d_pix, slot, d_lnL, d_spec, B);
         return d_spec ? launch_lnl_n<0, true, false>(r, d_pix, slot, d_lnL, d_spec, B)
                       : launch_lnl_n<0, false, false>(r, d_pix, slot, d_lnL, d_spec, B);
     default:
