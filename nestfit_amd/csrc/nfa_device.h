@@ -568,64 +568,49 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
 // FastExp's table product for the float X (its bits in a register), all lanes of EXEC: the three gathers issued, nothing
 // waited for.  u = bits - (122 << 23) holds l = exponent - 122 (fastexp.c:262) in bits 23..26 and (l, j0) = the A index
 // as its upper half-word; j1 and j2 are bytes 1 and 0 of the bits (fastexp.c:276-278).  Sub-dword operand selects do
-// the extractions inside the shifts: seven address instructions (round 3: nine -- a bit-field extract and a shift-add
-// per index).  A lane below 2^-5 (u negative; its value comes from the Taylor form) forms an A address far beyond the
-// workgroup's LDS: such a read returns nothing and faults nothing; its B and C addresses stay inside row 15's reach.
-#define NFA_TABLE_GATHER_LINE(X, G0, G1, G2) NFA_TABLE_GATHER(X, G0, G1, G2)
-#define NFA_TABLE_GATHER(X, G0, G1, G2)                                                                    \
-        "v_add_u32 %[t0], 0xc3000000, %[" #X "]\n\t"              /* bits - (122 << 23) */                 \
+// the extractions inside the shifts.  Six address instructions (round 3: nine -- a bit-field extract and a shift-add per
+// index; round 4: seven -- a row register and a shift-add per table): u << 1 has l as its top byte (bits 27..30 of u are
+// clear for a float in the table's range); ONE byte permute puts (l, j1) and (l, j2) into the two half-words of a
+// register, and each half-word shifted by three is an address.  A lane outside the table's range (u negative: the Taylor
+// form's; 32 and more, NaN: an exact zero instead) forms addresses beyond the workgroup's LDS for all three: such a read
+// returns nothing and faults nothing.
+// (The C factor gathered through the vector-memory path instead: profiles/r05/ab_table_cgather_vmem.txt; that build's
+// macros are in this file as of commit 4af2f27.)
+#define NFA_TABLE_ADDR(X, G0, G1, G2)                             /* u in t0 */                            \
         "v_lshlrev_b32_sdwa %[t1], 3, %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* (l, j0) * 8 */ \
         "ds_read_b64 %[" #G0 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_A) "\n\t"                              \
-        "v_bfe_u32 %[t0], %[t0], 23, 4\n\t"                       /* row l of B and C */                   \
-        "v_lshlrev_b32_sdwa %[t1], 3, %[" #X "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" /* j1 * 8 */ \
-        "v_lshl_add_u32 %[t1], %[t0], 11, %[t1]\n\t"                                                       \
+        "v_lshlrev_b32 %[t0], 1, %[t0]\n\t"                       /* top byte: l */                        \
+        "v_perm_b32 %[t0], %[t0], %[" #X "], %[psel]\n\t"          /* bytes (l, j1, l, j2) */               \
+        "v_lshlrev_b32_sdwa %[t1], 3, %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* (l, j1) * 8 */ \
         "ds_read_b64 %[" #G1 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_B) "\n\t"                              \
-        "v_lshlrev_b32_sdwa %[t1], 3, %[" #X "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" /* j2 * 8 */ \
-        "v_lshl_add_u32 %[t1], %[t0], 11, %[t1]\n\t"                                                       \
+        "v_lshlrev_b32_sdwa %[t1], 3, %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" /* (l, j2) * 8 */ \
         "ds_read_b64 %[" #G2 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_C) "\n\t"
-#ifdef NFA_CGATHER_VMEM
-// experiment (profiles/r05/ab_table_cgather_vmem.txt): the C factor gathered from the global copy of the tables through
-// the vector-memory path (its own counter, vmcnt) instead of the LDS; issued first, it has the longest way
-#undef NFA_TABLE_GATHER_LINE
-#define NFA_TABLE_GATHER_LINE(X, G0, G1, G2)                                                               \
-        "v_add_u32 %[t0], 0xc3000000, %[" #X "]\n\t"                                                       \
-        "v_lshlrev_b32_sdwa %[t1], 3, %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
-        "v_bfe_u32 %[t0], %[t0], 23, 4\n\t"                                                                \
-        "ds_read_b64 %[" #G0 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_A) "\n\t"                              \
-        "v_lshlrev_b32_sdwa %[t1], 3, %[" #X "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
-        "v_lshl_add_u32 %[t1], %[t0], 11, %[t1]\n\t"                                                       \
-        "global_load_dwordx2 %[" #G2 "], %[t1], %[gc]\n\t"                                                 \
-        "v_lshlrev_b32_sdwa %[t1], 3, %[" #X "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
-        "v_lshl_add_u32 %[t1], %[t0], 11, %[t1]\n\t"                                                       \
-        "ds_read_b64 %[" #G1 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_B) "\n\t"
-#define NFA_W_A01 "s_waitcnt lgkmcnt(2)\n\t"
-#define NFA_W_A2  "s_waitcnt vmcnt(1)\n\t"
-#define NFA_W_B01 "s_waitcnt lgkmcnt(0)\n\t"
-#define NFA_W_B2  "s_waitcnt vmcnt(0)\n\t"
-#define NFA_W_S01 "s_waitcnt lgkmcnt(0)\n\t"
-#define NFA_W_S2  "s_waitcnt vmcnt(0)\n\t"
-#define NFA_GC_OPERAND , [gc] "s"(gC)
-#else
+#define NFA_TABLE_GATHER(X, G0, G1, G2)                                                                    \
+        "v_add_u32 %[t0], 0xc3000000, %[" #X "]\n\t"              /* bits - (122 << 23) */                 \
+        NFA_TABLE_ADDR(X, G0, G1, G2)
+#define NFA_PSEL_OPERAND , [psel] "s"(0x07010700u)             // v_perm_b32 D, S0, S1: selector bytes 4..7 = S0's, 0..3 = S1's
+// The line blocks' form: the subtraction's carry -- set where the bits are at least 122 << 23, i.e. where x >= 2^-5 -- lands
+// in VCC, and the lanes of the Taylor form (fastexp.c:264) are EXEC without VCC: one scalar instruction where round 4 spent
+// a vector compare per line x row step.
 #define NFA_W_A01 "s_waitcnt lgkmcnt(4)\n\t"
 #define NFA_W_A2  "s_waitcnt lgkmcnt(3)\n\t"
 #define NFA_W_B01 "s_waitcnt lgkmcnt(1)\n\t"
 #define NFA_W_B2  "s_waitcnt lgkmcnt(0)\n\t"
 #define NFA_W_S01 "s_waitcnt lgkmcnt(1)\n\t"
 #define NFA_W_S2  "s_waitcnt lgkmcnt(0)\n\t"
-#define NFA_GC_OPERAND
-#endif
 #define NFA_TABLE_LOOKUP(X, G0, G1, G2, NUC, ID)                                                           \
         "v_add_f64 %[" #G0 "], %[xj], -%[" #NUC "]\n\t"                                                    \
         "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #G0 "]\n\t"                                                 \
         "v_mul_f64 %[" #G0 "], %[" #G0 "], %[" #ID "]\n\t"                                                 \
         "v_cvt_f32_f64 %[" #X "], %[" #G0 "]\n\t"                 /* math.pxd:17 narrowing */             \
-        NFA_TABLE_GATHER_LINE(X, G0, G1, G2)
+        "v_add_co_u32 %[t0], vcc, 0xc3000000, %[" #X "]\n\t"      /* bits - (122 << 23); VCC: x >= 2^-5 */ \
+        NFA_TABLE_ADDR(X, G0, G1, G2)
 // FastExp's Taylor form (fastexp.c:264-270: 1 - t (1 - t/2 (1 - t/3)), one IEEE operation per operation of the
 // reference) for the lanes in VCC.  The middle step 1 - (t ty) 0.5 is ONE fused multiply-add: a product with 0.5 is
 // exact, so fma(t ty, -0.5, 1) rounds once, where the reference's multiplication and subtraction round once too.
-#define NFA_TABLE_TAYLOR(X, G0, G1, G2, LBL)                                                               \
-        "s_cbranch_vccz " LBL "%=\n\t"                                                                     \
-        "s_mov_b64 exec, vcc\n\t"                                 /* (a subset of the window; SCC untouched) */ \
+#define NFA_TABLE_TAYLOR(X, G0, G1, G2, LBL, M, BR, TM)                                                              \
+        BR " " LBL "%=\n\t"                                                                     \
+        "s_mov_b64 exec, " TM "\n\t"                                 /* (a subset of the window) */                \
         "v_cvt_f64_f32 %[" #G1 "], %[" #X "]\n\t"                                                          \
         "v_mul_f64 %[" #G2 "], %[" #G1 "], %[nthird]\n\t"          /* 1 - t / 3 */                         \
         "v_add_f64 %[" #G2 "], %[" #G2 "], 1.0\n\t"                                                        \
@@ -633,6 +618,7 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
         "v_fma_f64 %[" #G2 "], %[" #G2 "], -0.5, 1.0\n\t"                                                  \
         "v_mul_f64 %[" #G1 "], %[" #G2 "], %[" #G1 "]\n\t"         /* 1 - t ty */                          \
         "v_add_f64 %[" #G0 "], -%[" #G1 "], 1.0\n\t"                                                       \
+        "s_mov_b64 exec, %[" #M "]\n\t"                           /* back to the window */                \
         LBL "%=:\n\t"
 
 // Two line x row steps of the table mode as one instruction block: both lines' FastExp arguments and table addresses
@@ -642,16 +628,14 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
 // neither the vector ALUs (75 % busy) nor the LDS array.)  The arithmetic is nf_fastexp<0, true, true>'s, operation
 // for operation: (x - nucen)^2 idenom (hyperfine.pyx:94), the float narrowing (math.pxd:17), A B C in that order
 // (fastexp.c:276-279), the Taylor form below 2^-5 (fastexp.c:264-270) where a lane of the line needs it, tau += w e.
-// EXEC is all ones on entry and on exit; no instruction in here writes SCC (the compiler keeps the pair loop's
-// condition there across the block).
+// EXEC is all ones on entry and on exit.
 __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj,
                                                 double nucA, double idA, double wA, float midA, float halfA,
-                                                double nucB, double idB, double wB, float midB, float halfB,
-                                                const double *gC = nullptr) {
+                                                double nucB, double idB, double wB, float midB, float halfB) {
     float xA, xB;
     uint32_t t0, t1;
     double a0, a1, a2, b0, b1, b2;
-    unsigned long long mA, mB;
+    unsigned long long mA, mB, tA;
     asm volatile(
         "v_sub_f32 %[t0], %[jf], %[midA]\n\t"
         "v_cmp_lt_f32_e64 %[mA], |%[t0]|, %[halfA]\n\t"
@@ -659,42 +643,40 @@ __device__ __forceinline__ void line_pair_table(double &tau, float jf, double xj
         "v_cmp_lt_f32_e64 %[mB], |%[t0]|, %[halfB]\n\t"
         "s_mov_b64 exec, %[mA]\n\t"
         NFA_TABLE_LOOKUP(xA, a0, a1, a2, nucA, idA)
+        "s_andn2_b64 %[tA], exec, vcc\n\t"                       // line A's lanes of the Taylor form
         "s_mov_b64 exec, %[mB]\n\t"
         NFA_TABLE_LOOKUP(xB, b0, b1, b2, nucB, idB)
+        "s_andn2_b64 vcc, exec, vcc\n\t"                         // line B's
         // line A: the product as its gathers land, the Taylor form where x < 2^-5, tau += w e
         "s_mov_b64 exec, %[mA]\n\t"
-        "v_cmp_gt_f32 vcc, 0x3d000000, %[xA]\n\t"
         NFA_W_A01
         "v_mul_f64 %[a0], %[a0], %[a1]\n\t"
         NFA_W_A2
         "v_mul_f64 %[a0], %[a0], %[a2]\n\t"
-        NFA_TABLE_TAYLOR(xA, a0, a1, a2, ".Lnfa_tpa_")
-        "s_mov_b64 exec, %[mA]\n\t"
+        "s_cmp_lg_u64 %[tA], 0\n\t"
+        NFA_TABLE_TAYLOR(xA, a0, a1, a2, ".Lnfa_tpa_", mA, "s_cbranch_scc0", "%[tA]")
         "v_fmac_f64 %[tau], %[wA], %[a0]\n\t"
         // line B
         "s_mov_b64 exec, %[mB]\n\t"
-        "v_cmp_gt_f32 vcc, 0x3d000000, %[xB]\n\t"
         NFA_W_B01
         "v_mul_f64 %[b0], %[b0], %[b1]\n\t"
         NFA_W_B2
         "v_mul_f64 %[b0], %[b0], %[b2]\n\t"
-        NFA_TABLE_TAYLOR(xB, b0, b1, b2, ".Lnfa_tpb_")
-        "s_mov_b64 exec, %[mB]\n\t"
+        NFA_TABLE_TAYLOR(xB, b0, b1, b2, ".Lnfa_tpb_", mB, "s_cbranch_vccz", "vcc")
         "v_fmac_f64 %[tau], %[wB], %[b0]\n\t"
         "s_mov_b64 exec, -1"
         : [tau] "+v"(tau), [xA] "=&v"(xA), [xB] "=&v"(xB), [t0] "=&v"(t0), [t1] "=&v"(t1),
           [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2),
-          [mA] "=&s"(mA), [mB] "=&s"(mB)
+          [mA] "=&s"(mA), [mB] "=&s"(mB), [tA] "=&s"(tA)
         : [jf] "v"(jf), [xj] "v"(xj), [nucA] "v"(nucA), [idA] "v"(idA), [wA] "v"(wA), [midA] "v"(midA), [halfA] "v"(halfA),
           [nucB] "v"(nucB), [idB] "v"(idB), [wB] "v"(wB), [midB] "v"(midB), [halfB] "v"(halfB),
-          [nthird] "s"(-(1.0 / 3.0)) NFA_GC_OPERAND
-        : "vcc");
+          [nthird] "s"(-(1.0 / 3.0)) NFA_PSEL_OPERAND
+        : "vcc", "scc");
 }
 
 // One line x row step of the table mode (the odd line of a run), the same arithmetic.
 __device__ __forceinline__ void line_single_table(double &tau, float jf, double xj,
-                                                  double nucA, double idA, double wA, float midA, float halfA,
-                                                  const double *gC = nullptr) {
+                                                  double nucA, double idA, double wA, float midA, float halfA) {
     float xA;
     uint32_t t0, t1;
     double a0, a1, a2;
@@ -704,20 +686,19 @@ __device__ __forceinline__ void line_single_table(double &tau, float jf, double 
         "v_cmp_lt_f32_e64 %[mA], |%[t0]|, %[halfA]\n\t"
         "s_mov_b64 exec, %[mA]\n\t"
         NFA_TABLE_LOOKUP(xA, a0, a1, a2, nucA, idA)
-        "v_cmp_gt_f32 vcc, 0x3d000000, %[xA]\n\t"
+        "s_andn2_b64 vcc, exec, vcc\n\t"                         // the lanes of the Taylor form
         NFA_W_S01
         "v_mul_f64 %[a0], %[a0], %[a1]\n\t"
         NFA_W_S2
         "v_mul_f64 %[a0], %[a0], %[a2]\n\t"
-        NFA_TABLE_TAYLOR(xA, a0, a1, a2, ".Lnfa_tps_")
-        "s_mov_b64 exec, %[mA]\n\t"
+        NFA_TABLE_TAYLOR(xA, a0, a1, a2, ".Lnfa_tps_", mA, "s_cbranch_vccz", "vcc")
         "v_fmac_f64 %[tau], %[wA], %[a0]\n\t"
         "s_mov_b64 exec, -1"
         : [tau] "+v"(tau), [xA] "=&v"(xA), [t0] "=&v"(t0), [t1] "=&v"(t1),
           [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [mA] "=&s"(mA)
         : [jf] "v"(jf), [xj] "v"(xj), [nucA] "v"(nucA), [idA] "v"(idA), [wA] "v"(wA), [midA] "v"(midA), [halfA] "v"(halfA),
-          [nthird] "s"(-(1.0 / 3.0)) NFA_GC_OPERAND
-        : "vcc");
+          [nthird] "s"(-(1.0 / 3.0)) NFA_PSEL_OPERAND
+        : "vcc", "scc");
 }
 
 // 1 - FastExp(tau) for the Tb pass of the table mode (hyperfine.pyx:109-113), tau >= +0 or NaN, every lane of a full
@@ -744,7 +725,7 @@ __device__ __forceinline__ double one_minus_fastexp_table_row(double tau) {
                      "s_waitcnt lgkmcnt(0)\n\t"
                      "v_mul_f64 %[a0], %[a0], %[a2]"
                      : [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2)
-                     : [x] "v"(x));
+                     : [x] "v"(x) NFA_PSEL_OPERAND);
         r = u >= 0 ? a0 : r;
         if (__builtin_amdgcn_sicmp(u, (int32_t)(10u << 23), 39 /* sge */) != 0ull) {      // l >= 10: x >= 32, inf, NaN
             asm volatile("" ::: "memory");
@@ -885,7 +866,12 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     constexpr bool PACK2 = (MODE == 2 || MODE == 0) && !WIDE && NCOMP == 2;
     constexpr bool HOISTX = false;                             // (round 4: the exact modes' Tb constants hoisted per unit; round 5: the cell form below needs none)
     int wlo2 = 0, whi2 = 0;
-    double ck_kind[NC], ck_a0x[NC], ck_b0x[NC];
+    double ck_a0x[NC], ck_b0x[NC];
+    // how a component's Tb pass goes, one scalar register formed once per unit (read where it is used, the model is a
+    // scalar load and a wait in the dependent chain of every (row, component); as compares of the record's doubles the
+    // classes are two register pairs per component)
+    int ck_cls[NC];
+    double ck_kind[NC];                                            // (fast mode: left to the compiler, which keeps the classes as lane masks)
     // exact modes: the constants of a component's Tb pass (excitation temperature, its reciprocal, the band's cell of
     // the 1/(e^x - 1) table) are read once per unit -- read where they are used, each is a scalar load and a wait in
     // the dependent chain of every (row, component)
@@ -902,6 +888,10 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
         lo = w.x; hi = w.y;
         if (!(l < G.nhf_max) || (ablate & 8)) { lo = 0; hi = 0; }
     };
+    // 3: no Tb pass (gaussian.pyx:50); 1: y(T0) one table cell over the band; 2: two cells; 0: the general form
+    auto tb_class = [&](double kind) {
+        return ((ablate & 1) || S.model == NFA_MODEL_GAUSSIAN) ? 3 : kind == 1.0 ? 1 : kind != 0.0 ? 2 : 0;
+    };
     if (NCOMP > 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -910,6 +900,10 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             asm volatile("" : "+v"(lbase_c[c]));
             const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
             ck_kind[c] = Dk[dko + DK_KIND]; ck_a0x[c] = Dk[dko + DK_A0X]; ck_b0x[c] = Dk[dko + DK_B0X];
+            if (MODE != 2) {
+                ck_cls[c] = __builtin_amdgcn_readfirstlane(tb_class(ck_kind[c]));
+                asm volatile("" : "+s"(ck_cls[c]));
+            }
             if (HOISTX) {
                 cx_tex[c] = Dk[c * 4]; cx_rtex[c] = Dk[c * 4 + 3];
                 cx_xkind[c] = Dk[dko + DK_XKIND]; cx_xs[c] = Dk[dko + DK_XS]; cx_xlo[c] = Dk[dko + DK_XLO]; cx_ylo[c] = Dk[dko + DK_YLO];
@@ -987,7 +981,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             }
             double pred = 0.0;
             // one component: the lines in `mask` add their optical depths, then the Tb pass
-            auto component = [&](int c, unsigned long long mask, double kind, double a0x, double b0x) {
+            auto component = [&](int c, unsigned long long mask, double kind, int cls_unit, double a0x, double b0x) {
                 unsigned lbase;
                 if (NCOMP > 0) {
                     lbase = lbase_c[c];
@@ -1040,7 +1034,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     // line to line -- finds no lane in its window and adds nothing).  The run is walked two lines at a
                     // time: the records of a pair are four reads off one address, which advances once per pair.
                     int first, n;
-                    if (FASTN || nhf <= 32) {                         // every NH3 transition: 32-bit mask arithmetic
+                    if (FASTN || (MODE == 0 && !WIDE) || nhf <= 32) { // every NH3 transition: 32-bit mask arithmetic
                         const unsigned m = (unsigned)mask;
                         first = __builtin_ctz(m);
                         n = 32 - __builtin_clz(m) - first;
@@ -1056,7 +1050,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         if constexpr (MODE == 0 && FWIN) {
                             const v2d wm = rec_ab(va + 16);
                             line_single_table(tau, jf, xj, ab.x, ab.y, wm.x, __int_as_float(__double2loint(wm.y)),
-                                              __int_as_float(__double2hiint(wm.y)), g_tabs + SM_FEC);
+                                              __int_as_float(__double2hiint(wm.y)));
                         } else {
                             const v4i hw = rec_hw(va);
                             step(ab, hw, wi);
@@ -1067,14 +1061,21 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         n -= 1;
                     }
                     while (n) {                                        // both records of a pair are read before the first step
+#ifdef NFA_EXP_HALFREC
+                        const v2d ab0 = rec_ab(va), ab1 = ab0;
+#else
                         const v2d ab0 = rec_ab(va), ab1 = rec_ab(va + 32);
+#endif
                         if constexpr (MODE == 0 && FWIN) {
                             // (w | mid, half) read as two doubles: the weight is then a register pair as it stands
+#ifdef NFA_EXP_HALFREC
+                            const v2d wm0 = rec_ab(va + 16), wm1 = wm0;      // timing experiment: wrong results
+#else
                             const v2d wm0 = rec_ab(va + 16), wm1 = rec_ab(va + 48);
+#endif
                             line_pair_table(tau, jf, xj, ab0.x, ab0.y, wm0.x, __int_as_float(__double2loint(wm0.y)),
                                             __int_as_float(__double2hiint(wm0.y)), ab1.x, ab1.y, wm1.x,
-                                            __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)),
-                                            g_tabs + SM_FEC);
+                                            __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)));
                         } else {
                             const v4i hw0 = rec_hw(va), hw1 = rec_hw(va + 32);
                             step(ab0, hw0, wi);
@@ -1092,19 +1093,38 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                 const unsigned long long livem = MODE == 2 ? __builtin_amdgcn_fcmpf((float)tau, 0.0f, NF_FCMP_UNE)
                                                            : __builtin_amdgcn_fcmp((double)tau, 0.0, NF_FCMP_UNE);
                 if (livem == 0ull) return;
-                if ((ablate & 1) || S.model == NFA_MODEL_GAUSSIAN) {      // gaussian.pyx:50: pred += peak * e
+                // (the class is tested through a copy the compiler cannot see through: left to itself it makes one switch of
+                // the chain below and the structured form of that costs a dozen scalar instructions on the way to the usual case)
+                // (fast mode: the class from the record's double where it is used, as round 4 had it -- one scalar register per
+                // component formed per unit measured 1.5 % slower there)
+                const int cls = MODE == 2 ? tb_class(kind) : cls_unit;
+                int cls_hot = __builtin_amdgcn_readfirstlane(cls);
+                if (MODE != 2) asm volatile("" : "+s"(cls_hot));
+                if (cls_hot == 1) {
+                    // The band lies in ONE cell of the 1/(e^x - 1) table (hyperfine.pyx:23-45; the usual case, first in the
+                    // chain: one scalar compare and a branch between the optical depth and the pass): the cell's
+                    // straight line in x = T0 / tex is a straight line in the channel's frequency, and
+                    //     T0 (y - tbg) = B0x x^2 + A0x x - T0 tbg          (Horner: no x^2 per row)
+                    // with the two coefficients formed once per (item, component, spectrum) by the set-up stage -- two
+                    // fused multiply-adds per channel where the reference's order of operations (division, cell, slope,
+                    // difference, product: eight in the exact modes, with the quotient by Markstein's step) rounds
+                    // differently in the sixteenth digit; the reference itself is built with -ffast-math and differs from
+                    // its own strict build by 1e-11.  FastExp of the optical depth, the factor with the table
+                    // indices, is the reference's to the bit in the table mode.  Lanes with tau == 0 (skipped by the
+                    // reference, hyperfine.pyx:104-105) get g * (1 - 1) = +-0: the sum needs no per-lane select.
+                    const double g = __builtin_fma(xj, __builtin_fma(b0x, xj, a0x), -p3);
+                    if (MODE == 2) pred = __builtin_fma(g, one_minus_fastexp_f32((float)tau, livem), pred);
+                    else pred = __builtin_fma(g, MODE == 0 ? one_minus_fastexp_table_row((double)tau) : nf_one_minus_fastexp_row<MODE>((double)tau, sm), pred);
+                    return;
+                }
+                if (cls == 3) {                                       // gaussian.pyx:50: pred += peak * e
                     pred += (double)tau;                              // tau == 0 adds nothing
                     return;
                 }
                 const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
                 if (MODE == 2) {
-                    // lanes with tau == 0 (the reference skips them, hyperfine.pyx:104-105) get g * 0:
-                    // adding it changes nothing, so the sum needs no per-lane select
                     double g;                                         // T0 (y(T0) - tbg)
-                    if (kind == 1.0) {                                // one table cell over the band (usual):
-                        // y = A0 + B0 T0 and T0 = kappa x:  g = B0x x^2 + A0x x - T0 tbg
-                        g = __builtin_fma(xj, __builtin_fma(b0x, xj, a0x), -p3);      // (Horner: no x^2 per row)
-                    } else if (kind != 0.0) {
+                    if (cls == 2) {
                         unsigned jr = jo;
                         asm volatile("" : "+v"(jr));                  // the two addresses are formed here, not in every row's head
                         const double T0 = *(const double *)((const char *)t0s + jr), tbg = *(const double *)((const char *)tbgs + jr);
@@ -1122,19 +1142,6 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         g = T0 * (y - tbg);
                     }
                     pred = __builtin_fma(g, one_minus_fastexp_f32((float)tau, livem), pred);
-                } else if (kind == 1.0) {
-                    // The band lies in ONE cell of the 1/(e^x - 1) table (hyperfine.pyx:23-45; the usual case): the cell's
-                    // straight line in x = T0 / tex is a straight line in the channel's frequency, and
-                    //     T0 (y - tbg) = B0x x^2 + A0x x - T0 tbg
-                    // with the two coefficients formed once per (item, component, spectrum) by the set-up stage -- two
-                    // fused multiply-adds per channel where the reference's order of operations (division, cell, slope,
-                    // difference, product: eight here, with the quotient by Markstein's step) rounds differently in the
-                    // sixteenth digit; the reference itself is built with -ffast-math and differs from its own strict
-                    // build by 1e-11.  FastExp of the optical depth, the factor with the table indices, is
-                    // the reference's to the bit.  Lanes with tau == 0 (skipped by the reference, hyperfine.pyx:104-105)
-                    // get g * (1 - 1) = +-0.
-                    const double g = __builtin_fma(xj, __builtin_fma(b0x, xj, a0x), -p3);
-                    pred = __builtin_fma(g, MODE == 0 ? one_minus_fastexp_table_row((double)tau) : nf_one_minus_fastexp_row<MODE>((double)tau, sm), pred);
                 } else {
                     unsigned jr = jo;
                     asm volatile("" : "+v"(jr));                      // the two addresses are formed here, not in every row's head
@@ -1171,7 +1178,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             if (NCOMP > 0) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
-                    if (hitm[c] != 0ull) component(c, hitm[c], ck_kind[c], ck_a0x[c], ck_b0x[c]);
+                    if (hitm[c] != 0ull) component(c, hitm[c], ck_kind[c], MODE != 2 ? ck_cls[c] : 0, ck_a0x[c], ck_b0x[c]);
             } else {
                 for (int c = 0; c < ncomp; ++c) {
                     int lo, hi;
@@ -1179,7 +1186,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64((lo < r0 + 64) & (hi > r0) & (hi > lo));
                     if (mask == 0ull) continue;
                     const int dko = 4 * ncomp + (c * nspec + s) * DREC_CS;
-                    component(c, mask, Dk[dko + DK_KIND], Dk[dko + DK_A0X], Dk[dko + DK_B0X]);
+                    component(c, mask, Dk[dko + DK_KIND], tb_class(Dk[dko + DK_KIND]), Dk[dko + DK_A0X], Dk[dko + DK_B0X]);
                 }
             }
             if (SPEC_DEFER) { pend_v = pred; pend_j = valid ? j : -1; }
