@@ -576,10 +576,11 @@ __device__ __forceinline__ void line_step_fastz(float &tau, float jf, double xj,
 // returns nothing and faults nothing.
 // (The C factor gathered through the vector-memory path instead: profiles/r05/ab_table_cgather_vmem.txt; that build's
 // macros are in this file as of commit 4af2f27.)
-#define NFA_TABLE_ADDR(X, G0, G1, G2)                             /* u in t0 */                            \
-        "v_lshlrev_b32_sdwa %[t1], 3, %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* (l, j0) * 8 */ \
+#define NFA_TABLE_ADDR(X, G0, G1, G2) NFA_TABLE_ADDR_U(t0, X, G0, G1, G2)        /* u in t0 */
+#define NFA_TABLE_ADDR_U(U, X, G0, G1, G2)                                                                 \
+        "v_lshlrev_b32_sdwa %[t1], 3, %[" #U "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* (l, j0) * 8 */ \
         "ds_read_b64 %[" #G0 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_A) "\n\t"                              \
-        "v_lshlrev_b32 %[t0], 1, %[t0]\n\t"                       /* top byte: l */                        \
+        "v_lshlrev_b32 %[t0], 1, %[" #U "]\n\t"                   /* top byte: l */                        \
         "v_perm_b32 %[t0], %[t0], %[" #X "], %[psel]\n\t"          /* bytes (l, j1, l, j2) */               \
         "v_lshlrev_b32_sdwa %[t1], 3, %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* (l, j1) * 8 */ \
         "ds_read_b64 %[" #G1 "], %[t1] offset:" NFA_STR(NFA_LDS_OFF_B) "\n\t"                              \
@@ -701,6 +702,14 @@ __device__ __forceinline__ void line_single_table(double &tau, float jf, double 
         : "vcc", "scc");
 }
 
+// a where the lane's bit of `m` is set, b elsewhere (the mask is already a scalar register pair: no compare)
+__device__ __forceinline__ double nf_select64(unsigned long long m, double a, double b) {
+    int lo, hi;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(b)), "v"(__double2loint(a)), "s"(m));
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(m));
+    return __hiloint2double(hi, lo);
+}
+
 // 1 - FastExp(tau) for the Tb pass of the table mode (hyperfine.pyx:109-113), tau >= +0 or NaN, every lane of a full
 // EXEC: bit for bit 1.0 - nf_fastexp<0, true>(tau).  The Taylor form (fastexp.c:264-270) for every lane first -- in the
 // line wings, most rows, every lane is below 2^-5 and that is all there is --; the table product only when a lane of
@@ -713,23 +722,27 @@ __device__ __forceinline__ double one_minus_fastexp_table_row(double tau) {
     double r = 1.0 - t * (1.0 / 3.0);                         // x == 0 gives exactly 1
     r = __builtin_fma(t * r, -0.5, 1.0);                      // = 1 - (t r) 0.5: the product with 0.5 is exact
     r = 1.0 - (t * r);
-    const int32_t u = (int32_t)(__float_as_uint(x) - (122u << 23));
-    const unsigned long long big = __builtin_amdgcn_sicmp(u, 0, 39 /* sge */);     // l >= 0: the table's range and beyond
+    // u = bits - (122 << 23); the subtraction's carry marks the lanes with l >= 0: the table's range and beyond (one
+    // instruction where a subtraction and two compares stood)
+    uint32_t u, t1;
+    unsigned long long big;
+    asm volatile("v_add_co_u32 %[u], vcc, 0xc3000000, %[x]\n\t"
+                 "s_mov_b64 %[big], vcc"
+                 : [u] "=v"(u), [big] "=s"(big) : [x] "v"(x) : "vcc");
     if (big != 0ull) {
-        asm volatile("" ::: "memory");                        // keep it a branch
-        uint32_t t0, t1;
+        uint32_t t0;
         double a0, a1, a2;
-        asm volatile(NFA_TABLE_GATHER(x, a0, a1, a2)
+        asm volatile(NFA_TABLE_ADDR_U(u, x, a0, a1, a2)
                      "s_waitcnt lgkmcnt(1)\n\t"
                      "v_mul_f64 %[a0], %[a0], %[a1]\n\t"
                      "s_waitcnt lgkmcnt(0)\n\t"
                      "v_mul_f64 %[a0], %[a0], %[a2]"
                      : [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2)
-                     : [x] "v"(x) NFA_PSEL_OPERAND);
-        r = u >= 0 ? a0 : r;
-        if (__builtin_amdgcn_sicmp(u, (int32_t)(10u << 23), 39 /* sge */) != 0ull) {      // l >= 10: x >= 32, inf, NaN
+                     : [x] "v"(x), [u] "v"(u) NFA_PSEL_OPERAND);
+        r = nf_select64(big, a0, r);
+        if (__builtin_amdgcn_sicmp((int32_t)u, (int32_t)(10u << 23), 39 /* sge */) != 0ull) {      // l >= 10: x >= 32, inf, NaN
             asm volatile("" ::: "memory");
-            r = u >= (int32_t)(10u << 23) ? 0.0 : r;
+            r = (int32_t)u >= (int32_t)(10u << 23) ? 0.0 : r;
         }
     }
     return 1.0 - r;
@@ -1061,18 +1074,10 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                         n -= 1;
                     }
                     while (n) {                                        // both records of a pair are read before the first step
-#ifdef NFA_EXP_HALFREC
-                        const v2d ab0 = rec_ab(va), ab1 = ab0;
-#else
                         const v2d ab0 = rec_ab(va), ab1 = rec_ab(va + 32);
-#endif
                         if constexpr (MODE == 0 && FWIN) {
                             // (w | mid, half) read as two doubles: the weight is then a register pair as it stands
-#ifdef NFA_EXP_HALFREC
-                            const v2d wm0 = rec_ab(va + 16), wm1 = wm0;      // timing experiment: wrong results
-#else
                             const v2d wm0 = rec_ab(va + 16), wm1 = rec_ab(va + 48);
-#endif
                             line_pair_table(tau, jf, xj, ab0.x, ab0.y, wm0.x, __int_as_float(__double2loint(wm0.y)),
                                             __int_as_float(__double2hiint(wm0.y)), ab1.x, ab1.y, wm1.x,
                                             __int_as_float(__double2loint(wm1.y)), __int_as_float(__double2hiint(wm1.y)));
