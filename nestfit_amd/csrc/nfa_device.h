@@ -949,8 +949,12 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
         bool any = false;
         if (PACK2) {
             const unsigned long long hit = lanes_lt(wlo2, r0 + 64) & lanes_gt(whi2, r0);
-            hitm[0] = hit & 0xffffffffull;
-            hitm[NC - 1] = hit >> 32;
+            // (the halves as 32-bit scalars of their own: the compiler tests "the upper half is not zero" as a 64-bit
+            // VECTOR compare of the pair against a constant otherwise)
+            unsigned h0 = (unsigned)hit, h1 = (unsigned)(hit >> 32);
+            asm volatile("" : "+s"(h0), "+s"(h1));
+            hitm[0] = h0;
+            hitm[NC - 1] = h1;
             any = hit != 0ull;
         } else if (NCOMP > 0) {
 #pragma unroll
