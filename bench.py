@@ -339,13 +339,14 @@ class Measure:
         self.buf = {'cap': 0, 'U': C.c_void_p(), 'lnL': C.c_void_p(), 'pix': C.c_void_p()}
         self.bytes_eval = algorithmic_bytes(self.trans, self.n_chan, self.ncomp)
         # What the engine makes of the steps: device-pointer batches of one shape that arrive back to back are launched
-        # together (option coalesce: up to four, a group below four waves per wave slot), and a sequence of launches
+        # together (option coalesce: up to eight, a group below eight waves per wave slot), and a sequence of launches
         # rotates over four stream lanes (six for launches of about one wave per wave slot).
         units, slots = self.B * len(self.trans), 256 * 32
-        self.group = args.coalesce or 4
+        self.group = args.coalesce or 8
+        gmax = int(os.environ.get('NFA_GROUP_MAX', 8))           # (experiment builds: -DNFA_GROUP_MAX=...)
         self.steps_per_launch = 1
-        if self.group > 1 and self.B % 64 == 0 and 2 * units <= 4 * slots:
-            self.steps_per_launch = int(max(1, min(self.group, (4 * slots) // units)))
+        if self.group > 1 and self.B % 64 == 0 and 2 * units <= gmax * slots:
+            self.steps_per_launch = int(max(1, min(self.group, (gmax * slots) // units)))
         launch_units = units * self.steps_per_launch
         self.lanes_used = args.streams or (6 if 4 * launch_units >= 3 * slots and 2 * launch_units <= 3 * slots else 4)
 
@@ -608,7 +609,7 @@ def main():
     ap.add_argument('--lnl-queue-wg', type=int, default=0, help='engine A/B knob (table mode): workgroups per CU of a queue launch')
     ap.add_argument('--lnl-queue', type=int, default=-1, help='engine A/B knob (table mode): 0 = one unit per wave always, 1 = large launches draw their units from a queue')
     ap.add_argument('--streams', type=int, default=0, help='engine A/B knob: stream lanes (0 = default)')
-    ap.add_argument('--coalesce', type=int, default=0, help='engine A/B knob: device-pointer batches launched together at most (1 = none; 0 = default 4)')
+    ap.add_argument('--coalesce', type=int, default=0, help='engine A/B knob: device-pointer batches launched together at most (1 = none; 0 = default 8)')
     ap.add_argument('--c5-ncomp', type=int, default=0, help='C5: only this number of components (A/B runs)')
     ap.add_argument('--sampler-walkers', type=int, default=0, help='engine A/B knob (C5): walkers per pixel of a walk cycle (64, 128, 192, 256; 0 = by the live points)')
     ap.add_argument('--sampler-ellipsoids', type=int, default=0, help='engine A/B knob (C5): 1 = one bounding ellipsoid per pixel whatever the dimension')

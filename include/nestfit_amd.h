@@ -73,7 +73,7 @@ int nfa_get_exp_mode(void);
  *                   nfa_runner_loglike_batch_dev calls over; 0 (default) = six streams of which a batch of
  *                   about one wavefront per wave slot of the GPU uses all six and any other batch four;
  *   "sampler_parts" groups of pixels the device sampler pipelines over the lanes (1..4, default 3);
- *   "coalesce"      1..4 (default 4): nfa_runner_loglike_batch_dev calls of one shape (same number of rows, a
+ *   "coalesce"      1..8 (default 8; 4 until round 5): nfa_runner_loglike_batch_dev calls of one shape (same number of rows, a
  *                   multiple of 64; pixels given or not) that follow each other are held and launched together,
  *                   at most this many (1 = every call its own launches).  Results are bitwise the same; anything
  *                   that looks at them or changes the way launches are made (nfa_runner_synchronize,

@@ -129,8 +129,11 @@ __host__ __device__ inline int drec_size(int ncomp, int nspec) { return 4 * ncom
 // Up to NFA_GROUP_MAX batches of `each` rows that a caller enqueues one after the other travel as ONE launch (the
 // engine coalesces them, nfa_engine.hip): item b of the launch is row b - c * each of batch c = b / each, and every
 // batch keeps its own pixel, unit-cube and result arrays.
+// (Eight since round 5 -- four before: the table mode's launch of 16384 evaluations spends its last ~80 of ~200 us with
+// fewer and fewer waves per SIMD, profiles/r05/queue_timeline.txt; eight batches in a launch halve that share:
+// 86.3 -> 87.8 M evaluations/s on the metric shape, 26.0 -> 27.2 M on config 4, the fast mode unchanged.)
 #ifndef NFA_GROUP_MAX
-#define NFA_GROUP_MAX 4
+#define NFA_GROUP_MAX 8
 #endif
 struct BatchGroup {
     const int *pix[NFA_GROUP_MAX];
@@ -141,10 +144,9 @@ struct BatchGroup {
 };
 __device__ __forceinline__ int group_of(const BatchGroup &g, long b) {
     if (g.n <= 1) return 0;
-    int c = (int)(b >= g.each) + (int)(b >= 2 * g.each) + (int)(b >= 3 * g.each);
-#if NFA_GROUP_MAX > 4
-    for (int k = 4; k < NFA_GROUP_MAX; ++k) c += (int)(b >= k * g.each);
-#endif
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < NFA_GROUP_MAX; ++k) c += (int)(b >= k * g.each);
     return c;
 }
 

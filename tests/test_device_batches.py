@@ -75,26 +75,26 @@ def test_device_batches_coalesced_or_not_give_the_host_call_bits(engine, mode):
         data = rng.normal(0, 0.2, (n_pix, 2 * n))
         noise = rng.uniform(0.1, 0.3, (n_pix, 2))
         ut = engine.get_irdc_priors(size=200, vsys=0.0)
-        # seven batches of 256 (a group of four and a rest of three), then the shape changes, then a batch whose size
+        # eleven batches of 256 (a group of eight and a rest of three), then the shape changes, then a batch whose size
         # is no multiple of 64 (never coalesced), then two more of the first shape
-        sizes = [256] * 7 + [320] * 3 + [200] + [256] * 2
+        sizes = [256] * 11 + [320] * 3 + [200] + [256] * 2
         batches = []
         for k, B in enumerate(sizes):
             pix = np.full(B, k % n_pix, dtype=np.int32) if k % 3 else rng.integers(0, n_pix, B).astype(np.int32)
             batches.append((pix, rng.uniform(size=(B, 12))))
-        for coalesce in (4, 1, 3):
+        for coalesce in (8, 1, 3, 4):
             _ffi.set_option('coalesce', coalesce)
             rc = CubeRunner(axes, (1, 2), data, noise, ut, ncomp=2)
             want = []
             for pix, U in batches:
                 Uh = U.copy()
                 want.append((Uh, rc.loglikelihood_batch(pix, Uh)))          # host-pointer call: theta in place, lnL
-            for sync_after in ((), (1, 5)):
+            for sync_after in ((), (1, 9)):
                 got = _run_on_device(_ffi, rc._run.handle, batches, sync_after)
                 for k, ((th, ln), (wt, wl)) in enumerate(zip(got, want)):
                     assert np.array_equal(th, wt) and np.array_equal(ln, wl, equal_nan=True), (mode, coalesce, sync_after, k)
     finally:
-        _ffi.set_option('coalesce', 4)
+        _ffi.set_option('coalesce', 8)
         engine.set_exp_mode('fast')
 
 

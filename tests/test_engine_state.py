@@ -69,7 +69,7 @@ def test_two_runners_in_different_modes_from_two_threads(engine, nfo):
 
 def test_option_keys(engine):
     from nestfit_amd import _ffi
-    for key, val in (('streams', 0), ('wpb', 1), ('wpb_table', 0), ('lnl_cap', 0), ('sampler_parts', 3), ('coalesce', 4),
+    for key, val in (('streams', 0), ('wpb', 1), ('wpb_table', 0), ('lnl_cap', 0), ('sampler_parts', 3), ('coalesce', 8),
                      ('sampler_ellipsoids', 0), ('sampler_walk_factor', 0), ('sampler_walkers', 0), ('sampler_refit_every', 4)):
         _ffi.set_option(key, val)
     for key, val in (('occ', 7), ('ablate', 1), ('no_such_option', 1), ('streams', 99), ('sampler_walkers', 100),
