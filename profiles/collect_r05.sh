@@ -11,7 +11,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r05; mkdir -p $out
-ONE="--streams 1 --modes one --no-cpu-baseline --skip-single-step --spectra-out off --configs off --blocks 3 --steps 60 --warmup 12"     # one lane; 72 steps = 18 launches of four steps: one launch shape
+ONE="--streams 1 --modes one --no-cpu-baseline --skip-single-step --spectra-out off --configs off --blocks 3 --steps 64 --warmup 16"     # one lane; blocks of 64 steps = launches of eight steps: one launch shape
 case "$1" in
 bench)
   python3 bench.py --steps 20 --warmup 5 > $out/bench_default.json 2> $out/bench_default.err || exit 1
@@ -46,8 +46,8 @@ pmc|pmc_fast)
     i=$((i+1))
     timeout -k 10 200 rocprofv3 --pmc $p --output-format csv -d $out/pmc_${tag}_$i -- python3 bench.py $ONE --exp-mode $mode > $out/pmc_${tag}_$i.log 2>&1 || echo "pmc pass $i failed"
   done
-  python3 profiles/pmc_to_json.py "$kern" 16384 $out/pmc_lnl_$tag.json $out/pmc_${tag}_*/*/*counter_collection.csv > $out/pmc_lnl_$tag.txt
-  [ "$1" = pmc ] && python3 profiles/pmc_to_json.py "setup_kernel" 16384 $out/pmc_setup.json $out/pmc_${tag}_*/*/*counter_collection.csv > $out/pmc_setup.txt
+  python3 profiles/pmc_to_json.py "$kern" 32768 $out/pmc_lnl_$tag.json $out/pmc_${tag}_*/*/*counter_collection.csv > $out/pmc_lnl_$tag.txt
+  [ "$1" = pmc ] && python3 profiles/pmc_to_json.py "setup_kernel" 32768 $out/pmc_setup.json $out/pmc_${tag}_*/*/*counter_collection.csv > $out/pmc_setup.txt
   rm -rf $out/pmc_${tag}_[0-9]
   ;;
 traffic)

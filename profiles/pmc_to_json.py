@@ -38,6 +38,9 @@ if 'SQ_ACTIVE_INST_VALU' in mean and 'GRBM_GUI_ACTIVE' in mean:
     res['valu_busy_cycles_per_simd'] = busy
     res['elapsed_cycles'] = elapsed
     res['valu_busy_frac'] = busy / elapsed
+    if busy > elapsed:
+        res['valu_busy_note'] = ('numerator and denominator come from different passes (separate runs of the same command): '
+                                 'a ratio a few per cent above 1 says the vector ALUs issue in every cycle of the launch')
     if 'SQ_ACTIVE_INST_SCA' in mean:
         res['scalar_busy_frac'] = mean['SQ_ACTIVE_INST_SCA'] * 4 / simds / elapsed      # per wave slot, like VALU
 if 'SQ_WAVE_CYCLES' in mean and 'GRBM_GUI_ACTIVE' in mean:
