@@ -147,7 +147,12 @@ __device__ double d_placement_draw(const DistDev &d, double x_lo, double x_hi, d
 }
 
 // prior k of PriorTransformer.c_transform (core.pyx:459-476) for the item of this lane
-__device__ void prior_apply_lane(const PriorProg &pp, int k, double *u, int n) {
+// (Inlined into its kernels since round 5: as a function of its own it was compiled to 248 vector registers -- a callee
+// has no occupancy to aim for -- and every kernel that calls it is allotted its callees' maximum: the set-up kernel ran
+// two waves per SIMD for a body that needs 165.  Inlined: three waves, and the launch stands less in the way of the
+// likelihood launches of the neighbouring lanes -- 152.7 -> 157.4 M evaluations/s on the metric shape in the fast mode,
+// config 5 (rounds 2-4's cube) 3.41 -> 3.38 s.  Held to 128 registers (four waves) it gains nothing more.)
+__device__ __forceinline__ void prior_apply_lane(const PriorProg &pp, int k, double *u, int n) {
     {
         const nfa_prior_desc &p = pp.pr[k];
         const int ix = p.p_ix * n;
