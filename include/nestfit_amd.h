@@ -82,7 +82,7 @@ int nfa_get_exp_mode(void);
  *   "prior_stage"   1 / 0: the set-up kernel stages the prior tables in LDS (default) or reads them from global
  *                   memory; taken over by priors created afterwards (A/B knob: no measurable difference in the
  *                   pipelined rates, the staged form is 5 us shorter when the stage runs alone);
- *   "setup_ti", "setup_threads"  items (8..64, default 64) and threads (256 / 512, default 256) per workgroup of
+ *   "setup_ti", "setup_threads"  items (8..64, default 64) and threads (256 .. 512 in steps of 64; default 256, 512 in the table mode) per workgroup of
  *                   the set-up kernel: A/B knobs, see DESIGN.md;
  *   "point"         1 / 0: single points and small batches (nfa_runner_loglike_batch with B <= 128,
  *                   nfa_loglike_callback) go through the one-launch point kernel (default: one workgroup per

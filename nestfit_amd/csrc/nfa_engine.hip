@@ -308,7 +308,7 @@ int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "coalesce") && value >= 1 && value <= NFA_GROUP_MAX) { g_eng.coalesce = value; return NFA_OK; }
     if (key && !strcmp(key, "prior_stage") && (value == 0 || value == 1)) { g_eng.prior_stage = value; return NFA_OK; }
     if (key && !strcmp(key, "setup_ti") && (value == 0 || value == 8 || value == 16 || value == 32 || value == 64)) { g_eng.setup_ti = value; return NFA_OK; }
-    if (key && !strcmp(key, "setup_threads") && (value == 0 || value == 256 || value == 512)) { g_eng.setup_threads = value; return NFA_OK; }
+    if (key && !strcmp(key, "setup_threads") && (value == 0 || value == 256 || value == 320 || value == 384 || value == 448 || value == 512)) { g_eng.setup_threads = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_refit_every") && value >= 1 && value <= 16) { g_eng.sampler_refit_every = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_walkers") && value >= 0 && value <= 256 && value % 64 == 0) { g_eng.sampler_walkers = value; return NFA_OK; }
@@ -777,9 +777,13 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     const PriorProg *prog = has_prior ? (const PriorProg *)r->pr->d_prog : nullptr;
     // items per workgroup and waves per workgroup (options setup_ti, setup_threads: A/B knobs)
     const int ti = g_eng.setup_ti > 0 ? g_eng.setup_ti : SETUP_TI;
-    const int threads = g_eng.setup_threads > 0 ? g_eng.setup_threads : SETUP_THREADS;
     const unsigned blocks = (unsigned)((B + ti - 1) / ti);
     const bool tables = setup_uses_tables(r, mode);
+    // Eight waves per workgroup where the partition sums go through FastExp's tables (52 KB of LDS per workgroup: two per
+    // CU whatever their size, and the sums are eight rounds of a four-wave workgroup): 57.7 -> 48.8 us per 32768 items,
+    // 88.4 -> 90.5 M evaluations/s on the metric shape.  The polynomial's set-up (fast mode) is faster with four
+    // (156.5 against 149.8 M): its workgroups are many per CU (scripts/gpu_setup_shape.sh).
+    const int threads = g_eng.setup_threads > 0 ? g_eng.setup_threads : tables ? 2 * SETUP_THREADS : SETUP_THREADS;
     const size_t lds = setup_lds_bytes(r, mode, has_prior);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "too many parameters for the set-up kernel");
     auto kern = tables ? setup_kernel<0, false> : mode == 2 ? setup_kernel<1, true> : setup_kernel<1, false>;
