@@ -620,6 +620,7 @@ def main():
     ap.add_argument('--sampler-parts', type=int, default=0, help='engine A/B knob (C5): groups of pixels pipelined over the lanes')
     ap.add_argument('--prior-stage', type=int, default=-1, help='engine A/B knob: prior tables staged in LDS (1) or left in global memory (0)')
     ap.add_argument('--setup-ti', type=int, default=0, help='engine A/B knob: items per set-up workgroup (0 = default)')
+    ap.add_argument('--setup-sub', type=int, default=0, help='engine A/B knob: 1 = one group of items per set-up workgroup in the table mode (default: two)')
     ap.add_argument('--setup-threads', type=int, default=0, help='engine A/B knob: threads per set-up workgroup (0 = default)')
     ap.add_argument('--ablate', type=int, default=0, help='timing experiment with the -DNFA_ABLATE build (INVALID results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -648,7 +649,7 @@ def main():
     if args.ablate and 'NFA_ENGINE_LIB' not in os.environ:
         raise SystemExit('--ablate needs the test library: NFA_ENGINE_LIB=nestfit_amd/lib/libnestfit_amd_test.so')
     for key, val in (('wpb', args.wpb), ('streams', args.streams), ('ablate', args.ablate), ('setup_ti', args.setup_ti), ('coalesce', args.coalesce),
-                     ('setup_threads', args.setup_threads), ('wpb_table', args.wpb_table)):
+                     ('setup_threads', args.setup_threads), ('wpb_table', args.wpb_table), ('setup_sub', args.setup_sub)):
         if val:
             _ffi.set_option(key, val)
     if args.lnl_cap >= 0:

@@ -84,6 +84,8 @@ int nfa_get_exp_mode(void);
  *                   pipelined rates, the staged form is 5 us shorter when the stage runs alone);
  *   "setup_ti", "setup_threads"  items (8..64, default 64) and threads (256 .. 512 in steps of 64; default 256, 512 in the table mode) per workgroup of
  *                   the set-up kernel: A/B knobs, see DESIGN.md;
+ *   "setup_sub"     1: one group of 64 items per set-up workgroup in the table mode; 0 (default): two groups behind one
+ *                   copy of the tables where every batch of the launch is a multiple of 128 rows;
  *   "point"         1 / 0: single points and small batches (nfa_runner_loglike_batch with B <= 128,
  *                   nfa_loglike_callback) go through the one-launch point kernel (default: one workgroup per
  *                   point, the result written to a mapped host buffer) or through the batch kernels;

@@ -82,6 +82,7 @@ struct Engine {
                                      // this many (1 = every batch its own launches)
     int    prior_stage = 1;          // prior tables staged in LDS by the set-up kernel (priors created afterwards)
     int    setup_ti = 0, setup_threads = 0;   // set-up kernel: items and threads per workgroup (0 = 64 / 256)
+    int    setup_sub = 0;                     // table mode: 1 = one group of items per set-up workgroup (0 = two where the batch allows)
     int    point = 1;                // single points: 1 = the one-launch point kernel, 0 = the batch kernels (graph replay)
     bool   have_t0 = false;
     double *d_tabs = nullptr;                      // SM_END_TABLE doubles
@@ -308,6 +309,7 @@ int nfa_set_option(const char *key, int value) {
     if (key && !strcmp(key, "coalesce") && value >= 1 && value <= NFA_GROUP_MAX) { g_eng.coalesce = value; return NFA_OK; }
     if (key && !strcmp(key, "prior_stage") && (value == 0 || value == 1)) { g_eng.prior_stage = value; return NFA_OK; }
     if (key && !strcmp(key, "setup_ti") && (value == 0 || value == 8 || value == 16 || value == 32 || value == 64)) { g_eng.setup_ti = value; return NFA_OK; }
+    if (key && !strcmp(key, "setup_sub") && (value == 0 || value == 1)) { g_eng.setup_sub = value; return NFA_OK; }
     if (key && !strcmp(key, "setup_threads") && (value == 0 || value == 256 || value == 320 || value == 384 || value == 448 || value == 512)) { g_eng.setup_threads = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_parts") && value >= 1 && value <= 4) { g_eng.sampler_parts = value; return NFA_OK; }
     if (key && !strcmp(key, "sampler_refit_every") && value >= 1 && value <= 16) { g_eng.sampler_refit_every = value; return NFA_OK; }
@@ -763,8 +765,8 @@ static int reserve_lane(nfa_runner *r, int slot, int64_t B) {
 
 // LDS of the set-up stage: exponential tables, theta + partition records + the prior program and its tables
 static bool setup_uses_tables(const nfa_runner *r, int mode) { return mode == 0 && r->ss->dev.model == NFA_MODEL_AMMONIA; }
-static size_t setup_lds_bytes(const nfa_runner *r, int mode, bool has_prior) {
-    const size_t work = (size_t)64 * r->ndim + (size_t)SETUP_TI * r->ncomp * QREC + sizeof(PriorProg) / sizeof(double) + 1
+static size_t setup_lds_bytes(const nfa_runner *r, int mode, bool has_prior, int nsub = 1) {
+    const size_t work = (size_t)nsub * ((size_t)64 * r->ndim + (size_t)SETUP_TI * r->ncomp * QREC) + sizeof(PriorProg) / sizeof(double) + 1
                         + (has_prior ? (size_t)r->pr->prog.stage_doubles : 0);
     return sizeof(double) * ((setup_uses_tables(r, mode) ? (SM_END_TABLE - SM_EXP2) : NFA_EXP2_N) + work);
 }
@@ -777,16 +779,25 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     const PriorProg *prog = has_prior ? (const PriorProg *)r->pr->d_prog : nullptr;
     // items per workgroup and waves per workgroup (options setup_ti, setup_threads: A/B knobs)
     const int ti = g_eng.setup_ti > 0 ? g_eng.setup_ti : SETUP_TI;
-    const unsigned blocks = (unsigned)((B + ti - 1) / ti);
     const bool tables = setup_uses_tables(r, mode);
     // Eight waves per workgroup where the partition sums go through FastExp's tables (52 KB of LDS per workgroup: two per
     // CU whatever their size, and the sums are eight rounds of a four-wave workgroup): 57.7 -> 48.8 us per 32768 items,
     // 88.4 -> 90.5 M evaluations/s on the metric shape.  The polynomial's set-up (fast mode) is faster with four
     // (156.5 against 149.8 M): its workgroups are many per CU (scripts/gpu_setup_shape.sh).
-    const int threads = g_eng.setup_threads > 0 ? g_eng.setup_threads : tables ? 2 * SETUP_THREADS : SETUP_THREADS;
-    const size_t lds = setup_lds_bytes(r, mode, has_prior);
+    int threads = g_eng.setup_threads > 0 ? g_eng.setup_threads : tables ? 2 * SETUP_THREADS : SETUP_THREADS;
+    // ... and two such groups per workgroup behind one copy of the tables (115 KB of LDS for one group: one workgroup per CU
+    // and two rounds of them for 32768 items; 133 KB for two: one round): 48.4 -> see profiles/r05/ab_table_linestep.txt.
+    // Every batch of the launch must hold whole workgroups.
+    int nsub = 1;
+    if (tables && g_eng.setup_threads == 0 && g_eng.setup_sub != 1 && ti == SETUP_TI && B % (2 * ti) == 0 && r->cur_group.each % (2 * ti) == 0
+        && setup_lds_bytes(r, mode, has_prior, 2) <= 160 * 1024) {
+        nsub = 2;
+        threads = 1024;
+    }
+    const unsigned blocks = (unsigned)((B + (int64_t)ti * nsub - 1) / ((int64_t)ti * nsub));
+    const size_t lds = setup_lds_bytes(r, mode, has_prior, nsub);
     if (lds > 160 * 1024) return fail(NFA_ERR_ARG, "too many parameters for the set-up kernel");
-    auto kern = tables ? setup_kernel<0, false> : mode == 2 ? setup_kernel<1, true> : setup_kernel<1, false>;
+    auto kern = nsub == 2 ? setup_kernel<0, false, 2> : tables ? setup_kernel<0, false> : mode == 2 ? setup_kernel<1, true> : setup_kernel<1, false>;
     { int rc2 = ensure_dynamic_lds((const void *)kern, lds); if (rc2) return rc2; }
     (void)d_U;                                               // the batches' arrays travel in r->cur_group
     if (r->ev_cur)      // profiling: the events ride on the dispatch itself -- its own start and stop, as a tracer sees them

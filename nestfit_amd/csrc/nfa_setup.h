@@ -435,41 +435,48 @@ __device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const doubl
 #define SETUP_THREADS 256
 // the set-up stage of the 64 items of workgroup `block_id`, by the blockDim.x threads of the workgroup (`sm` =
 // the staged exponential tables, n_shared doubles at the start of smem)
-template <int MODE, bool FAST = false>
+template <int MODE, bool FAST = false, int NSUB = 1>
 __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, const SpecDev &S,
                                            double *__restrict__ U, double *__restrict__ D, long B, int has_prior,
                                            const double *__restrict__ g_tabs, int ablate_in, double *smem,
                                            const double *sm, int n_shared, unsigned block_id, int ti = SETUP_TI) {
+    constexpr int nsub = NSUB;
 #ifdef NFA_ABLATE
     const int ablate = ablate_in;      // timing experiments: 16 skip the priors, 32 the partition sums, 64 the derive phase
 #else
     const int ablate = 0;
 #endif
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    // nsub > 1: the workgroup is `nsub` groups of threads, each with `ti` items of its own (theta and partition records
+    // side by side in LDS) behind ONE copy of the exponential tables, the prior program and its tables -- the table
+    // mode's 92 KB of tables are then staged once per 128 items, and the device holds the whole batch in one round of
+    // workgroups instead of two
+    const int tid_wg = threadIdx.x, nthr_wg = blockDim.x;
+    const int nthr = nthr_wg / nsub, sub = tid_wg / nthr, tid = tid_wg - sub * nthr;
     const int ncomp = S.ncomp, nspec = S.n_spec, ndim = S.npar * ncomp;
     const int drec = drec_size(ncomp, nspec);
-    double *th_all = smem + n_shared;                          // theta of item `it`: th_all[k * 64 + it]
+    const int per_sub = 64 * ndim + SETUP_TI * ncomp * QREC;
+    double *th_all = smem + n_shared + sub * per_sub;          // theta of item `it`: th_all[k * 64 + it]
     double *q_all = th_all + 64 * ndim;
-    PriorProg *lp = (PriorProg *)(q_all + SETUP_TI * ncomp * QREC);
+    PriorProg *lp = (PriorProg *)(smem + n_shared + nsub * per_sub);
     double *tab = (double *)(lp + 1);
-    const long b0 = (long)block_id * ti;                       // ti <= SETUP_TI items per workgroup (the LDS layout is SETUP_TI's)
-    const int n_it = (int)(B - b0 < ti ? B - b0 : ti);
+    const long b0 = ((long)block_id * nsub + sub) * ti;        // ti <= SETUP_TI items per group (the LDS layout is SETUP_TI's)
+    const int n_it = (int)(B - b0 < ti ? (B - b0 > 0 ? B - b0 : 0) : ti);
     const bool do_prior = has_prior && !(ablate & 16);
     // ---- phase 0: the program and its tables -> LDS (flat copies: all loads in flight at once); theta -> LDS
     if (do_prior) {
         const int nw = (int)(sizeof(PriorProg) / sizeof(int));
-        for (int k = tid; k < nw; k += nthr) ((int *)lp)[k] = ((const int *)ppp)[k];
+        for (int k = tid_wg; k < nw; k += nthr_wg) ((int *)lp)[k] = ((const int *)ppp)[k];
         const double *image = ppp->stage_image;
         const int n_tab = ppp->stage_doubles;
-        for (int k = tid; k < n_tab; k += nthr) tab[k] = image[k];
+        for (int k = tid_wg; k < n_tab; k += nthr_wg) tab[k] = image[k];
     }
     for (int q = tid; q < n_it * ndim; q += nthr) {            // coalesced; LDS holds it transposed
         const int it = q / ndim, k = q - it * ndim;
         th_all[k * 64 + it] = U[b0 * ndim + q];
     }
     __syncthreads();
-    if (do_prior && tid < lp->n_stage) {                       // the LDS copy of the program points at the LDS tables
-        const StageItem it = lp->stage[tid];
+    if (do_prior && tid_wg < lp->n_stage) {                    // the LDS copy of the program points at the LDS tables
+        const StageItem it = lp->stage[tid_wg];
         DistDev &d = lp->ds[it.dist];
         const double *p = tab + it.off;
         if (it.field == ST_XAX) d.xax = p; else if (it.field == ST_PDF) d.pdf = p; else if (it.field == ST_PPF) d.ppf = p;
@@ -519,20 +526,21 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
 }
 
 // MODE: the exponential of the partition sums (0 the reference's tables, 1 the polynomial); FAST: the record of the fast mode
-template <int MODE, bool FAST = false>
-__global__ void __launch_bounds__(512) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
+// NSUB = 2: sixteen waves, two groups of eight with `ti` items each (setup_body)
+template <int MODE, bool FAST = false, int NSUB = 1>
+__global__ void __launch_bounds__(512 * NSUB) __attribute__((amdgpu_waves_per_eu(3))) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
                                                     BatchGroup grp, double *__restrict__ D,
                                                     long B, int has_prior,
                                                     const double *__restrict__ g_tabs, int ablate_in, int ti) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // the workgroup's items belong to one batch of the group (the host sees to it that `each` is a multiple of ti):
     // its unit-cube array, shifted so that the body can go on indexing it with the item's number in the launch
-    const int c = group_of(grp, (long)blockIdx.x * ti);
+    const int c = group_of(grp, (long)blockIdx.x * ti * NSUB);
     double *U = grp.U[c] - (long)c * grp.each * (S.npar * S.ncomp);
     __builtin_amdgcn_s_setprio(3);
     int n_shared;
     const double *sm = stage_exp_tables<MODE>(smem, g_tabs, &n_shared);
-    setup_body<MODE, FAST>(ppp, S, U, D, B, has_prior, g_tabs, ablate_in, smem, sm, n_shared, blockIdx.x, ti);
+    setup_body<MODE, FAST, NSUB>(ppp, S, U, D, B, has_prior, g_tabs, ablate_in, smem, sm, n_shared, blockIdx.x, ti);
 }
 
 // ---------------------------------------------------------------------------
