@@ -528,11 +528,13 @@ class Measure:
         (nestfit/main.py:1106-1113, 1182-1188).  Algorithmic bytes per evaluation = the likelihood's + sum_s N_s * 8."""
         args, B, lib, _ffi = self.args, self.B, self.lib, self._ffi
         chan_tot = len(self.trans) * self.n_chan
-        n_out = 6                                              # output buffers in rotation: more than the stream lanes
+        spl = self.steps_per_launch                           # consecutive predict calls of one shape travel as one launch, like the likelihood's
+        n_out = 4 * max(spl, 2)                                # output buffers in rotation: every batch of the launches in flight its own
         out = C.c_void_p()
         _ffi.check(lib.nfa_malloc(C.byref(out), n_out * B * chan_tot * 8))
         theta = self.U_host.copy()
         self.ut.transform_batch(theta, self.ncomp)             # physical parameters of the same draws
+        theta = np.ascontiguousarray(np.tile(theta, (spl, 1)))  # (spl copies: the one-lane measurement launches spl steps as one call)
         d_theta = C.c_void_p()
         _ffi.check(lib.nfa_malloc(C.byref(d_theta), theta.nbytes))
         _ffi.check(lib.nfa_memcpy_h2d(d_theta, theta.ctypes.data_as(C.c_void_p), theta.nbytes))
@@ -557,11 +559,19 @@ class Measure:
         entry['pipeline_achieved_GBs'] = pipe
         entry['pipeline_frac'] = pipe / (HBM_PEAK_GBS * self.world)
         if self.rank == 0 and self.world == 1:
-            lnl_us, setup_us, n_l = self.one_lane_kernel_times(1, lambda h, k: step(h, k))
-            ach = bytes_eval * B / (lnl_us * 1e-6) / 1e9
-            entry.update({'lnl_kernel_us': lnl_us, 'setup_kernel_us': setup_us, 'one_lane_launches': n_l, 'evals_per_launch': B,
-                          'achieved_GBs': ach, 'frac': ach / HBM_PEAK_GBS,
+            def launch(handle, k):                              # the launch the engine makes of spl steps, as one call over their rows
+                _ffi.check(lib.nfa_runner_predict_batch_dev(handle, C.c_void_p(buf['pix'].value + k * spl * B * 4), d_theta, spl * B,
+                                                            C.c_void_p(out.value + (k % (n_out // spl)) * spl * B * chan_tot * 8),
+                                                            C.c_void_p(buf['lnL'].value + k * spl * B * 8)))
+            lnl_us, setup_us, n_l = self.one_lane_kernel_times(spl, launch)
+            ach = bytes_eval * B * spl / (lnl_us * 1e-6) / 1e9
+            entry.update({'lnl_kernel_us': lnl_us, 'setup_kernel_us': setup_us, 'one_lane_launches': n_l, 'evals_per_launch': B * spl,
+                          'steps_per_launch': spl, 'achieved_GBs': ach, 'frac': ach / HBM_PEAK_GBS,
                           'kernel': f'lnl_kernel<{0 if mode == "table" else 2}, true, false, {self.ncomp}>'})
+            if spl > 1:
+                l1, s1, n1 = self.one_lane_kernel_times(1, lambda h, k: step(h, k))
+                entry['single_step_launch'] = {'lnl_kernel_us': l1, 'setup_kernel_us': s1, 'one_lane_launches': n1,
+                                               'frac': bytes_eval * B / (l1 * 1e-6) / 1e9 / HBM_PEAK_GBS}
         lib.nfa_free(out)
         lib.nfa_free(d_theta)
         return entry
@@ -845,8 +855,8 @@ def main():
             try:
                 f = profile_file('pmc_traffic_spectra_out.json')
                 tr = json.loads(f.read_text())
-                spectra['traffic'] = tr['bytes_per_launch']
-                spectra['traffic_frac_of_peak'] = tr['bytes_per_launch'] / (spectra['lnl_kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                spectra['traffic'] = tr['bytes_per_launch'] * spectra.get('steps_per_launch', 1)      # (measured per 4096-row batch)
+                spectra['traffic_frac_of_peak'] = spectra['traffic'] / (spectra['lnl_kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS
                 spectra['traffic_source'] = rel(f)
                 roof['spectra_out_traffic'] = spectra['traffic']
                 roof['spectra_out_traffic_frac_of_peak'] = spectra['traffic_frac_of_peak']

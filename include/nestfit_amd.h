@@ -252,7 +252,10 @@ int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_
  * generate_predicted_profiles, nestfit/main.py:1106-1113, 1182-1188, for a caller whose MAP cube and
  * profile cube stay in HBM): d_theta [B x ndim] physical parameters (read only), d_spectra
  * [B x chan_tot] or NULL, d_lnL [B] or NULL (not both NULL).  Asynchronous and rotating over the
- * runner's streams like nfa_runner_loglike_batch_dev; same results as nfa_runner_predict_batch. */
+ * runner's streams like nfa_runner_loglike_batch_dev, and like its batches consecutive calls of one
+ * shape (same B, a multiple of 64; the same of d_pix / d_spectra / d_lnL given) travel as one launch,
+ * every batch writing its own arrays (option "coalesce"; since round 5: a launch of one 4096-row batch is
+ * as long as its longest wave); same results as nfa_runner_predict_batch. */
 int nfa_runner_predict_batch_dev(nfa_runner *r, const int32_t *d_pix, const double *d_theta, int64_t B,
                                  double *d_spectra, double *d_lnL);
 int nfa_runner_synchronize(nfa_runner *r);

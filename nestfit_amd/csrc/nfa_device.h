@@ -139,6 +139,7 @@ struct BatchGroup {
     const int *pix[NFA_GROUP_MAX];
     double    *U[NFA_GROUP_MAX];
     double    *lnL[NFA_GROUP_MAX];
+    double    *spec[NFA_GROUP_MAX];          // spectra out: the batch's B x chan_tot array (null: the launch writes none)
     long       each;
     int        n;
 };
@@ -820,10 +821,12 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
     const int t = S.trans[s] - 1, N = S.size[s], off = S.off[s];
     const int nhf = __builtin_amdgcn_readfirstlane(c_nhf[t]);
     long p_ix = 0;
+    double *so = WRITE_SPEC ? spec_out + b * S.chan_tot + off : nullptr;     // spectra out: the unit's model spectrum
     if (grp) {                                                    // batch kernels: the item's batch of the group has the pixels
         const int c = group_of(*grp, b);
         const int *pp = grp->pix[c];
         if (pp) p_ix = (long)__builtin_amdgcn_readfirstlane(pp[b - c * grp->each]);
+        if (WRITE_SPEC && grp->spec[0]) so = grp->spec[c] + (b - c * grp->each) * S.chan_tot + off;     // every batch its own array
     } else if (pix) {
         p_ix = (long)__builtin_amdgcn_readfirstlane(pix[b]);
     }
@@ -974,7 +977,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
         // Spectra out (main.py:1106-1113, 1182-1188): a row no line window touches is zeros, written without reading the row
         // (write-once data, past the caches: non-temporal).
         if (WRITE_SPEC && !any) {
-            if (j < N) __builtin_nontemporal_store(0.0, spec_out + b * S.chan_tot + off + j);
+            if (j < N) __builtin_nontemporal_store(0.0, so + j);
             continue;
         }
         if (any) {
@@ -995,7 +998,7 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
             // per CU -- and store where the row ends.)
             if (SPEC_DEFER) {
                 asm volatile("" ::: "memory");                        // (the loads above stay above, the store below)
-                if (pend_j >= 0) __builtin_nontemporal_store(pend_v, spec_out + b * S.chan_tot + off + pend_j);
+                if (pend_j >= 0) __builtin_nontemporal_store(pend_v, so + pend_j);
                 asm volatile("" ::: "memory");
             }
             double pred = 0.0;
@@ -1201,13 +1204,13 @@ __device__ __forceinline__ void lnl_body(const SpecDev &S, const int *__restrict
                 }
             }
             if (SPEC_DEFER) { pend_v = pred; pend_j = valid ? j : -1; }
-            else if (WRITE_SPEC) { if (valid) __builtin_nontemporal_store(pred, spec_out + b * S.chan_tot + off + j); }
+            else if (WRITE_SPEC) { if (valid) __builtin_nontemporal_store(pred, so + j); }
             if (any) acc = __builtin_fma(pred, __builtin_fma(-2.0, dj, pred), acc);       // lanes beyond N: pred = 0
         }
     }
     if (split == 1) tot += acc; else w_part[h * 64 + lane] = acc;
     }
-    if (SPEC_DEFER && pend_j >= 0) __builtin_nontemporal_store(pend_v, spec_out + b * S.chan_tot + off + pend_j);
+    if (SPEC_DEFER && pend_j >= 0) __builtin_nontemporal_store(pend_v, so + pend_j);
     if (split > 1) {
         __syncthreads();
         if (rpart != 0) return;

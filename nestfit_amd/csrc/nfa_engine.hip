@@ -240,6 +240,7 @@ struct nfa_runner {
     hipEvent_t *ev_cur = nullptr;        // profiling: [set-up start, stop, likelihood start, stop] of the call under way
     BatchGroup  cur_group = {};          // the batches of the launches being enqueued (run_group)
     BatchGroup  pending = {};            // device-pointer batches accepted but not yet launched (coalescing)
+    bool        pending_prior = true;    // ... loglike batches (unit cube, prior transform) or predict batches (physical parameters)
     // One in-flight call per runner is the contract (include/nestfit_amd.h); the process-wide calls
     // (nfa_device_synchronize, nfa_set_exp_mode) walk every live runner from whatever thread makes them, so the state a
     // launch touches -- pending, cur_group, n_calls, lane_busy, the lanes themselves -- is guarded: every public entry
@@ -1034,7 +1035,7 @@ static int flush_pending(nfa_runner *r) {
     if (r->pending.n == 0) return NFA_OK;
     const BatchGroup g = r->pending;
     r->pending.n = 0;
-    return run_group(r, g, nullptr, true, -1, nullptr);
+    return run_group(r, g, g.spec[0], r->pending_prior, -1, nullptr);
 }
 static int flush_all_runners() {
     std::lock_guard<std::mutex> lk(g_runners_m);
@@ -1064,25 +1065,32 @@ static int check_pix(const nfa_runner *r, const int32_t *pix, int64_t B) {
 
 extern "C" {
 
+// a device-pointer batch: launched with its neighbours of the same kind and shape, or on its own
+static int enqueue_dev(nfa_runner *r, const int32_t *d_pix, double *d_U, double *d_lnL, double *d_spec, int64_t B, bool has_prior) {
+    const int ti = g_eng.setup_ti > 0 ? g_eng.setup_ti : SETUP_TI;
+    const int64_t units = B * r->ss->dev.n_spec, slots = (int64_t)g_eng.n_cu * 32;
+    BatchGroup &p = r->pending;
+    const int group = g_eng.coalesce;                  // read per call: a knob, not part of a runner's identity
+    const bool fits = group > 1 && !r->profiling && B % ti == 0 && 2 * units <= NFA_GROUP_MAX * slots;   // (a group stays below NFA_GROUP_MAX waves per slot)
+    if (p.n > 0 && (!fits || p.each != (long)B || r->pending_prior != has_prior || (p.pix[0] == nullptr) != (d_pix == nullptr) ||
+                    (p.lnL[0] == nullptr) != (d_lnL == nullptr) || (p.spec[0] == nullptr) != (d_spec == nullptr) ||
+                    (int64_t)(p.n + 1) * units > NFA_GROUP_MAX * slots)) {
+        int rc = flush_pending(r); if (rc) return rc;
+    }
+    if (!fits) return run_batch(r, d_pix, d_U, d_lnL, d_spec, B, has_prior, -1, nullptr);
+    p.pix[p.n] = d_pix; p.U[p.n] = d_U; p.lnL[p.n] = d_lnL; p.spec[p.n] = d_spec; p.each = (long)B; p.n += 1;
+    r->pending_prior = has_prior;
+    if (p.n >= group || (int64_t)(p.n + 1) * units > NFA_GROUP_MAX * slots) return flush_pending(r);
+    return NFA_OK;
+}
+
 int nfa_runner_loglike_batch_dev(nfa_runner *r, const int32_t *d_pix, double *d_U, double *d_lnL,
                                  int64_t B) {
     if (!r || !d_U || !d_lnL) return fail(NFA_ERR_ARG, "null argument");
     if (!r->pr) return fail(NFA_ERR_STATE, "runner has no priors (predict-only)");
     if (B <= 0) return NFA_OK;
     RUNNER_LOCK(r);
-    const int ti = g_eng.setup_ti > 0 ? g_eng.setup_ti : SETUP_TI;
-    const int64_t units = B * r->ss->dev.n_spec, slots = (int64_t)g_eng.n_cu * 32;
-    BatchGroup &p = r->pending;
-    const int group = g_eng.coalesce;                  // read per call: a knob, not part of a runner's identity
-    const bool fits = group > 1 && !r->profiling && B % ti == 0 && 2 * units <= NFA_GROUP_MAX * slots;   // (a group stays below NFA_GROUP_MAX waves per slot)
-    if (p.n > 0 && (!fits || p.each != (long)B || (p.pix[0] == nullptr) != (d_pix == nullptr) ||
-                    (int64_t)(p.n + 1) * units > NFA_GROUP_MAX * slots)) {
-        int rc = flush_pending(r); if (rc) return rc;
-    }
-    if (!fits) return run_batch(r, d_pix, d_U, d_lnL, nullptr, B, true, -1, nullptr);
-    p.pix[p.n] = d_pix; p.U[p.n] = d_U; p.lnL[p.n] = d_lnL; p.each = (long)B; p.n += 1;
-    if (p.n >= group || (int64_t)(p.n + 1) * units > NFA_GROUP_MAX * slots) return flush_pending(r);
-    return NFA_OK;
+    return enqueue_dev(r, d_pix, d_U, d_lnL, nullptr, B, true);
 }
 
 int nfa_runner_set_profiling(nfa_runner *r, int on) {
@@ -1398,8 +1406,9 @@ int nfa_runner_predict_batch_dev(nfa_runner *r, const int32_t *d_pix, const doub
     if (!r || !d_theta || (!d_spectra && !d_lnL)) return fail(NFA_ERR_ARG, "null argument");
     if (B <= 0) return NFA_OK;
     RUNNER_LOCK(r);
-    int rc = flush_pending(r); if (rc) return rc;
-    return run_batch(r, d_pix, const_cast<double *>(d_theta), d_lnL, d_spectra, B, false, -1, nullptr);
+    // (coalesced like the likelihood's batches: a launch of one 4096-row batch is one wave per wave slot and as long as its
+    // longest wave, 37.8 us against 26 per batch in a launch of eight)
+    return enqueue_dev(r, d_pix, const_cast<double *>(d_theta), d_lnL, d_spectra, B, false);
 }
 
 void nfa_loglike_callback(double *Cube, int *ndim, int *npars, double *lnew, void *ctx) {

@@ -221,3 +221,61 @@ def test_predict_batch_dev_equals_the_host_call(engine, mode):
     finally:
         dev.free()
         engine.set_exp_mode('fast')
+
+
+@pytest.mark.parametrize('mode', ['fast', 'table'])
+def test_predict_batches_coalesced_or_not_give_the_host_call_bits(engine, mode):
+    """Consecutive nfa_runner_predict_batch_dev calls of one shape travel as one launch (round 5: like the likelihood's
+    batches), every batch writing its own spectra and lnL arrays: eleven batches (a group of eight and a rest), a
+    likelihood batch in between (another kind: what is held is launched first), spectra-only batches behind it."""
+    from nestfit_amd import _ffi
+    from nestfit_amd.cube import CubeRunner
+    engine.set_exp_mode(mode)
+    rng = np.random.default_rng(33)
+    xarrs = [freq_axis(t, 320) for t in (1, 2)]
+    data = rng.normal(0, 0.2, (4, 640))
+    ut = engine.get_irdc_priors(size=200, vsys=0.0)
+    run = CubeRunner(xarrs, [1, 2], data, np.full((4, 2), 0.2), ut, ncomp=2)
+    lib = _ffi.load()
+    dev = _DeviceArrays(lib, _ffi.check)
+    rows = 256
+
+    def draw():
+        theta = np.column_stack([rng.uniform(-2, 2, rows), rng.uniform(-2, 2, rows), rng.uniform(8, 20, rows), rng.uniform(8, 20, rows),
+                                 rng.uniform(3, 8, rows), rng.uniform(3, 8, rows), rng.uniform(13.5, 15, rows), rng.uniform(13.5, 15, rows),
+                                 rng.uniform(0.2, 1, rows), rng.uniform(0.2, 1, rows), rng.uniform(0, 0.5, rows), rng.uniform(0, 0.5, rows)])
+        pix = rng.integers(0, 4, rows).astype(np.int32)
+        return pix, theta
+    try:
+        batches = []
+        for k in range(16):
+            pix, theta = draw()
+            want_spec, want_lnl = run.predict_batch(pix, theta)
+            batches.append((pix, theta, want_spec, want_lnl))
+        U = rng.uniform(size=(rows, 12))
+        pix_l = rng.integers(0, 4, rows).astype(np.int32)
+        Uh = U.copy()
+        want_l = run.loglikelihood_batch(pix_l, Uh)
+        for coalesce in (8, 1, 3):
+            _ffi.set_option('coalesce', coalesce)
+            got = []
+            for k, (pix, theta, want_spec, want_lnl) in enumerate(batches):
+                d_t, d_p = dev.upload(theta), dev.upload(pix)
+                d_s = dev.empty(rows * 640 * 8)
+                d_l = dev.empty(rows * 8) if k < 13 else None                     # the last three: spectra only
+                if k == 11:                                                          # a likelihood batch cuts the run of predict batches
+                    d_u, d_pl, d_ll = dev.upload(U), dev.upload(pix_l), dev.empty(rows * 8)
+                    _ffi.check(lib.nfa_runner_loglike_batch_dev(run._run.handle, d_pl, d_u, d_ll, rows))
+                _ffi.check(lib.nfa_runner_predict_batch_dev(run._run.handle, d_p, d_t, rows, d_s, d_l))
+                got.append((d_s, d_l, d_t))
+            _ffi.check(lib.nfa_runner_synchronize(run._run.handle))
+            for (d_s, d_l, d_t), (pix, theta, want_spec, want_lnl) in zip(got, batches):
+                assert np.array_equal(dev.download(d_s, want_spec), want_spec), (mode, coalesce)
+                if d_l is not None:
+                    assert np.array_equal(dev.download(d_l, want_lnl), want_lnl), (mode, coalesce)
+                assert np.array_equal(dev.download(d_t, theta), theta)
+            assert np.array_equal(dev.download(d_ll, want_l), want_l, equal_nan=True) and np.array_equal(dev.download(d_u, Uh), Uh)
+    finally:
+        _ffi.set_option('coalesce', 8)
+        dev.free()
+        engine.set_exp_mode('fast')
