@@ -31,7 +31,7 @@ rocprof)
     python3 profiles/fourlane_summary.py $out/fourlane_$m/*/*kernel_trace.csv $out/bench_fourlane_$m.json > $out/fourlane_${m}_summary.txt
     rm -rf $out/fourlane_$m
   done
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/spectra -- python3 bench.py --steps 20 --warmup 5 --streams 1 --spectra-out only --exp-mode fast --blocks 5 > $out/bench_spectra_out_onelane.json 2> $out/spectra.err || exit 2
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/spectra -- python3 bench.py --steps 24 --warmup 8 --streams 1 --spectra-out only --exp-mode fast --blocks 5 > $out/bench_spectra_out_onelane.json 2> $out/spectra.err || exit 2
   cp $out/spectra/*/*kernel_stats.csv $out/onelane_kernel_stats_spectra_out.csv
   rm -rf $out/onelane $out/onelane_table $out/spectra
   ;;
