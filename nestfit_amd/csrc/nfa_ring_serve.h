@@ -59,6 +59,8 @@ __global__ void __launch_bounds__(POINT_THREADS) ring_serve_kernel(const PriorPr
     constexpr int SMODE = MODE == 0 ? 0 : 1;
     int n_shared;
     const double *sm = stage_exp_tables<SMODE>(smem, g_tabs, &n_shared);          // once per instance, not per point
+    // ... and so are the prior program and its tables (round 5); the likelihood's line tables go behind them
+    const int n_lines = n_shared + setup_stage_priors(ppp, S, smem, n_shared);
     volatile int *ctl = (volatile int *)(smem + A.ctl_double);                     // [0] command, [1] slot
     const int tid = threadIdx.x, ndim = A.ndim;
     const long wg = blockIdx.x;
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(POINT_THREADS) ring_serve_kernel(const PriorPr
         if (!bad) {
             if (tid == 0 && A.has_pix) d_pix[wg] = my_pix;
             __syncthreads();                                    // (the unit cube wave 0 wrote to U: the barrier's workgroup-scope release)
-            setup_body<SMODE, MODE == 2>(ppp, S, U, D, 1, 1, g_tabs, 0, smem, sm, n_shared, 0u);
+            setup_body<SMODE, MODE == 2, 1, true>(ppp, S, U, D, 1, 1, g_tabs, 0, smem, sm, n_shared, 0u);
             __threadfence();                                    // theta in U, the derived record in D: at L2, stale lines of the last point gone
             __syncthreads();
             __builtin_amdgcn_s_dcache_inv();
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(POINT_THREADS) ring_serve_kernel(const PriorPr
                 if (blk) __syncthreads();
                 // (the line tables go BEHIND the staged exponential table in every mode: the point kernel lets the fast
                 // mode's waves overwrite it, but here the next point's set-up stage wants it again)
-                lnl_body<MODE, false, false, NCOMP>(S, pix, D, part, nullptr, 1, G, g_tabs, smem, sm, n_shared, (unsigned)blk);
+                lnl_body<MODE, false, false, NCOMP>(S, pix, D, part, nullptr, 1, G, g_tabs, smem, sm, n_lines, (unsigned)blk);
             }
             __threadfence();
             __syncthreads();
@@ -214,8 +216,9 @@ int nfa_ring_serve_device(nfa_ring *ring, nfa_runner *run, int lifetime_ms, int 
     const int upw = POINT_WAVES / G.split;
     const int n_shared = mode == 0 ? (SM_END_TABLE - SM_EXP2) : 0;
     const size_t n_staged = mode == 0 ? (SM_END_TABLE - SM_EXP2) : NFA_EXP2_N;
-    size_t lds = std::max(setup_lds_bytes(run, 1, true) + sizeof(double) * (n_staged - NFA_EXP2_N),
-                          sizeof(double) * (n_staged + ((size_t)G.wave_doubles + (G.split > 1 ? LNL_PARTS * 64 : 0)) * upw));
+    // [exponential tables][theta, partition records][prior program + tables: staged once][line tables of the likelihood waves]
+    size_t lds = setup_lds_bytes(run, 1, true) + sizeof(double) * (n_staged - NFA_EXP2_N)
+                 + sizeof(double) * (((size_t)G.wave_doubles + (G.split > 1 ? LNL_PARTS * 64 : 0)) * upw);
     if (mode == 0) lds = std::max(lds, sizeof(double) * (size_t)(n_shared + SM_TABLE_TAIL));
     lds = (lds + 15) & ~(size_t)15;
     const int ctl_double = (int)(lds / sizeof(double));

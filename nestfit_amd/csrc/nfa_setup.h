@@ -437,7 +437,8 @@ __device__ __forceinline__ void derive_simple_lane(const SpecDev &S, const doubl
 #define SETUP_THREADS 256
 // the set-up stage of the 64 items of workgroup `block_id`, by the blockDim.x threads of the workgroup (`sm` =
 // the staged exponential tables, n_shared doubles at the start of smem)
-template <int MODE, bool FAST = false, int NSUB = 1>
+// STAGED: the prior program and its tables are in LDS already (setup_stage_priors, once per resident workgroup)
+template <int MODE, bool FAST = false, int NSUB = 1, bool STAGED = false>
 __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, const SpecDev &S,
                                            double *__restrict__ U, double *__restrict__ D, long B, int has_prior,
                                            const double *__restrict__ g_tabs, int ablate_in, double *smem,
@@ -465,7 +466,7 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
     const int n_it = (int)(B - b0 < ti ? (B - b0 > 0 ? B - b0 : 0) : ti);
     const bool do_prior = has_prior && !(ablate & 16);
     // ---- phase 0: the program and its tables -> LDS (flat copies: all loads in flight at once); theta -> LDS
-    if (do_prior) {
+    if (do_prior && !STAGED) {
         const int nw = (int)(sizeof(PriorProg) / sizeof(int));
         for (int k = tid_wg; k < nw; k += nthr_wg) ((int *)lp)[k] = ((const int *)ppp)[k];
         const double *image = ppp->stage_image;
@@ -477,14 +478,16 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
         th_all[k * 64 + it] = U[b0 * ndim + q];
     }
     __syncthreads();
-    if (do_prior && tid_wg < lp->n_stage) {                    // the LDS copy of the program points at the LDS tables
-        const StageItem it = lp->stage[tid_wg];
-        DistDev &d = lp->ds[it.dist];
-        const double *p = tab + it.off;
-        if (it.field == ST_XAX) d.xax = p; else if (it.field == ST_PDF) d.pdf = p; else if (it.field == ST_PPF) d.ppf = p;
-        else if (it.field == ST_M0) d.m0 = p; else if (it.field == ST_M1) d.m1 = p; else d.m2 = p;
+    if (!STAGED) {
+        if (do_prior && tid_wg < lp->n_stage) {                // the LDS copy of the program points at the LDS tables
+            const StageItem it = lp->stage[tid_wg];
+            DistDev &d = lp->ds[it.dist];
+            const double *p = tab + it.off;
+            if (it.field == ST_XAX) d.xax = p; else if (it.field == ST_PDF) d.pdf = p; else if (it.field == ST_PPF) d.ppf = p;
+            else if (it.field == ST_M0) d.m0 = p; else if (it.field == ST_M1) d.m1 = p; else d.m2 = p;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // ---- phase 1: lanes = items (core.pyx:459-476); priors that share no parameter slot take a wave each
     // (a wave interprets ONE prior for its 64 items: no divergence, and the longest prior sets the time)
     if (do_prior) {
@@ -528,6 +531,32 @@ __device__ __forceinline__ void setup_body(const PriorProg *__restrict__ ppp, co
 }
 
 // MODE: the exponential of the partition sums (0 the reference's tables, 1 the polynomial); FAST: the record of the fast mode
+// The prior program and its tables -> LDS, where setup_body<..., STAGED = true> expects them (one group of items): for a
+// resident workgroup that serves point after point with the same priors (the ring's kernel: 1.7 us of every point's ~23
+// went into this copy and its two barriers).  Doubles of LDS from `smem + n_shared` up to the end of the tables: the
+// caller keeps everything else (line tables) behind that.
+__device__ __forceinline__ int setup_stage_priors(const PriorProg *__restrict__ ppp, const SpecDev &S, double *smem, int n_shared) {
+    const int ncomp = S.ncomp, ndim = S.npar * ncomp;
+    const int per_sub = 64 * ndim + SETUP_TI * ncomp * QREC;
+    PriorProg *lp = (PriorProg *)(smem + n_shared + per_sub);
+    double *tab = (double *)(lp + 1);
+    const int nw = (int)(sizeof(PriorProg) / sizeof(int));
+    for (int k = threadIdx.x; k < nw; k += blockDim.x) ((int *)lp)[k] = ((const int *)ppp)[k];
+    const double *image = ppp->stage_image;
+    const int n_tab = ppp->stage_doubles;
+    for (int k = threadIdx.x; k < n_tab; k += blockDim.x) tab[k] = image[k];
+    __syncthreads();
+    if ((int)threadIdx.x < lp->n_stage) {
+        const StageItem it = lp->stage[threadIdx.x];
+        DistDev &d = lp->ds[it.dist];
+        const double *p = tab + it.off;
+        if (it.field == ST_XAX) d.xax = p; else if (it.field == ST_PDF) d.pdf = p; else if (it.field == ST_PPF) d.ppf = p;
+        else if (it.field == ST_M0) d.m0 = p; else if (it.field == ST_M1) d.m1 = p; else d.m2 = p;
+    }
+    __syncthreads();
+    return per_sub + (int)(sizeof(PriorProg) / sizeof(double)) + 1 + n_tab;
+}
+
 // NSUB = 2: sixteen waves, two groups of eight with `ti` items each (setup_body)
 template <int MODE, bool FAST = false, int NSUB = 1>
 __global__ void __launch_bounds__(512 * NSUB) __attribute__((amdgpu_waves_per_eu(3))) setup_kernel(const PriorProg *__restrict__ ppp, SpecDev S,
