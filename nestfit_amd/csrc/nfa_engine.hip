@@ -788,9 +788,12 @@ static int launch_setup(nfa_runner *r, double *d_U, int64_t B, bool has_prior, i
     int threads = g_eng.setup_threads > 0 ? g_eng.setup_threads : tables ? 2 * SETUP_THREADS : SETUP_THREADS;
     // ... and two such groups per workgroup behind one copy of the tables (115 KB of LDS for one group: one workgroup per CU
     // and two rounds of them for 32768 items; 133 KB for two: one round): 48.4 -> see profiles/r05/ab_table_linestep.txt.
-    // Every batch of the launch must hold whole workgroups.
+    // Every batch of a group must hold whole workgroups; a launch of ONE batch may have any size (the last workgroup's
+    // second group then has fewer items, or none: the sampler's batches).  Small launches keep one group per workgroup:
+    // they are latency, not rounds.
     int nsub = 1;
-    if (tables && g_eng.setup_threads == 0 && g_eng.setup_sub != 1 && ti == SETUP_TI && B % (2 * ti) == 0 && r->cur_group.each % (2 * ti) == 0
+    const bool whole = r->cur_group.n <= 1 || (B % (2 * ti) == 0 && r->cur_group.each % (2 * ti) == 0);
+    if (tables && g_eng.setup_threads == 0 && g_eng.setup_sub != 1 && ti == SETUP_TI && whole && B > (int64_t)ti * g_eng.n_cu
         && setup_lds_bytes(r, mode, has_prior, 2) <= 160 * 1024) {
         nsub = 2;
         threads = 1024;
